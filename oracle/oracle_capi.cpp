@@ -1,0 +1,430 @@
+// ORACLE — TEST INFRASTRUCTURE ONLY (see jet.h header).  PARITY UNPINNED.
+//
+// Flat C entry points so tests/ (ctypes), __graft_entry__.smoke() and bench.py's cpu_baseline leg
+// can drive the CPU restatement.  Nothing under 2dliw-slam_amd/ links or loads this library.
+// All matrices crossing this interface are ROW-MAJOR.
+#include <chrono>
+#include <cstring>
+
+#include "solver.h"
+
+using namespace oracle;
+
+extern "C" {
+
+struct oracle_params_c {
+    double T_imu_to_wheel[16];   // row-major 4x4
+    double T_imu_to_laser[16];
+    double g, line_to_line_sigma, manifold_p_sigma, manifold_q_sigma;
+    double imu_noise_acc_sigma[3], imu_bias_acc_sigma[3], imu_noise_gyro_sigma[3], imu_bias_gyro_sigma[3];
+    double wheel_sigma[3];
+    int fast_mode;
+    int normalize_extrinsics;    // 1: quaternion round trip like src/utilies/params.cpp:44-54
+};
+
+// Same flat window description the product C-ABI uses (include/liw_window.h, liw_window).
+struct oracle_window_c {
+    int n, L;
+    double* states;              // [n][15] p q v ba bw (in/out)
+    const int* laser_frame;      // [L] owning frame, ascending
+    const double* laser_pts;     // [L][12] l1_p1 l1_p2 l2_p1 l2_p2
+    double* match_pose;          // [n][12] p1 q1 p2 q2 (in/out)
+    const unsigned char* has_match;  // [n]
+    const double* imu_X;         // [n-1][15]   entry k: frames k -> k+1
+    const double* imu_J;         // [n-1][225]
+    const double* imu_sqrtP;     // [n-1][225]
+    const double* imu_Dt;        // [n-1]
+    const double* wheel_T;       // [n-1][12]  R(9) t(3)
+    const double* wheel_sqrtP;   // [n-1][9]
+    const double* wheel_Dt;      // [n-1]
+};
+
+static Iso3<double> iso_from16(const double* m, bool renorm) {
+    Iso3<double> T;
+    for (int i = 0; i < 3; ++i) { for (int j = 0; j < 3; ++j) T.R(i, j) = m[i * 4 + j]; T.t(i) = m[i * 4 + 3]; }
+    if (renorm) lie::normalize_tf<double>(T);
+    return T;
+}
+static void fill_params(const oracle_params_c* c, params& p) {
+    p.T_imu_to_wheel = iso_from16(c->T_imu_to_wheel, c->normalize_extrinsics != 0);
+    p.T_imu_to_laser = iso_from16(c->T_imu_to_laser, c->normalize_extrinsics != 0);
+    p.g = c->g; p.line_to_line_sigma = c->line_to_line_sigma;
+    p.manifold_p_sigma = c->manifold_p_sigma; p.manifold_q_sigma = c->manifold_q_sigma;
+    for (int k = 0; k < 3; ++k) {
+        p.imu_noise_acc_sigma[k] = c->imu_noise_acc_sigma[k]; p.imu_bias_acc_sigma[k] = c->imu_bias_acc_sigma[k];
+        p.imu_noise_gyro_sigma[k] = c->imu_noise_gyro_sigma[k]; p.imu_bias_gyro_sigma[k] = c->imu_bias_gyro_sigma[k];
+        p.wheel_sigma[k] = c->wheel_sigma[k];
+    }
+    p.fast_mode = c->fast_mode != 0;
+}
+
+struct oracle_ctx {
+    params prm;
+    solver* slv;
+    solver::frames frames;
+    oracle_window_c win;
+};
+
+void* oracle_create(const oracle_params_c* c) {
+    oracle_ctx* h = new oracle_ctx();
+    fill_params(c, h->prm);
+    h->slv = new solver(&h->prm);
+    return h;
+}
+void oracle_destroy(void* hv) {
+    oracle_ctx* h = (oracle_ctx*)hv;
+    delete h->slv;
+    delete h;
+}
+// normalised extrinsics back out (so the product can be given bit-identical ones)
+void oracle_get_extrinsics(void* hv, double* T_iw16, double* T_il16) {
+    oracle_ctx* h = (oracle_ctx*)hv;
+    auto put = [](const Iso3<double>& T, double* m) {
+        for (int i = 0; i < 3; ++i) { for (int j = 0; j < 3; ++j) m[i * 4 + j] = T.R(i, j); m[i * 4 + 3] = T.t(i); }
+        m[12] = m[13] = m[14] = 0.0; m[15] = 1.0;
+    };
+    put(h->prm.T_imu_to_wheel, T_iw16);
+    put(h->prm.T_imu_to_laser, T_il16);
+}
+
+static void build_frames(oracle_ctx* h, const oracle_window_c* w) {
+    h->win = *w;
+    h->frames.clear();
+    int lpos = 0;
+    for (int i = 0; i < w->n; ++i) {
+        auto f = std::make_shared<frame_info>();
+        const double* s = w->states + i * 15;
+        for (int k = 0; k < 3; ++k) { f->p[k] = s[k]; f->q[k] = s[3 + k]; f->v[k] = s[6 + k]; }
+        for (int k = 0; k < 6; ++k) f->bs[k] = s[9 + k];
+        for (int k = 0; k < 36; ++k) f->sqrt_H[k] = (k % 7 == 0) ? 1.0 : 0.0;
+        if (i > 0) {
+            auto r = std::make_shared<imu_preint_result>();
+            std::memcpy(r->X, w->imu_X + (i - 1) * 15, 15 * sizeof(double));
+            std::memcpy(r->J, w->imu_J + (i - 1) * 225, 225 * sizeof(double));
+            std::memcpy(r->sqrt_inverse_P, w->imu_sqrtP + (i - 1) * 225, 225 * sizeof(double));
+            r->Dt = w->imu_Dt[i - 1];
+            f->imu_observation_reslut = r;
+            auto wr = std::make_shared<wheel_odom_preint_result>();
+            const double* T = w->wheel_T + (i - 1) * 12;
+            for (int a = 0; a < 3; ++a) { for (int b = 0; b < 3; ++b) wr->delta_Tij.R(a, b) = T[a * 3 + b]; wr->delta_Tij.t(a) = T[9 + a]; }
+            std::memcpy(wr->sqrt_inverse_P, w->wheel_sqrtP + (i - 1) * 9, 9 * sizeof(double));
+            wr->Dt = w->wheel_Dt ? w->wheel_Dt[i - 1] : 0.0;
+            f->wheel_observation_reslut = wr;
+        }
+        if (w->has_match[i]) {
+            auto lm = std::make_shared<laser_match>();
+            const double* mp = w->match_pose + i * 12;
+            for (int k = 0; k < 3; ++k) { lm->p1[k] = mp[k]; lm->q1[k] = mp[3 + k]; lm->p2[k] = mp[6 + k]; lm->q2[k] = mp[9 + k]; }
+            while (lpos < w->L && w->laser_frame[lpos] == i) {
+                const double* q = w->laser_pts + size_t(lpos) * 12;
+                line a, b;
+                a.p1 = Vec3<double>(q[0], q[1], q[2]); a.p2 = Vec3<double>(q[3], q[4], q[5]);
+                b.p1 = Vec3<double>(q[6], q[7], q[8]); b.p2 = Vec3<double>(q[9], q[10], q[11]);
+                lm->lines1.push_back(a); lm->lines2.push_back(b);
+                ++lpos;
+            }
+            f->laser_match_ptr = lm;
+            f->type = frame_info::laser;
+        }
+        h->frames.push_back(f);
+    }
+}
+static void scatter_back(oracle_ctx* h) {
+    oracle_window_c& w = h->win;
+    for (int i = 0; i < w.n; ++i) {
+        auto& f = h->frames[i];
+        double* s = w.states + i * 15;
+        for (int k = 0; k < 3; ++k) { s[k] = f->p[k]; s[3 + k] = f->q[k]; s[6 + k] = f->v[k]; }
+        for (int k = 0; k < 6; ++k) s[9 + k] = f->bs[k];
+        if (f->laser_match_ptr) {
+            double* mp = w.match_pose + i * 12;
+            auto& lm = *f->laser_match_ptr;
+            for (int k = 0; k < 3; ++k) { mp[k] = lm.p1[k]; mp[3 + k] = lm.q1[k]; mp[6 + k] = lm.p2[k]; mp[9 + k] = lm.q2[k]; }
+        }
+    }
+}
+
+void oracle_set_max_iterations(void* hv, int k) { ((oracle_ctx*)hv)->slv->options.max_num_iterations = k; }
+void oracle_set_dense_product(void* hv, int on) { ((oracle_ctx*)hv)->slv->dense_product = on != 0; }
+
+// lvio_2d::solver::init_solve / solve / marginalization on a flat window; results scattered back in place
+void oracle_init_solve(void* hv, oracle_window_c* w) { oracle_ctx* h = (oracle_ctx*)hv; build_frames(h, w); h->slv->init_solve(h->frames); scatter_back(h); }
+void oracle_solve(void* hv, oracle_window_c* w) { oracle_ctx* h = (oracle_ctx*)hv; build_frames(h, w); h->slv->solve(h->frames); scatter_back(h); }
+void oracle_marginalization(void* hv, oracle_window_c* w, double* sqrt_H36) {
+    oracle_ctx* h = (oracle_ctx*)hv;
+    build_frames(h, w);
+    h->slv->marginalization(h->frames);
+    scatter_back(h);
+    if (sqrt_H36) std::memcpy(sqrt_H36, h->frames.back()->sqrt_H, 36 * sizeof(double));
+}
+
+// summary + per-iteration state history of the last init_solve/solve
+int oracle_summary(void* hv, int* termination, int* successful, double* initial_cost, double* final_cost) {
+    auto& s = ((oracle_ctx*)hv)->slv->last_summary;
+    if (termination) *termination = s.termination;
+    if (successful) *successful = s.num_successful_steps;
+    if (initial_cost) *initial_cost = s.initial_cost;
+    if (final_cost) *final_cost = s.final_cost;
+    return s.num_iterations;
+}
+int oracle_iteration_count(void* hv) { return int(((oracle_ctx*)hv)->slv->last_summary.iterations.size()); }
+// out: [cost, candidate_cost, model_cost_change, relative_decrease, radius, valid, successful]; x: free-state vector
+int oracle_iteration(void* hv, int k, double* out7, double* x, int x_cap) {
+    auto& it = ((oracle_ctx*)hv)->slv->last_summary.iterations[k];
+    out7[0] = it.cost; out7[1] = it.candidate_cost; out7[2] = it.model_cost_change; out7[3] = it.relative_decrease;
+    out7[4] = it.radius; out7[5] = it.step_is_valid; out7[6] = it.step_is_successful;
+    const int nx = int(it.x.size());
+    for (int i = 0; i < nx && i < x_cap; ++i) x[i] = it.x[i];
+    return nx;
+}
+
+// prior block kept across calls (solver.h:31-37)
+int oracle_get_prior(void* hv, double* X15, double* J225, double* R15) {
+    solver* s = ((oracle_ctx*)hv)->slv;
+    if (!s->has_linearized_block) return 0;
+    std::memcpy(X15, s->linearized_X.data(), 15 * sizeof(double));
+    std::memcpy(J225, s->linearized_jacobians.d.data(), 225 * sizeof(double));
+    std::memcpy(R15, s->linearized_residuals.data(), 15 * sizeof(double));
+    return 1;
+}
+void oracle_set_prior(void* hv, int has, const double* X15, const double* J225, const double* R15) {
+    solver* s = ((oracle_ctx*)hv)->slv;
+    s->has_linearized_block = has != 0;
+    if (!has) return;
+    s->linearized_X.assign(X15, X15 + 15);
+    s->linearized_jacobians = DMat(15, 15);
+    std::memcpy(s->linearized_jacobians.d.data(), J225, 225 * sizeof(double));
+    s->linearized_residuals.assign(R15, R15 + 15);
+}
+// dense pieces of the last marginalization: sizes via rows/cols query (pass null to query)
+void oracle_marg_dims(void* hv, int* rows, int* cols) { solver* s = ((oracle_ctx*)hv)->slv; *rows = s->J.rows; *cols = s->J.cols; }
+void oracle_marg_get(void* hv, double* J, double* R, double* H, double* g, double* dH225, double* dg15) {
+    solver* s = ((oracle_ctx*)hv)->slv;
+    if (J) std::memcpy(J, s->J.d.data(), s->J.d.size() * sizeof(double));
+    if (R) std::memcpy(R, s->R.data(), s->R.size() * sizeof(double));
+    if (H) std::memcpy(H, s->H.d.data(), s->H.d.size() * sizeof(double));
+    if (g) std::memcpy(g, s->g.data(), s->g.size() * sizeof(double));
+    if (dH225) std::memcpy(dH225, s->Delta_H.d.data(), 225 * sizeof(double));
+    if (dg15) std::memcpy(dg15, s->Delta_g.data(), 15 * sizeof(double));
+}
+
+// LM-sense linearisation (what ceres evaluates at iteration 0): tangent-space H = J^T J, g = J^T r,
+// cost = 1/2 |r|^2, over the FULL 15n state ordering [p q v ba bw] x n (constant blocks -> zero rows/cols).
+// mode 0 = init topology (solver.cpp:50-169), 1 = tracking topology (solver.cpp:631-820).
+void oracle_linearize(void* hv, oracle_window_c* w, int mode, double* Hd, double* gd, double* cost) {
+    oracle_ctx* h = (oracle_ctx*)hv;
+    build_frames(h, w);
+    // run the corresponding solve with zero iterations and read H, g out of the minimiser: reproduce
+    // the problem construction by calling the solver with max_num_iterations = 0 and a hook.
+    struct Hook : solver {
+        using solver::solver;
+    };
+    solver& s = *h->slv;
+    miniceres::Problem problem;
+    auto& fi = h->frames;
+    if (mode == 0) {
+        for (size_t i = 0; i < fi.size(); ++i)
+            if (fi[i]->type == frame_info::laser && fi[i]->laser_match_ptr) {
+                auto& lm = *fi[i]->laser_match_ptr;
+                for (size_t j = 0; j < lm.lines1.size(); ++j) {
+                    s.add_laser(problem, lm.lines1[j], lm.lines2[j], fi[0]->p, fi[0]->q, fi[i]->p, fi[i]->q);
+                    problem.SetParameterization(fi[0]->q);
+                    problem.SetParameterization(fi[i]->q);
+                }
+            }
+        s.add_imu_wheel_ground(problem, fi);
+    } else {
+        size_t i = fi.size() - 1;
+        if (fi[i]->type == frame_info::laser && fi[i]->laser_match_ptr) {
+            auto& lm = *fi[i]->laser_match_ptr;
+            for (size_t j = 0; j < lm.lines1.size(); ++j) {
+                s.add_laser(problem, lm.lines1[j], lm.lines2[j], lm.p1, lm.q1, fi[i]->p, fi[i]->q);
+                problem.SetParameterBlockConstant(lm.p1);
+                problem.SetParameterBlockConstant(lm.q1);
+                problem.SetParameterization(lm.q1);
+                problem.SetParameterization(fi[i]->q);
+            }
+        }
+        s.add_imu_wheel_ground(problem, fi);
+        if (!h->prm.fast_mode && s.has_linearized_block) {
+            auto fp = fi[fi.size() - 2];
+            const double* LJ = s.linearized_jacobians.d.data();
+            const double* LX = s.linearized_X.data();
+            problem.AddResidualBlock(15, {fp->p, fp->q, fp->v, fp->bs}, {3, 3, 3, 6},
+                [LJ, LX](const double* const* x, double* res, double** jac) {
+                    marginalization_factor f(LJ, LX);
+                    if (jac) auto_diff::compute_res_and_jacobi<marginalization_factor, 15, 3, 3, 3, 6>(f, x, res, jac);
+                    else auto_diff::compute_res_only<marginalization_factor, 15, 4>(f, x, res);
+                });
+            problem.SetParameterization(fp->q);
+        }
+        for (size_t k = 0; k + 1 < fi.size(); ++k) {
+            problem.SetParameterBlockConstant(fi[k]->p);
+            problem.SetParameterBlockConstant(fi[k]->q);
+            if (h->prm.fast_mode) problem.SetParameterBlockConstant(fi[k]->bs);
+        }
+    }
+    miniceres::Options o;
+    o.max_num_iterations = 0;
+    miniceres::Minimizer m(problem, o);
+    miniceres::Summary sum;
+    m.Solve(&sum);
+    const int n = w->n, N = 15 * n;
+    std::vector<int> map(m.n_tan > 0 ? m.n_tan : 0, -1);   // tangent index -> full index
+    for (auto& b : problem.pblocks) {
+        if (b.constant) continue;
+        for (int f = 0; f < n; ++f) {
+            int base = -1;
+            if (b.user == fi[f]->p) base = f * 15 + 0;
+            else if (b.user == fi[f]->q) base = f * 15 + 3;
+            else if (b.user == fi[f]->v) base = f * 15 + 6;
+            else if (b.user == fi[f]->bs) base = f * 15 + 9;
+            if (base >= 0) for (int k = 0; k < b.size; ++k) map[b.tan_off + k] = base + k;
+        }
+    }
+    std::memset(Hd, 0, sizeof(double) * size_t(N) * N);
+    std::memset(gd, 0, sizeof(double) * N);
+    for (int i = 0; i < m.n_tan; ++i) {
+        gd[map[i]] = m.g[i];
+        for (int j = 0; j < m.n_tan; ++j) Hd[size_t(map[i]) * N + map[j]] = m.H(i, j);
+    }
+    *cost = sum.initial_cost;
+}
+
+// ---- single-factor evaluation (residual + ambient Jacobians, row-major blocks concatenated)
+void oracle_eval_laser(void* hv, const double* pts12, const double* pi, const double* qi, const double* pj, const double* qj,
+                       double* res2, double* jac /*4 blocks of 2x3*/) {
+    oracle_ctx* h = (oracle_ctx*)hv;
+    laser_factor f(&h->prm, Vec3<double>(pts12[0], pts12[1], pts12[2]), Vec3<double>(pts12[3], pts12[4], pts12[5]),
+                   Vec3<double>(pts12[6], pts12[7], pts12[8]), Vec3<double>(pts12[9], pts12[10], pts12[11]));
+    const double* x[4] = {pi, qi, pj, qj};
+    double* jp[4] = {jac, jac + 6, jac + 12, jac + 18};
+    auto_diff::compute_res_and_jacobi<laser_factor, 2, 3, 3, 3, 3>(f, x, res2, jp);
+}
+void oracle_eval_imu(void* hv, const double* X15, const double* J225, const double* sqrtP225, double Dt,
+                     const double* si15, const double* sj15, double* res15, double* jac /*15x30 row-major, cols = [xi(15) xj(15)]*/) {
+    oracle_ctx* h = (oracle_ctx*)hv;
+    imu_preint_result r;
+    std::memcpy(r.X, X15, sizeof(r.X)); std::memcpy(r.J, J225, sizeof(r.J)); std::memcpy(r.sqrt_inverse_P, sqrtP225, sizeof(r.sqrt_inverse_P));
+    r.Dt = Dt;
+    imu_factor f(&h->prm, &r);
+    const double* x[8] = {si15, si15 + 3, si15 + 6, si15 + 9, sj15, sj15 + 3, sj15 + 6, sj15 + 9};
+    double jb[8][90];
+    double* jp[8] = {jb[0], jb[1], jb[2], jb[3], jb[4], jb[5], jb[6], jb[7]};
+    auto_diff::compute_res_and_jacobi<imu_factor, 15, 3, 3, 3, 6, 3, 3, 3, 6>(f, x, res15, jp);
+    const int sz[8] = {3, 3, 3, 6, 3, 3, 3, 6};
+    int off = 0;
+    for (int b = 0; b < 8; ++b) {
+        for (int i = 0; i < 15; ++i) for (int k = 0; k < sz[b]; ++k) jac[i * 30 + off + k] = jb[b][i * sz[b] + k];
+        off += sz[b];
+    }
+}
+void oracle_eval_wheel(void* hv, const double* T12, const double* sqrtP9, const double* pi, const double* qi, const double* pj,
+                       const double* qj, double* res3, double* jac /*3x12 row-major*/) {
+    oracle_ctx* h = (oracle_ctx*)hv;
+    wheel_odom_preint_result r;
+    for (int a = 0; a < 3; ++a) { for (int b = 0; b < 3; ++b) r.delta_Tij.R(a, b) = T12[a * 3 + b]; r.delta_Tij.t(a) = T12[9 + a]; }
+    std::memcpy(r.sqrt_inverse_P, sqrtP9, sizeof(r.sqrt_inverse_P));
+    r.Dt = 0;
+    wheel_odom_factor f(&h->prm, &r);
+    const double* x[4] = {pi, qi, pj, qj};
+    double jb[4][9];
+    double* jp[4] = {jb[0], jb[1], jb[2], jb[3]};
+    auto_diff::compute_res_and_jacobi<wheel_odom_factor, 3, 3, 3, 3, 3>(f, x, res3, jp);
+    for (int b = 0; b < 4; ++b) for (int i = 0; i < 3; ++i) for (int k = 0; k < 3; ++k) jac[i * 12 + b * 3 + k] = jb[b][i * 3 + k];
+}
+void oracle_eval_ground(void* hv, const double* p, const double* q, double* res2 /*[p-res, q-res]*/, double* jac /*2x6*/) {
+    oracle_ctx* h = (oracle_ctx*)hv;
+    const double* x[2] = {p, q};
+    double j0[3], j1[3];
+    double* jp[2] = {j0, j1};
+    ground_factor_p fp(&h->prm);
+    auto_diff::compute_res_and_jacobi<ground_factor_p, 1, 3, 3>(fp, x, res2, jp);
+    for (int k = 0; k < 3; ++k) { jac[k] = j0[k]; jac[3 + k] = j1[k]; }
+    ground_factor_q fq(&h->prm);
+    auto_diff::compute_res_and_jacobi<ground_factor_q, 1, 3, 3>(fq, x, res2 + 1, jp);
+    for (int k = 0; k < 3; ++k) { jac[6 + k] = j0[k]; jac[9 + k] = j1[k]; }
+}
+// lie helpers for the python cross-check
+void oracle_exp_so3(const double* a, double* R9) {
+    Mat3<double> R = lie::exp_so3<double>(Vec3<double>(a[0], a[1], a[2]));
+    for (int i = 0; i < 3; ++i) for (int j = 0; j < 3; ++j) R9[i * 3 + j] = R(i, j);
+}
+void oracle_log_SO3(const double* R9, double* a) {
+    Mat3<double> R;
+    for (int i = 0; i < 3; ++i) for (int j = 0; j < 3; ++j) R(i, j) = R9[i * 3 + j];
+    Vec3<double> v = lie::log_SO3<double>(R);
+    a[0] = v(0); a[1] = v(1); a[2] = v(2);
+}
+void oracle_so3_plus(const double* x, const double* d, double* out, double* jac9) {
+    miniceres::so3_plus(x, d, out);
+    if (jac9) miniceres::so3_plus_jacobian(x, jac9);
+}
+
+// ---- pre-integration replay.  samples: [N][7] = t, acc(3), gyro(3); returns result at t_end
+void oracle_imu_preint(void* hv, const double* samples, int N, double t_start, double t_end, const double* bias6,
+                       double* X15, double* J225, double* sqrtP225, double* Dt) {
+    oracle_ctx* h = (oracle_ctx*)hv;
+    imu_preintegraption pre(&h->prm);
+    // samples[0] (time <= t_start) seeds last_info exactly like the sample that preceded the reset in the
+    // reference (trajectory.cpp:176-184: reset_imu_measure keeps last_info); integration starts at t_start.
+    for (int i = 0; i < N; ++i) {
+        imu_sample s;
+        s.time_stamp = samples[i * 7];
+        s.acc = Vec3<double>(samples[i * 7 + 1], samples[i * 7 + 2], samples[i * 7 + 3]);
+        s.gyro = Vec3<double>(samples[i * 7 + 4], samples[i * 7 + 5], samples[i * 7 + 6]);
+        pre.add_imu_measure(s);
+        if (i == 0) pre.reset_imu_measure(t_start, bias6, bias6 + 3);
+    }
+    pre.update_only_t(t_end);
+    imu_preint_result r = pre.get_preintegraption_result();
+    std::memcpy(X15, r.X, sizeof(r.X)); std::memcpy(J225, r.J, sizeof(r.J)); std::memcpy(sqrtP225, r.sqrt_inverse_P, sizeof(r.sqrt_inverse_P));
+    *Dt = r.Dt;
+}
+// samples: [N][13] = t, R(9 row-major), t(3)
+void oracle_wheel_preint(void* hv, const double* samples, int N, double t_start, double t_end, double* T12, double* sqrtP9, double* Dt) {
+    oracle_ctx* h = (oracle_ctx*)hv;
+    wheel_odom_preintegration pre(&h->prm);
+    // samples before t_start only establish the body twist (v, omega); the accumulator is reset at
+    // t_start like the reference does at every laser frame (trajectory.cpp:176-184).
+    bool did_reset = false;
+    for (int i = 0; i < N; ++i) {
+        wheel_sample s;
+        const double* q = samples + i * 13;
+        s.time_stamp = q[0];
+        for (int a = 0; a < 3; ++a) { for (int b = 0; b < 3; ++b) s.pose.R(a, b) = q[1 + a * 3 + b]; s.pose.t(a) = q[10 + a]; }
+        if (!did_reset && s.time_stamp > t_start) { pre.update_only_t(t_start); pre.reset_wheel_odom_measure(t_start); did_reset = true; }
+        pre.add_wheel_odom_measure(s);
+    }
+    if (!did_reset) { pre.update_only_t(t_start); pre.reset_wheel_odom_measure(t_start); }
+    pre.update_only_t(t_end);
+    wheel_odom_preint_result r = pre.get_preintegraption_result();
+    for (int a = 0; a < 3; ++a) { for (int b = 0; b < 3; ++b) T12[a * 3 + b] = r.delta_Tij.R(a, b); T12[9 + a] = r.delta_Tij.t(a); }
+    std::memcpy(sqrtP9, r.sqrt_inverse_P, sizeof(r.sqrt_inverse_P));
+    *Dt = r.Dt;
+}
+
+// ---- timed CPU baseline: `reps` x (init_solve + marginalization) on copies of the window; seconds total
+double oracle_time_solves(void* hv, oracle_window_c* w, int reps, int max_iters, int dense_product, int* iters_out) {
+    oracle_ctx* h = (oracle_ctx*)hv;
+    std::vector<double> st(w->states, w->states + w->n * 15), mp(w->match_pose, w->match_pose + w->n * 12);
+    h->slv->options.max_num_iterations = max_iters;
+    h->slv->dense_product = dense_product != 0;
+    int iters = 0;
+    auto t0 = std::chrono::steady_clock::now();
+    for (int r = 0; r < reps; ++r) {
+        std::memcpy(w->states, st.data(), st.size() * sizeof(double));
+        std::memcpy(w->match_pose, mp.data(), mp.size() * sizeof(double));
+        h->slv->has_linearized_block = false;
+        build_frames(h, w);
+        h->slv->init_solve(h->frames);
+        iters += h->slv->last_summary.num_iterations;
+        h->slv->marginalization(h->frames);
+        scatter_back(h);
+    }
+    auto t1 = std::chrono::steady_clock::now();
+    if (iters_out) *iters_out = iters;
+    return std::chrono::duration<double>(t1 - t0).count();
+}
+
+}  // extern "C"

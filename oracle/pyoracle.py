@@ -1,0 +1,243 @@
+"""ORACLE — TEST INFRASTRUCTURE ONLY.  ctypes front-end of oracle/liboracle.so.
+
+Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may import this module; the
+product package (2dliw-slam_amd/) never does.  PARITY UNPINNED: the reference has no golden vectors and
+cannot be built here (see oracle/jet.h).
+"""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB = None
+
+dp = C.POINTER(C.c_double)
+
+
+def build(force=False):
+    so = os.path.join(_HERE, "liboracle.so")
+    srcs = [os.path.join(_HERE, f) for f in os.listdir(_HERE) if f.endswith((".h", ".cpp"))]
+    if force or not os.path.exists(so) or any(os.path.getmtime(s) > os.path.getmtime(so) for s in srcs):
+        subprocess.check_call(["make", "-C", _HERE, "liboracle.so"], stdout=subprocess.DEVNULL)
+    return so
+
+
+def lib():
+    global _LIB
+    if _LIB is None:
+        so = os.path.join(_HERE, "liboracle.so")
+        if not os.path.exists(so):
+            build()
+        _LIB = C.CDLL(so)
+        _LIB.oracle_create.restype = C.c_void_p
+        _LIB.oracle_time_solves.restype = C.c_double
+    return _LIB
+
+
+class ParamsC(C.Structure):
+    _fields_ = [("T_imu_to_wheel", C.c_double * 16), ("T_imu_to_laser", C.c_double * 16),
+                ("g", C.c_double), ("line_to_line_sigma", C.c_double),
+                ("manifold_p_sigma", C.c_double), ("manifold_q_sigma", C.c_double),
+                ("imu_noise_acc_sigma", C.c_double * 3), ("imu_bias_acc_sigma", C.c_double * 3),
+                ("imu_noise_gyro_sigma", C.c_double * 3), ("imu_bias_gyro_sigma", C.c_double * 3),
+                ("wheel_sigma", C.c_double * 3), ("fast_mode", C.c_int), ("normalize_extrinsics", C.c_int)]
+
+
+class WindowC(C.Structure):
+    _fields_ = [("n", C.c_int), ("L", C.c_int), ("states", dp), ("laser_frame", C.POINTER(C.c_int)),
+                ("laser_pts", dp), ("match_pose", dp), ("has_match", C.POINTER(C.c_ubyte)),
+                ("imu_X", dp), ("imu_J", dp), ("imu_sqrtP", dp), ("imu_Dt", dp),
+                ("wheel_T", dp), ("wheel_sqrtP", dp), ("wheel_Dt", dp)]
+
+
+def _p(a):
+    return a.ctypes.data_as(dp)
+
+
+def params_struct(prm):
+    """prm: dict with the keys of 2dliw-slam_amd Params (see synth.office_params())."""
+    s = ParamsC()
+    s.T_imu_to_wheel[:] = list(np.asarray(prm["T_imu_to_wheel"], dtype=np.float64).reshape(16))
+    s.T_imu_to_laser[:] = list(np.asarray(prm["T_imu_to_laser"], dtype=np.float64).reshape(16))
+    for k in ("g", "line_to_line_sigma", "manifold_p_sigma", "manifold_q_sigma"):
+        setattr(s, k, float(prm[k]))
+    for k in ("imu_noise_acc_sigma", "imu_bias_acc_sigma", "imu_noise_gyro_sigma", "imu_bias_gyro_sigma", "wheel_sigma"):
+        getattr(s, k)[:] = [float(v) for v in prm[k]]
+    s.fast_mode = int(bool(prm.get("fast_mode", False)))
+    s.normalize_extrinsics = int(bool(prm.get("normalize_extrinsics", True)))
+    return s
+
+
+class Window:
+    """Owns contiguous numpy arrays of one flat window and the matching WindowC view."""
+
+    FIELDS = ("states", "laser_frame", "laser_pts", "match_pose", "has_match", "imu_X", "imu_J", "imu_sqrtP",
+              "imu_Dt", "wheel_T", "wheel_sqrtP", "wheel_Dt")
+
+    def __init__(self, d):
+        self.n = int(d["n"])
+        self.a = {}
+        for k in self.FIELDS:
+            dt = np.int32 if k == "laser_frame" else (np.uint8 if k == "has_match" else np.float64)
+            self.a[k] = np.ascontiguousarray(np.array(d[k], dtype=dt, copy=True))
+        self.L = int(self.a["laser_frame"].shape[0])
+        if self.n < 2:   # keep ctypes pointers valid for empty factor arrays
+            for k in ("imu_X", "imu_J", "imu_sqrtP", "imu_Dt", "wheel_T", "wheel_sqrtP", "wheel_Dt"):
+                if self.a[k].size == 0:
+                    self.a[k] = np.zeros(1, dtype=np.float64)
+        if self.L == 0:
+            self.a["laser_frame"] = np.zeros(1, dtype=np.int32)
+            self.a["laser_pts"] = np.zeros(12, dtype=np.float64)
+        c = WindowC()
+        c.n, c.L = self.n, self.L
+        for k in self.FIELDS:
+            if k == "laser_frame":
+                c.laser_frame = self.a[k].ctypes.data_as(C.POINTER(C.c_int))
+            elif k == "has_match":
+                c.has_match = self.a[k].ctypes.data_as(C.POINTER(C.c_ubyte))
+            else:
+                setattr(c, k, _p(self.a[k]))
+        self.c = c
+
+    def __getitem__(self, k):
+        return self.a[k]
+
+
+class Oracle:
+    def __init__(self, prm):
+        self.L = lib()
+        self._ps = params_struct(prm)
+        self.h = C.c_void_p(self.L.oracle_create(C.byref(self._ps)))
+
+    def __del__(self):
+        try:
+            self.L.oracle_destroy(self.h)
+        except Exception:
+            pass
+
+    def extrinsics(self):
+        a, b = np.zeros(16), np.zeros(16)
+        self.L.oracle_get_extrinsics(self.h, _p(a), _p(b))
+        return a.reshape(4, 4), b.reshape(4, 4)
+
+    # ---- single factors
+    def eval_laser(self, pts12, pi, qi, pj, qj):
+        pts12, pi, qi, pj, qj = [np.ascontiguousarray(v, dtype=np.float64) for v in (pts12, pi, qi, pj, qj)]
+        res, jac = np.zeros(2), np.zeros(24)
+        self.L.oracle_eval_laser(self.h, _p(pts12), _p(pi), _p(qi), _p(pj), _p(qj), _p(res), _p(jac))
+        J = np.concatenate([jac[k * 6:(k + 1) * 6].reshape(2, 3) for k in range(4)], axis=1)
+        return res, J
+
+    def eval_imu(self, X, J, sqrtP, Dt, si, sj):
+        X, J, sqrtP, si, sj = [np.ascontiguousarray(v, dtype=np.float64) for v in (X, J, sqrtP, si, sj)]
+        res, jac = np.zeros(15), np.zeros(15 * 30)
+        self.L.oracle_eval_imu(self.h, _p(X), _p(J), _p(sqrtP), C.c_double(Dt), _p(si), _p(sj), _p(res), _p(jac))
+        return res, jac.reshape(15, 30)
+
+    def eval_wheel(self, T12, sqrtP9, pi, qi, pj, qj):
+        T12, sqrtP9, pi, qi, pj, qj = [np.ascontiguousarray(v, dtype=np.float64) for v in (T12, sqrtP9, pi, qi, pj, qj)]
+        res, jac = np.zeros(3), np.zeros(36)
+        self.L.oracle_eval_wheel(self.h, _p(T12), _p(sqrtP9), _p(pi), _p(qi), _p(pj), _p(qj), _p(res), _p(jac))
+        return res, jac.reshape(3, 12)
+
+    def eval_ground(self, p, q):
+        p, q = [np.ascontiguousarray(v, dtype=np.float64) for v in (p, q)]
+        res, jac = np.zeros(2), np.zeros(12)
+        self.L.oracle_eval_ground(self.h, _p(p), _p(q), _p(res), _p(jac))
+        return res, jac.reshape(2, 6)
+
+    def exp_so3(self, a):
+        a = np.ascontiguousarray(a, dtype=np.float64)
+        R = np.zeros(9)
+        self.L.oracle_exp_so3(_p(a), _p(R))
+        return R.reshape(3, 3)
+
+    def log_SO3(self, R):
+        R = np.ascontiguousarray(R, dtype=np.float64).reshape(9)
+        a = np.zeros(3)
+        self.L.oracle_log_SO3(_p(R), _p(a))
+        return a
+
+    def so3_plus(self, x, d):
+        x, d = [np.ascontiguousarray(v, dtype=np.float64) for v in (x, d)]
+        out, jac = np.zeros(3), np.zeros(9)
+        self.L.oracle_so3_plus(_p(x), _p(d), _p(out), _p(jac))
+        return out, jac.reshape(3, 3)
+
+    # ---- pre-integration
+    def imu_preint(self, samples, t_start, t_end, bias6):
+        samples = np.ascontiguousarray(samples, dtype=np.float64)
+        bias6 = np.ascontiguousarray(bias6, dtype=np.float64)
+        X, J, P, Dt = np.zeros(15), np.zeros(225), np.zeros(225), C.c_double(0)
+        self.L.oracle_imu_preint(self.h, _p(samples), C.c_int(samples.shape[0]), C.c_double(t_start), C.c_double(t_end),
+                                 _p(bias6), _p(X), _p(J), _p(P), C.byref(Dt))
+        return X, J.reshape(15, 15), P.reshape(15, 15), Dt.value
+
+    def wheel_preint(self, samples, t_start, t_end):
+        samples = np.ascontiguousarray(samples, dtype=np.float64)
+        T, P, Dt = np.zeros(12), np.zeros(9), C.c_double(0)
+        self.L.oracle_wheel_preint(self.h, _p(samples), C.c_int(samples.shape[0]), C.c_double(t_start), C.c_double(t_end), _p(T), _p(P), C.byref(Dt))
+        return T, P.reshape(3, 3), Dt.value
+
+    # ---- window level
+    def set_max_iterations(self, k):
+        self.L.oracle_set_max_iterations(self.h, C.c_int(k))
+
+    def init_solve(self, w):
+        self.L.oracle_init_solve(self.h, C.byref(w.c))
+
+    def solve(self, w):
+        self.L.oracle_solve(self.h, C.byref(w.c))
+
+    def marginalization(self, w):
+        s = np.zeros(36)
+        self.L.oracle_marginalization(self.h, C.byref(w.c), _p(s))
+        return s.reshape(6, 6)
+
+    def summary(self):
+        t, s, c0, c1 = C.c_int(0), C.c_int(0), C.c_double(0), C.c_double(0)
+        it = self.L.oracle_summary(self.h, C.byref(t), C.byref(s), C.byref(c0), C.byref(c1))
+        return dict(iterations=it, termination=t.value, successful=s.value, initial_cost=c0.value, final_cost=c1.value)
+
+    def iterations(self):
+        out = []
+        for k in range(self.L.oracle_iteration_count(self.h)):
+            o7, x = np.zeros(7), np.zeros(4096)
+            nx = self.L.oracle_iteration(self.h, C.c_int(k), _p(o7), _p(x), C.c_int(4096))
+            out.append(dict(cost=o7[0], candidate_cost=o7[1], model_cost_change=o7[2], relative_decrease=o7[3],
+                            radius=o7[4], valid=bool(o7[5]), successful=bool(o7[6]), x=x[:nx].copy()))
+        return out
+
+    def get_prior(self):
+        X, J, R = np.zeros(15), np.zeros(225), np.zeros(15)
+        has = self.L.oracle_get_prior(self.h, _p(X), _p(J), _p(R))
+        return (X, J.reshape(15, 15), R) if has else None
+
+    def set_prior(self, prior):
+        if prior is None:
+            z = np.zeros(225)
+            self.L.oracle_set_prior(self.h, C.c_int(0), _p(z), _p(z), _p(z))
+            return
+        X, J, R = [np.ascontiguousarray(v, dtype=np.float64) for v in prior]
+        self.L.oracle_set_prior(self.h, C.c_int(1), _p(X), _p(J.reshape(225)), _p(R))
+
+    def marg_pieces(self):
+        r, c = C.c_int(0), C.c_int(0)
+        self.L.oracle_marg_dims(self.h, C.byref(r), C.byref(c))
+        J, R = np.zeros((r.value, c.value)), np.zeros(r.value)
+        H, g, dH, dg = np.zeros((c.value, c.value)), np.zeros(c.value), np.zeros((15, 15)), np.zeros(15)
+        self.L.oracle_marg_get(self.h, _p(J), _p(R), _p(H), _p(g), _p(dH), _p(dg))
+        return dict(J=J, R=R, H=H, g=g, Delta_H=dH, Delta_g=dg)
+
+    def linearize(self, w, mode):
+        N = 15 * w.n
+        H, g, c = np.zeros((N, N)), np.zeros(N), C.c_double(0)
+        self.L.oracle_linearize(self.h, C.byref(w.c), C.c_int(mode), _p(H), _p(g), C.byref(c))
+        return H, g, c.value
+
+    def time_solves(self, w, reps, max_iters=50, dense_product=True):
+        it = C.c_int(0)
+        sec = self.L.oracle_time_solves(self.h, C.byref(w.c), C.c_int(reps), C.c_int(max_iters), C.c_int(int(dense_product)), C.byref(it))
+        return sec, it.value
