@@ -1,0 +1,188 @@
+"""Batched / multi-GPU host side of the estimator: device-resident windows (torch tensors as plain HBM
+allocations), the LM launch sequence, and factor sharding with an RCCL all-reduce of the laser partial sums.
+
+torch is plumbing here (device memory, streams, torch.distributed); every kernel is in libliw_window.so.
+"""
+import ctypes as C
+
+import numpy as np
+
+
+def shard_laser(win, rank, world):
+    """Factor-parallel partition of ONE window: rank r keeps a contiguous slice of the (frame-sorted) laser blocks;
+    states, IMU / wheel blocks and poses are replicated.  Union over ranks = all blocks, slices are disjoint."""
+    L = int(np.asarray(win["laser_frame"]).shape[0])
+    lo, hi = (L * rank) // world, (L * (rank + 1)) // world
+    out = dict(win)
+    out["laser_frame"] = np.asarray(win["laser_frame"])[lo:hi].copy()
+    out["laser_pts"] = np.asarray(win["laser_pts"])[lo:hi].copy()
+    return out
+
+
+def allreduce_sum_(t, group=None):
+    """Sum-all-reduce a tensor in place over the process group (RCCL on GPUs, gloo on CPU); no-op single process."""
+    import torch.distributed as dist
+    if dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1:
+        dist.all_reduce(t, op=dist.ReduceOp.SUM, group=group)
+    return t
+
+
+class BatchSolver:
+    """B independent windows (uniform n) resident on one GPU.
+
+    windows: list of window dicts (synth.make_window layout).  With `world > 1` each window's laser blocks are
+    sharded across ranks (`shard_laser`), the small factors are evaluated on every rank, and `solve` all-reduces
+    the laser partial sums after every linearisation (one exchange per LM iteration)."""
+
+    def __init__(self, prm, windows, device="cuda:0", history_records=0, rank=0, world=1, group=None):
+        import torch
+        from . import BatchC, WsLayoutC, lib, params_struct, LiwError
+        self.torch = torch
+        self.LiwError = LiwError
+        self.L = lib()
+        self.dev = torch.device(device)
+        dev_index = self.dev.index if self.dev.index is not None else 0
+        self._ps = params_struct(prm, dev_index)
+        self.h = C.c_void_p(self.L.liw_create(C.byref(self._ps)))
+        self.rank, self.world, self.group = rank, world, group
+        if world > 1:
+            windows = [shard_laser(w, rank, world) for w in windows]
+        self.B = len(windows)
+        self.n = int(windows[0]["n"])
+        n, B = self.n, self.B
+        for w in windows:
+            assert int(w["n"]) == n, "uniform n per batch"
+        Ls = [int(np.asarray(w["laser_frame"]).shape[0]) for w in windows]
+        self.Ltot = int(sum(Ls))
+        off = np.zeros(B + 1, dtype=np.int32)
+        off[1:] = np.cumsum(Ls)
+        cat = lambda k, dt: np.ascontiguousarray(np.concatenate([np.asarray(w[k], dtype=dt).reshape(-1) for w in windows]))
+        pts = np.concatenate([np.asarray(w["laser_pts"], dtype=np.float64).reshape(-1, 12) for w in windows], axis=0) if self.Ltot else np.zeros((1, 12))
+        host = dict(
+            x=cat("states", np.float64), laser_off=off, laser_frame=cat("laser_frame", np.int32) if self.Ltot else np.zeros(1, np.int32),
+            laser_pts=np.ascontiguousarray(pts.T).reshape(-1),   # component-major [12][Ltot]
+            match_pose=cat("match_pose", np.float64), has_match=cat("has_match", np.uint8),
+            imu_X=cat("imu_X", np.float64), imu_J=cat("imu_J", np.float64), imu_sqrtP=cat("imu_sqrtP", np.float64), imu_Dt=cat("imu_Dt", np.float64),
+            wheel_T=cat("wheel_T", np.float64), wheel_sqrtP=cat("wheel_sqrtP", np.float64),
+            prior_X=np.zeros(B * 15), prior_J=np.zeros(B * 225), prior_R=np.zeros(B * 15), has_prior=np.zeros(B, dtype=np.int32))
+        self.t = {}
+        for k, a in host.items():
+            if a.size == 0:
+                a = np.zeros(1, dtype=a.dtype)
+            self.t[k] = torch.from_numpy(a).to(self.dev)
+        self.history_records = int(history_records)
+        lay = WsLayoutC()
+        r = self.L.liw_batch_ws_layout(C.c_int(B), C.c_int(n), C.c_int(self.history_records), C.byref(lay))
+        if r < 0:
+            raise LiwError(r, "liw_batch_ws_layout")
+        self.lay = lay
+        self.ws = torch.zeros(int(lay.bytes), dtype=torch.uint8, device=self.dev)
+        b = BatchC()
+        b.B, b.n, b.Ltot = B, n, self.Ltot
+        for k in ("x", "laser_off", "laser_frame", "laser_pts", "match_pose", "has_match", "imu_X", "imu_J", "imu_sqrtP", "imu_Dt",
+                  "wheel_T", "wheel_sqrtP", "prior_X", "prior_J", "prior_R", "has_prior"):
+            setattr(b, k, self.t[k].data_ptr())
+        b.eval_small = 1
+        b.history_records = self.history_records
+        self.b = b
+        # views of the laser partial sums (what a factor-sharded run all-reduces)
+        nd = int(lay.laser_partial_bytes) // 8
+        self.PL = [self.ws[int(lay.laser_partial_off[k]):int(lay.laser_partial_off[k]) + nd * 8].view(torch.float64) for k in range(2)]
+
+    def close(self):
+        if self.h:
+            self.L.liw_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _chk(self, r):
+        if r < 0:
+            raise self.LiwError(r, self.L.liw_last_error(self.h).decode())
+        return r
+
+    def _stream(self):
+        return C.c_void_p(self.torch.cuda.current_stream(self.dev).cuda_stream)
+
+    def _wsp(self):
+        return C.c_void_p(self.ws.data_ptr())
+
+    # ---- LM pieces
+    def solve(self, mode, max_iters=0, use_graph=False):
+        """Runs the whole LM loop.  Single rank: one native call (optionally a captured hipGraph).  Factor-sharded:
+        the loop is driven here so the all-reduce sits between linearise and step."""
+        if self.world == 1:
+            self._chk(self.L.liw_batch_solve(self.h, C.byref(self.b), C.c_int(mode), C.c_int(max_iters), self._wsp(), self._stream(), C.c_int(int(use_graph))))
+            return
+        K = self._chk(self.L.liw_batch_set_max_iters(self.h, C.c_int(mode), C.c_int(max_iters)))
+        s = self._stream()
+        self._chk(self.L.liw_batch_lm_begin(self.h, C.byref(self.b), C.c_int(mode), C.c_int(K), self._wsp(), s))
+        self._chk(self.L.liw_batch_lm_linearize(self.h, C.byref(self.b), C.c_int(mode), C.c_int(0), self._wsp(), s))
+        allreduce_sum_(self.PL[0], self.group)
+        for _ in range(K):
+            self._chk(self.L.liw_batch_lm_step(self.h, C.byref(self.b), C.c_int(mode), self._wsp(), s))
+            self._chk(self.L.liw_batch_lm_linearize(self.h, C.byref(self.b), C.c_int(mode), C.c_int(1), self._wsp(), s))
+            allreduce_sum_(self.PL[1], self.group)
+        self._chk(self.L.liw_batch_lm_step(self.h, C.byref(self.b), C.c_int(mode), self._wsp(), s))
+        self._chk(self.L.liw_batch_lm_finish(self.h, C.byref(self.b), C.c_int(mode), self._wsp(), s))
+
+    def linearize(self, mode):
+        self._chk(self.L.liw_batch_linearize(self.h, C.byref(self.b), C.c_int(mode), self._wsp(), self._stream()))
+        if self.world > 1:
+            allreduce_sum_(self.PL[0], self.group)
+
+    def export_dense(self, mode):
+        N = 15 * self.n
+        torch = self.torch
+        H = torch.zeros((self.B, N, N), dtype=torch.float64, device=self.dev)
+        g = torch.zeros((self.B, N), dtype=torch.float64, device=self.dev)
+        c = torch.zeros(self.B, dtype=torch.float64, device=self.dev)
+        self._chk(self.L.liw_batch_export_dense(self.h, C.byref(self.b), C.c_int(mode), C.c_int(0), self._wsp(), C.c_void_p(H.data_ptr()),
+                                                C.c_void_p(g.data_ptr()), C.c_void_p(c.data_ptr()), self._stream()))
+        return H, g, c
+
+    def marginalize(self):
+        torch = self.torch
+        sH = torch.zeros((self.B, 36), dtype=torch.float64, device=self.dev)
+        dH = torch.zeros((self.B, 225), dtype=torch.float64, device=self.dev)
+        dg = torch.zeros((self.B, 15), dtype=torch.float64, device=self.dev)
+        s = self._stream()
+        self._chk(self.L.liw_batch_marg_linearize(self.h, C.byref(self.b), self._wsp(), s))
+        if self.world > 1:
+            allreduce_sum_(self.PL[0], self.group)
+        self._chk(self.L.liw_batch_marg_schur(self.h, C.byref(self.b), self._wsp(), C.c_void_p(sH.data_ptr()), C.c_void_p(dH.data_ptr()),
+                                              C.c_void_p(dg.data_ptr()), s))
+        return sH, dH, dg
+
+    # ---- results
+    def states(self):
+        return self.t["x"].cpu().numpy().reshape(self.B, self.n, 15)
+
+    def set_states(self, x):
+        self.t["x"].copy_(self.torch.from_numpy(np.ascontiguousarray(x, dtype=np.float64).reshape(-1)).to(self.dev))
+
+    def summaries(self):
+        from . import SummaryC
+        raw = self.ws[int(self.lay.info_off):int(self.lay.info_off) + C.sizeof(SummaryC) * self.B].cpu().numpy().tobytes()
+        arr = (SummaryC * self.B).from_buffer_copy(raw)
+        return [dict(iterations=a.iterations, successful=a.successful_steps, termination=a.termination,
+                     initial_cost=a.initial_cost, final_cost=a.final_cost) for a in arr]
+
+    def history(self):
+        if not self.history_records:
+            return None
+        nd = self.history_records * self.B * self.n * 15
+        o = int(self.lay.history_off)
+        return self.ws[o:o + nd * 8].view(self.torch.float64).cpu().numpy().reshape(self.history_records, self.B, self.n, 15)
+
+    def set_timing(self, on):
+        self._chk(self.L.liw_set_timing(self.h, C.c_int(int(on))))
+
+    def get_timing(self):
+        a, b, c, d = C.c_double(0), C.c_int(0), C.c_double(0), C.c_int(0)
+        self._chk(self.L.liw_get_timing(self.h, C.byref(a), C.byref(b), C.byref(c), C.byref(d)))
+        return dict(linearize_ms=a.value, linearize_launches=b.value, step_ms=c.value, step_launches=d.value)

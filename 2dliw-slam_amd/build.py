@@ -1,0 +1,56 @@
+"""Build recipe of libliw_window.so (hipcc, gfx950 only, in-tree so the .so travels to the GPU box)."""
+import os
+import subprocess
+import sys
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(HERE, "csrc")
+LIB = os.path.join(HERE, "libliw_window.so")
+SOURCES = ["k_linearize.hip", "k_lm.hip", "liw_capi.hip", "liw_preint.cpp"]
+HEADERS = ["liw_dual.hpp", "liw_kernels.hpp", os.path.join("..", "..", "include", "liw_window.h")]
+FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wno-unused-result"]
+
+
+def _hipcc():
+    for c in ("/opt/rocm/bin/hipcc", "hipcc"):
+        if os.path.exists(c) or c == "hipcc":
+            return c
+    return "hipcc"
+
+
+def needs_build():
+    if not os.path.exists(LIB):
+        return True
+    t = os.path.getmtime(LIB)
+    deps = [os.path.join(CSRC, s) for s in SOURCES + HEADERS] + [os.path.abspath(__file__)]
+    return any(os.path.getmtime(d) > t for d in deps if os.path.exists(d))
+
+
+def build(force=False, verbose=False):
+    """Compile every HIP translation unit for gfx950 and link the shared library."""
+    if not force and not needs_build():
+        return LIB
+    objs = []
+    procs = []
+    odir = os.path.join(HERE, "build")
+    os.makedirs(odir, exist_ok=True)
+    for s in SOURCES:
+        o = os.path.join(odir, s.rsplit(".", 1)[0] + ".o")
+        cmd = [_hipcc()] + FLAGS + (["-x", "hip"] if s.endswith(".cpp") else []) + ["-c", os.path.join(CSRC, s), "-o", o]
+        if verbose:
+            print(" ".join(cmd), file=sys.stderr)
+        procs.append((subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT), cmd))
+        objs.append(o)
+    for p, cmd in procs:
+        out, _ = p.communicate()
+        if p.returncode != 0:
+            raise RuntimeError("hipcc failed: %s\n%s" % (" ".join(cmd), out.decode(errors="replace")))
+    cmd = [_hipcc(), "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + objs
+    r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT)
+    if r.returncode != 0:
+        raise RuntimeError("link failed: %s\n%s" % (" ".join(cmd), r.stdout.decode(errors="replace")))
+    return LIB
+
+
+if __name__ == "__main__":
+    print(build(force="--force" in sys.argv, verbose=True))

@@ -1,0 +1,499 @@
+// k_linearize.hip — factor residual/Jacobian evaluation + J^T J block partial sums (gfx950, fp64).
+//
+// One launch evaluates every residual block of every window of a batch.  Work is split into ROLES, one
+// wavefront (64-thread work-group) per work item:
+//   laser  : one (window, owning frame) group; a LANE is one laser_factor block (reference
+//            src/factor/laser_factor.h:45-89, two point-to-line rows), 64 blocks per pass, coalesced reads of
+//            the component-major end-point arrays; the frame transforms and their derivatives w.r.t. the
+//            rotation vector are computed once per wave (dual numbers, direction-per-lane) and broadcast.
+//   imu    : two imu_factor blocks per wave (src/factor/imu_factor.h:13-89), 32 lanes each: lane d < 30 carries
+//            derivative direction d of the 30 parameters, lane 30 carries the value column.
+//   wheel  : four wheel_odom_factor blocks per wave (src/factor/wheel_factor.h:12-73), 16 lanes each.
+//   ground : eight frames per wave, ground_factor_p + ground_factor_q (src/factor/ground_factor.h:27-82), 8 lanes
+//            each; the n-fold duplication of solver.cpp:142-159 is applied as an integer weight n.
+// Every role stacks its rows as Y = [J | r] in LDS and reduces G = Y^T Y with a fixed pair->lane mapping, so
+// the sums are deterministic (no atomics).  G blocks go to the partial-sum slots described in liw_kernels.hpp;
+// k_lm.hip assembles them.  Jacobians here are w.r.t. the AMBIENT parameters, exactly like
+// auto_diff::compute_res_and_jacobi (src/utilies/common.h:201-217); the so3 local parameterisation is applied
+// at assembly.
+#include "liw_kernels.hpp"
+
+namespace liw {
+
+__device__ __forceinline__ double bcast(double v, int src_lane) { return __shfl(v, src_lane, 64); }
+
+// ------------------------------------------------------------------------------------------- laser
+struct Tf2 {          // rows 0,1 of  make_tf(p,theta) * T_imu_to_laser  and d/dtheta_k
+    double M[2][3], t[2];
+    double dM[3][2][3], dt[3][2];
+};
+
+__device__ __forceinline__ void frame_tf2(const DevParams& P, const double* pose6, Tf2& o) {
+    const int lane = threadIdx.x & 63;
+    const int dir = lane & 3;  // 0..2 -> d/dtheta_dir ; 3 -> value only
+    V3<LJ> p = cast_v3<LJ>(pose6);
+    V3<LJ> th(LJ(pose6[3], dir == 0 ? 1.0 : 0.0), LJ(pose6[4], dir == 1 ? 1.0 : 0.0), LJ(pose6[5], dir == 2 ? 1.0 : 0.0));
+    Iso<LJ> Twl = mul(make_tf(p, th), cast_iso<LJ>(P.Ril, P.til));
+#pragma unroll
+    for (int r = 0; r < 2; ++r) {
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            o.M[r][c] = Twl.R(r, c).v;
+#pragma unroll
+            for (int k = 0; k < 3; ++k) o.dM[k][r][c] = bcast(Twl.R(r, c).d, k);
+        }
+    }
+    const LJ tt[2] = {Twl.t.x, Twl.t.y};
+#pragma unroll
+    for (int r = 0; r < 2; ++r) {
+        o.t[r] = tt[r].v;
+#pragma unroll
+        for (int k = 0; k < 3; ++k) o.dt[k][r] = bcast(tt[r].d, k);
+    }
+}
+
+template <bool BOTH>
+__device__ void laser_group(const LinArgs& A, const DevParams& P, int b, int i, double* lds) {
+    constexpr int NC = BOTH ? 11 : 6;          // [a_x a_y a_th0..2 |] b_x b_y b_th0..2 | r
+    constexpr int NP = NC * (NC + 1) / 2;
+    const int lane = threadIdx.x & 63;
+    const int n = A.n;
+    double* out = A.PL + ((size_t)b * n + i) * LP;
+    const int j0 = A.group_off[b * (n + 1) + i], j1 = A.group_off[b * (n + 1) + i + 1];
+    const bool on = A.has_match[b * n + i] && j1 > j0 && (A.mode != LIW_MODE_TRACK || i == n - 1);
+    if (!on) { out[lane] = 0.0; out[lane + 64] = 0.0; return; }
+
+    const double* xb = A.x + ((size_t)b * n + i) * 15;
+    const double* xa = BOTH ? (A.x + (size_t)b * n * 15) : (A.match_pose + ((size_t)b * n + i) * 12);
+    Tf2 Ta, Tb;
+    frame_tf2(P, xa, Ta);
+    frame_tf2(P, xb, Tb);
+
+    double* Y = lds;                 // [128][NC]
+    double* G = lds + 128 * NC;      // [NC*NC] staging of the reduced pairs
+    // pair -> lane mapping (fixed): pair e = lane and lane + 64
+    int pc1[2], pc2[2];
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+        int e = lane + 64 * q, c1 = 0, rem = e;
+        while (c1 < NC && rem >= NC - c1) { rem -= NC - c1; ++c1; }
+        pc1[q] = c1; pc2[q] = c1 + rem;
+    }
+    double acc[2] = {0.0, 0.0};
+    const size_t Lt = (size_t)A.Ltot;
+    for (int base = j0; base < j1; base += 64) {
+        const int j = base + lane;
+        double row[2][NC];
+#pragma unroll
+        for (int k = 0; k < 2; ++k)
+#pragma unroll
+            for (int c = 0; c < NC; ++c) row[k][c] = 0.0;
+        if (j < j1) {
+            double q[12];
+#pragma unroll
+            for (int c = 0; c < 12; ++c) q[c] = A.laser_pts[c * Lt + j];
+            // laser_factor ctor: len1, len2, sum   (laser_factor.h:30-43)
+            const double d1x = q[0] - q[3], d1y = q[1] - q[4], d1z = q[2] - q[5];
+            const double d2x = q[6] - q[9], d2y = q[7] - q[10], d2z = q[8] - q[11];
+            const double len1 = sqrt(d1x * d1x + d1y * d1y + d1z * d1z), len2 = sqrt(d2x * d2x + d2y * d2y + d2z * d2z);
+            const double sum = sqrt(fmin(len1, len2) / 2.0 / 0.02);
+            // world points, z dropped (laser_factor.h:67-77)
+            double Ap[2], Bp[2], C[2][2];
+#pragma unroll
+            for (int r = 0; r < 2; ++r) {
+                Ap[r] = Ta.M[r][0] * q[0] + Ta.M[r][1] * q[1] + Ta.M[r][2] * q[2] + Ta.t[r];
+                Bp[r] = Ta.M[r][0] * q[3] + Ta.M[r][1] * q[4] + Ta.M[r][2] * q[5] + Ta.t[r];
+                C[0][r] = Tb.M[r][0] * q[6] + Tb.M[r][1] * q[7] + Tb.M[r][2] * q[8] + Tb.t[r];
+                C[1][r] = Tb.M[r][0] * q[9] + Tb.M[r][1] * q[10] + Tb.M[r][2] * q[11] + Tb.t[r];
+            }
+            const double ux = Bp[0] - Ap[0], uy = Bp[1] - Ap[1];
+            const double zz = ux * ux + uy * uy;
+            const bool regular = zz > 0.0;
+            const double len = regular ? sqrt(zz) : 1.0;
+            const double lx = ux / len, ly = uy / len;     // degenerate: stays the (zero) difference vector
+            // derivatives of the line direction w.r.t. theta_a
+            double dBx[3], dBy[3], dlx[3], dly[3];
+            if (BOTH) {
+#pragma unroll
+                for (int k = 0; k < 3; ++k) {
+                    const double dAx = Ta.dM[k][0][0] * q[0] + Ta.dM[k][0][1] * q[1] + Ta.dM[k][0][2] * q[2] + Ta.dt[k][0];
+                    const double dAy = Ta.dM[k][1][0] * q[0] + Ta.dM[k][1][1] * q[1] + Ta.dM[k][1][2] * q[2] + Ta.dt[k][1];
+                    dBx[k] = Ta.dM[k][0][0] * q[3] + Ta.dM[k][0][1] * q[4] + Ta.dM[k][0][2] * q[5] + Ta.dt[k][0];
+                    dBy[k] = Ta.dM[k][1][0] * q[3] + Ta.dM[k][1][1] * q[4] + Ta.dM[k][1][2] * q[5] + Ta.dt[k][1];
+                    const double dux = dBx[k] - dAx, duy = dBy[k] - dAy;
+                    const double pr = lx * dux + ly * duy;
+                    dlx[k] = (dux - lx * pr) / len;
+                    dly[k] = (duy - ly * pr) / len;
+                }
+            }
+#pragma unroll
+            for (int k = 0; k < 2; ++k) {
+                const double* pt = q + 6 + 3 * k;
+                const double ex = C[k][0] - Bp[0], ey = C[k][1] - Bp[1];
+                double dCx[3], dCy[3];
+#pragma unroll
+                for (int m = 0; m < 3; ++m) {
+                    dCx[m] = Tb.dM[m][0][0] * pt[0] + Tb.dM[m][0][1] * pt[1] + Tb.dM[m][0][2] * pt[2] + Tb.dt[m][0];
+                    dCy[m] = Tb.dM[m][1][0] * pt[0] + Tb.dM[m][1][1] * pt[1] + Tb.dM[m][1][2] * pt[2] + Tb.dt[m][1];
+                }
+                double dist, jc[10];
+                if (regular) {
+                    const double s = lx * ey - ly * ex;
+                    const double sg = s < 0.0 ? -1.0 : 1.0;
+                    dist = fabs(s);
+                    jc[0] = sg * ly; jc[1] = -sg * lx;
+#pragma unroll
+                    for (int m = 0; m < 3; ++m) {
+                        jc[2 + m] = BOTH ? sg * (dlx[m] * ey - dly[m] * ex - lx * dBy[m] + ly * dBx[m]) : 0.0;
+                        jc[7 + m] = sg * (lx * dCy[m] - ly * dCx[m]);
+                    }
+                    jc[5] = -sg * ly; jc[6] = sg * lx;
+                } else {  // zero-length reference segment: distance to the point B (Jet semantics of normalized(0))
+                    dist = sqrt(ex * ex + ey * ey);
+                    const double nx = ex / dist, ny = ey / dist;
+                    jc[0] = -nx; jc[1] = -ny;
+#pragma unroll
+                    for (int m = 0; m < 3; ++m) {
+                        jc[2 + m] = BOTH ? -(nx * dBx[m] + ny * dBy[m]) : 0.0;
+                        jc[7 + m] = nx * dCx[m] + ny * dCy[m];
+                    }
+                    jc[5] = nx; jc[6] = ny;
+                }
+                const double w = sum * P.laser_sqrt_info;
+                const double res = sum * (P.laser_sqrt_info * dist);
+                if (BOTH) {
+#pragma unroll
+                    for (int c = 0; c < 10; ++c) row[k][c] = w * jc[c];
+                } else {
+#pragma unroll
+                    for (int c = 0; c < 5; ++c) row[k][c] = w * jc[5 + c];
+                }
+                row[k][NC - 1] = res;
+                if (A.dbg_laser_res) A.dbg_laser_res[(size_t)j * 2 + k] = res;
+                if (A.dbg_laser_jac) {
+                    double* dj = A.dbg_laser_jac + ((size_t)j * 2 + k) * 12;
+                    dj[0] = w * jc[0]; dj[1] = w * jc[1]; dj[2] = 0.0;
+                    dj[3] = w * jc[2]; dj[4] = w * jc[3]; dj[5] = w * jc[4];
+                    dj[6] = w * jc[5]; dj[7] = w * jc[6]; dj[8] = 0.0;
+                    dj[9] = w * jc[7]; dj[10] = w * jc[8]; dj[11] = w * jc[9];
+                }
+            }
+        }
+        __syncthreads();   // previous pass's readers are done
+#pragma unroll
+        for (int k = 0; k < 2; ++k)
+#pragma unroll
+            for (int c = 0; c < NC; ++c) Y[(2 * lane + k) * NC + c] = row[k][c];
+        __syncthreads();
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+            if (lane + 64 * q < NP) {
+                double s = 0.0;
+                const int c1 = pc1[q], c2 = pc2[q];
+#pragma unroll 8
+                for (int r = 0; r < 128; ++r) s += Y[r * NC + c1] * Y[r * NC + c2];
+                acc[q] += s;
+            }
+        }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int q = 0; q < 2; ++q)
+        if (lane + 64 * q < NP) { G[pc1[q] * NC + pc2[q]] = acc[q]; G[pc2[q] * NC + pc1[q]] = acc[q]; }
+    __syncthreads();
+    // compose the 128-slot record; pose index (0..5 = px py pz th0 th1 th2) -> column (pz has none)
+    auto colof = [](int idx) { return idx < 2 ? idx : (idx == 2 ? -1 : idx - 1); };
+    constexpr int OFFB = BOTH ? 5 : 0;
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+        const int s = lane + 64 * q;
+        double v = 0.0;
+        if (s < 36) {
+            const int ca = colof(s / 6), cb = colof(s % 6);
+            if (BOTH && ca >= 0 && cb >= 0) v = G[ca * NC + cb];
+        } else if (s < 72) {
+            const int ca = colof((s - 36) / 6), cb = colof((s - 36) % 6);
+            if (ca >= 0 && cb >= 0) v = G[(OFFB + ca) * NC + OFFB + cb];
+        } else if (s < 108) {
+            const int ca = colof((s - 72) / 6), cb = colof((s - 72) % 6);
+            if (BOTH && ca >= 0 && cb >= 0) v = G[ca * NC + OFFB + cb];
+        } else if (s < 114) {
+            const int ca = colof(s - 108);
+            if (BOTH && ca >= 0) v = G[ca * NC + NC - 1];
+        } else if (s < 120) {
+            const int cb = colof(s - 114);
+            if (cb >= 0) v = G[(OFFB + cb) * NC + NC - 1];
+        } else if (s == 120) {
+            v = G[(NC - 1) * NC + NC - 1];
+        }
+        out[s] = v;
+    }
+}
+
+// ------------------------------------------------------------------------------------------- imu
+// raw (un-whitened) residual of imu_factor::operator(), src/factor/imu_factor.h:41-83
+template <class T>
+__device__ __forceinline__ void imu_raw(const DevParams& P, const double* X, const double* Jp, double Dt_, const T* si, const T* sj, T* raw) {
+    V3<T> pi(si[0], si[1], si[2]), thetai(si[3], si[4], si[5]), vi(si[6], si[7], si[8]), bai(si[9], si[10], si[11]), bwi(si[12], si[13], si[14]);
+    V3<T> pj(sj[0], sj[1], sj[2]), thetaj(sj[3], sj[4], sj[5]), vj(sj[6], sj[7], sj[8]), baj(sj[9], sj[10], sj[11]), bwj(sj[12], sj[13], sj[14]);
+    const T g_norm(P.g), Dt(Dt_);
+    V3<T> g(T(0.0), T(0.0), T(1.0));
+    V3<T> alpha = cast_v3<T>(X), beta = cast_v3<T>(X + 3), gamma = cast_v3<T>(X + 6);
+    V3<T> ba = cast_v3<T>(X + 9), bw = cast_v3<T>(X + 12);
+    M3<T> bk_R_w = exp_so3(-thetai);
+    auto blk = [&](int ro, int co) {
+        M3<T> m;
+#pragma unroll
+        for (int r = 0; r < 3; ++r)
+#pragma unroll
+            for (int c = 0; c < 3; ++c) m(r, c) = T(Jp[(ro + r) * 15 + co + c]);
+        return m;
+    };
+    const V3<T> dba = bai - ba, dbw = bwi - bw;
+    alpha = alpha + mul(blk(0, 9), dba) + mul(blk(0, 12), dbw);
+    beta = beta + mul(blk(3, 9), dba) + mul(blk(3, 12), dbw);
+    gamma = gamma + mul(blk(6, 12), dbw);
+    V3<T> res_alpha = alpha - mul(bk_R_w, pj - pi + ((g * T(0.5)) * g_norm) * Dt * Dt - vi * Dt);
+    V3<T> res_beta = beta - mul(bk_R_w, vj + (g * g_norm) * Dt - vi);
+    V3<T> res_gamma = log_SO3(mul(exp_so3(-gamma), mul(bk_R_w, exp_so3(thetaj))));
+    V3<T> res_ba = baj - bai, res_bw = bwj - bwi;
+    raw[0] = res_alpha.x; raw[1] = res_alpha.y; raw[2] = res_alpha.z;
+    raw[3] = res_beta.x;  raw[4] = res_beta.y;  raw[5] = res_beta.z;
+    raw[6] = res_gamma.x; raw[7] = res_gamma.y; raw[8] = res_gamma.z;
+    raw[9] = res_ba.x;    raw[10] = res_ba.y;   raw[11] = res_ba.z;
+    raw[12] = res_bw.x;   raw[13] = res_bw.y;   raw[14] = res_bw.z;
+}
+
+__device__ void imu_pair(const LinArgs& A, const DevParams& P, int b, int item, int sel, double* lds) {
+    const int lane = threadIdx.x & 63, half = lane >> 5, dir = lane & 31;
+    const int n = A.n, k = 2 * item + half;
+    const bool on = k < n - 1;
+    double* S = lds + half * 240;                 // 15x15 whitening matrix of this half's block
+    double* Y = lds + 480 + half * (15 * 31);     // [15][31]
+    const size_t fk = (size_t)b * (n - 1) + (on ? k : 0);
+    if (on)
+        for (int e = dir; e < 225; e += 32) S[e] = A.imu_sqrtP[fk * 225 + e];
+    double y[15], xc[15];   // xc: this lane's column of [J_raw | r_raw]
+#pragma unroll
+    for (int r = 0; r < 15; ++r) { y[r] = 0.0; xc[r] = 0.0; }
+    if (on) {
+        const double* si_ = A.x + ((size_t)b * n + k) * 15;
+        const double* sj_ = si_ + 15;
+        LJ si[15], sj[15], raw[15];
+#pragma unroll
+        for (int e = 0; e < 15; ++e) {
+            si[e] = LJ(si_[e], dir == e ? 1.0 : 0.0);
+            sj[e] = LJ(sj_[e], dir == 15 + e ? 1.0 : 0.0);
+        }
+        imu_raw<LJ>(P, A.imu_X + fk * 15, A.imu_J + fk * 225, A.imu_Dt[fk], si, sj, raw);
+#pragma unroll
+        for (int r = 0; r < 15; ++r) xc[r] = dir < 30 ? raw[r].d : (dir == 30 ? raw[r].v : 0.0);
+    }
+    __syncthreads();
+    if (on) {
+        // res_all = sqrt_info * res_all, dense 15x15 (imu_factor.h:85-86), applied to every column
+#pragma unroll
+        for (int r = 0; r < 15; ++r) {
+            double s = S[r * 15] * xc[0];
+#pragma unroll
+            for (int c = 1; c < 15; ++c) s += S[r * 15 + c] * xc[c];
+            y[r] = s;
+        }
+    }
+    if (dir < 31)
+#pragma unroll
+        for (int r = 0; r < 15; ++r) Y[r * 31 + dir] = y[r];
+    if (on && dir == 30 && A.dbg_imu_res)
+        for (int r = 0; r < 15; ++r) A.dbg_imu_res[fk * 15 + r] = y[r];
+    if (on && dir < 30 && A.dbg_imu_jac)
+        for (int r = 0; r < 15; ++r) A.dbg_imu_jac[(fk * 15 + r) * 30 + dir] = y[r];
+    __syncthreads();
+    if (on) {
+        double* out = A.PI[sel] + fk * PIS;
+        // 496 pairs over 32 lanes: pair e = dir + 32*t
+        for (int e = dir; e < 496; e += 32) {
+            int c1 = 0, rem = e;
+            while (rem >= 31 - c1) { rem -= 31 - c1; ++c1; }
+            const int c2 = c1 + rem;
+            double s = 0.0;
+#pragma unroll
+            for (int r = 0; r < 15; ++r) s += Y[r * 31 + c1] * Y[r * 31 + c2];
+            out[c1 * 31 + c2] = s;
+            out[c2 * 31 + c1] = s;
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------- wheel
+// wheel_odom_factor::operator(), src/factor/wheel_factor.h:12-73
+template <class T>
+__device__ __forceinline__ void wheel_res(const DevParams& P, const double* T12, const double* sq9, const T* pi_, const T* qi_, const T* pj_, const T* qj_, T* res) {
+    V3<T> pi(pi_[0], pi_[1], pi_[2]), thetai(qi_[0], qi_[1], qi_[2]), pj(pj_[0], pj_[1], pj_[2]), thetaj(qj_[0], qj_[1], qj_[2]);
+    Iso<T> T_i_w = cast_iso<T>(P.Riw, P.tiw);
+    Iso<T> tf_i = mul(make_tf(pi, thetai), T_i_w);
+    Iso<T> tf_j = mul(make_tf(pj, thetaj), T_i_w);
+    Iso<T> w_tf_ij = mul(inverse(tf_i), tf_j);
+    V3<T> p = w_tf_ij.t, q = log_SO3(w_tf_ij.R);
+    Iso<T> od = cast_iso<T>(T12, T12 + 9);
+    V3<T> op = od.t, oq = log_SO3(od.R);
+    T o_len = dsqrt(op.x * op.x + op.y * op.y);
+    T len = dsqrt(p.x * p.x + p.y * p.y);
+    V3<T> o_dir(op.x, op.y, T(0.0)), dir(p.x, p.y, T(0.0));
+    T angle(0.0);
+    if (norm(o_dir) > T(0.0001) && norm(dir) > T(0.0001)) {
+        o_dir = normalized(o_dir);
+        dir = normalized(dir);
+        T sinn = norm(cross(o_dir, dir));
+        angle = dasin(sinn);
+    } else {
+        angle = norm(dir);
+    }
+    if (len < T(0.0001) || o_len < T(0.0001)) res[0] = T(sq9[0]) * len;
+    else res[0] = T(sq9[0]) * (o_len - len);
+    res[1] = T(sq9[4]) * angle;
+    if (norm(q) < T(0.001) || norm(oq) < T(0.001)) res[2] = T(sq9[8]) * norm(q);
+    else res[2] = T(sq9[8]) * (norm(oq) - norm(q));
+}
+
+__device__ void wheel_quad(const LinArgs& A, const DevParams& P, int b, int item, int sel, double* lds) {
+    const int lane = threadIdx.x & 63, sub = lane >> 4, dir = lane & 15;
+    const int n = A.n, k = 4 * item + sub;
+    const bool on = k < n - 1;
+    double* Y = lds + sub * 40;   // [3][13]
+    const size_t fk = (size_t)b * (n - 1) + (on ? k : 0);
+    double y[3] = {0.0, 0.0, 0.0};
+    if (on) {
+        const double* si_ = A.x + ((size_t)b * n + k) * 15;
+        const double* sj_ = si_ + 15;
+        LJ pi[3], qi[3], pj[3], qj[3], res[3];
+#pragma unroll
+        for (int e = 0; e < 3; ++e) {
+            pi[e] = LJ(si_[e], dir == e ? 1.0 : 0.0);
+            qi[e] = LJ(si_[3 + e], dir == 3 + e ? 1.0 : 0.0);
+            pj[e] = LJ(sj_[e], dir == 6 + e ? 1.0 : 0.0);
+            qj[e] = LJ(sj_[3 + e], dir == 9 + e ? 1.0 : 0.0);
+        }
+        wheel_res<LJ>(P, A.wheel_T + fk * 12, A.wheel_sqrtP + fk * 9, pi, qi, pj, qj, res);
+#pragma unroll
+        for (int r = 0; r < 3; ++r) y[r] = dir < 12 ? res[r].d : (dir == 12 ? res[r].v : 0.0);
+    }
+    if (dir < 13)
+#pragma unroll
+        for (int r = 0; r < 3; ++r) Y[r * 13 + dir] = y[r];
+    if (on && dir == 12 && A.dbg_wheel_res)
+        for (int r = 0; r < 3; ++r) A.dbg_wheel_res[fk * 3 + r] = y[r];
+    if (on && dir < 12 && A.dbg_wheel_jac)
+        for (int r = 0; r < 3; ++r) A.dbg_wheel_jac[(fk * 3 + r) * 12 + dir] = y[r];
+    __syncthreads();
+    if (on) {
+        double* out = A.PW[sel] + fk * PWS;
+        for (int e = dir; e < 91; e += 16) {
+            int c1 = 0, rem = e;
+            while (rem >= 13 - c1) { rem -= 13 - c1; ++c1; }
+            const int c2 = c1 + rem;
+            const double s = Y[c1] * Y[c2] + Y[13 + c1] * Y[13 + c2] + Y[26 + c1] * Y[26 + c2];
+            out[c1 * 13 + c2] = s;
+            out[c2 * 13 + c1] = s;
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------- ground
+// ground_factor_p / ground_factor_q, src/factor/ground_factor.h:27-48, :59-82
+template <class T>
+__device__ __forceinline__ void ground_res(const DevParams& P, const T* p_, const T* q_, T* res) {
+    Iso<T> tf_w_o = mul(make_tf(V3<T>(p_[0], p_[1], p_[2]), V3<T>(q_[0], q_[1], q_[2])), cast_iso<T>(P.Riw, P.tiw));
+    res[0] = T(P.ground_p_info) * tf_w_o.t.z;
+    V3<T> ABC(T(0.0), T(0.0), T(1.0));
+    V3<T> z_axis(tf_w_o.R(0, 2), tf_w_o.R(1, 2), tf_w_o.R(2, 2));
+    T sinn = norm(cross(z_axis, ABC));
+    res[1] = T(P.ground_q_info) * dasin(sinn);
+}
+
+__device__ void ground_oct(const LinArgs& A, const DevParams& P, int b, int item, int sel, double* lds) {
+    const int lane = threadIdx.x & 63, sub = lane >> 3, dir = lane & 7;
+    const int n = A.n, i = 8 * item + sub;
+    const bool on = i < n;
+    double* Y = lds + sub * 16;   // [2][7]
+    const size_t fi = (size_t)b * n + (on ? i : 0);
+    double y[2] = {0.0, 0.0};
+    if (on) {
+        const double* s_ = A.x + fi * 15;
+        LJ p[3], q[3], res[2];
+#pragma unroll
+        for (int e = 0; e < 3; ++e) {
+            p[e] = LJ(s_[e], dir == e ? 1.0 : 0.0);
+            q[e] = LJ(s_[3 + e], dir == 3 + e ? 1.0 : 0.0);
+        }
+        ground_res<LJ>(P, p, q, res);
+#pragma unroll
+        for (int r = 0; r < 2; ++r) y[r] = dir < 6 ? res[r].d : (dir == 6 ? res[r].v : 0.0);
+    }
+    if (dir < 7) { Y[dir] = y[0]; Y[7 + dir] = y[1]; }
+    if (on && dir == 6 && A.dbg_ground_res) { A.dbg_ground_res[fi * 2] = y[0]; A.dbg_ground_res[fi * 2 + 1] = y[1]; }
+    if (on && dir < 6 && A.dbg_ground_jac) { A.dbg_ground_jac[(fi * 2) * 6 + dir] = y[0]; A.dbg_ground_jac[(fi * 2 + 1) * 6 + dir] = y[1]; }
+    __syncthreads();
+    if (on) {
+        double* out = A.PG[sel] + fi * PGS;
+        const double mult = (double)n;   // the block set is added once per outer frame index (solver.cpp:142-159)
+        for (int e = dir; e < 28; e += 8) {
+            int c1 = 0, rem = e;
+            while (rem >= 7 - c1) { rem -= 7 - c1; ++c1; }
+            const int c2 = c1 + rem;
+            const double s = mult * (Y[c1] * Y[c2] + Y[7 + c1] * Y[7 + c2]);
+            out[c1 * 7 + c2] = s;
+            out[c2 * 7 + c1] = s;
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------- dispatch
+__host__ __device__ inline int lin_items_per_window(int n) { return n + (n - 1 + 1) / 2 + (n - 1 + 3) / 4 + (n + 7) / 8; }
+
+__global__ __launch_bounds__(64) void k_linearize(LinArgs A, DevParams P) {
+    __shared__ double lds[128 * 11 + 121 + 7];
+    const int n = A.n;
+    const int items = lin_items_per_window(n);
+    const int b = blockIdx.x / items;
+    int item = blockIdx.x % items;
+    if (b >= A.B) return;
+    if (A.lm && A.lm[b].done) return;
+    if (item < n) {
+        if (A.mode == LIW_MODE_INIT) laser_group<true>(A, P, b, item, lds);
+        else laser_group<false>(A, P, b, item, lds);
+        return;
+    }
+    if (!A.eval_small) return;
+    const int sel = A.lm ? (A.candidate ? 1 - A.lm[b].cur : A.lm[b].cur) : 0;
+    item -= n;
+    const int n_imu = (n - 1 + 1) / 2, n_wheel = (n - 1 + 3) / 4;
+    if (item < n_imu) { imu_pair(A, P, b, item, sel, lds); return; }
+    item -= n_imu;
+    if (item < n_wheel) { wheel_quad(A, P, b, item, sel, lds); return; }
+    item -= n_wheel;
+    ground_oct(A, P, b, item, sel, lds);
+}
+
+// laser block range of every (window, frame): first block of window b owned by a frame >= i
+__global__ void k_group_offsets(int B, int n, const int* laser_off, const int* laser_frame, int* group_off) {
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= B * (n + 1)) return;
+    const int b = t / (n + 1), i = t % (n + 1);
+    int lo = laser_off[b], hi = laser_off[b + 1];
+    while (lo < hi) {
+        const int mid = (lo + hi) >> 1;
+        if (laser_frame[mid] < i) lo = mid + 1; else hi = mid;
+    }
+    group_off[t] = lo;
+}
+
+void launch_linearize(const LinArgs& A, const DevParams& P, hipStream_t s) {
+    const int items = lin_items_per_window(A.n);
+    hipLaunchKernelGGL(k_linearize, dim3((unsigned)(A.B * items)), dim3(64), 0, s, A, P);
+}
+void launch_group_offsets(int B, int n, const int* laser_off, const int* laser_frame, int* group_off, hipStream_t s) {
+    const int tot = B * (n + 1);
+    hipLaunchKernelGGL(k_group_offsets, dim3((tot + 255) / 256), dim3(256), 0, s, B, n, laser_off, laser_frame, group_off);
+}
+
+}  // namespace liw

@@ -1,0 +1,788 @@
+// k_lm.hip — normal-equation assembly, Levenberg–Marquardt step, Schur marginalisation (gfx950, fp64).
+//
+// One wavefront per window.  The normal equations of a window are block tri-diagonal (IMU / wheel blocks couple
+// frames i-1,i) plus, in the init topology, an "arrow" from frame 0's pose to every laser frame (reference
+// src/factor/solver.cpp:93-106).  Frames are eliminated n-1 .. 1 and frame 0 last, so no fill is created
+// beyond a 6x15 arrow row.  Per eliminated frame: 15x15 Cholesky in LDS, 22 forward substitutions on 22 lanes,
+// and the Schur-complement products  [Wo|z]^T[Wo|z],  [Wr|0]^T[Wo|z],  [Wr|0]^T[Wr|0]  as 16x16x16 fp64 MFMA
+// tiles (v_mfma_f64_16x16x4_f64; 15 padded to 16 is the natural tile of this problem).
+//
+// What is restated from Ceres (third-party, not vendored; call sites solver.cpp:161-168, :795-802): the
+// TRUST_REGION/LEVENBERG_MARQUARDT loop with default options — Jacobi scaling 1/(1+|col|) fixed at iteration 0,
+// LM diagonal clamp(diag, 1e-6, 1e32)/radius, rho = cost change / model change, accept if rho > 1e-3 with
+// radius / max(1/3, 1-(2rho-1)^3), reject -> radius/nu, nu*=2; parameter / function tolerance are tested on the
+// candidate BEFORE acceptance and end the solve without applying that candidate; so3 Plus = normalize_so3(x+d)
+// (src/factor/factor_common.h:41-53).  Marginalisation restates solver.cpp:4-40 and :390-402 on the same
+// block structure (chain elimination 0..n-2, eigen floor 1e-8).
+#include "liw_kernels.hpp"
+
+namespace liw {
+
+typedef double d4 __attribute__((ext_vector_type(4)));
+
+struct StepArgs {
+    int B, n, mode, max_iters, fast_mode;
+    double* x;                   // [B][n][15] live states
+    double* match_pose;
+    const unsigned char* has_match;
+    const double* prior_X; const double* prior_J; const int* has_prior;
+    WsView w;
+};
+
+constexpr double kMinDiag = 1e-6, kMaxDiag = 1e32, kMinRelDec = 1e-3, kFuncTol = 1e-6, kGradTol = 1e-10, kParamTol = 1e-8;
+constexpr double kMaxRadius = 1e16, kMinRadius = 1e-32, kInitRadius = 1e4;
+constexpr double kPi = 3.141592653589793238462643383279, kTwoPi = 6.283185307179586476925286766559;
+
+__device__ __forceinline__ double wave_sum(double v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+__device__ __forceinline__ double wave_max(double v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = fmax(v, __shfl_xor(v, o, 64));
+    return v;
+}
+
+// so3 Plus and its Jacobian at delta = 0 (factor_common.h:41-53 through AutoDiffLocalParameterization)
+__device__ __forceinline__ void so3_plus(const double* x, const double* d, double* out) {
+    V3<double> r = normalize_so3(V3<double>(x[0] + d[0], x[1] + d[1], x[2] + d[2]));
+    out[0] = r.x; out[1] = r.y; out[2] = r.z;
+}
+__device__ __forceinline__ bool so3_plus_jac(const double* x, double* P9) {
+    const double a = sqrt(x[0] * x[0] + x[1] * x[1] + x[2] * x[2]);
+    if (!(a > kPi)) return false;  // identity
+    const double k = floor((a + kPi) / kTwoPi);
+    const double c = kTwoPi * k / a;
+    const double u[3] = {x[0] / a, x[1] / a, x[2] / a};
+    for (int i = 0; i < 3; ++i)
+        for (int j = 0; j < 3; ++j) P9[i * 3 + j] = (i == j ? 1.0 : 0.0) - c * ((i == j ? 1.0 : 0.0) - u[i] * u[j]);
+    return true;
+}
+
+__device__ __forceinline__ bool var_is_const(int mode, int fast, int n, int i, int v) {
+    if (mode != LIW_MODE_TRACK) return false;
+    if (i >= n - 1) return false;
+    return v < 6 || (fast && v >= 9);
+}
+
+struct AsmCtx {
+    int n, mode, fast, b, buf;
+    const double* PL; const double* PI; const double* PW; const double* PG;   // of window b already offset? no: batch base
+    const double* x;          // states the partials were evaluated at, window base [n][15]
+    const double* pJ; const double* pX; bool prior_on;
+};
+
+// prior residual r = linearized_J (X - linearized_X)  (marginalization_factor.h:22-53, linearized_R omitted there)
+__device__ __forceinline__ double prior_r(const AsmCtx& c, int k) {
+    const double* xs = c.x + (size_t)(c.n - 2) * 15;
+    double s = 0.0;
+    for (int j = 0; j < 15; ++j) s += c.pJ[k * 15 + j] * (xs[j] - c.pX[j]);
+    return s;
+}
+
+// Assemble frame i's blocks (ambient -> tangent, constants masked), UNSCALED, into 16x16 LDS tiles (ld 16):
+//   Dm = H[i,i], Om = H[i-1,i] (rows: frame i-1), Rm rows 0..5 = H[0(pose), i] (init arrow, i >= 2), gv = g_i.
+__device__ void assemble_frame(const AsmCtx& c, int i, double* Dm, double* Om, double* Rm, double* gv, double* tmp) {
+    const int lane = threadIdx.x & 63;
+    const int n = c.n;
+    const double* PLb = c.PL + (size_t)c.b * n * LP;
+    const double* PIb = c.PI + (size_t)c.b * (n - 1) * PIS;
+    const double* PWb = c.PW + (size_t)c.b * (n - 1) * PWS;
+    const double* PGb = c.PG + (size_t)c.b * n * PGS;
+    const bool prior_here = c.prior_on && i == n - 2;
+    if (prior_here) {   // stage r_prior
+        if (lane < 15) tmp[lane] = prior_r(c, lane);
+        __syncthreads();
+    }
+    for (int e = lane; e < 256; e += 64) {
+        const int r = e >> 4, cc = e & 15;
+        double d = 0.0, o = 0.0, rr = 0.0;
+        if (r < 15 && cc < 15) {
+            const bool pose = r < 6 && cc < 6;
+            if (pose) {
+                d += PLb[(size_t)i * LP + 36 + r * 6 + cc];
+                if (i == 0) for (int j = 0; j < n; ++j) d += PLb[(size_t)j * LP + r * 6 + cc];
+                if (i >= 1) d += PWb[(size_t)(i - 1) * PWS + (6 + r) * 13 + 6 + cc];
+                if (i <= n - 2) d += PWb[(size_t)i * PWS + r * 13 + cc];
+                d += PGb[(size_t)i * PGS + r * 7 + cc];
+            }
+            if (i >= 1) d += PIb[(size_t)(i - 1) * PIS + (15 + r) * 31 + 15 + cc];
+            if (i <= n - 2) d += PIb[(size_t)i * PIS + r * 31 + cc];
+            if (prior_here) { double s = 0.0; for (int k = 0; k < 15; ++k) s += c.pJ[k * 15 + r] * c.pJ[k * 15 + cc]; d += s; }
+            if (i >= 1) {
+                o = PIb[(size_t)(i - 1) * PIS + r * 31 + 15 + cc];
+                if (pose) {
+                    o += PWb[(size_t)(i - 1) * PWS + r * 13 + 6 + cc];
+                    if (i == 1) o += PLb[(size_t)1 * LP + 72 + r * 6 + cc];
+                }
+            }
+            if (pose && i >= 2) rr = PLb[(size_t)i * LP + 72 + r * 6 + cc];
+        }
+        Dm[e] = d; Om[e] = o; Rm[e] = rr;
+    }
+    if (lane < 16) {
+        const int r = lane;
+        double g = 0.0;
+        if (r < 15) {
+            if (r < 6) {
+                g += PLb[(size_t)i * LP + 114 + r];
+                if (i == 0) for (int j = 0; j < n; ++j) g += PLb[(size_t)j * LP + 108 + r];
+                if (i >= 1) g += PWb[(size_t)(i - 1) * PWS + (6 + r) * 13 + 12];
+                if (i <= n - 2) g += PWb[(size_t)i * PWS + r * 13 + 12];
+                g += PGb[(size_t)i * PGS + r * 7 + 6];
+            }
+            if (i >= 1) g += PIb[(size_t)(i - 1) * PIS + (15 + r) * 31 + 30];
+            if (i <= n - 2) g += PIb[(size_t)i * PIS + r * 31 + 30];
+            if (prior_here) { double s = 0.0; for (int k = 0; k < 15; ++k) s += c.pJ[k * 15 + r] * tmp[k]; g += s; }
+        }
+        gv[r] = g;
+    }
+    __syncthreads();
+    if (c.mode == LIW_MODE_MARG) return;
+    // ---- so3 local parameterisation (identity unless |q| > pi) on the q rows/cols (3..5)
+    double Pi[9], Pm[9], P0[9];
+    const bool li = so3_plus_jac(c.x + (size_t)i * 15 + 3, Pi);
+    const bool lm = i >= 1 && so3_plus_jac(c.x + (size_t)(i - 1) * 15 + 3, Pm);
+    const bool l0 = i >= 2 && so3_plus_jac(c.x + 3, P0);
+    if (li || lm || l0) {   // rare path, one lane
+        if (lane == 0) {
+            auto right = [&](double* M, const double* P) {   // M[:,3:6] <- M[:,3:6] P
+                for (int r = 0; r < 15; ++r) {
+                    double t[3];
+                    for (int k = 0; k < 3; ++k) t[k] = M[r * 16 + 3] * P[k] + M[r * 16 + 4] * P[3 + k] + M[r * 16 + 5] * P[6 + k];
+                    for (int k = 0; k < 3; ++k) M[r * 16 + 3 + k] = t[k];
+                }
+            };
+            auto left = [&](double* M, const double* P) {    // M[3:6,:] <- P^T M[3:6,:]
+                for (int cc = 0; cc < 15; ++cc) {
+                    double t[3];
+                    for (int k = 0; k < 3; ++k) t[k] = P[k] * M[3 * 16 + cc] + P[3 + k] * M[4 * 16 + cc] + P[6 + k] * M[5 * 16 + cc];
+                    for (int k = 0; k < 3; ++k) M[(3 + k) * 16 + cc] = t[k];
+                }
+            };
+            if (li) {
+                right(Dm, Pi); left(Dm, Pi); right(Om, Pi); right(Rm, Pi);
+                double t[3];
+                for (int k = 0; k < 3; ++k) t[k] = Pi[k] * gv[3] + Pi[3 + k] * gv[4] + Pi[6 + k] * gv[5];
+                for (int k = 0; k < 3; ++k) gv[3 + k] = t[k];
+            }
+            if (lm) left(Om, Pm);
+            if (l0) left(Rm, P0);
+        }
+        __syncthreads();
+    }
+    // ---- constant parameter blocks (solver.cpp:787-794): drop their rows / columns
+    if (c.mode == LIW_MODE_TRACK) {
+        for (int e = lane; e < 256; e += 64) {
+            const int r = e >> 4, cc = e & 15;
+            if (r < 15 && cc < 15) {
+                const bool cr = var_is_const(c.mode, c.fast, n, i, r), ccn = var_is_const(c.mode, c.fast, n, i, cc);
+                if (cr || ccn) Dm[e] = 0.0;
+                if ((i >= 1 && var_is_const(c.mode, c.fast, n, i - 1, r)) || ccn) Om[e] = 0.0;
+            }
+        }
+        if (lane < 15 && var_is_const(c.mode, c.fast, n, i, lane)) gv[lane] = 0.0;
+        __syncthreads();
+    }
+}
+
+// cost = 1/2 sum r^2 over the residual blocks ceres keeps (blocks whose parameters are all constant are dropped)
+__device__ double window_cost(const AsmCtx& c) {
+    const int lane = threadIdx.x & 63;
+    const int n = c.n;
+    const double* PLb = c.PL + (size_t)c.b * n * LP;
+    const double* PIb = c.PI + (size_t)c.b * (n - 1) * PIS;
+    const double* PWb = c.PW + (size_t)c.b * (n - 1) * PWS;
+    const double* PGb = c.PG + (size_t)c.b * n * PGS;
+    const bool track = c.mode == LIW_MODE_TRACK;
+    double s = 0.0;
+    for (int i = lane; i < n; i += 64) {
+        s += PLb[(size_t)i * LP + 120];
+        if (!(track && i < n - 1)) s += PGb[(size_t)i * PGS + 48];
+    }
+    for (int k = lane; k < n - 1; k += 64) {
+        s += PIb[(size_t)k * PIS + 30 * 31 + 30];
+        if (!(track && k < n - 2)) s += PWb[(size_t)k * PWS + 12 * 13 + 12];
+    }
+    if (c.prior_on && lane < 15) { const double r = prior_r(c, lane); s += r * r; }
+    return 0.5 * wave_sum(s);
+}
+
+// in-place Cholesky of the leading 15x15 of a 16x16 LDS tile (lower), one wave.  returns false on a bad pivot
+__device__ bool chol15(double* A) {
+    const int lane = threadIdx.x & 63;
+    bool ok = true;
+    for (int j = 0; j < 15; ++j) {
+        const double piv = A[j * 16 + j];
+        if (!(piv > 0.0) || !isfinite(piv)) { ok = false; break; }
+        const double dj = sqrt(piv);
+        __syncthreads();
+        if (lane >= j && lane < 15) A[lane * 16 + j] = (lane == j) ? dj : A[lane * 16 + j] / dj;
+        __syncthreads();
+        // trailing update A[r][c] -= L[r][j] L[c][j], r,c > j  (lower part only needed)
+        for (int e = lane; e < 225; e += 64) {
+            const int r = e / 15, cc = e % 15;
+            if (r > j && cc > j && cc <= r) A[r * 16 + cc] -= A[r * 16 + j] * A[cc * 16 + j];
+        }
+        __syncthreads();
+    }
+    return ok;
+}
+
+// P = X^T Y for two [16(k)][16] LDS tiles with fp64 MFMA 16x16x4; lane l gets P[(l>>4)+4r][l&15] in acc[r]
+__device__ __forceinline__ d4 xty16(const double* X, const double* Y) {
+    const int lane = threadIdx.x & 63;
+    d4 acc = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+        const int k = (lane >> 4) + 4 * c;
+        acc = __builtin_amdgcn_mfma_f64_16x16x4f64(X[k * 16 + (lane & 15)], Y[k * 16 + (lane & 15)], acc, 0, 0, 0);
+    }
+    return acc;
+}
+
+struct LdsTiles {
+    double D[256], O[256], R[256], W[256], Wa[256], CD[256], CR[256];
+    double g[16], Cg[16], y0[16], yprev[16], tmp[16], D0acc[36], g0acc[8];
+};
+
+// ---------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(64) void k_lm_step(StepArgs a) {
+    __shared__ LdsTiles T;
+    const int b = blockIdx.x, lane = threadIdx.x & 63;
+    if (b >= a.B) return;
+    LmState& st = a.w.lm[b];
+    if (st.done) return;
+    const int n = a.n;
+    double* xw = a.x + (size_t)b * n * 15;
+    double* xc = a.w.x_cand + (size_t)b * n * 15;
+
+    AsmCtx c;
+    c.n = n; c.mode = a.mode; c.fast = a.fast_mode; c.b = b;
+    c.pJ = a.prior_J + (size_t)b * 225; c.pX = a.prior_X + (size_t)b * 15;
+    c.prior_on = a.mode == LIW_MODE_TRACK && a.has_prior[b] && !a.fast_mode;
+
+    // uniform copies of the LM state
+    double radius = st.radius, dec = st.decrease_factor, x_cost = st.x_cost, x_norm = st.x_norm;
+    int reuse = st.reuse_diagonal, iteration = st.iteration, cur = st.cur;
+    bool last_successful = true;
+    bool fresh = false;   // true when (H,g) at the current x was not factorised yet (scaling init)
+
+    if (iteration == 0 && !st.have_candidate) {
+        // ---- iteration 0: cost at the initial point
+        c.buf = cur; c.PL = a.w.PL[0]; c.PI = a.w.PI[cur]; c.PW = a.w.PW[cur]; c.PG = a.w.PG[cur]; c.x = xw;
+        x_cost = window_cost(c);
+        double s = 0.0;
+        for (int e = lane; e < n * 15; e += 64) if (!var_is_const(a.mode, a.fast_mode, n, e / 15, e % 15)) s += xw[e] * xw[e];
+        x_norm = sqrt(wave_sum(s));
+        if (lane == 0) { st.initial_cost = x_cost; st.minimum_cost = x_cost; }
+        fresh = true;
+    } else if (st.have_candidate) {
+        // ---- candidate evaluated by the previous linearise launch
+        const int cb = 1 - cur;
+        c.buf = cb; c.PL = a.w.PL[1]; c.PI = a.w.PI[cb]; c.PW = a.w.PW[cb]; c.PG = a.w.PG[cb]; c.x = xc;
+        double cand_cost = window_cost(c);
+        if (!isfinite(cand_cost)) cand_cost = 1.7976931348623157e308;
+        int term = 0;
+        if (st.cand_step_norm <= kParamTol * (x_norm + kParamTol)) term = 3;
+        else if (fabs(x_cost - cand_cost) <= kFuncTol * x_cost) term = 2;
+        if (term) {
+            if (a.w.history && iteration < a.w.history_records)
+                for (int e = lane; e < n * 15; e += 64) a.w.history[((size_t)iteration * a.B + b) * n * 15 + e] = xw[e];
+            if (lane == 0) { st.done = 1; st.termination = term; }
+            return;
+        }
+        const double rho = (x_cost - cand_cost) / st.model_cost_change;
+        if (rho > kMinRelDec) {
+            for (int e = lane; e < n * 15; e += 64) xw[e] = xc[e];
+            {   // laser partial sums: candidate region -> current region (copy-on-accept)
+                const double* src = a.w.PL[1] + (size_t)b * n * LP;
+                double* dst = a.w.PL[0] + (size_t)b * n * LP;
+                for (int e = lane; e < n * LP; e += 64) dst[e] = src[e];
+            }
+            cur = cb;
+            x_cost = cand_cost;
+            double s = 0.0;
+            for (int e = lane; e < n * 15; e += 64) if (!var_is_const(a.mode, a.fast_mode, n, e / 15, e % 15)) s += xc[e] * xc[e];
+            x_norm = sqrt(wave_sum(s));
+            radius = radius / fmax(1.0 / 3.0, 1.0 - pow(2.0 * rho - 1.0, 3.0));
+            radius = fmin(kMaxRadius, radius);
+            dec = 2.0; reuse = 0;
+            if (lane == 0) { st.successful += 1; if (x_cost < st.minimum_cost) st.minimum_cost = x_cost; }
+            last_successful = true;
+        } else {
+            radius = radius / dec; dec *= 2.0; reuse = 1;
+            last_successful = false;
+        }
+        __syncthreads();
+        if (a.w.history && iteration < a.w.history_records)
+            for (int e = lane; e < n * 15; e += 64) a.w.history[((size_t)iteration * a.B + b) * n * 15 + e] = xw[e];
+    } else {
+        last_successful = false;   // previous step was invalid
+        if (a.w.history && iteration < a.w.history_records)
+            for (int e = lane; e < n * 15; e += 64) a.w.history[((size_t)iteration * a.B + b) * n * 15 + e] = xw[e];
+    }
+    if (iteration == 0 && fresh && a.w.history && a.w.history_records > 0)
+        for (int e = lane; e < n * 15; e += 64) a.w.history[((size_t)b) * n * 15 + e] = xw[e];
+
+    // current linearisation
+    __syncthreads();
+    c.buf = cur; c.PL = a.w.PL[0]; c.PI = a.w.PI[cur]; c.PW = a.w.PW[cur]; c.PG = a.w.PG[cur]; c.x = xw;
+
+    // ---- pass 1 over the frames: diag(H) (Jacobi scaling at iteration 0, LM diagonal), gradient max norm
+    double gmax = 0.0;
+    for (int i = 0; i < n; ++i) {
+        assemble_frame(c, i, T.D, T.O, T.R, T.g, T.tmp);
+        if (lane < 15) {
+            const int v = lane;
+            const bool cst = var_is_const(a.mode, a.fast_mode, n, i, v);
+            const double hjj = T.D[v * 16 + v];
+            const double sc = cst ? 1.0 : (fresh ? 1.0 / (1.0 + sqrt(hjj)) : st.scale[i * 15 + v]);
+            if (fresh) st.scale[i * 15 + v] = sc;
+            if (!reuse) st.diagonal[i * 15 + v] = fmin(fmax(hjj * sc * sc, kMinDiag), kMaxDiag);
+        }
+        // |x - Plus(x, -g)| over the free variables
+        if (lane == 0) {
+            const double* xs = xw + (size_t)i * 15;
+            double m = 0.0;
+            for (int v = 0; v < 15; ++v) {
+                if (var_is_const(a.mode, a.fast_mode, n, i, v)) continue;
+                if (v < 3 || v >= 6) m = fmax(m, fabs(T.g[v]));
+            }
+            if (!var_is_const(a.mode, a.fast_mode, n, i, 3)) {
+                double ng[3] = {-T.g[3], -T.g[4], -T.g[5]}, qn[3];
+                so3_plus(xs + 3, ng, qn);
+                for (int k = 0; k < 3; ++k) m = fmax(m, fabs(xs[3 + k] - qn[k]));
+            }
+            T.tmp[15] = m;
+        }
+        __syncthreads();
+        gmax = fmax(gmax, T.tmp[15]);
+        __syncthreads();
+    }
+    __threadfence_block();
+
+    // ---- FinalizeIterationAndCheckIfMinimizerCanContinue
+    int term = 0;
+    if (iteration == 0 && fresh) { if (gmax <= kGradTol) term = 1; }
+    if (!term) {
+        if (iteration >= a.max_iters) term = 4;
+        else if (iteration > 0 && last_successful && gmax <= kGradTol) term = 1;
+        else if (!(radius > kMinRadius)) term = 5;
+    }
+    if (term) {
+        if (lane == 0) {
+            st.done = 1; st.termination = term; st.radius = radius; st.decrease_factor = dec; st.x_cost = x_cost; st.x_norm = x_norm;
+            st.reuse_diagonal = reuse; st.cur = cur; st.have_candidate = 0;
+        }
+        return;
+    }
+    ++iteration;
+
+    // ---- pass 2: eliminate frames n-1 .. 1 of (S H S + D^2) y = S g
+    for (int e = lane; e < 256; e += 64) { T.CD[e] = 0.0; T.CR[e] = 0.0; }
+    if (lane < 16) T.Cg[lane] = 0.0;
+    if (lane < 36) T.D0acc[lane] = 0.0;
+    if (lane < 8) T.g0acc[lane] = 0.0;
+    __syncthreads();
+    bool solved = true;
+    const double* scl = st.scale;
+    const double* dg = st.diagonal;
+    double* sws = a.w.solve_ws + (size_t)b * n * SOLVE_WS;
+    for (int i = n - 1; i >= 0; --i) {
+        assemble_frame(c, i, T.D, T.O, T.R, T.g, T.tmp);
+        // scale, damp, add the carried Schur terms
+        for (int e = lane; e < 256; e += 64) {
+            const int r = e >> 4, cc = e & 15;
+            if (r < 15 && cc < 15) {
+                double d = T.D[e] * scl[i * 15 + r] * scl[i * 15 + cc] + T.CD[e];
+                if (r == cc) {
+                    if (var_is_const(a.mode, a.fast_mode, n, i, r)) d = 1.0;
+                    else d += dg[i * 15 + r] / radius;
+                }
+                T.D[e] = d;
+                if (i >= 1) T.O[e] = T.O[e] * scl[(i - 1) * 15 + r] * scl[i * 15 + cc];
+                double rv = 0.0;
+                if (r < 6) rv = T.R[e] * scl[r] * scl[i * 15 + cc] + T.CR[e];
+                T.R[e] = rv;
+            } else { T.D[e] = 0.0; T.O[e] = 0.0; T.R[e] = 0.0; }
+        }
+        if (lane < 16) T.g[lane] = lane < 15 ? T.g[lane] * scl[i * 15 + lane] + T.Cg[lane] : 0.0;
+        __syncthreads();
+        if (i == 0) {
+            for (int e = lane; e < 36; e += 64) T.D[(e / 6) * 16 + e % 6] += T.D0acc[e];
+            if (lane < 6) T.g[lane] += T.g0acc[lane];
+            __syncthreads();
+        }
+        if (i == 1) {   // frame 0 is both the chain neighbour and the arrow target
+            for (int e = lane; e < 256; e += 64) { if ((e >> 4) < 6) T.O[e] += T.R[e]; T.R[e] = 0.0; }
+            __syncthreads();
+        }
+        if (!chol15(T.D)) { solved = false; break; }
+        // forward substitutions L w = rhs : lanes 0..14 -> columns of O^T (Wo), 15..20 -> columns of R^T (Wr), 21 -> g (z)
+        if (lane < 22) {
+            double wv[15];
+#pragma unroll
+            for (int r = 0; r < 15; ++r) {
+                double rhs;
+                if (lane < 15) rhs = T.O[lane * 16 + r];            // O^T[r][lane]
+                else if (lane < 21) rhs = T.R[(lane - 15) * 16 + r];
+                else rhs = T.g[r];
+#pragma unroll
+                for (int k = 0; k < r; ++k) rhs -= T.D[r * 16 + k] * wv[k];
+                wv[r] = rhs / T.D[r * 16 + r];
+            }
+#pragma unroll
+            for (int r = 0; r < 15; ++r) {
+                if (lane < 15) T.W[r * 16 + lane] = wv[r];
+                else if (lane < 21) T.Wa[r * 16 + (lane - 15)] = wv[r];
+                else T.W[r * 16 + 15] = wv[r];
+            }
+        } else if (lane < 32) {
+            const int cc = lane - 22 + 6;   // zero the unused columns 6..15 of Wa
+            for (int r = 0; r < 15; ++r) T.Wa[r * 16 + cc] = 0.0;
+        }
+        if (lane < 16) { T.W[15 * 16 + lane] = 0.0; T.Wa[15 * 16 + lane] = 0.0; }
+        __syncthreads();
+        // keep the factor for the back substitution: L (lower 15x15), Wo, Wr, z
+        {
+            double* f = sws + (size_t)i * SOLVE_WS;
+            for (int e = lane; e < 225; e += 64) { const int r = e / 15, cc = e % 15; f[e] = T.D[r * 16 + cc]; f[225 + 90 + 15 + e] = T.W[r * 16 + cc]; }
+            for (int e = lane; e < 90; e += 64) f[225 + e] = T.Wa[(e / 6) * 16 + e % 6];
+            if (lane < 15) f[225 + 90 + lane] = T.W[lane * 16 + 15];
+        }
+        if (i >= 1) {
+            // Schur products on the matrix cores
+            const d4 p1 = xty16(T.W, T.W);     // [Wo|z]^T [Wo|z]
+            const d4 p2 = xty16(T.Wa, T.W);    // [Wr|0]^T [Wo|z]
+            const d4 p3 = xty16(T.Wa, T.Wa);   // [Wr|0]^T [Wr|0]
+            __syncthreads();
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int row = (lane >> 4) + 4 * r, col = lane & 15;
+                if (row < 15 && col < 15) T.CD[row * 16 + col] = -p1[r];
+                if (row < 15 && col == 15) T.Cg[row] = -p1[r];
+                if (row < 6 && col < 15) T.CR[row * 16 + col] = -p2[r];
+                if (i >= 2) {
+                    if (row < 6 && col == 15) T.g0acc[row] -= p2[r];
+                    if (row < 6 && col < 6) T.D0acc[row * 6 + col] -= p3[r];
+                }
+            }
+            __syncthreads();
+        }
+    }
+    double model_cost_change = 0.0, step_norm = 0.0;
+    bool valid = false;
+    if (solved) {
+        // ---- frame 0 solve and back substitution (y kept in x_cand as scratch, frame by frame)
+        double* f0 = sws;
+        if (lane == 0) {
+            double z[15], y[15];
+            for (int r = 0; r < 15; ++r) z[r] = f0[225 + 90 + r];
+            for (int r = 14; r >= 0; --r) {
+                double s = z[r];
+                for (int k = r + 1; k < 15; ++k) s -= f0[k * 15 + r] * y[k];
+                y[r] = s / f0[r * 15 + r];
+            }
+            for (int r = 0; r < 15; ++r) { T.y0[r] = y[r]; T.yprev[r] = y[r]; }
+        }
+        __syncthreads();
+        // step (scaled space) of frame 0 -> candidate
+        double sg = 0.0;
+        auto emit = [&](int i) {
+            // T.yprev holds y of frame i (solution of the damped system); step = -y ; delta = step * scale
+            if (lane == 0) {
+                const double* xs = xw + (size_t)i * 15;
+                double* xo = xc + (size_t)i * 15;
+                double del[15];
+                for (int v = 0; v < 15; ++v) del[v] = var_is_const(a.mode, a.fast_mode, n, i, v) ? 0.0 : -T.yprev[v] * scl[i * 15 + v];
+                for (int v = 0; v < 15; ++v) if (v < 3 || v >= 6) xo[v] = xs[v] + del[v];
+                if (var_is_const(a.mode, a.fast_mode, n, i, 3)) { xo[3] = xs[3]; xo[4] = xs[4]; xo[5] = xs[5]; }
+                else so3_plus(xs + 3, del + 3, xo + 3);
+                double sn = 0.0;
+                for (int v = 0; v < 15; ++v) if (!var_is_const(a.mode, a.fast_mode, n, i, v)) sn += (xs[v] - xo[v]) * (xs[v] - xo[v]);
+                T.tmp[0] = sn;
+            }
+        };
+        // the steps are kept per frame in solve_ws (slot "spare") for the model-cost pass
+        emit(0);
+        if (lane < 15) sws[225 + 90 + 15 + 225 + lane] = -T.y0[lane];
+        __syncthreads();
+        step_norm += T.tmp[0];
+        for (int i = 1; i < n; ++i) {
+            const double* f = sws + (size_t)i * SOLVE_WS;
+            if (lane < 15) {
+                double s = f[225 + 90 + lane];
+                for (int k = 0; k < 15; ++k) s -= f[225 + 90 + 15 + lane * 15 + k] * T.yprev[k];   // Wo[r][k]: row r = lane
+                if (i >= 2) for (int k = 0; k < 6; ++k) s -= f[225 + lane * 6 + k] * T.y0[k];
+                T.tmp[lane] = s;
+            }
+            __syncthreads();
+            if (lane == 0) {
+                double y[15];
+                for (int r = 14; r >= 0; --r) {
+                    double s = T.tmp[r];
+                    for (int k = r + 1; k < 15; ++k) s -= f[k * 15 + r] * y[k];
+                    y[r] = s / f[r * 15 + r];
+                }
+                for (int r = 0; r < 15; ++r) T.yprev[r] = y[r];
+            }
+            __syncthreads();
+            emit(i);
+            if (lane < 15) sws[(size_t)i * SOLVE_WS + 225 + 90 + 15 + 225 + lane] = -T.yprev[lane];
+            __syncthreads();
+            step_norm += T.tmp[0];
+        }
+        step_norm = sqrt(step_norm);
+        // ---- model cost change  -(s'g_s + s' A s / 2),  A = S H S (undamped), third pass over the blocks
+        double q_sg = 0.0, q_sAs = 0.0;
+        for (int i = 0; i < n; ++i) {
+            assemble_frame(c, i, T.D, T.O, T.R, T.g, T.tmp);
+            const double* si = sws + (size_t)i * SOLVE_WS + 225 + 90 + 15 + 225;
+            const double* sm = i >= 1 ? sws + (size_t)(i - 1) * SOLVE_WS + 225 + 90 + 15 + 225 : si;
+            const double* s0 = sws + 225 + 90 + 15 + 225;
+            double part = 0.0;
+            for (int e = lane; e < 256; e += 64) {
+                const int r = e >> 4, cc = e & 15;
+                if (r < 15 && cc < 15) {
+                    part += si[r] * T.D[e] * scl[i * 15 + r] * scl[i * 15 + cc] * si[cc];
+                    if (i >= 1) part += 2.0 * sm[r] * T.O[e] * scl[(i - 1) * 15 + r] * scl[i * 15 + cc] * si[cc];
+                    if (i >= 2 && r < 6) part += 2.0 * s0[r] * T.R[e] * scl[r] * scl[i * 15 + cc] * si[cc];
+                }
+            }
+            q_sAs += part;
+            if (lane < 15) q_sg += si[lane] * T.g[lane] * scl[i * 15 + lane];
+            __syncthreads();
+        }
+        q_sAs = wave_sum(q_sAs);
+        q_sg = wave_sum(q_sg);
+        model_cost_change = -(q_sg + 0.5 * q_sAs);
+        valid = model_cost_change > 0.0 && isfinite(model_cost_change);
+    }
+    if (lane == 0) {
+        st.iteration = iteration; st.cur = cur; st.x_cost = x_cost; st.x_norm = x_norm;
+        if (valid) {
+            st.radius = radius; st.decrease_factor = dec; st.reuse_diagonal = 1;
+            st.model_cost_change = model_cost_change; st.cand_step_norm = step_norm; st.have_candidate = 1; st.invalid_steps = 0;
+        } else {
+            st.invalid_steps += 1;
+            st.have_candidate = 0;
+            if (st.invalid_steps >= 5) { st.done = 1; st.termination = 6; st.iteration = iteration - 1; }
+            st.radius = radius / dec; st.decrease_factor = dec * 2.0; st.reuse_diagonal = 1;
+        }
+    }
+}
+
+__global__ void k_lm_begin(int B, int n, LmState* lm) {
+    const int b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= B) return;
+    LmState& s = lm[b];
+    s.radius = kInitRadius; s.decrease_factor = 2.0; s.x_cost = 0.0; s.x_norm = 0.0; s.minimum_cost = 0.0;
+    s.cand_step_norm = 0.0; s.model_cost_change = 0.0; s.reuse_diagonal = 0; s.iteration = 0; s.done = 0; s.termination = 0;
+    s.successful = 0; s.cur = 0; s.invalid_steps = 0; s.have_candidate = 0; s.initial_cost = 0.0;
+}
+
+// write-backs the reference does after ceres::Solve (solver.cpp:176-190 init, :804-814 tracking) + summaries
+__global__ void k_lm_finish(StepArgs a) {
+    const int b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= a.B) return;
+    const int n = a.n;
+    LmState& st = a.w.lm[b];
+    const double* xw = a.x + (size_t)b * n * 15;
+    double* mp = a.match_pose + (size_t)b * n * 12;
+    if (a.mode == LIW_MODE_INIT) {
+        for (int i = 0; i < n; ++i)
+            if (a.has_match[b * n + i])
+                for (int k = 0; k < 6; ++k) { mp[i * 12 + k] = xw[k]; mp[i * 12 + 6 + k] = xw[(size_t)i * 15 + k]; }
+    } else if (a.mode == LIW_MODE_TRACK) {
+        const int i = n - 1;
+        if (a.has_match[b * n + i]) for (int k = 0; k < 6; ++k) mp[i * 12 + 6 + k] = xw[(size_t)i * 15 + k];
+    }
+    liw_summary& o = a.w.info[b];
+    o.iterations = st.iteration; o.successful_steps = st.successful; o.termination = st.termination;
+    o.initial_cost = st.initial_cost; o.final_cost = st.x_cost;
+}
+
+// ---------------------------------------------------------------------------------------------------
+// dense export of the assembled normal equations (tests, liw_linearize): H [15n x 15n], g, cost
+struct ExportArgs {
+    int B, n, mode, fast_mode, buf;
+    const double* x; const double* prior_X; const double* prior_J; const int* has_prior;
+    WsView w;
+    double* H; double* g; double* cost;
+};
+__global__ __launch_bounds__(64) void k_export_dense(ExportArgs a) {
+    __shared__ LdsTiles T;
+    const int b = blockIdx.x, lane = threadIdx.x & 63, n = a.n, N = 15 * n;
+    AsmCtx c;
+    c.n = n; c.mode = a.mode; c.fast = a.fast_mode; c.b = b; c.buf = a.buf;
+    c.PL = a.w.PL[0]; c.PI = a.w.PI[0]; c.PW = a.w.PW[0]; c.PG = a.w.PG[0];   // standalone linearise writes buffer 0
+    c.x = a.x + (size_t)b * n * 15;
+    c.pJ = a.prior_J + (size_t)b * 225; c.pX = a.prior_X + (size_t)b * 15;
+    c.prior_on = a.has_prior[b] && ((a.mode == LIW_MODE_TRACK && !a.fast_mode) || a.mode == LIW_MODE_MARG);
+    double* H = a.H + (size_t)b * N * N;
+    double* g = a.g + (size_t)b * N;
+    for (size_t e = lane; e < (size_t)N * N; e += 64) H[e] = 0.0;
+    __syncthreads();
+    const double sgn = a.mode == LIW_MODE_MARG ? -1.0 : 1.0;
+    for (int i = 0; i < n; ++i) {
+        assemble_frame(c, i, T.D, T.O, T.R, T.g, T.tmp);
+        for (int e = lane; e < 256; e += 64) {
+            const int r = e >> 4, cc = e & 15;
+            if (r < 15 && cc < 15) {
+                H[(size_t)(i * 15 + r) * N + i * 15 + cc] = T.D[e];
+                if (i >= 1) { H[(size_t)((i - 1) * 15 + r) * N + i * 15 + cc] = T.O[e]; H[(size_t)(i * 15 + cc) * N + (i - 1) * 15 + r] = T.O[e]; }
+                if (i >= 2 && r < 6) { H[(size_t)r * N + i * 15 + cc] = T.R[e]; H[(size_t)(i * 15 + cc) * N + r] = T.R[e]; }
+            }
+        }
+        if (lane < 15) g[i * 15 + lane] = sgn * T.g[lane];
+        __syncthreads();
+    }
+    const double cst = window_cost(c);
+    if (lane == 0) a.cost[b] = cst;
+}
+
+// ---------------------------------------------------------------------------------------------------
+// marginalisation: chain Schur complement of frames 0..n-2 onto frame n-1 (marginalization_matrix,
+// solver.cpp:4-40, on the block tri-diagonal H), eigen square root (solver.cpp:390-402), prior update (:407-441)
+struct MargArgs {
+    int B, n;
+    const double* x; double* prior_X; double* prior_J; double* prior_R; int* has_prior;
+    WsView w;
+    double* sqrt_H; double* Delta_H; double* Delta_g; int* status;
+};
+__global__ __launch_bounds__(64) void k_marg_schur(MargArgs a) {
+    __shared__ LdsTiles T;
+    __shared__ double V[256], Am[256];
+    const int b = blockIdx.x, lane = threadIdx.x & 63, n = a.n;
+    AsmCtx c;
+    c.n = n; c.mode = LIW_MODE_MARG; c.fast = 0; c.b = b; c.buf = 0;
+    c.PL = a.w.PL[0]; c.PI = a.w.PI[0]; c.PW = a.w.PW[0]; c.PG = a.w.PG[0];
+    c.x = a.x + (size_t)b * n * 15;
+    c.pJ = a.prior_J + (size_t)b * 225; c.pX = a.prior_X + (size_t)b * 15;
+    c.prior_on = a.has_prior[b] != 0;
+    for (int e = lane; e < 256; e += 64) T.CD[e] = 0.0;
+    if (lane < 16) T.Cg[lane] = 0.0;
+    __syncthreads();
+    bool ok = true;
+    // frame i is eliminated using its coupling O_{i+1} = H[i, i+1]; O of frame i+1 is assembled one frame ahead
+    for (int i = 0; i < n; ++i) {
+        // D_i, g_i  (+ carried Schur terms); O tile of THIS call is H[i-1,i], so fetch H[i,i+1] from the next frame
+        assemble_frame(c, i, T.D, T.O, T.R, T.g, T.tmp);
+        for (int e = lane; e < 256; e += 64) {
+            const int r = e >> 4, cc = e & 15;
+            T.D[e] = (r < 15 && cc < 15) ? T.D[e] + T.CD[e] : 0.0;
+        }
+        if (lane < 16) T.g[lane] = lane < 15 ? T.g[lane] + T.Cg[lane] : 0.0;
+        __syncthreads();
+        if (i == n - 1) break;
+        // coupling block H[i, i+1]: assemble frame i+1's O tile into T.R (scratch tiles W/Wa used as dummies)
+        assemble_frame(c, i + 1, T.W, T.R, T.Wa, T.y0, T.tmp);   // T.R <- H[i, i+1] (rows: frame i)
+        if (!chol15(T.D)) { ok = false; break; }
+        // W = L^-1 [O | g] : lanes 0..14 columns of O (H[i, i+1][:, col]), lane 15 -> g
+        if (lane < 16) {
+            double wv[15];
+#pragma unroll
+            for (int r = 0; r < 15; ++r) {
+                double rhs = lane < 15 ? T.R[r * 16 + lane] : T.g[r];
+#pragma unroll
+                for (int k = 0; k < r; ++k) rhs -= T.D[r * 16 + k] * wv[k];
+                wv[r] = rhs / T.D[r * 16 + r];
+            }
+#pragma unroll
+            for (int r = 0; r < 15; ++r) T.W[r * 16 + lane] = wv[r];
+            T.W[15 * 16 + lane] = 0.0;
+        }
+        __syncthreads();
+        const d4 p1 = xty16(T.W, T.W);
+        __syncthreads();
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int row = (lane >> 4) + 4 * r, col = lane & 15;
+            if (row < 15 && col < 15) T.CD[row * 16 + col] = -p1[r];
+            if (row < 15 && col == 15) T.Cg[row] = -p1[r];
+        }
+        __syncthreads();
+    }
+    if (a.status && lane == 0) a.status[b] = ok ? 0 : 1;
+    if (!ok) return;
+    // Delta_H = T.D (15x15), Delta_g = -T.g  (g = -J^T R in the reference)
+    if (a.Delta_H) for (int e = lane; e < 225; e += 64) a.Delta_H[(size_t)b * 225 + e] = T.D[(e / 15) * 16 + e % 15];
+    if (a.Delta_g && lane < 15) a.Delta_g[(size_t)b * 15 + lane] = -T.g[lane];
+    // ---- symmetric eigen-decomposition by cyclic Jacobi (15x15), A -> Am, eigenvectors -> V (columns)
+    for (int e = lane; e < 256; e += 64) {
+        const int r = e >> 4, cc = e & 15;
+        Am[e] = (r < 15 && cc < 15) ? 0.5 * (T.D[r * 16 + cc] + T.D[cc * 16 + r]) : 0.0;
+        V[e] = r == cc ? 1.0 : 0.0;
+    }
+    __syncthreads();
+    for (int sweep = 0; sweep < 60; ++sweep) {
+        double off = 0.0, dgn = 0.0;
+        for (int e = lane; e < 225; e += 64) {
+            const int r = e / 15, cc = e % 15;
+            const double v = Am[r * 16 + cc];
+            if (cc > r) off += v * v;
+            if (cc == r) dgn += v * v;
+        }
+        off = wave_sum(off); dgn = wave_sum(dgn);
+        if (off <= 1e-60 * dgn || off == 0.0) break;
+        for (int p = 0; p < 14; ++p)
+            for (int q = p + 1; q < 15; ++q) {
+                const double apq = Am[p * 16 + q];
+                if (apq == 0.0) continue;          // uniform: every lane reads the same LDS word
+                const double app = Am[p * 16 + p], aqq = Am[q * 16 + q];
+                const double tau = (aqq - app) / (2.0 * apq);
+                const double t = (tau >= 0.0 ? 1.0 : -1.0) / (fabs(tau) + sqrt(1.0 + tau * tau));
+                const double cs = 1.0 / sqrt(1.0 + t * t), sn = t * cs;
+                __syncthreads();
+                if (lane < 15) {   // columns p,q of A and V
+                    const double akp = Am[lane * 16 + p], akq = Am[lane * 16 + q];
+                    Am[lane * 16 + p] = cs * akp - sn * akq;
+                    Am[lane * 16 + q] = sn * akp + cs * akq;
+                    const double vkp = V[lane * 16 + p], vkq = V[lane * 16 + q];
+                    V[lane * 16 + p] = cs * vkp - sn * vkq;
+                    V[lane * 16 + q] = sn * vkp + cs * vkq;
+                }
+                __syncthreads();
+                if (lane < 15) {   // rows p,q of A
+                    const double apk = Am[p * 16 + lane], aqk = Am[q * 16 + lane];
+                    Am[p * 16 + lane] = cs * apk - sn * aqk;
+                    Am[q * 16 + lane] = sn * apk + cs * aqk;
+                }
+                __syncthreads();
+            }
+    }
+    // sort ascending (rank by counting; ties by index), sign convention: largest |component| positive
+    if (lane < 15) {
+        const double w = Am[lane * 16 + lane];
+        int rank = 0;
+        for (int k = 0; k < 15; ++k) { const double wk = Am[k * 16 + k]; if (wk < w || (wk == w && k < lane)) ++rank; }
+        int m = 0;
+        for (int k = 1; k < 15; ++k) if (fabs(V[k * 16 + lane]) > fabs(V[m * 16 + lane])) m = k;
+        const double sg = V[m * 16 + lane] < 0.0 ? -1.0 : 1.0;
+        const double eps = 1e-8;
+        const double S = w > eps ? w : 0.0, Sinv = w > eps ? 1.0 / w : 0.0;
+        const double ssq = sqrt(S), sisq = sqrt(Sinv);
+        double dotg = 0.0;
+        for (int k = 0; k < 15; ++k) dotg += sg * V[k * 16 + lane] * (-T.g[k]);   // V^T Delta_g
+        // linearized_jacobians row `rank` = sqrt(S) v^T ; linearized_residuals[rank] = -(S^-1/2 v^T Delta_g)
+        for (int k = 0; k < 15; ++k) a.prior_J[(size_t)b * 225 + rank * 15 + k] = ssq * sg * V[k * 16 + lane];
+        a.prior_R[(size_t)b * 15 + rank] = -(sisq * dotg);
+    }
+    __syncthreads();
+    __threadfence_block();
+    if (lane < 15) a.prior_X[(size_t)b * 15 + lane] = c.x[(size_t)(n - 1) * 15 + lane];
+    if (a.sqrt_H) for (int e = lane; e < 36; e += 64) a.sqrt_H[(size_t)b * 36 + e] = a.prior_J[(size_t)b * 225 + (e / 6) * 15 + e % 6];
+    if (lane == 0) a.has_prior[b] = 1;
+}
+
+void launch_lm_begin(int B, int n, LmState* lm, hipStream_t s) {
+    hipLaunchKernelGGL(k_lm_begin, dim3((B + 63) / 64), dim3(64), 0, s, B, n, lm);
+}
+void launch_lm_step(const StepArgs& a, hipStream_t s) { hipLaunchKernelGGL(k_lm_step, dim3(a.B), dim3(64), 0, s, a); }
+void launch_lm_finish(const StepArgs& a, hipStream_t s) { hipLaunchKernelGGL(k_lm_finish, dim3((a.B + 63) / 64), dim3(64), 0, s, a); }
+void launch_export_dense(const ExportArgs& a, hipStream_t s) { hipLaunchKernelGGL(k_export_dense, dim3(a.B), dim3(64), 0, s, a); }
+void launch_marg_schur(const MargArgs& a, hipStream_t s) { hipLaunchKernelGGL(k_marg_schur, dim3(a.B), dim3(64), 0, s, a); }
+
+}  // namespace liw

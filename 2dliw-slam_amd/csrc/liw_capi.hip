@@ -1,0 +1,646 @@
+// liw_capi.hip — the extern "C" boundary declared in include/liw_window.h (host side, HIP runtime).
+// No CPU fallback: without a usable gfx950 device every compute entry point returns LIW_ENODEV.
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "liw_kernels.hpp"
+
+namespace liw {
+// kernel launchers (k_linearize.hip, k_lm.hip)
+void launch_linearize(const LinArgs& A, const DevParams& P, hipStream_t s);
+void launch_group_offsets(int B, int n, const int* laser_off, const int* laser_frame, int* group_off, hipStream_t s);
+struct StepArgs {
+    int B, n, mode, max_iters, fast_mode;
+    double* x; double* match_pose; const unsigned char* has_match;
+    const double* prior_X; const double* prior_J; const int* has_prior;
+    WsView w;
+};
+struct ExportArgs {
+    int B, n, mode, fast_mode, buf;
+    const double* x; const double* prior_X; const double* prior_J; const int* has_prior;
+    WsView w;
+    double* H; double* g; double* cost;
+};
+struct MargArgs {
+    int B, n;
+    const double* x; double* prior_X; double* prior_J; double* prior_R; int* has_prior;
+    WsView w;
+    double* sqrt_H; double* Delta_H; double* Delta_g; int* status;
+};
+void launch_lm_begin(int B, int n, LmState* lm, hipStream_t s);
+void launch_lm_step(const StepArgs& a, hipStream_t s);
+void launch_lm_finish(const StepArgs& a, hipStream_t s);
+void launch_export_dense(const ExportArgs& a, hipStream_t s);
+void launch_marg_schur(const MargArgs& a, hipStream_t s);
+}  // namespace liw
+
+using namespace liw;
+
+struct DevBuf {
+    void* p = nullptr;
+    size_t cap = 0;
+    int ensure(size_t bytes) {
+        if (bytes <= cap && p) return 0;
+        if (p) (void)hipFree(p);
+        p = nullptr; cap = 0;
+        if (hipMalloc(&p, bytes ? bytes : 8) != hipSuccess) return -1;
+        cap = bytes ? bytes : 8;
+        return 0;
+    }
+    void release() { if (p) (void)hipFree(p); p = nullptr; cap = 0; }
+    template <class T> T* as() const { return (T*)p; }
+};
+
+struct liw_ctx {
+    liw_params prm;
+    DevParams dp;
+    std::string err;
+    bool have_device = false;
+    hipStream_t stream = nullptr;
+    // single-window state
+    liw_window hw{};
+    bool have_window = false;
+    int n = 0, L = 0;
+    DevBuf x, laser_off, laser_frame, laser_pts, match_pose, has_match, imu_X, imu_J, imu_P, imu_Dt, wheel_T, wheel_P;
+    DevBuf prior_X, prior_J, prior_R, has_prior, ws, scratch;
+    liw_batch sb{};
+    liw_ws_layout lay{};
+    int hist_records = 0;
+    int last_iters = 0;
+    // timing
+    bool timing = false;
+    std::vector<hipEvent_t> ev_lin, ev_step;
+    size_t ev_lin_used = 0, ev_step_used = 0;
+    // graph cache
+    hipGraphExec_t gexec = nullptr;
+    std::vector<unsigned char> gkey;
+};
+
+static int fail(liw_ctx* c, int code, const char* what, hipError_t e = hipSuccess) {
+    if (c) {
+        char buf[256];
+        if (e != hipSuccess) snprintf(buf, sizeof buf, "%s: %s", what, hipGetErrorString(e));
+        else snprintf(buf, sizeof buf, "%s", what);
+        c->err = buf;
+    }
+    return code;
+}
+#define HIPCHK(c, call)                                                   \
+    do {                                                                  \
+        hipError_t e_ = (call);                                           \
+        if (e_ != hipSuccess) return fail((c), LIW_EHIP, #call, e_);      \
+    } while (0)
+#define NEEDDEV(c)                                                                                         \
+    do {                                                                                                   \
+        if (!(c)) return LIW_EINVAL;                                                                       \
+        if (!(c)->have_device) return fail((c), LIW_ENODEV, "no usable gfx950 device (no CPU fallback)"); \
+    } while (0)
+
+// Quaternion(R).toRotationMatrix() round trip of the parameter loader (reference src/utilies/params.cpp:44-54,
+// src/utilies/common.h:183-189); no normalisation of the quaternion in between, as there.
+static void normalize_tf_host(double* R) {
+    double c[4];
+    double t = R[0] + R[4] + R[8];
+    auto M = [&](int r, int cc) { return R[r * 3 + cc]; };
+    if (t > 0.0) {
+        t = std::sqrt(t + 1.0);
+        c[3] = 0.5 * t; t = 0.5 / t;
+        c[0] = (M(2, 1) - M(1, 2)) * t; c[1] = (M(0, 2) - M(2, 0)) * t; c[2] = (M(1, 0) - M(0, 1)) * t;
+    } else {
+        int i = 0;
+        if (M(1, 1) > M(0, 0)) i = 1;
+        if (M(2, 2) > M(i, i)) i = 2;
+        int j = (i + 1) % 3, k = (j + 1) % 3;
+        t = std::sqrt(M(i, i) - M(j, j) - M(k, k) + 1.0);
+        c[i] = 0.5 * t; t = 0.5 / t;
+        c[3] = (M(k, j) - M(j, k)) * t; c[j] = (M(j, i) + M(i, j)) * t; c[k] = (M(k, i) + M(i, k)) * t;
+    }
+    const double qw = c[3], qx = c[0], qy = c[1], qz = c[2];
+    const double tx = 2 * qx, ty = 2 * qy, tz = 2 * qz;
+    const double twx = tx * qw, twy = ty * qw, twz = tz * qw, txx = tx * qx, txy = ty * qx, txz = tz * qx, tyy = ty * qy, tyz = tz * qy, tzz = tz * qz;
+    R[0] = 1 - (tyy + tzz); R[1] = txy - twz;       R[2] = txz + twy;
+    R[3] = txy + twz;       R[4] = 1 - (txx + tzz); R[5] = tyz - twx;
+    R[6] = txz - twy;       R[7] = tyz + twx;       R[8] = 1 - (txx + tyy);
+}
+void liw_fill_devparams(const liw_params* prm, DevParams* dp) {
+    for (int i = 0; i < 3; ++i) {
+        for (int j = 0; j < 3; ++j) { dp->Riw[i * 3 + j] = prm->T_imu_to_wheel[i * 4 + j]; dp->Ril[i * 3 + j] = prm->T_imu_to_laser[i * 4 + j]; }
+        dp->tiw[i] = prm->T_imu_to_wheel[i * 4 + 3];
+        dp->til[i] = prm->T_imu_to_laser[i * 4 + 3];
+    }
+    if (prm->normalize_extrinsics) { normalize_tf_host(dp->Riw); normalize_tf_host(dp->Ril); }
+    dp->g = prm->g;
+    dp->laser_sqrt_info = 1.0 / prm->line_to_line_sigma;
+    dp->ground_p_info = 1.0 / prm->manifold_p_sigma;
+    dp->ground_q_info = 1.0 / prm->manifold_q_sigma;
+    dp->fast_mode = prm->fast_mode;
+}
+
+extern "C" {
+
+liw_ctx* liw_create(const liw_params* prm) {
+    if (!prm) return nullptr;
+    liw_ctx* c = new liw_ctx();
+    c->prm = *prm;
+    liw_fill_devparams(prm, &c->dp);
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) == hipSuccess && ndev > prm->device && prm->device >= 0) {
+        hipDeviceProp_t props;
+        if (hipSetDevice(prm->device) == hipSuccess && hipGetDeviceProperties(&props, prm->device) == hipSuccess) {
+            if (std::strstr(props.gcnArchName, "gfx950") != nullptr) {
+                if (hipStreamCreate(&c->stream) == hipSuccess) c->have_device = true;
+            } else {
+                c->err = std::string("device is ") + props.gcnArchName + ", this library is built for gfx950 only";
+            }
+        }
+    }
+    if (!c->have_device && c->err.empty()) c->err = "no HIP device";
+    return c;
+}
+
+void liw_destroy(liw_ctx* c) {
+    if (!c) return;
+    if (c->have_device) {
+        (void)hipSetDevice(c->prm.device);
+        DevBuf* bufs[] = {&c->x, &c->laser_off, &c->laser_frame, &c->laser_pts, &c->match_pose, &c->has_match, &c->imu_X, &c->imu_J, &c->imu_P,
+                          &c->imu_Dt, &c->wheel_T, &c->wheel_P, &c->prior_X, &c->prior_J, &c->prior_R, &c->has_prior, &c->ws, &c->scratch};
+        for (DevBuf* b : bufs) b->release();
+        for (auto e : c->ev_lin) (void)hipEventDestroy(e);
+        for (auto e : c->ev_step) (void)hipEventDestroy(e);
+        if (c->gexec) (void)hipGraphExecDestroy(c->gexec);
+        if (c->stream) (void)hipStreamDestroy(c->stream);
+    }
+    delete c;
+}
+
+const char* liw_last_error(const liw_ctx* c) { return c ? c->err.c_str() : "null ctx"; }
+
+int liw_get_extrinsics(const liw_ctx* c, double* A, double* Bm) {
+    if (!c) return LIW_EINVAL;
+    auto put = [](const double* R, const double* t, double* m) {
+        for (int i = 0; i < 3; ++i) { for (int j = 0; j < 3; ++j) m[i * 4 + j] = R[i * 3 + j]; m[i * 4 + 3] = t[i]; }
+        m[12] = m[13] = m[14] = 0.0; m[15] = 1.0;
+    };
+    if (A) put(c->dp.Riw, c->dp.tiw, A);
+    if (Bm) put(c->dp.Ril, c->dp.til, Bm);
+    return LIW_OK;
+}
+
+// ------------------------------------------------------------------------------------------ workspace
+static size_t al256(size_t v) { return (v + 255) & ~(size_t)255; }
+struct FullLayout {
+    size_t PL[2], PI[2], PW[2], PG[2], x_cand, group_off, lm, solve_ws, info, history, bytes;
+};
+static FullLayout full_layout(int B, int n, int hist) {
+    FullLayout f{};
+    size_t o = 0;
+    const int nm = n > 1 ? n - 1 : 1;
+    for (int k = 0; k < 2; ++k) { f.PL[k] = o; o = al256(o + sizeof(double) * (size_t)B * n * LP); }
+    for (int k = 0; k < 2; ++k) { f.PI[k] = o; o = al256(o + sizeof(double) * (size_t)B * nm * PIS); }
+    for (int k = 0; k < 2; ++k) { f.PW[k] = o; o = al256(o + sizeof(double) * (size_t)B * nm * PWS); }
+    for (int k = 0; k < 2; ++k) { f.PG[k] = o; o = al256(o + sizeof(double) * (size_t)B * n * PGS); }
+    f.x_cand = o; o = al256(o + sizeof(double) * (size_t)B * n * 15);
+    f.group_off = o; o = al256(o + sizeof(int) * (size_t)B * (n + 1));
+    f.lm = o; o = al256(o + sizeof(LmState) * (size_t)B);
+    f.solve_ws = o; o = al256(o + sizeof(double) * (size_t)B * n * SOLVE_WS);
+    f.info = o; o = al256(o + sizeof(liw_summary) * (size_t)B);
+    f.history = hist > 0 ? o : 0;
+    if (hist > 0) o = al256(o + sizeof(double) * (size_t)hist * B * n * 15);
+    f.bytes = o;
+    return f;
+}
+static WsView make_view(void* ws, int B, int n, int hist) {
+    FullLayout f = full_layout(B, n, hist);
+    char* base = (char*)ws;
+    WsView v{};
+    for (int k = 0; k < 2; ++k) {
+        v.PL[k] = (double*)(base + f.PL[k]); v.PI[k] = (double*)(base + f.PI[k]);
+        v.PW[k] = (double*)(base + f.PW[k]); v.PG[k] = (double*)(base + f.PG[k]);
+    }
+    v.x_cand = (double*)(base + f.x_cand);
+    v.group_off = (int*)(base + f.group_off);
+    v.lm = (LmState*)(base + f.lm);
+    v.solve_ws = (double*)(base + f.solve_ws);
+    v.info = (liw_summary*)(base + f.info);
+    v.history = hist > 0 ? (double*)(base + f.history) : nullptr;
+    v.history_records = hist;
+    v.marg = nullptr;
+    return v;
+}
+
+int liw_batch_ws_layout(int B, int n, int history_records, liw_ws_layout* out) {
+    if (!out || B <= 0 || n <= 0 || n > 64) return LIW_EINVAL;
+    FullLayout f = full_layout(B, n, history_records);
+    out->bytes = f.bytes;
+    out->laser_partial_off[0] = f.PL[0];
+    out->laser_partial_off[1] = f.PL[1];
+    out->laser_partial_bytes = sizeof(double) * (size_t)B * n * LP;
+    out->info_off = f.info;
+    out->history_off = f.history;
+    return LIW_OK;
+}
+
+// ------------------------------------------------------------------------------------------ batch API
+static int check_batch(liw_ctx* c, const liw_batch* b) {
+    if (!b || b->B <= 0 || b->n <= 0 || b->n > 64) return fail(c, LIW_EINVAL, "bad batch (need 1 <= n <= 64, B >= 1)");
+    return LIW_OK;
+}
+static LinArgs lin_args(const liw_batch* b, int mode, const double* x, const WsView& v, int candidate, bool use_lm) {
+    LinArgs A{};
+    A.B = b->B; A.n = b->n; A.mode = mode; A.eval_small = b->eval_small;
+    A.x = x; A.group_off = v.group_off; A.laser_off = b->laser_off; A.laser_pts = b->laser_pts; A.Ltot = b->Ltot;
+    A.match_pose = b->match_pose; A.has_match = b->has_match;
+    A.imu_X = b->imu_X; A.imu_J = b->imu_J; A.imu_sqrtP = b->imu_sqrtP; A.imu_Dt = b->imu_Dt;
+    A.wheel_T = b->wheel_T; A.wheel_sqrtP = b->wheel_sqrtP;
+    A.PL = v.PL[candidate ? 1 : 0];
+    for (int k = 0; k < 2; ++k) { A.PI[k] = v.PI[k]; A.PW[k] = v.PW[k]; A.PG[k] = v.PG[k]; }
+    A.lm = use_lm ? v.lm : nullptr;
+    A.candidate = candidate;
+    return A;
+}
+static StepArgs step_args(liw_ctx* c, const liw_batch* b, int mode, int max_iters, const WsView& v) {
+    StepArgs a{};
+    a.B = b->B; a.n = b->n; a.mode = mode; a.max_iters = max_iters; a.fast_mode = c->prm.fast_mode;
+    a.x = b->x; a.match_pose = b->match_pose; a.has_match = b->has_match;
+    a.prior_X = b->prior_X; a.prior_J = b->prior_J; a.has_prior = b->has_prior;
+    a.w = v;
+    return a;
+}
+static int resolve_iters(liw_ctx* c, int mode, int max_iters) {
+    if (max_iters > 0) return max_iters;
+    return (mode == LIW_MODE_TRACK && c->prm.fast_mode) ? 10 : 50;   // solver.cpp:800-801
+}
+
+// ws carries the history record count in the ctx (single-window path) — batch callers pass 0 history
+
+int liw_batch_lm_begin(liw_ctx* c, const liw_batch* b, int mode, int max_iters, void* ws, void* stream) {
+    NEEDDEV(c);
+    if (int r = check_batch(c, b)) return r;
+    (void)mode; (void)max_iters;
+    WsView v = make_view(ws, b->B, b->n, b->history_records);
+    hipStream_t s = (hipStream_t)stream;
+    launch_group_offsets(b->B, b->n, b->laser_off, b->laser_frame, v.group_off, s);
+    launch_lm_begin(b->B, b->n, v.lm, s);
+    HIPCHK(c, hipGetLastError());
+    return LIW_OK;
+}
+int liw_batch_lm_linearize(liw_ctx* c, const liw_batch* b, int mode, int candidate, void* ws, void* stream) {
+    NEEDDEV(c);
+    if (int r = check_batch(c, b)) return r;
+    WsView v = make_view(ws, b->B, b->n, b->history_records);
+    LinArgs A = lin_args(b, mode, candidate ? v.x_cand : b->x, v, candidate != 0, true);
+    launch_linearize(A, c->dp, (hipStream_t)stream);
+    HIPCHK(c, hipGetLastError());
+    return LIW_OK;
+}
+int liw_batch_lm_step(liw_ctx* c, const liw_batch* b, int mode, void* ws, void* stream) {
+    NEEDDEV(c);
+    if (int r = check_batch(c, b)) return r;
+    WsView v = make_view(ws, b->B, b->n, b->history_records);
+    StepArgs a = step_args(c, b, mode, c->last_iters, v);
+    launch_lm_step(a, (hipStream_t)stream);
+    HIPCHK(c, hipGetLastError());
+    return LIW_OK;
+}
+int liw_batch_lm_finish(liw_ctx* c, const liw_batch* b, int mode, void* ws, void* stream) {
+    NEEDDEV(c);
+    if (int r = check_batch(c, b)) return r;
+    WsView v = make_view(ws, b->B, b->n, b->history_records);
+    StepArgs a = step_args(c, b, mode, c->last_iters, v);
+    launch_lm_finish(a, (hipStream_t)stream);
+    HIPCHK(c, hipGetLastError());
+    return LIW_OK;
+}
+/* the iteration cap the step kernel enforces (set before liw_batch_lm_step when driving the loop by hand) */
+int liw_batch_set_max_iters(liw_ctx* c, int mode, int max_iters) {
+    if (!c) return LIW_EINVAL;
+    c->last_iters = resolve_iters(c, mode, max_iters);
+    return c->last_iters;
+}
+
+static hipEvent_t next_event(std::vector<hipEvent_t>& pool, size_t& used) {
+    if (used == pool.size()) { hipEvent_t e; (void)hipEventCreate(&e); pool.push_back(e); }
+    return pool[used++];
+}
+
+static int enqueue_solve(liw_ctx* c, const liw_batch* b, int mode, int K, void* ws, hipStream_t s, bool timed) {
+    WsView v = make_view(ws, b->B, b->n, b->history_records);
+    launch_group_offsets(b->B, b->n, b->laser_off, b->laser_frame, v.group_off, s);
+    launch_lm_begin(b->B, b->n, v.lm, s);
+    StepArgs st = step_args(c, b, mode, K, v);
+    auto lin = [&](int cand) {
+        LinArgs A = lin_args(b, mode, cand ? v.x_cand : b->x, v, cand, true);
+        if (timed) (void)hipEventRecord(next_event(c->ev_lin, c->ev_lin_used), s);
+        launch_linearize(A, c->dp, s);
+        if (timed) (void)hipEventRecord(next_event(c->ev_lin, c->ev_lin_used), s);
+    };
+    auto step = [&]() {
+        if (timed) (void)hipEventRecord(next_event(c->ev_step, c->ev_step_used), s);
+        launch_lm_step(st, s);
+        if (timed) (void)hipEventRecord(next_event(c->ev_step, c->ev_step_used), s);
+    };
+    lin(0);
+    for (int k = 0; k < K; ++k) { step(); lin(1); }
+    step();
+    launch_lm_finish(st, s);
+    return LIW_OK;
+}
+
+int liw_batch_solve(liw_ctx* c, const liw_batch* b, int mode, int max_iters, void* ws, void* stream, int use_graph) {
+    NEEDDEV(c);
+    if (int r = check_batch(c, b)) return r;
+    if (mode != LIW_MODE_INIT && mode != LIW_MODE_TRACK) return fail(c, LIW_EINVAL, "liw_batch_solve: mode must be INIT or TRACK");
+    const int K = resolve_iters(c, mode, max_iters);
+    c->last_iters = K;
+    hipStream_t s = (hipStream_t)stream;
+    if (c->timing) { c->ev_lin_used = 0; c->ev_step_used = 0; }
+    if (use_graph && !c->timing) {
+        // cache key: everything the captured launches depend on
+        std::vector<unsigned char> key(sizeof(liw_batch) + sizeof(int) * 2 + sizeof(void*));
+        std::memcpy(key.data(), b, sizeof(liw_batch));
+        std::memcpy(key.data() + sizeof(liw_batch), &mode, sizeof(int));
+        std::memcpy(key.data() + sizeof(liw_batch) + sizeof(int), &K, sizeof(int));
+        std::memcpy(key.data() + sizeof(liw_batch) + 2 * sizeof(int), &ws, sizeof(void*));
+        if (!c->gexec || key != c->gkey) {
+            if (c->gexec) { (void)hipGraphExecDestroy(c->gexec); c->gexec = nullptr; }
+            hipGraph_t g = nullptr;
+            HIPCHK(c, hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal));
+            enqueue_solve(c, b, mode, K, ws, s, false);
+            HIPCHK(c, hipStreamEndCapture(s, &g));
+            HIPCHK(c, hipGraphInstantiate(&c->gexec, g, nullptr, nullptr, 0));
+            (void)hipGraphDestroy(g);
+            c->gkey = key;
+        }
+        HIPCHK(c, hipGraphLaunch(c->gexec, s));
+        return LIW_OK;
+    }
+    enqueue_solve(c, b, mode, K, ws, s, c->timing);
+    HIPCHK(c, hipGetLastError());
+    return LIW_OK;
+}
+
+int liw_batch_marg_linearize(liw_ctx* c, const liw_batch* b, void* ws, void* stream) {
+    NEEDDEV(c);
+    if (int r = check_batch(c, b)) return r;
+    WsView v = make_view(ws, b->B, b->n, b->history_records);
+    hipStream_t s = (hipStream_t)stream;
+    launch_group_offsets(b->B, b->n, b->laser_off, b->laser_frame, v.group_off, s);
+    LinArgs A = lin_args(b, LIW_MODE_MARG, b->x, v, 0, false);
+    if (c->timing) (void)hipEventRecord(next_event(c->ev_lin, c->ev_lin_used), s);
+    launch_linearize(A, c->dp, s);
+    if (c->timing) (void)hipEventRecord(next_event(c->ev_lin, c->ev_lin_used), s);
+    HIPCHK(c, hipGetLastError());
+    return LIW_OK;
+}
+int liw_batch_marg_schur(liw_ctx* c, const liw_batch* b, void* ws, double* sqrt_H, double* Delta_H, double* Delta_g, void* stream) {
+    NEEDDEV(c);
+    if (int r = check_batch(c, b)) return r;
+    if (c->prm.fast_mode) return LIW_OK;
+    WsView v = make_view(ws, b->B, b->n, b->history_records);
+    MargArgs a{};
+    a.B = b->B; a.n = b->n; a.x = b->x;
+    a.prior_X = b->prior_X; a.prior_J = b->prior_J; a.prior_R = b->prior_R; a.has_prior = b->has_prior;
+    a.w = v; a.sqrt_H = sqrt_H; a.Delta_H = Delta_H; a.Delta_g = Delta_g; a.status = nullptr;
+    launch_marg_schur(a, (hipStream_t)stream);
+    HIPCHK(c, hipGetLastError());
+    return LIW_OK;
+}
+int liw_batch_export_dense(liw_ctx* c, const liw_batch* b, int mode, int buf, void* ws, double* H, double* g, double* cost, void* stream) {
+    NEEDDEV(c);
+    if (int r = check_batch(c, b)) return r;
+    WsView v = make_view(ws, b->B, b->n, b->history_records);
+    ExportArgs a{};
+    a.B = b->B; a.n = b->n; a.mode = mode; a.fast_mode = c->prm.fast_mode; a.buf = buf;
+    a.x = b->x; a.prior_X = b->prior_X; a.prior_J = b->prior_J; a.has_prior = b->has_prior;
+    a.w = v; a.H = H; a.g = g; a.cost = cost;
+    launch_export_dense(a, (hipStream_t)stream);
+    HIPCHK(c, hipGetLastError());
+    return LIW_OK;
+}
+/* standalone linearisation at b->x into buffer 0 (no LM state): liw_linearize / tests / bench kernel timing */
+int liw_batch_linearize(liw_ctx* c, const liw_batch* b, int mode, void* ws, void* stream) {
+    NEEDDEV(c);
+    if (int r = check_batch(c, b)) return r;
+    WsView v = make_view(ws, b->B, b->n, b->history_records);
+    hipStream_t s = (hipStream_t)stream;
+    launch_group_offsets(b->B, b->n, b->laser_off, b->laser_frame, v.group_off, s);
+    LinArgs A = lin_args(b, mode, b->x, v, 0, false);
+    if (c->timing) (void)hipEventRecord(next_event(c->ev_lin, c->ev_lin_used), s);
+    launch_linearize(A, c->dp, s);
+    if (c->timing) (void)hipEventRecord(next_event(c->ev_lin, c->ev_lin_used), s);
+    HIPCHK(c, hipGetLastError());
+    return LIW_OK;
+}
+
+int liw_set_timing(liw_ctx* c, int enable) {
+    if (!c) return LIW_EINVAL;
+    c->timing = enable != 0;
+    c->ev_lin_used = c->ev_step_used = 0;
+    return LIW_OK;
+}
+int liw_get_timing(liw_ctx* c, double* lin_ms, int* lin_n, double* step_ms, int* step_n) {
+    NEEDDEV(c);
+    auto total = [&](std::vector<hipEvent_t>& pool, size_t used, double* ms, int* cnt) {
+        double t = 0.0; int k = 0;
+        for (size_t i = 0; i + 1 < used; i += 2) {
+            float f = 0.f;
+            if (hipEventSynchronize(pool[i + 1]) != hipSuccess) continue;
+            if (hipEventElapsedTime(&f, pool[i], pool[i + 1]) == hipSuccess) { t += f; ++k; }
+        }
+        if (ms) *ms = k ? t / k : 0.0;
+        if (cnt) *cnt = k;
+    };
+    total(c->ev_lin, c->ev_lin_used, lin_ms, lin_n);
+    total(c->ev_step, c->ev_step_used, step_ms, step_n);
+    c->ev_lin_used = c->ev_step_used = 0;
+    return LIW_OK;
+}
+
+// ------------------------------------------------------------------------------------------ single window
+int liw_set_window(liw_ctx* c, const liw_window* w) {
+    NEEDDEV(c);
+    if (!w || w->n < 1 || w->n > 64 || w->L < 0) return fail(c, LIW_EINVAL, "liw_set_window: need 1 <= n <= 64, L >= 0");
+    HIPCHK(c, hipSetDevice(c->prm.device));
+    const int n = w->n, L = w->L, nm = n > 1 ? n - 1 : 1;
+    // laser blocks must be sorted by owning frame
+    for (int j = 1; j < L; ++j) if (w->laser_frame[j] < w->laser_frame[j - 1]) return fail(c, LIW_EINVAL, "laser_frame must be ascending");
+    for (int j = 0; j < L; ++j) if (w->laser_frame[j] < 0 || w->laser_frame[j] >= n) return fail(c, LIW_EINVAL, "laser_frame out of range");
+    struct Up { DevBuf* d; const void* src; size_t bytes; };
+    std::vector<double> soa((size_t)12 * (L ? L : 1));
+    for (int j = 0; j < L; ++j) for (int k = 0; k < 12; ++k) soa[(size_t)k * L + j] = w->laser_pts[(size_t)j * 12 + k];
+    int off[2] = {0, L};
+    Up ups[] = {
+        {&c->x, w->states, sizeof(double) * n * 15}, {&c->laser_off, off, sizeof(off)},
+        {&c->laser_frame, w->laser_frame, sizeof(int) * (size_t)L}, {&c->laser_pts, soa.data(), sizeof(double) * 12 * (size_t)L},
+        {&c->match_pose, w->match_pose, sizeof(double) * n * 12}, {&c->has_match, w->has_match, (size_t)n},
+        {&c->imu_X, w->imu_X, sizeof(double) * (n - 1) * 15}, {&c->imu_J, w->imu_J, sizeof(double) * (n - 1) * 225},
+        {&c->imu_P, w->imu_sqrtP, sizeof(double) * (n - 1) * 225}, {&c->imu_Dt, w->imu_Dt, sizeof(double) * (n - 1)},
+        {&c->wheel_T, w->wheel_T, sizeof(double) * (n - 1) * 12}, {&c->wheel_P, w->wheel_sqrtP, sizeof(double) * (n - 1) * 9},
+    };
+    for (auto& u : ups) {
+        if (u.d->ensure(u.bytes)) return fail(c, LIW_ENOMEM, "hipMalloc");
+        if (u.bytes) HIPCHK(c, hipMemcpyAsync(u.d->p, u.src, u.bytes, hipMemcpyHostToDevice, c->stream));
+    }
+    (void)nm;
+    bool fresh_prior = c->prior_X.p == nullptr;
+    if (c->prior_X.ensure(sizeof(double) * 15) || c->prior_J.ensure(sizeof(double) * 225) || c->prior_R.ensure(sizeof(double) * 15) ||
+        c->has_prior.ensure(sizeof(int)))
+        return fail(c, LIW_ENOMEM, "hipMalloc");
+    if (fresh_prior) {
+        HIPCHK(c, hipMemsetAsync(c->prior_X.p, 0, sizeof(double) * 15, c->stream));
+        HIPCHK(c, hipMemsetAsync(c->prior_J.p, 0, sizeof(double) * 225, c->stream));
+        HIPCHK(c, hipMemsetAsync(c->prior_R.p, 0, sizeof(double) * 15, c->stream));
+        HIPCHK(c, hipMemsetAsync(c->has_prior.p, 0, sizeof(int), c->stream));
+    }
+    c->hist_records = 64;
+    FullLayout f = full_layout(1, n, c->hist_records);
+    if (c->ws.ensure(f.bytes)) return fail(c, LIW_ENOMEM, "hipMalloc workspace");
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    c->hw = *w; c->have_window = true; c->n = n; c->L = L;
+    liw_batch& b = c->sb;
+    b.B = 1; b.n = n; b.Ltot = L;
+    b.x = c->x.as<double>(); b.laser_off = c->laser_off.as<int>(); b.laser_frame = c->laser_frame.as<int>();
+    b.laser_pts = c->laser_pts.as<double>(); b.match_pose = c->match_pose.as<double>(); b.has_match = c->has_match.as<unsigned char>();
+    b.imu_X = c->imu_X.as<double>(); b.imu_J = c->imu_J.as<double>(); b.imu_sqrtP = c->imu_P.as<double>(); b.imu_Dt = c->imu_Dt.as<double>();
+    b.wheel_T = c->wheel_T.as<double>(); b.wheel_sqrtP = c->wheel_P.as<double>();
+    b.prior_X = c->prior_X.as<double>(); b.prior_J = c->prior_J.as<double>(); b.prior_R = c->prior_R.as<double>(); b.has_prior = c->has_prior.as<int>();
+    b.eval_small = 1; b.history_records = c->hist_records;
+    return LIW_OK;
+}
+#define NEEDWIN(c)                                                                          \
+    do {                                                                                    \
+        NEEDDEV(c);                                                                         \
+        if (!(c)->have_window) return fail((c), LIW_ESTATE, "liw_set_window was not called"); \
+        HIPCHK(c, hipSetDevice((c)->prm.device));                                           \
+    } while (0)
+
+static int download_states(liw_ctx* c) {
+    HIPCHK(c, hipMemcpyAsync(c->hw.states, c->x.p, sizeof(double) * c->n * 15, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipMemcpyAsync(c->hw.match_pose, c->match_pose.p, sizeof(double) * c->n * 12, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    return LIW_OK;
+}
+
+int liw_solve(liw_ctx* c, int mode, int max_iters, liw_summary* summary) {
+    NEEDWIN(c);
+    int K = resolve_iters(c, mode, max_iters);
+    if (K + 1 > c->hist_records) {   // grow the history region
+        c->hist_records = K + 1;
+        c->sb.history_records = c->hist_records;
+        FullLayout f = full_layout(1, c->n, c->hist_records);
+        if (c->ws.ensure(f.bytes)) return fail(c, LIW_ENOMEM, "hipMalloc workspace");
+    }
+    if (int r = liw_batch_solve(c, &c->sb, mode, K, c->ws.p, c->stream, 0)) return r;
+    FullLayout f = full_layout(1, c->n, c->hist_records);
+    liw_summary s{};
+    HIPCHK(c, hipMemcpyAsync(&s, (char*)c->ws.p + f.info, sizeof(s), hipMemcpyDeviceToHost, c->stream));
+    if (int r = download_states(c)) return r;
+    if (summary) *summary = s;
+    return LIW_OK;
+}
+int liw_get_history(liw_ctx* c, double* x, int max_records) {
+    NEEDWIN(c);
+    FullLayout f = full_layout(1, c->n, c->hist_records);
+    liw_summary s{};
+    HIPCHK(c, hipMemcpy(&s, (char*)c->ws.p + f.info, sizeof(s), hipMemcpyDeviceToHost));
+    int rec = s.iterations + 1;
+    if (rec > max_records) rec = max_records;
+    if (rec > c->hist_records) rec = c->hist_records;
+    HIPCHK(c, hipMemcpy(x, (char*)c->ws.p + f.history, sizeof(double) * (size_t)rec * c->n * 15, hipMemcpyDeviceToHost));
+    return rec;
+}
+int liw_linearize(liw_ctx* c, int mode, double* H, double* g, double* cost) {
+    NEEDWIN(c);
+    const size_t N = (size_t)15 * c->n;
+    if (c->scratch.ensure(sizeof(double) * (N * N + N + 1))) return fail(c, LIW_ENOMEM, "hipMalloc");
+    double* dH = c->scratch.as<double>();
+    double* dg = dH + N * N;
+    double* dc = dg + N;
+    if (int r = liw_batch_linearize(c, &c->sb, mode, c->ws.p, c->stream)) return r;
+    if (int r = liw_batch_export_dense(c, &c->sb, mode, 0, c->ws.p, dH, dg, dc, c->stream)) return r;
+    if (H) HIPCHK(c, hipMemcpyAsync(H, dH, sizeof(double) * N * N, hipMemcpyDeviceToHost, c->stream));
+    if (g) HIPCHK(c, hipMemcpyAsync(g, dg, sizeof(double) * N, hipMemcpyDeviceToHost, c->stream));
+    if (cost) HIPCHK(c, hipMemcpyAsync(cost, dc, sizeof(double), hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    return LIW_OK;
+}
+int liw_eval_factors(liw_ctx* c, int mode, double* laser_res, double* laser_jac, double* imu_res, double* imu_jac, double* wheel_res,
+                     double* wheel_jac, double* ground_res, double* ground_jac) {
+    NEEDWIN(c);
+    const size_t n = c->n, L = c->L, nm = n - 1;
+    const size_t sz[8] = {L * 2, L * 24, nm * 15, nm * 450, nm * 3, nm * 36, n * 2, n * 12};
+    size_t tot = 0;
+    for (size_t v : sz) tot += v;
+    if (c->scratch.ensure(sizeof(double) * (tot + 8))) return fail(c, LIW_ENOMEM, "hipMalloc");
+    HIPCHK(c, hipMemsetAsync(c->scratch.p, 0, sizeof(double) * (tot + 8), c->stream));
+    double* base = c->scratch.as<double>();
+    double* dptr[8];
+    size_t o = 0;
+    for (int k = 0; k < 8; ++k) { dptr[k] = base + o; o += sz[k]; }
+    WsView v = make_view(c->ws.p, 1, c->n, c->sb.history_records);
+    launch_group_offsets(1, c->n, c->sb.laser_off, c->sb.laser_frame, v.group_off, c->stream);
+    LinArgs A = lin_args(&c->sb, mode, c->sb.x, v, 0, false);
+    A.dbg_laser_res = dptr[0]; A.dbg_laser_jac = dptr[1]; A.dbg_imu_res = dptr[2]; A.dbg_imu_jac = dptr[3];
+    A.dbg_wheel_res = dptr[4]; A.dbg_wheel_jac = dptr[5]; A.dbg_ground_res = dptr[6]; A.dbg_ground_jac = dptr[7];
+    launch_linearize(A, c->dp, c->stream);
+    HIPCHK(c, hipGetLastError());
+    double* hptr[8] = {laser_res, laser_jac, imu_res, imu_jac, wheel_res, wheel_jac, ground_res, ground_jac};
+    for (int k = 0; k < 8; ++k)
+        if (hptr[k] && sz[k]) HIPCHK(c, hipMemcpyAsync(hptr[k], dptr[k], sizeof(double) * sz[k], hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    return LIW_OK;
+}
+int liw_marginalize(liw_ctx* c, double* sqrt_H36, double* Delta_H225, double* Delta_g15) {
+    NEEDWIN(c);
+    if (c->prm.fast_mode) return LIW_OK;   // solver.cpp:259-260
+    if (c->scratch.ensure(sizeof(double) * (36 + 225 + 15))) return fail(c, LIW_ENOMEM, "hipMalloc");
+    double* d = c->scratch.as<double>();
+    if (int r = liw_batch_marg_linearize(c, &c->sb, c->ws.p, c->stream)) return r;
+    if (int r = liw_batch_marg_schur(c, &c->sb, c->ws.p, d, d + 36, d + 36 + 225, c->stream)) return r;
+    double h[36 + 225 + 15];
+    HIPCHK(c, hipMemcpyAsync(h, d, sizeof(h), hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    if (sqrt_H36) std::memcpy(sqrt_H36, h, sizeof(double) * 36);
+    if (Delta_H225) std::memcpy(Delta_H225, h + 36, sizeof(double) * 225);
+    if (Delta_g15) std::memcpy(Delta_g15, h + 36 + 225, sizeof(double) * 15);
+    return LIW_OK;
+}
+int liw_get_prior(liw_ctx* c, double* X15, double* J225, double* R15) {
+    NEEDDEV(c);
+    if (!c->prior_X.p) return 0;
+    int has = 0;
+    HIPCHK(c, hipMemcpy(&has, c->has_prior.p, sizeof(int), hipMemcpyDeviceToHost));
+    if (!has) return 0;
+    if (X15) HIPCHK(c, hipMemcpy(X15, c->prior_X.p, sizeof(double) * 15, hipMemcpyDeviceToHost));
+    if (J225) HIPCHK(c, hipMemcpy(J225, c->prior_J.p, sizeof(double) * 225, hipMemcpyDeviceToHost));
+    if (R15) HIPCHK(c, hipMemcpy(R15, c->prior_R.p, sizeof(double) * 15, hipMemcpyDeviceToHost));
+    return 1;
+}
+int liw_set_prior(liw_ctx* c, int has_prior, const double* X15, const double* J225, const double* R15) {
+    NEEDDEV(c);
+    HIPCHK(c, hipSetDevice(c->prm.device));
+    if (c->prior_X.ensure(sizeof(double) * 15) || c->prior_J.ensure(sizeof(double) * 225) || c->prior_R.ensure(sizeof(double) * 15) ||
+        c->has_prior.ensure(sizeof(int)))
+        return fail(c, LIW_ENOMEM, "hipMalloc");
+    int has = has_prior ? 1 : 0;
+    HIPCHK(c, hipMemcpy(c->has_prior.p, &has, sizeof(int), hipMemcpyHostToDevice));
+    if (has) {
+        if (!X15 || !J225) return fail(c, LIW_EINVAL, "liw_set_prior: X and J required");
+        double z[15] = {0};
+        HIPCHK(c, hipMemcpy(c->prior_X.p, X15, sizeof(double) * 15, hipMemcpyHostToDevice));
+        HIPCHK(c, hipMemcpy(c->prior_J.p, J225, sizeof(double) * 225, hipMemcpyHostToDevice));
+        HIPCHK(c, hipMemcpy(c->prior_R.p, R15 ? R15 : z, sizeof(double) * 15, hipMemcpyHostToDevice));
+    }
+    if (c->have_window) {
+        c->sb.prior_X = c->prior_X.as<double>(); c->sb.prior_J = c->prior_J.as<double>();
+        c->sb.prior_R = c->prior_R.as<double>(); c->sb.has_prior = c->has_prior.as<int>();
+    }
+    return LIW_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,78 @@
+// liw_kernels.hpp — shared device-side declarations of libliw_window.so (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/liw_window.h"
+#include "liw_dual.hpp"
+
+namespace liw {
+
+// Device copy of the parameters the factors read.
+struct DevParams {
+    double Riw[9], tiw[3];  // T_imu_to_wheel (wheel frame in IMU frame)
+    double Ril[9], til[3];  // T_imu_to_laser
+    double g;
+    double laser_sqrt_info;    // 1/line_to_line_sigma   (laser_noise, laser_factor.h:19-24)
+    double ground_p_info;      // 1/manifold_p_sigma     (ground_noise, ground_factor.h:18-22)
+    double ground_q_info;      // 1/manifold_q_sigma
+    int fast_mode;
+};
+
+// Partial-sum slots written by k_linearize, per buffer (doubles):
+//   PL[B][n][LP]   laser group (window, owning frame): Haa(36) Hbb(36) Hab(36) ga(6) gb(6) sum r^2 (1), pad -> 128
+//   PI[B][n-1][PIS] IMU block k (frames k,k+1): G = Y^T Y, Y = [J(15x30) | r], 31x31 row-major, pad -> 964
+//   PW[B][n-1][PWS] wheel block k: G 13x13 (Y = [J(3x12) | r]), pad -> 172
+//   PG[B][n][PGS]   ground of frame i: n * G 7x7 (Y = [J(2x6) | r]), pad -> 52
+constexpr int LP = LIW_LASER_PARTIAL;
+constexpr int PIS = 964;
+constexpr int PWS = 172;
+constexpr int PGS = 52;
+
+// per-window LM state kept on the device across the launches of one solve
+struct LmState {
+    double radius, decrease_factor, x_cost, x_norm, minimum_cost;
+    double cand_step_norm, model_cost_change;
+    int reuse_diagonal, iteration, done, termination, successful, cur, invalid_steps, have_candidate;
+    double initial_cost;
+    double scale[15 * 64];      // Jacobi scaling, up to n = 64 frames
+    double diagonal[15 * 64];
+};
+
+struct WsView {
+    // all device pointers into the caller's workspace
+    // laser partial sums: fixed "current" (0) and "candidate" (1) regions, copy-on-accept (these are the only
+    // partials a factor-sharded multi-GPU run all-reduces); IMU/wheel/ground partials: two buffers, the current
+    // one of window b is lm[b].cur and the candidate goes to the other.
+    double* PL[2]; double* PI[2]; double* PW[2]; double* PG[2];
+    double* x_cand;       // [B][n][15]
+    int* group_off;       // [B][n+1] laser block range of each (window, frame)
+    LmState* lm;          // [B]
+    double* solve_ws;     // [B][n][SOLVE_WS] factorisation scratch
+    liw_summary* info;    // [B]
+    double* history;      // [(records)][B][n][15] or null
+    int history_records;
+    double* marg;         // [B][...] marginalisation scratch
+};
+constexpr int SOLVE_WS = 15 * 15 + 6 * 15 + 15 + 15 * 15 + 15;  // L, Wr(15x6), z, Wo, spare
+
+struct LinArgs {
+    int B, n, mode, eval_small;
+    const double* x;            // states to linearise at [B][n][15]
+    const int* group_off;
+    const int* laser_off;
+    const double* laser_pts; int Ltot;
+    const double* match_pose;
+    const unsigned char* has_match;
+    const double* imu_X; const double* imu_J; const double* imu_sqrtP; const double* imu_Dt;
+    const double* wheel_T; const double* wheel_sqrtP;
+    double* PL;                 // laser partial region to write (current or candidate)
+    double* PI[2]; double* PW[2]; double* PG[2];
+    const LmState* lm;          // null (buffer 0, no skipping), or per-window state: done windows skip
+    int candidate;              // 1: write the small-factor partials of window b into buffer 1 - lm[b].cur
+    // optional per-factor outputs (liw_eval_factors)
+    double* dbg_laser_res; double* dbg_laser_jac; double* dbg_imu_res; double* dbg_imu_jac;
+    double* dbg_wheel_res; double* dbg_wheel_jac; double* dbg_ground_res; double* dbg_ground_jac;
+};
+
+}  // namespace liw

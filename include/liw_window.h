@@ -1,0 +1,209 @@
+/* liw_window.h — C ABI of the MI355X-native sliding-window estimator (libliw_window.so).
+ *
+ * Drop-in boundary for the hot path of LittleDang/2DLIW-SLAM: the library replaces what
+ * `lvio_2d::solver` (reference src/factor/solver.h:28-79, src/factor/solver.cpp) and the factor
+ * functors under src/factor/ compute, behind plain pointers and sizes.  The reference has no FFI of
+ * its own (single C++ process); each entry point below names the C++ interface it stands in for.
+ * INTEGRATION.md shows the `lvio_2d::solver` shim a maintainer adds on the reference side.
+ *
+ * Conventions
+ *   - all floating point is IEEE fp64; every matrix crossing the ABI is ROW-MAJOR;
+ *   - state of a frame = 15 doubles [p(3) q(3) v(3) ba(3) bw(3)], q = rotation vector world<-IMU
+ *     (reference src/trajectory/trajectory_type.h:23-26, order src/factor/solver.cpp:332-342);
+ *   - return 0 on success, negative LIW_E* otherwise; no exceptions cross the ABI; a ctx is not
+ *     thread-safe (the reference's solver is driven by one dispatch thread, src/trajectory/dispatch.h:240);
+ *   - there is NO CPU fallback: every compute entry point fails with LIW_ENODEV when no gfx950 device
+ *     is usable.  (The host-side pre-integrators are sequential per-message code by design.)
+ */
+#ifndef LIW_WINDOW_H
+#define LIW_WINDOW_H
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define LIW_OK 0
+#define LIW_EINVAL (-22)
+#define LIW_ENOMEM (-12)
+#define LIW_ENODEV (-19)
+#define LIW_EHIP (-5)
+#define LIW_ESTATE (-1)
+
+/* Topology of the residual blocks (who the laser blocks tie to, which states are held constant).
+ *   LIW_MODE_INIT  = solver::do_init_solve  (solver.cpp:50-169): laser (frame 0, frame i), all 15n free
+ *   LIW_MODE_TRACK = solver::solve          (solver.cpp:631-820): laser on the newest frame only against the
+ *                    constant laser_match (p1,q1); p,q of frames 0..n-2 constant (bs too in fast_mode);
+ *                    prior block on frame n-2 when one is stored and !fast_mode
+ *   LIW_MODE_MARG  = solver::marginalization (solver.cpp:257-442): every frame's laser rows w.r.t. its own
+ *                    pose only, prior rows on frame n-2, g = -J^T R                                     */
+enum { LIW_MODE_INIT = 0, LIW_MODE_TRACK = 1, LIW_MODE_MARG = 2 };
+
+/* The subset of param::manager the path reads (reference src/utilies/params.h; values config/office.yaml). */
+typedef struct liw_params {
+    double T_imu_to_wheel[16]; /* 4x4 row-major, as in the YAML */
+    double T_imu_to_laser[16];
+    double g;
+    double line_to_line_sigma;
+    double manifold_p_sigma, manifold_q_sigma;
+    double imu_noise_acc_sigma[3], imu_bias_acc_sigma[3], imu_noise_gyro_sigma[3], imu_bias_gyro_sigma[3];
+    double wheel_sigma[3];
+    int fast_mode;
+    int normalize_extrinsics; /* 1: re-orthonormalise through a quaternion like src/utilies/params.cpp:44-54 */
+    int device;               /* HIP device ordinal */
+} liw_params;
+
+/* One window, host memory, array-of-frames flattening of std::deque<frame_info::ptr>
+ * (src/trajectory/trajectory_type.h:9-75) and its laser_match (src/trajectory/laser_type.h:76-85). */
+typedef struct liw_window {
+    int n;                        /* frames */
+    int L;                        /* laser_factor blocks (src/factor/laser_factor.h:26-100) */
+    double* states;               /* [n][15]            in/out */
+    const int* laser_frame;       /* [L] owning frame (frame_infos[i]->laser_match_ptr), ascending */
+    const double* laser_pts;      /* [L][12] lines1[j].p1, lines1[j].p2, lines2[j].p1, lines2[j].p2 */
+    double* match_pose;           /* [n][12] laser_match p1 q1 p2 q2   in/out */
+    const unsigned char* has_match; /* [n] frame type == laser && laser_match_ptr != nullptr */
+    const double* imu_X;          /* [n-1][15]  entry k = frame_infos[k+1]->imu_observation_reslut */
+    const double* imu_J;          /* [n-1][225] */
+    const double* imu_sqrtP;      /* [n-1][225] sqrt_inverse_P */
+    const double* imu_Dt;         /* [n-1] */
+    const double* wheel_T;        /* [n-1][12]  delta_Tij: R (9, row-major) then t (3) */
+    const double* wheel_sqrtP;    /* [n-1][9]   */
+    const double* wheel_Dt;       /* [n-1]      (carried, unused by the factors) */
+} liw_window;
+
+/* ceres::Solver::Summary subset (the reference discards it, solver.cpp:166-168; kept for tests/bench). */
+typedef struct liw_summary {
+    int iterations;        /* LM iterations executed (iteration 0 excluded) */
+    int successful_steps;
+    int termination;       /* 1 gradient tol, 2 function tol, 3 parameter tol, 4 max iterations, 5 min radius, 6 failure */
+    double initial_cost, final_cost;
+} liw_summary;
+
+typedef struct liw_ctx liw_ctx;
+
+/* ---- lifetime ------------------------------------------------------------------------------------ */
+/* replaces: lvio_2d::solver::solver() (solver.cpp:43-48) + the PARAM()/noise singletons the factors read. */
+liw_ctx* liw_create(const liw_params* prm);
+void liw_destroy(liw_ctx* ctx);
+const char* liw_last_error(const liw_ctx* ctx);
+/* extrinsics actually used (after optional re-orthonormalisation), 4x4 row-major each */
+int liw_get_extrinsics(const liw_ctx* ctx, double* T_imu_to_wheel16, double* T_imu_to_laser16);
+
+/* ---- single window, host buffers (the lvio_2d::solver drop-in) ----------------------------------- */
+/* Upload one window (batch of 1).  The liw_window arrays must stay valid until the next liw_set_window:
+ * liw_solve / liw_marginalize scatter results back into `states` and `match_pose` in place, as the
+ * reference mutates frame_info / laser_match in place. */
+int liw_set_window(liw_ctx* ctx, const liw_window* w);
+/* replaces: solver::init_solve (mode INIT, incl. the laser_match fix-up solver.cpp:176-190) and
+ * solver::solve (mode TRACK, incl. the p2,q2 write-back solver.cpp:804-814).  max_iters <= 0 -> Ceres
+ * default 50 (10 in fast_mode for TRACK, solver.cpp:800-801). */
+int liw_solve(liw_ctx* ctx, int mode, int max_iters, liw_summary* summary);
+/* Per-iteration free-state history of the last liw_solve: x[(iters+1)][n][15] (all states, constant ones
+ * included); returns the number of records written (tests / parity gate, BASELINE.md "equality gate"). */
+int liw_get_history(liw_ctx* ctx, double* x, int max_records);
+/* Normal equations at the current states, dense over the full ordering [p q v ba bw] x n:
+ * INIT/TRACK: tangent-space H = J^T J, g = J^T r (constant blocks -> zero rows/cols), cost = 1/2|r|^2
+ * (what ceres evaluates); MARG: H = J^T J, g = -J^T R as solver.cpp:12-13.  H is (15n)^2 row-major. */
+int liw_linearize(liw_ctx* ctx, int mode, double* H, double* g, double* cost);
+/* Per-factor residuals and ambient Jacobians (auto_diff::compute_res_and_jacobi, src/utilies/common.h:201-217).
+ * Any pointer may be NULL.  laser_jac [L][2][12] cols = [p_a q_a p_b q_b]; imu_jac [n-1][15][30] cols =
+ * [x_i(15) x_j(15)]; wheel_jac [n-1][3][12]; ground_res [n][2] (p then q), ground_jac [n][2][6]. */
+int liw_eval_factors(liw_ctx* ctx, int mode, double* laser_res, double* laser_jac, double* imu_res, double* imu_jac,
+                     double* wheel_res, double* wheel_jac, double* ground_res, double* ground_jac);
+/* replaces: solver::marginalization (solver.cpp:257-442): updates the ctx-owned prior
+ * (linearized_X / linearized_jacobians / linearized_residuals) and returns frame_infos.back()->sqrt_H (6x6).
+ * No-op returning 0 in fast_mode (solver.cpp:259-260).  Delta_H (15x15) / Delta_g (15) optional outputs. */
+int liw_marginalize(liw_ctx* ctx, double* sqrt_H36, double* Delta_H225, double* Delta_g15);
+/* the solver's persistent private state (solver.h:31-37); returns 1/0 = has_linearized_block */
+int liw_get_prior(liw_ctx* ctx, double* X15, double* J225, double* R15);
+int liw_set_prior(liw_ctx* ctx, int has_prior, const double* X15, const double* J225, const double* R15);
+
+/* ---- batched windows, device-resident buffers (throughput path; caller owns all device memory) ---- */
+typedef struct liw_batch {
+    int B;                     /* windows */
+    int n;                     /* frames per window (uniform) */
+    int Ltot;                  /* total laser blocks in the batch */
+    double* x;                 /* [B][n][15]   states, updated in place by liw_batch_solve */
+    const int* laser_off;      /* [B+1] window b owns blocks laser_off[b] .. laser_off[b+1]-1 */
+    const int* laser_frame;    /* [Ltot] owning frame inside its window, ascending per window */
+    const double* laser_pts;   /* [12][Ltot] component-major (SoA): c = 3*point + axis, points l1_p1,l1_p2,l2_p1,l2_p2 */
+    double* match_pose;        /* [B][n][12] */
+    const unsigned char* has_match; /* [B][n] */
+    const double* imu_X;       /* [B][n-1][15] */
+    const double* imu_J;       /* [B][n-1][225] */
+    const double* imu_sqrtP;   /* [B][n-1][225] */
+    const double* imu_Dt;      /* [B][n-1] */
+    const double* wheel_T;     /* [B][n-1][12] */
+    const double* wheel_sqrtP; /* [B][n-1][9] */
+    double* prior_X;           /* [B][15]   in/out (liw_batch_marginalize writes it) */
+    double* prior_J;           /* [B][225]  */
+    double* prior_R;           /* [B][15]   */
+    int* has_prior;            /* [B] */
+    /* factor sharding (multi-GPU): this rank evaluates laser blocks only; small factors are evaluated when
+     * eval_small != 0 (every rank evaluates them redundantly, only laser partial sums are all-reduced). */
+    int eval_small;
+    /* > 0: liw_batch_lm_step records the states after every LM iteration into the workspace (tests) */
+    int history_records;
+} liw_batch;
+
+/* Workspace: one caller-allocated device buffer; layout queried here so the host (torch.distributed) can
+ * all-reduce the laser partial-sum region between liw_batch_lm_linearize and liw_batch_lm_step. */
+typedef struct liw_ws_layout {
+    size_t bytes;                /* total */
+    size_t laser_partial_off[2]; /* byte offset of the laser partial sums: [0] current point, [1] candidate point */
+    size_t laser_partial_bytes;  /* B*n*LIW_LASER_PARTIAL doubles */
+    size_t info_off;             /* liw_summary[B] (device) */
+    size_t history_off;          /* optional x history, 0 if not requested */
+} liw_ws_layout;
+#define LIW_LASER_PARTIAL 128
+int liw_batch_ws_layout(int B, int n, int history_records, liw_ws_layout* out);
+
+/* LM driver pieces (what ceres::Solve iterates, solver.cpp:168,802).  All launches go to `stream`
+ * (a hipStream_t passed as void*); nothing synchronises.  Sequence for a solve:
+ *   liw_batch_lm_begin -> liw_batch_lm_linearize(buf 0 at x) -> [ liw_batch_lm_step ; liw_batch_lm_linearize(candidate) ] x K
+ *   -> liw_batch_lm_finish.   liw_batch_solve runs exactly that (optionally as one hipGraph). */
+int liw_batch_set_max_iters(liw_ctx* ctx, int mode, int max_iters); /* cap enforced by liw_batch_lm_step; returns it */
+/* stand-alone linearisation at b->x (partials "current", no LM state): what liw_linearize and the bench kernel
+ * timing use */
+int liw_batch_linearize(liw_ctx* ctx, const liw_batch* b, int mode, void* ws, void* stream);
+int liw_batch_lm_begin(liw_ctx* ctx, const liw_batch* b, int mode, int max_iters, void* ws, void* stream);
+int liw_batch_lm_linearize(liw_ctx* ctx, const liw_batch* b, int mode, int candidate, void* ws, void* stream);
+int liw_batch_lm_step(liw_ctx* ctx, const liw_batch* b, int mode, void* ws, void* stream);
+int liw_batch_lm_finish(liw_ctx* ctx, const liw_batch* b, int mode, void* ws, void* stream);
+int liw_batch_solve(liw_ctx* ctx, const liw_batch* b, int mode, int max_iters, void* ws, void* stream, int use_graph);
+/* marginalisation of every window of the batch (linearise in MARG topology + chain Schur + eigen sqrt);
+ * sqrt_H [B][36], Delta_H [B][225], Delta_g [B][15] optional device outputs */
+int liw_batch_marg_linearize(liw_ctx* ctx, const liw_batch* b, void* ws, void* stream);
+int liw_batch_marg_schur(liw_ctx* ctx, const liw_batch* b, void* ws, double* sqrt_H, double* Delta_H, double* Delta_g, void* stream);
+/* dense export of the assembled normal equations of buffer `buf` (tests / liw_linearize) */
+int liw_batch_export_dense(liw_ctx* ctx, const liw_batch* b, int mode, int buf, void* ws, double* H, double* g, double* cost, void* stream);
+/* timing hook for bench.py: average device time (ms) of the last `liw_batch_solve`'s linearise launches,
+ * measured with hipEvents on `stream` (0 if timing was not enabled) */
+int liw_set_timing(liw_ctx* ctx, int enable);
+int liw_get_timing(liw_ctx* ctx, double* linearize_ms_avg, int* linearize_launches, double* step_ms_avg, int* step_launches);
+
+/* ---- host pre-integrators (sequential per message; replace imu_preintegraption / wheel_odom_preintegration,
+ *      src/factor/imu_preintegraption.h:105-208, src/factor/wheel_odom_preintegration.h:44-152) -------- */
+typedef struct liw_imu_preint liw_imu_preint;
+liw_imu_preint* liw_imu_preint_create(const liw_params* prm);
+void liw_imu_preint_destroy(liw_imu_preint* p);
+void liw_imu_preint_reset(liw_imu_preint* p, double time, const double* acc_bias3, const double* gyr_bias3);
+int liw_imu_preint_add(liw_imu_preint* p, double time_stamp, const double* acc3, const double* gyro3); /* 1 if integrated */
+void liw_imu_preint_update_only_t(liw_imu_preint* p, double time);
+double liw_imu_preint_Dt(const liw_imu_preint* p);
+void liw_imu_preint_result(const liw_imu_preint* p, double* X15, double* J225, double* sqrt_inverse_P225, double* Dt);
+
+typedef struct liw_wheel_preint liw_wheel_preint;
+liw_wheel_preint* liw_wheel_preint_create(const liw_params* prm);
+void liw_wheel_preint_destroy(liw_wheel_preint* p);
+void liw_wheel_preint_reset(liw_wheel_preint* p, double time);
+int liw_wheel_preint_add(liw_wheel_preint* p, double time_stamp, const double* pose_R9, const double* pose_t3);
+void liw_wheel_preint_update_only_t(liw_wheel_preint* p, double time);
+void liw_wheel_preint_result(const liw_wheel_preint* p, double* T12, double* sqrt_inverse_P9, double* Dt);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* LIW_WINDOW_H */

@@ -57,6 +57,7 @@ struct Summary {
     int termination = 0;          // 0 none, 1 gradient tol, 2 function tol, 3 parameter tol, 4 max iters, 5 min radius, 6 failure
     double initial_cost = 0, final_cost = 0, fixed_cost = 0;
     std::vector<IterationRecord> iterations;
+    std::vector<std::pair<double*, int>> layout;   // (user pointer, size) of the non-constant blocks, in x order
 };
 
 typedef std::function<void(const double* const* params, double* res, double** jac)> EvalFn;
@@ -211,6 +212,8 @@ public:
             sum->fixed_cost = evaluate(x, false);
             active_r = keep;
         }
+        sum->layout.clear();
+        for (auto& b : pr.pblocks) if (!b.constant) sum->layout.push_back(std::make_pair(b.user, b.size));
         if (n_tan == 0) { sum->termination = 1; return; }
 
         // ---- iteration 0

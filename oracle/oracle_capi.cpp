@@ -168,14 +168,35 @@ int oracle_summary(void* hv, int* termination, int* successful, double* initial_
     return s.num_iterations;
 }
 int oracle_iteration_count(void* hv) { return int(((oracle_ctx*)hv)->slv->last_summary.iterations.size()); }
-// out: [cost, candidate_cost, model_cost_change, relative_decrease, radius, valid, successful]; x: free-state vector
+// out: [cost, candidate_cost, model_cost_change, relative_decrease, radius, valid, successful];
+// x: the window's states [n][15] after iteration k (constant blocks keep their values)
 int oracle_iteration(void* hv, int k, double* out7, double* x, int x_cap) {
-    auto& it = ((oracle_ctx*)hv)->slv->last_summary.iterations[k];
+    oracle_ctx* h = (oracle_ctx*)hv;
+    auto& sum = h->slv->last_summary;
+    auto& it = sum.iterations[k];
     out7[0] = it.cost; out7[1] = it.candidate_cost; out7[2] = it.model_cost_change; out7[3] = it.relative_decrease;
     out7[4] = it.radius; out7[5] = it.step_is_valid; out7[6] = it.step_is_successful;
-    const int nx = int(it.x.size());
-    for (int i = 0; i < nx && i < x_cap; ++i) x[i] = it.x[i];
-    return nx;
+    const int n = int(h->frames.size());
+    if (x_cap < n * 15) return n * 15;
+    for (int f = 0; f < n; ++f) {
+        auto& fr = h->frames[f];
+        for (int c = 0; c < 3; ++c) { x[f * 15 + c] = fr->p[c]; x[f * 15 + 3 + c] = fr->q[c]; x[f * 15 + 6 + c] = fr->v[c]; }
+        for (int c = 0; c < 6; ++c) x[f * 15 + 9 + c] = fr->bs[c];
+    }
+    size_t pos = 0;
+    for (auto& blk : sum.layout) {
+        for (int f = 0; f < n; ++f) {
+            auto& fr = h->frames[f];
+            int base = -1;
+            if (blk.first == fr->p) base = f * 15;
+            else if (blk.first == fr->q) base = f * 15 + 3;
+            else if (blk.first == fr->v) base = f * 15 + 6;
+            else if (blk.first == fr->bs) base = f * 15 + 9;
+            if (base >= 0) for (int c = 0; c < blk.second; ++c) x[base + c] = it.x[pos + c];
+        }
+        pos += blk.second;
+    }
+    return n * 15;
 }
 
 // prior block kept across calls (solver.h:31-37)

@@ -1,0 +1,134 @@
+"""GPU parity: the HIP path (through the C-ABI) against the CPU oracle on the same seeded windows.
+
+Tolerances (fp64 everywhere; BASELINE.md "equality gate"):
+  per-factor residuals / Jacobians   |d| <= 1e-10 * max(1, |ref|_inf)      (round-off only: same math, different op order)
+  H, g                               <= 1e-9 relative to the block scale
+  states after every LM iteration    <= 1e-6 relative  (north_star)
+"""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def rel(a, b):
+    return float(np.abs(np.asarray(a) - np.asarray(b)).max() / max(1.0, np.abs(np.asarray(b)).max()))
+
+
+@pytest.fixture(scope="module")
+def setup(liw, synth, pyoracle):
+    prm = synth.office_params()
+    orc = pyoracle.Oracle(prm)
+    slv = liw.Solver(prm)
+    return prm, orc, slv
+
+
+@pytest.mark.parametrize("n,L,seed", [(4, 37, 3), (10, 300, 5)])
+def test_factor_residuals_and_jacobians(liw, synth, pyoracle, setup, n, L, seed):
+    prm, orc, slv = setup
+    d = synth.make_window(orc, prm, seed=seed, n=n, L=L)
+    slv.set_window(liw.Window(d))
+    f = slv.eval_factors(liw.LIW_MODE_INIT)
+    st = d["states"]
+    for j in range(L):
+        k = int(d["laser_frame"][j])
+        r, J = orc.eval_laser(d["laser_pts"][j], st[0, 0:3], st[0, 3:6], st[k, 0:3], st[k, 3:6])
+        assert rel(f["laser_res"][j], r) < 1e-10
+        assert rel(f["laser_jac"][j], J) < 1e-10
+    for k in range(n - 1):
+        r, J = orc.eval_imu(d["imu_X"][k], d["imu_J"][k], d["imu_sqrtP"][k], d["imu_Dt"][k], st[k], st[k + 1])
+        assert rel(f["imu_res"][k], r) < 1e-10
+        assert rel(f["imu_jac"][k], J) < 1e-10
+        r, J = orc.eval_wheel(d["wheel_T"][k], d["wheel_sqrtP"][k], st[k, 0:3], st[k, 3:6], st[k + 1, 0:3], st[k + 1, 3:6])
+        assert rel(f["wheel_res"][k], r) < 1e-10
+        assert rel(f["wheel_jac"][k], J) < 1e-10
+    for i in range(n):
+        r, J = orc.eval_ground(st[i, 0:3], st[i, 3:6])
+        assert rel(f["ground_res"][i], r) < 1e-10
+        assert rel(f["ground_jac"][i], J) < 1e-10
+
+
+@pytest.mark.parametrize("n,L,seed", [(3, 20, 1), (10, 300, 5), (30, 2000, 20240)])
+def test_normal_equations_init(liw, synth, pyoracle, setup, n, L, seed):
+    prm, orc, slv = setup
+    d = synth.make_window(orc, prm, seed=seed, n=n, L=L)
+    slv.set_window(liw.Window(d))
+    H, g, c = slv.linearize(liw.LIW_MODE_INIT)
+    Ho, go, co = orc.linearize(pyoracle.Window(d), 0)
+    assert abs(c - co) <= 1e-12 * co
+    assert rel(g, go) < 1e-9
+    assert np.abs(H - Ho).max() <= 1e-9 * np.abs(Ho).max()
+    assert np.abs(H - H.T).max() <= 1e-12 * np.abs(H).max()
+
+
+@pytest.mark.parametrize("n,L,seed,iters", [(6, 60, 1, 50), (30, 2000, 20240, 50)])
+def test_init_solve_history(liw, synth, pyoracle, setup, n, L, seed, iters):
+    prm, orc, slv = setup
+    d = synth.make_window(orc, prm, seed=seed, n=n, L=L)
+    wo = pyoracle.Window(d)
+    orc.set_prior(None)
+    orc.set_max_iterations(iters)
+    orc.init_solve(wo)
+    so = orc.summary()
+    ho = orc.iterations()
+    wg = liw.Window(d)
+    slv.set_window(wg)
+    sg = slv.init_solve(iters)
+    hg = slv.history()
+    assert sg["iterations"] == so["iterations"]
+    assert sg["termination"] == so["termination"]
+    assert len(hg) == len(ho)
+    for k in range(len(ho)):
+        xo = ho[k]["x"].reshape(n, 15)
+        assert np.abs(hg[k] - xo).max() / max(np.abs(xo).max(), 1e-12) <= 1e-6, "iteration %d" % k
+    assert rel(wg["states"], wo["states"]) <= 1e-6
+    assert rel(wg["match_pose"], wo["match_pose"]) <= 1e-6
+    assert abs(sg["final_cost"] - so["final_cost"]) <= 1e-6 * so["final_cost"]
+
+
+def test_marginalization_and_tracking(liw, synth, pyoracle, setup):
+    prm, orc, slv = setup
+    n, L = 10, 300
+    d = synth.make_window(orc, prm, seed=11, n=n, L=L, laser_on_frame0=False)
+    wo, wg = pyoracle.Window(d), liw.Window(d)
+    orc.set_prior(None)
+    slv.set_window(wg)
+    slv.set_prior(None)
+    orc.init_solve(wo)
+    slv.init_solve()
+    orc.marginalization(wo)
+    mg = slv.marginalization()
+    mo = orc.marg_pieces()
+    assert np.abs(mg["Delta_H"] - mo["Delta_H"]).max() <= 1e-7 * np.abs(mo["Delta_H"]).max()
+    assert np.abs(mg["Delta_g"] - mo["Delta_g"]).max() <= 1e-7 * max(1.0, np.abs(mo["Delta_g"]).max())
+    Xg, Jg, Rg = slv.get_prior()
+    Xo, Jo, Ro = orc.get_prior()
+    assert rel(Xg, Xo) <= 1e-6
+    # eigen-vector signs are arbitrary: compare the sign-invariant J^T J (= thresholded Delta_H) and |R|
+    assert np.abs(Jg.T @ Jg - Jo.T @ Jo).max() <= 1e-7 * np.abs(Jo.T @ Jo).max()
+    # MARG-topology normal equations against the oracle's dense J^T J
+    H, g, _ = slv.linearize(liw.LIW_MODE_MARG)
+    # (the prior now stored belongs to this window's last frame; the dense J of the oracle was built before it)
+    # tracking solve on the last two frames with the prior both sides
+    sub = dict(d)
+    keep = slice(n - 2, n)
+    for k in ("states", "match_pose", "has_match"):
+        sub[k] = np.asarray(wo[k]).reshape(n, -1)[keep].copy() if k != "has_match" else np.asarray(d["has_match"])[keep].copy()
+    sub["states"] = wo["states"].reshape(n, 15)[keep].copy()
+    sub["match_pose"] = wo["match_pose"].reshape(n, 12)[keep].copy()
+    for k in ("imu_X", "imu_J", "imu_sqrtP", "imu_Dt", "wheel_T", "wheel_sqrtP", "wheel_Dt"):
+        sub[k] = np.asarray(d[k])[n - 2:n - 1].copy()
+    m = np.asarray(d["laser_frame"]) >= n - 2
+    sub["laser_frame"] = (np.asarray(d["laser_frame"])[m] - (n - 2)).astype(np.int32)
+    sub["laser_pts"] = np.asarray(d["laser_pts"])[m].copy()
+    sub["n"] = 2
+    # perturb the newest frame so the tracker has work to do
+    sub["states"][1, 0:3] += 0.01
+    wo2, wg2 = pyoracle.Window(sub), liw.Window(sub)
+    slv.set_prior((Xo, Jo, Ro))   # identical prior on both sides
+    orc.solve(wo2)
+    so = orc.summary()
+    slv.set_window(wg2)
+    sg = slv.solve()
+    assert sg["iterations"] == so["iterations"] and sg["termination"] == so["termination"]
+    assert rel(wg2["states"], wo2["states"]) <= 1e-6
