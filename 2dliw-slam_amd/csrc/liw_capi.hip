@@ -358,7 +358,6 @@ int liw_batch_solve(liw_ctx* c, const liw_batch* b, int mode, int max_iters, voi
     const int K = resolve_iters(c, mode, max_iters);
     c->last_iters = K;
     hipStream_t s = (hipStream_t)stream;
-    if (c->timing) { c->ev_lin_used = 0; c->ev_step_used = 0; }
     if (use_graph && !c->timing) {
         // cache key: everything the captured launches depend on
         std::vector<unsigned char> key(sizeof(liw_batch) + sizeof(int) * 2 + sizeof(void*));

@@ -1,0 +1,204 @@
+#!/usr/bin/env python
+"""bench.py — sliding-window solves/second of the MI355X-native estimator (BASELINE.json metric).
+
+A "step" = one pass of the hot path over one batch of synthetic input: for each of the B windows of the batch
+(config C2: 30 key-frames, 2 000 laser_factor blocks, 29 IMU + 29 wheel pre-integrated blocks, 2*30^2 ground
+blocks) one init-topology Levenberg–Marquardt solve to Ceres termination (cap 50 iterations) followed by one
+marginalisation — i.e. what `lvio_2d::solver::init_solve` + `solver::marginalization` do for the reference's
+trajectory (src/trajectory/trajectory.cpp:446,479).  Inputs are resident in HBM before the timed region.
+
+N > 1 (launched by torch.distributed.run, one rank per GPU): windows are independent, so ranks hold disjoint
+window batches (replicas, weak scaling, no data-path collective); the factor-sharded mode (laser blocks of each
+window split across ranks, RCCL all-reduce of the laser partial sums per LM iteration) is measured separately on
+the C4-shaped window and reported under "factor_sharded".
+"""
+import argparse
+import importlib
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+# algorithmic bytes per residual block ("materialised-J" convention)
+BYTES_LASER_BOTH, BYTES_LASER_ONE, BYTES_IMU, BYTES_WHEEL, BYTES_GROUND, BYTES_STATE = 312, 216, 7448, 520, 60, 120
+HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8 TB/s
+
+
+def algorithmic_bytes(n, L, both_free):
+    return L * (BYTES_LASER_BOTH if both_free else BYTES_LASER_ONE) + (n - 1) * (BYTES_IMU + BYTES_WHEEL) + 2 * n * n * BYTES_GROUND + n * BYTES_STATE
+
+
+def make_batch(liw, synth, prm, B, n, L, seed0, n_base=4):
+    """B windows: n_base fully generated windows (distinct seeds), tiled with per-window state perturbations."""
+    hp = liw.HostPreint(prm)
+    base = [synth.make_window(hp, prm, seed=seed0 + k, n=n, L=L) for k in range(min(n_base, B))]
+    rng = np.random.default_rng(seed0 + 1000)
+    out = []
+    for b in range(B):
+        w = dict(base[b % len(base)])
+        if b >= len(base):
+            st = np.array(w["states"], copy=True)
+            st[:, 0:3] += rng.normal(0.0, 2e-3, (n, 3))
+            st[:, 6:9] += rng.normal(0.0, 2e-3, (n, 3))
+            w["states"] = st
+            mp = np.array(w["match_pose"], copy=True)
+            mp[:, 0:6] = st[0, 0:6]
+            mp[:, 6:12] = st[:, 0:6]
+            w["match_pose"] = mp
+        out.append(w)
+    return out
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--batch", type=int, default=int(os.environ.get("LIW_BENCH_BATCH", 1024)), help="windows per GPU per step")
+    ap.add_argument("--frames", type=int, default=30)
+    ap.add_argument("--laser", type=int, default=2000)
+    ap.add_argument("--iters", type=int, default=50, help="LM iteration cap (Ceres default 50)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-reps", type=int, default=12)
+    ap.add_argument("--skip-sharded", action="store_true")
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+
+    rank = int(os.environ.get("RANK", 0))
+    world = int(os.environ.get("WORLD_SIZE", 1))
+    local_rank = int(os.environ.get("LOCAL_RANK", 0))
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        dist.init_process_group(backend="nccl", rank=rank, world_size=world)
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU (the estimator has no CPU fallback)")
+    torch.cuda.set_device(local_rank)
+    dev = "cuda:%d" % local_rank
+
+    liw = importlib.import_module("2dliw-slam_amd")
+    synth = importlib.import_module("2dliw-slam_amd.synth")
+    prm = synth.office_params()
+    n, L, B = args.frames, args.laser, args.batch
+
+    windows = make_batch(liw, synth, prm, B, n, L, seed0=20240 + 7919 * rank)
+    bs = liw.BatchSolver(prm, windows, device=dev)
+    x0 = bs.t["x"].clone()
+    mp0 = bs.t["match_pose"].clone()
+
+    def one_step():
+        bs.t["x"].copy_(x0)
+        bs.t["match_pose"].copy_(mp0)
+        bs.t["has_prior"].zero_()
+        bs.solve(liw.LIW_MODE_INIT, args.iters)
+        bs.marginalize()
+
+    def barrier():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        one_step()
+    barrier()
+    bs.set_timing(True)
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        one_step()
+    barrier()
+    t1 = time.perf_counter()
+    elapsed = t1 - t0
+    tm = bs.get_timing()
+    bs.set_timing(False)
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    summ = bs.summaries()
+    iters = np.array([s["iterations"] for s in summ])
+    term = np.array([s["termination"] for s in summ])
+
+    # ---- roofline of the dominant kernel (k_linearize), from the HIP-event durations of the timed region
+    # window-launches: every window takes part in the initial linearisation, one per LM iteration, and the
+    # marginalisation linearisation (one pose free per laser block there)
+    bytes_init = algorithmic_bytes(n, L, True)
+    bytes_marg = algorithmic_bytes(n, L, False)
+    lm_window_launches = int((iters + 1).sum())
+    alg_bytes_total = args.steps * (lm_window_launches * bytes_init + B * bytes_marg)
+    lin_time_s = tm["linearize_ms"] * tm["linearize_launches"] * 1e-3
+    achieved = alg_bytes_total / lin_time_s / 1e9 if lin_time_s > 0 else 0.0
+    traffic = None
+    pmc = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+    if os.path.exists(pmc):
+        try:
+            traffic = json.load(open(pmc)).get("k_linearize_hbm_bytes_per_launch")
+        except Exception:
+            traffic = None
+    roofline = {"bound": "hbm", "kernel": "k_linearize", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
+                "avg_launch_ms": round(tm["linearize_ms"], 5), "launches": tm["linearize_launches"],
+                "algorithmic_bytes_per_window": bytes_init,
+                "algorithmic_bytes_per_full_launch": B * bytes_init,
+                "lm_step_kernel_avg_ms": round(tm["step_ms"], 5), "lm_step_launches": tm["step_launches"]}
+
+    # ---- CPU baseline: the oracle (port of the reference algorithm) on the host cores, rank 0, N = 1 only
+    cpu = None
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        from oracle import pyoracle
+        orc = pyoracle.Oracle(prm)
+        w = pyoracle.Window(windows[0])
+        sec, it = orc.time_solves(w, args.cpu_reps, args.iters, dense_product=True)
+        cpu = {"value": round(args.cpu_reps / sec, 4), "unit": "solves/s", "cores": 1, "kind": "port",
+               "sample": "%d x (init_solve + marginalization) of window seed 20240 (n=%d, L=%d), %d LM iterations total, %.1f s"
+                         % (args.cpu_reps, n, L, it, sec),
+               "host_cpu_count": os.cpu_count()}
+
+    # ---- factor-sharded mode (N > 1): C4-shaped window, RCCL all-reduce of the laser partial sums per iteration
+    sharded = None
+    if world > 1 and not args.skip_sharded:
+        Bs, Ls = 64, 20000
+        hp = liw.HostPreint(prm)
+        wfull = [synth.make_window(hp, prm, seed=4242 + k, n=n, L=Ls) for k in range(2)]
+        wl = [wfull[k % 2] for k in range(Bs)]
+        sb = liw.BatchSolver(prm, wl, device=dev, rank=rank, world=world)
+        xs0 = sb.t["x"].clone()
+        for rep in range(2):
+            sb.t["x"].copy_(xs0)
+            barrier()
+            ts = time.perf_counter()
+            sb.solve(liw.LIW_MODE_INIT, 10)
+            barrier()
+            te = time.perf_counter()
+        sharded = {"workload": "C4: %d windows x (n=%d, L=%d) laser blocks split over %d ranks, 10 LM iterations" % (Bs, n, Ls, world),
+                   "solves_per_s": round(Bs / (te - ts), 3), "allreduce_bytes_per_iteration": int(sb.lay.laser_partial_bytes)}
+
+    if rank == 0:
+        total = B * world * args.steps
+        out = {"metric": "sliding-window solves/sec (30 KF, 2k scan pts)", "value": round(total / elapsed, 3), "unit": "solves/s",
+               "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(1e3 * elapsed / args.steps, 3),
+               "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+               "config": {"workload": "C2 synthetic: %d windows/GPU x (n=%d frames, L=%d laser_factor blocks, %d IMU + %d wheel, %d ground); "
+                                      "step = init-topology LM solve (cap %d iters) + marginalization per window" % (B, n, L, n - 1, n - 1, 2 * n * n, args.iters),
+                          "windows_per_gpu": B, "frames": n, "laser_blocks": L, "lm_iteration_cap": args.iters,
+                          "parallelism": "windows replicated over %d GPU(s), no data-path collective" % world,
+                          "lm_iterations_mean": float(iters.mean()), "terminations": {str(int(k)): int((term == k).sum()) for k in np.unique(term)}},
+               "roofline": roofline, "cpu_baseline": cpu}
+        if cpu:
+            out["speedup_vs_cpu_1core"] = round(out["value"] / cpu["value"], 1)
+        if sharded:
+            out["factor_sharded"] = sharded
+        print(json.dumps(out))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()
