@@ -248,8 +248,39 @@ struct LdsTiles {
 };
 
 // ---------------------------------------------------------------------------------------------------
+// diag(H) of frame i in tangent space (lane v < 15 returns H_vv), for the Jacobi scaling fixed at iteration 0
+__device__ double frame_diag(const AsmCtx& c, int i, LdsTiles& T) {
+    const int lane = threadIdx.x & 63, n = c.n;
+    double Pq[9];
+    if (so3_plus_jac(c.x + (size_t)i * 15 + 3, Pq)) {   // rare: |q| > pi -> full tangent assembly
+        assemble_frame(c, i, T.D, T.O, T.R, T.g, T.tmp);
+        const double d = lane < 15 ? T.D[lane * 16 + lane] : 0.0;
+        __syncthreads();
+        return d;
+    }
+    if (lane >= 15) return 0.0;
+    const int r = lane;
+    const double* PLb = c.PL + (size_t)c.b * n * LP;
+    const double* PIb = c.PI + (size_t)c.b * (n - 1) * PIS;
+    const double* PWb = c.PW + (size_t)c.b * (n - 1) * PWS;
+    const double* PGb = c.PG + (size_t)c.b * n * PGS;
+    double d = 0.0;
+    if (r < 6) {
+        d += PLb[(size_t)i * LP + 36 + r * 7];
+        if (i == 0) for (int j = 0; j < n; ++j) d += PLb[(size_t)j * LP + r * 7];
+        if (i >= 1) d += PWb[(size_t)(i - 1) * PWS + (6 + r) * 14];
+        if (i <= n - 2) d += PWb[(size_t)i * PWS + r * 14];
+        d += PGb[(size_t)i * PGS + r * 8];
+    }
+    if (i >= 1) d += PIb[(size_t)(i - 1) * PIS + (15 + r) * 32];
+    if (i <= n - 2) d += PIb[(size_t)i * PIS + r * 32];
+    if (c.prior_on && i == n - 2) { double s = 0.0; for (int k = 0; k < 15; ++k) s += c.pJ[k * 15 + r] * c.pJ[k * 15 + r]; d += s; }
+    return d;
+}
+
 __global__ __launch_bounds__(64) void k_lm_step(StepArgs a) {
     __shared__ LdsTiles T;
+    __shared__ double Fb[SOLVE_WS + 6];   // one frame's factor record staged for the back substitution
     const int b = blockIdx.x, lane = threadIdx.x & 63;
     if (b >= a.B) return;
     LmState& st = a.w.lm[b];
@@ -263,11 +294,10 @@ __global__ __launch_bounds__(64) void k_lm_step(StepArgs a) {
     c.pJ = a.prior_J + (size_t)b * 225; c.pX = a.prior_X + (size_t)b * 15;
     c.prior_on = a.mode == LIW_MODE_TRACK && a.has_prior[b] && !a.fast_mode;
 
-    // uniform copies of the LM state
     double radius = st.radius, dec = st.decrease_factor, x_cost = st.x_cost, x_norm = st.x_norm;
     int reuse = st.reuse_diagonal, iteration = st.iteration, cur = st.cur;
     bool last_successful = true;
-    bool fresh = false;   // true when (H,g) at the current x was not factorised yet (scaling init)
+    bool fresh = false;
 
     if (iteration == 0 && !st.have_candidate) {
         // ---- iteration 0: cost at the initial point
@@ -278,6 +308,8 @@ __global__ __launch_bounds__(64) void k_lm_step(StepArgs a) {
         x_norm = sqrt(wave_sum(s));
         if (lane == 0) { st.initial_cost = x_cost; st.minimum_cost = x_cost; }
         fresh = true;
+        if (a.w.history && a.w.history_records > 0)
+            for (int e = lane; e < n * 15; e += 64) a.w.history[((size_t)b) * n * 15 + e] = xw[e];
     } else if (st.have_candidate) {
         // ---- candidate evaluated by the previous linearise launch
         const int cb = 1 - cur;
@@ -323,75 +355,62 @@ __global__ __launch_bounds__(64) void k_lm_step(StepArgs a) {
         if (a.w.history && iteration < a.w.history_records)
             for (int e = lane; e < n * 15; e += 64) a.w.history[((size_t)iteration * a.B + b) * n * 15 + e] = xw[e];
     }
-    if (iteration == 0 && fresh && a.w.history && a.w.history_records > 0)
-        for (int e = lane; e < n * 15; e += 64) a.w.history[((size_t)b) * n * 15 + e] = xw[e];
+
+    // ---- FinalizeIterationAndCheckIfMinimizerCanContinue, part 1 (the gradient test needs the assembled g and is
+    //      applied after the pass below; it can only pre-empt the min-radius exit, never the iteration cap)
+    if (iteration >= a.max_iters && !(iteration == 0 && fresh)) {
+        if (lane == 0) {
+            st.done = 1; st.termination = 4; st.radius = radius; st.decrease_factor = dec; st.x_cost = x_cost; st.x_norm = x_norm;
+            st.reuse_diagonal = reuse; st.cur = cur; st.have_candidate = 0;
+        }
+        return;
+    }
 
     // current linearisation
     __syncthreads();
     c.buf = cur; c.PL = a.w.PL[0]; c.PI = a.w.PI[cur]; c.PW = a.w.PW[cur]; c.PG = a.w.PG[cur]; c.x = xw;
 
-    // ---- pass 1 over the frames: diag(H) (Jacobi scaling at iteration 0, LM diagonal), gradient max norm
-    double gmax = 0.0;
-    for (int i = 0; i < n; ++i) {
-        assemble_frame(c, i, T.D, T.O, T.R, T.g, T.tmp);
-        if (lane < 15) {
-            const int v = lane;
-            const bool cst = var_is_const(a.mode, a.fast_mode, n, i, v);
-            const double hjj = T.D[v * 16 + v];
-            const double sc = cst ? 1.0 : (fresh ? 1.0 / (1.0 + sqrt(hjj)) : st.scale[i * 15 + v]);
-            if (fresh) st.scale[i * 15 + v] = sc;
-            if (!reuse) st.diagonal[i * 15 + v] = fmin(fmax(hjj * sc * sc, kMinDiag), kMaxDiag);
-        }
-        // |x - Plus(x, -g)| over the free variables
-        if (lane == 0) {
-            const double* xs = xw + (size_t)i * 15;
-            double m = 0.0;
-            for (int v = 0; v < 15; ++v) {
-                if (var_is_const(a.mode, a.fast_mode, n, i, v)) continue;
-                if (v < 3 || v >= 6) m = fmax(m, fabs(T.g[v]));
-            }
-            if (!var_is_const(a.mode, a.fast_mode, n, i, 3)) {
-                double ng[3] = {-T.g[3], -T.g[4], -T.g[5]}, qn[3];
-                so3_plus(xs + 3, ng, qn);
-                for (int k = 0; k < 3; ++k) m = fmax(m, fabs(xs[3 + k] - qn[k]));
-            }
-            T.tmp[15] = m;
+    if (fresh) {   // Jacobi scaling 1/(1+sqrt(H_jj)), computed once per solve
+        for (int i = 0; i < n; ++i) {
+            const double hjj = frame_diag(c, i, T);
+            if (lane < 15) st.scale[i * 15 + lane] = var_is_const(a.mode, a.fast_mode, n, i, lane) ? 1.0 : 1.0 / (1.0 + sqrt(hjj));
         }
         __syncthreads();
-        gmax = fmax(gmax, T.tmp[15]);
-        __syncthreads();
     }
-    __threadfence_block();
+    const double* scl = st.scale;
+    double* dgl = st.diagonal;
+    double* sws = a.w.solve_ws + (size_t)b * n * SOLVE_WS;
 
-    // ---- FinalizeIterationAndCheckIfMinimizerCanContinue
-    int term = 0;
-    if (iteration == 0 && fresh) { if (gmax <= kGradTol) term = 1; }
-    if (!term) {
-        if (iteration >= a.max_iters) term = 4;
-        else if (iteration > 0 && last_successful && gmax <= kGradTol) term = 1;
-        else if (!(radius > kMinRadius)) term = 5;
-    }
-    if (term) {
-        if (lane == 0) {
-            st.done = 1; st.termination = term; st.radius = radius; st.decrease_factor = dec; st.x_cost = x_cost; st.x_norm = x_norm;
-            st.reuse_diagonal = reuse; st.cur = cur; st.have_candidate = 0;
-        }
-        return;
-    }
-    ++iteration;
-
-    // ---- pass 2: eliminate frames n-1 .. 1 of (S H S + D^2) y = S g
+    // ---- single pass: eliminate frames n-1 .. 1, then 0, of (S H S + D^2) y = S g
     for (int e = lane; e < 256; e += 64) { T.CD[e] = 0.0; T.CR[e] = 0.0; }
     if (lane < 16) T.Cg[lane] = 0.0;
     if (lane < 36) T.D0acc[lane] = 0.0;
     if (lane < 8) T.g0acc[lane] = 0.0;
     __syncthreads();
     bool solved = true;
-    const double* scl = st.scale;
-    const double* dg = st.diagonal;
-    double* sws = a.w.solve_ws + (size_t)b * n * SOLVE_WS;
+    double gmax = 0.0;
     for (int i = n - 1; i >= 0; --i) {
         assemble_frame(c, i, T.D, T.O, T.R, T.g, T.tmp);
+        // LM diagonal of this frame (LevenbergMarquardtStrategy::ComputeStep) and |x - Plus(x,-g)|
+        double myd = 0.0;
+        if (lane < 15) {
+            const bool cst = var_is_const(a.mode, a.fast_mode, n, i, lane);
+            const double sc = scl[i * 15 + lane];
+            if (!reuse) dgl[i * 15 + lane] = fmin(fmax(T.D[lane * 16 + lane] * sc * sc, kMinDiag), kMaxDiag);
+            myd = dgl[i * 15 + lane];
+            double m = 0.0;
+            if (!cst) {
+                if (lane < 3 || lane >= 6) m = fabs(T.g[lane]);
+                else {
+                    const double* xs = xw + (size_t)i * 15;
+                    double ng[3] = {-T.g[3], -T.g[4], -T.g[5]}, qn[3];
+                    so3_plus(xs + 3, ng, qn);
+                    m = fabs(xs[lane] - qn[lane - 3]);
+                }
+            }
+            gmax = fmax(gmax, m);
+        }
+        __syncthreads();
         // scale, damp, add the carried Schur terms
         for (int e = lane; e < 256; e += 64) {
             const int r = e >> 4, cc = e & 15;
@@ -399,7 +418,7 @@ __global__ __launch_bounds__(64) void k_lm_step(StepArgs a) {
                 double d = T.D[e] * scl[i * 15 + r] * scl[i * 15 + cc] + T.CD[e];
                 if (r == cc) {
                     if (var_is_const(a.mode, a.fast_mode, n, i, r)) d = 1.0;
-                    else d += dg[i * 15 + r] / radius;
+                    else d += dgl[i * 15 + r] / radius;
                 }
                 T.D[e] = d;
                 if (i >= 1) T.O[e] = T.O[e] * scl[(i - 1) * 15 + r] * scl[i * 15 + cc];
@@ -408,7 +427,12 @@ __global__ __launch_bounds__(64) void k_lm_step(StepArgs a) {
                 T.R[e] = rv;
             } else { T.D[e] = 0.0; T.O[e] = 0.0; T.R[e] = 0.0; }
         }
-        if (lane < 16) T.g[lane] = lane < 15 ? T.g[lane] * scl[i * 15 + lane] + T.Cg[lane] : 0.0;
+        (void)myd;
+        if (lane < 16) {
+            const double gsv = lane < 15 ? T.g[lane] * scl[i * 15 + lane] : 0.0;
+            if (lane < 15) sws[(size_t)i * SOLVE_WS + 225 + 90 + 15 + 225 + lane] = gsv;   // original scaled gradient
+            T.g[lane] = lane < 15 ? gsv + T.Cg[lane] : 0.0;
+        }
         __syncthreads();
         if (i == 0) {
             for (int e = lane; e < 36; e += 64) T.D[(e / 6) * 16 + e % 6] += T.D0acc[e];
@@ -445,7 +469,7 @@ __global__ __launch_bounds__(64) void k_lm_step(StepArgs a) {
         }
         if (lane < 16) { T.W[15 * 16 + lane] = 0.0; T.Wa[15 * 16 + lane] = 0.0; }
         __syncthreads();
-        // keep the factor for the back substitution: L (lower 15x15), Wo, Wr, z
+        // keep the factor for the back substitution: L (lower 15x15), Wr, z, Wo
         {
             double* f = sws + (size_t)i * SOLVE_WS;
             for (int e = lane; e < 225; e += 64) { const int r = e / 15, cc = e % 15; f[e] = T.D[r * 16 + cc]; f[225 + 90 + 15 + e] = T.W[r * 16 + cc]; }
@@ -472,92 +496,76 @@ __global__ __launch_bounds__(64) void k_lm_step(StepArgs a) {
             __syncthreads();
         }
     }
+    gmax = wave_max(gmax);
+    // ---- FinalizeIterationAndCheck, part 2
+    {
+        int term = 0;
+        if (iteration == 0 && fresh) { if (gmax <= kGradTol) term = 1; }
+        else if (last_successful && gmax <= kGradTol) term = 1;
+        if (!term && !(radius > kMinRadius)) term = 5;
+        if (term) {
+            if (lane == 0) {
+                st.done = 1; st.termination = term; st.radius = radius; st.decrease_factor = dec; st.x_cost = x_cost; st.x_norm = x_norm;
+                st.reuse_diagonal = reuse; st.cur = cur; st.have_candidate = 0;
+            }
+            return;
+        }
+    }
+    ++iteration;
+
     double model_cost_change = 0.0, step_norm = 0.0;
     bool valid = false;
     if (solved) {
-        // ---- frame 0 solve and back substitution (y kept in x_cand as scratch, frame by frame)
-        double* f0 = sws;
-        if (lane == 0) {
-            double z[15], y[15];
-            for (int r = 0; r < 15; ++r) z[r] = f0[225 + 90 + r];
-            for (int r = 14; r >= 0; --r) {
-                double s = z[r];
-                for (int k = r + 1; k < 15; ++k) s -= f0[k * 15 + r] * y[k];
-                y[r] = s / f0[r * 15 + r];
-            }
-            for (int r = 0; r < 15; ++r) { T.y0[r] = y[r]; T.yprev[r] = y[r]; }
-        }
-        __syncthreads();
-        // step (scaled space) of frame 0 -> candidate
-        double sg = 0.0;
-        auto emit = [&](int i) {
-            // T.yprev holds y of frame i (solution of the damped system); step = -y ; delta = step * scale
-            if (lane == 0) {
-                const double* xs = xw + (size_t)i * 15;
-                double* xo = xc + (size_t)i * 15;
-                double del[15];
-                for (int v = 0; v < 15; ++v) del[v] = var_is_const(a.mode, a.fast_mode, n, i, v) ? 0.0 : -T.yprev[v] * scl[i * 15 + v];
-                for (int v = 0; v < 15; ++v) if (v < 3 || v >= 6) xo[v] = xs[v] + del[v];
-                if (var_is_const(a.mode, a.fast_mode, n, i, 3)) { xo[3] = xs[3]; xo[4] = xs[4]; xo[5] = xs[5]; }
-                else so3_plus(xs + 3, del + 3, xo + 3);
-                double sn = 0.0;
-                for (int v = 0; v < 15; ++v) if (!var_is_const(a.mode, a.fast_mode, n, i, v)) sn += (xs[v] - xo[v]) * (xs[v] - xo[v]);
-                T.tmp[0] = sn;
-            }
-        };
-        // the steps are kept per frame in solve_ws (slot "spare") for the model-cost pass
-        emit(0);
-        if (lane < 15) sws[225 + 90 + 15 + 225 + lane] = -T.y0[lane];
-        __syncthreads();
-        step_norm += T.tmp[0];
-        for (int i = 1; i < n; ++i) {
-            const double* f = sws + (size_t)i * SOLVE_WS;
-            if (lane < 15) {
-                double s = f[225 + 90 + lane];
-                for (int k = 0; k < 15; ++k) s -= f[225 + 90 + 15 + lane * 15 + k] * T.yprev[k];   // Wo[r][k]: row r = lane
-                if (i >= 2) for (int k = 0; k < 6; ++k) s -= f[225 + lane * 6 + k] * T.y0[k];
-                T.tmp[lane] = s;
-            }
-            __syncthreads();
-            if (lane == 0) {
-                double y[15];
-                for (int r = 14; r >= 0; --r) {
-                    double s = T.tmp[r];
-                    for (int k = r + 1; k < 15; ++k) s -= f[k * 15 + r] * y[k];
-                    y[r] = s / f[r * 15 + r];
-                }
-                for (int r = 0; r < 15; ++r) T.yprev[r] = y[r];
-            }
-            __syncthreads();
-            emit(i);
-            if (lane < 15) sws[(size_t)i * SOLVE_WS + 225 + 90 + 15 + 225 + lane] = -T.yprev[lane];
-            __syncthreads();
-            step_norm += T.tmp[0];
-        }
-        step_norm = sqrt(step_norm);
-        // ---- model cost change  -(s'g_s + s' A s / 2),  A = S H S (undamped), third pass over the blocks
-        double q_sg = 0.0, q_sAs = 0.0;
+        // ---- back substitution, frame 0 first; every frame's record is staged in LDS with coalesced loads
+        double ytg = 0.0, dsum = 0.0, sn2 = 0.0;
         for (int i = 0; i < n; ++i) {
-            assemble_frame(c, i, T.D, T.O, T.R, T.g, T.tmp);
-            const double* si = sws + (size_t)i * SOLVE_WS + 225 + 90 + 15 + 225;
-            const double* sm = i >= 1 ? sws + (size_t)(i - 1) * SOLVE_WS + 225 + 90 + 15 + 225 : si;
-            const double* s0 = sws + 225 + 90 + 15 + 225;
-            double part = 0.0;
-            for (int e = lane; e < 256; e += 64) {
-                const int r = e >> 4, cc = e & 15;
-                if (r < 15 && cc < 15) {
-                    part += si[r] * T.D[e] * scl[i * 15 + r] * scl[i * 15 + cc] * si[cc];
-                    if (i >= 1) part += 2.0 * sm[r] * T.O[e] * scl[(i - 1) * 15 + r] * scl[i * 15 + cc] * si[cc];
-                    if (i >= 2 && r < 6) part += 2.0 * s0[r] * T.R[e] * scl[r] * scl[i * 15 + cc] * si[cc];
+            const double* f = sws + (size_t)i * SOLVE_WS;
+            for (int e = lane; e < SOLVE_WS; e += 64) Fb[e] = f[e];
+            __syncthreads();
+            // rhs = z - Wo y_{i-1} - Wr y_0[0:6]
+            double t = 0.0;
+            if (lane < 15) {
+                t = Fb[225 + 90 + lane];
+                if (i >= 1) {
+#pragma unroll
+                    for (int k = 0; k < 15; ++k) t -= Fb[225 + 90 + 15 + lane * 15 + k] * T.yprev[k];
+                }
+                if (i >= 2) {
+#pragma unroll
+                    for (int k = 0; k < 6; ++k) t -= Fb[225 + lane * 6 + k] * T.y0[k];
                 }
             }
-            q_sAs += part;
-            if (lane < 15) q_sg += si[lane] * T.g[lane] * scl[i * 15 + lane];
+            // L^T y = rhs, lanes hold one unknown each
+#pragma unroll
+            for (int r = 14; r >= 0; --r) {
+                const double yr = __shfl(t, r, 64) / Fb[r * 15 + r];
+                if (lane == r) t = yr;
+                else if (lane < r) t -= Fb[r * 15 + lane] * yr;
+            }
+            __syncthreads();
+            if (lane < 15) { T.yprev[lane] = t; if (i == 0) T.y0[lane] = t; }
+            // candidate of this frame: delta = -y * scale ; Plus
+            const bool cst = lane < 15 && var_is_const(a.mode, a.fast_mode, n, i, lane);
+            const double del = (lane < 15 && !cst) ? -t * scl[i * 15 + lane] : 0.0;
+            const double* xs = xw + (size_t)i * 15;
+            double dq[3] = {__shfl(del, 3, 64), __shfl(del, 4, 64), __shfl(del, 5, 64)}, qn[3];
+            so3_plus(xs + 3, dq, qn);
+            if (lane < 15) {
+                const double xold = xs[lane];
+                double xnew = xold + del;
+                if (lane >= 3 && lane < 6) xnew = var_is_const(a.mode, a.fast_mode, n, i, 3) ? xold : qn[lane - 3];
+                xc[(size_t)i * 15 + lane] = xnew;
+                if (!cst) {
+                    sn2 += (xold - xnew) * (xold - xnew);
+                    ytg += t * Fb[225 + 90 + 15 + 225 + lane];
+                    dsum += dgl[i * 15 + lane] / radius * t * t;
+                }
+            }
             __syncthreads();
         }
-        q_sAs = wave_sum(q_sAs);
-        q_sg = wave_sum(q_sg);
-        model_cost_change = -(q_sg + 0.5 * q_sAs);
+        step_norm = sqrt(wave_sum(sn2));
+        // model cost change -(s'g_s + s'A s/2) with s = -y and (A + D^2) y = g_s  ==  (y'g_s + y'D^2 y)/2
+        model_cost_change = 0.5 * (wave_sum(ytg) + wave_sum(dsum));
         valid = model_cost_change > 0.0 && isfinite(model_cost_change);
     }
     if (lane == 0) {
