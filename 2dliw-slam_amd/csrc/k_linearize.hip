@@ -23,71 +23,87 @@ namespace liw {
 __device__ __forceinline__ double bcast(double v, int src_lane) { return __shfl(v, src_lane, 64); }
 
 // ------------------------------------------------------------------------------------------- laser
-struct Tf2 {          // rows 0,1 of  make_tf(p,theta) * T_imu_to_laser  and d/dtheta_k
-    double M[2][3], t[2];
-    double dM[3][2][3], dt[3][2];
-};
-
-__device__ __forceinline__ void frame_tf2(const DevParams& P, const double* pose6, Tf2& o) {
-    const int lane = threadIdx.x & 63;
-    const int dir = lane & 3;  // 0..2 -> d/dtheta_dir ; 3 -> value only
+// Frame transform record (FTF doubles): rows 0,1 of  make_tf(p,theta) * T_imu_to_laser  and d/dtheta_k, k = 0..2:
+//   [0..5] M[2][3]   [6..7] t[2]   [8+6k .. 8+6k+5] dM_k[2][3]   [26+2k .. 26+2k+1] dt_k[2]
+// k_frame_tf writes two records per (window, frame): slot 0 at the frame's own pose, slot 1 at the constant
+// laser_match pose (p1,q1) the tracking / marginalisation topologies tie the frame to.
+__global__ void k_frame_tf(int B, int n, const double* x, const double* match_pose, double* ftf, DevParams P, const LmState* lm) {
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    const int dir = t & 3, rec = t >> 2;           // 4 lanes per record: 3 derivative directions + value
+    if (rec >= B * n * 2) return;
+    const int slot = rec & 1, fi = rec >> 1;
+    if (lm && lm[fi / n].done) return;
+    const double* pose6 = slot ? (match_pose + (size_t)fi * 12) : (x + (size_t)fi * 15);
     V3<LJ> p = cast_v3<LJ>(pose6);
     V3<LJ> th(LJ(pose6[3], dir == 0 ? 1.0 : 0.0), LJ(pose6[4], dir == 1 ? 1.0 : 0.0), LJ(pose6[5], dir == 2 ? 1.0 : 0.0));
     Iso<LJ> Twl = mul(make_tf(p, th), cast_iso<LJ>(P.Ril, P.til));
-#pragma unroll
-    for (int r = 0; r < 2; ++r) {
-#pragma unroll
-        for (int c = 0; c < 3; ++c) {
-            o.M[r][c] = Twl.R(r, c).v;
-#pragma unroll
-            for (int k = 0; k < 3; ++k) o.dM[k][r][c] = bcast(Twl.R(r, c).d, k);
-        }
-    }
+    double* o = ftf + (size_t)rec * FTF;
     const LJ tt[2] = {Twl.t.x, Twl.t.y};
-#pragma unroll
-    for (int r = 0; r < 2; ++r) {
-        o.t[r] = tt[r].v;
-#pragma unroll
-        for (int k = 0; k < 3; ++k) o.dt[k][r] = bcast(tt[r].d, k);
+    if (dir == 3) {
+        for (int r = 0; r < 2; ++r) { for (int c = 0; c < 3; ++c) o[r * 3 + c] = Twl.R(r, c).v; o[6 + r] = tt[r].v; }
+    } else {
+        for (int r = 0; r < 2; ++r) { for (int c = 0; c < 3; ++c) o[8 + 6 * dir + r * 3 + c] = Twl.R(r, c).d; o[26 + 2 * dir + r] = tt[r].d; }
     }
 }
 
+// Wave-wide sums of V per-lane values (V = 32 or 16) in V-1 pair exchanges + log2(64/V) plain steps: each step pairs
+// value j with value j + V/2 across the lane bit BIT, halving the values a lane still owns.  Afterwards every lane
+// holds the total of value  lane >> log2(64/V).
+template <int V, int BIT>
+__device__ __forceinline__ void bfly_step(double* v, int lane) {
+    if constexpr (V > 1) {
+        const bool up = (lane & BIT) != 0;
+#pragma unroll
+        for (int j = 0; j < V / 2; ++j) {
+            const double send = up ? v[j] : v[j + V / 2];
+            const double keep = up ? v[j + V / 2] : v[j];
+            v[j] = keep + __shfl_xor(send, BIT, 64);
+        }
+        if constexpr (BIT > 1) bfly_step<V / 2, BIT / 2>(v, lane);
+    } else {
+        v[0] += __shfl_xor(v[0], BIT, 64);
+        if constexpr (BIT > 1) bfly_step<1, BIT / 2>(v, lane);
+    }
+}
+
+// Laser group kernel.  Columns of a block's two Jacobian rows: the translation columns of the two poses differ only
+// in sign (d s/d p_b = - d s/d p_a), so the unique columns are  BOTH: [a_x a_y a_th0..2 b_th0..2 r] (9, 45 pairs),
+// one free pose: [b_x b_y b_th0..2 r] (6, 21 pairs).  Every lane accumulates its blocks' pair products in
+// registers over all passes; one butterfly per group reduces them across the wave.
 template <bool BOTH>
-__device__ void laser_group(const LinArgs& A, const DevParams& P, int b, int i, double* lds) {
-    constexpr int NC = BOTH ? 11 : 6;          // [a_x a_y a_th0..2 |] b_x b_y b_th0..2 | r
+__global__ __launch_bounds__(64, 2) void k_lin_laser(LinArgs A, DevParams P) {
+    constexpr int NC = BOTH ? 9 : 6;
     constexpr int NP = NC * (NC + 1) / 2;
     const int lane = threadIdx.x & 63;
     const int n = A.n;
+    const int b = blockIdx.x / n, i = blockIdx.x % n;
+    if (b >= A.B) return;
+    if (A.lm && A.lm[b].done) return;
     double* out = A.PL + ((size_t)b * n + i) * LP;
     const int j0 = A.group_off[b * (n + 1) + i], j1 = A.group_off[b * (n + 1) + i + 1];
     const bool on = A.has_match[b * n + i] && j1 > j0 && (A.mode != LIW_MODE_TRACK || i == n - 1);
     if (!on) { out[lane] = 0.0; out[lane + 64] = 0.0; return; }
 
-    const double* xb = A.x + ((size_t)b * n + i) * 15;
-    const double* xa = BOTH ? (A.x + (size_t)b * n * 15) : (A.match_pose + ((size_t)b * n + i) * 12);
-    Tf2 Ta, Tb;
-    frame_tf2(P, xa, Ta);
-    frame_tf2(P, xb, Tb);
-
-    double* Y = lds;                 // [128][NC]
-    double* G = lds + 128 * NC;      // [NC*NC] staging of the reduced pairs
-    // pair -> lane mapping (fixed): pair e = lane and lane + 64
-    int pc1[2], pc2[2];
-#pragma unroll
-    for (int q = 0; q < 2; ++q) {
-        int e = lane + 64 * q, c1 = 0, rem = e;
-        while (c1 < NC && rem >= NC - c1) { rem -= NC - c1; ++c1; }
-        pc1[q] = c1; pc2[q] = c1 + rem;
+    // frame transforms (wave-uniform): a = frame 0 (init) or the constant laser_match pose, b = frame i
+    // staged in LDS (one coalesced load) and read back as broadcasts, which keeps 64 doubles out of the VGPRs
+    __shared__ double tf[2 * FTF];   // re-read (ds_read broadcast) close to each use instead of keeping 64 doubles live
+    {
+        const double* Tag = A.ftf + (BOTH ? ((size_t)b * n * 2) : (((size_t)b * n + i) * 2 + 1)) * FTF;
+        const double* Tbg = A.ftf + (((size_t)b * n + i) * 2) * FTF;
+        tf[lane] = lane < FTF ? Tag[lane] : Tbg[lane - FTF];
     }
-    double acc[2] = {0.0, 0.0};
+    __syncthreads();
+#define TA(k) tf[(k)]
+#define TB(k) tf[FTF + (k)]
+
+    constexpr int NACC = BOTH ? 48 : 32;   // 45 / 21 pair accumulators, padded to 32 (+16)
+    double acc[NACC];
+#pragma unroll
+    for (int e = 0; e < NACC; ++e) acc[e] = 0.0;
     const size_t Lt = (size_t)A.Ltot;
     for (int base = j0; base < j1; base += 64) {
         const int j = base + lane;
-        double row[2][NC];
-#pragma unroll
-        for (int k = 0; k < 2; ++k)
-#pragma unroll
-            for (int c = 0; c < NC; ++c) row[k][c] = 0.0;
+        asm volatile("" ::: "memory");   // keeps the LDS reads of the transforms inside the pass (no loop-invariant hoisting)
         if (j < j1) {
             double q[12];
 #pragma unroll
@@ -101,42 +117,50 @@ __device__ void laser_group(const LinArgs& A, const DevParams& P, int b, int i, 
             double Ap[2], Bp[2], C[2][2];
 #pragma unroll
             for (int r = 0; r < 2; ++r) {
-                Ap[r] = Ta.M[r][0] * q[0] + Ta.M[r][1] * q[1] + Ta.M[r][2] * q[2] + Ta.t[r];
-                Bp[r] = Ta.M[r][0] * q[3] + Ta.M[r][1] * q[4] + Ta.M[r][2] * q[5] + Ta.t[r];
-                C[0][r] = Tb.M[r][0] * q[6] + Tb.M[r][1] * q[7] + Tb.M[r][2] * q[8] + Tb.t[r];
-                C[1][r] = Tb.M[r][0] * q[9] + Tb.M[r][1] * q[10] + Tb.M[r][2] * q[11] + Tb.t[r];
+                Ap[r] = TA(r * 3) * q[0] + TA(r * 3 + 1) * q[1] + TA(r * 3 + 2) * q[2] + TA(6 + r);
+                Bp[r] = TA(r * 3) * q[3] + TA(r * 3 + 1) * q[4] + TA(r * 3 + 2) * q[5] + TA(6 + r);
+                C[0][r] = TB(r * 3) * q[6] + TB(r * 3 + 1) * q[7] + TB(r * 3 + 2) * q[8] + TB(6 + r);
+                C[1][r] = TB(r * 3) * q[9] + TB(r * 3 + 1) * q[10] + TB(r * 3 + 2) * q[11] + TB(6 + r);
             }
             const double ux = Bp[0] - Ap[0], uy = Bp[1] - Ap[1];
             const double zz = ux * ux + uy * uy;
             const bool regular = zz > 0.0;
             const double len = regular ? sqrt(zz) : 1.0;
             const double lx = ux / len, ly = uy / len;     // degenerate: stays the (zero) difference vector
-            // derivatives of the line direction w.r.t. theta_a
             double dBx[3], dBy[3], dlx[3], dly[3];
+            __builtin_amdgcn_sched_barrier(0);
             if (BOTH) {
 #pragma unroll
                 for (int k = 0; k < 3; ++k) {
-                    const double dAx = Ta.dM[k][0][0] * q[0] + Ta.dM[k][0][1] * q[1] + Ta.dM[k][0][2] * q[2] + Ta.dt[k][0];
-                    const double dAy = Ta.dM[k][1][0] * q[0] + Ta.dM[k][1][1] * q[1] + Ta.dM[k][1][2] * q[2] + Ta.dt[k][1];
-                    dBx[k] = Ta.dM[k][0][0] * q[3] + Ta.dM[k][0][1] * q[4] + Ta.dM[k][0][2] * q[5] + Ta.dt[k][0];
-                    dBy[k] = Ta.dM[k][1][0] * q[3] + Ta.dM[k][1][1] * q[4] + Ta.dM[k][1][2] * q[5] + Ta.dt[k][1];
+                    __builtin_amdgcn_sched_barrier(0);
+                    const int dMo = 8 + 6 * k, dto = 26 + 2 * k;
+                    const double m0 = TA(dMo), m1 = TA(dMo + 1), m2 = TA(dMo + 2), m3 = TA(dMo + 3), m4 = TA(dMo + 4), m5 = TA(dMo + 5);
+                    const double t0 = TA(dto), t1 = TA(dto + 1);
+                    const double dAx = m0 * q[0] + m1 * q[1] + m2 * q[2] + t0;
+                    const double dAy = m3 * q[0] + m4 * q[1] + m5 * q[2] + t1;
+                    dBx[k] = m0 * q[3] + m1 * q[4] + m2 * q[5] + t0;
+                    dBy[k] = m3 * q[3] + m4 * q[4] + m5 * q[5] + t1;
                     const double dux = dBx[k] - dAx, duy = dBy[k] - dAy;
                     const double pr = lx * dux + ly * duy;
                     dlx[k] = (dux - lx * pr) / len;
                     dly[k] = (duy - ly * pr) / len;
                 }
             }
+            const double w = sum * P.laser_sqrt_info;
 #pragma unroll
             for (int k = 0; k < 2; ++k) {
+                __builtin_amdgcn_sched_barrier(0);
                 const double* pt = q + 6 + 3 * k;
                 const double ex = C[k][0] - Bp[0], ey = C[k][1] - Bp[1];
                 double dCx[3], dCy[3];
 #pragma unroll
                 for (int m = 0; m < 3; ++m) {
-                    dCx[m] = Tb.dM[m][0][0] * pt[0] + Tb.dM[m][0][1] * pt[1] + Tb.dM[m][0][2] * pt[2] + Tb.dt[m][0];
-                    dCy[m] = Tb.dM[m][1][0] * pt[0] + Tb.dM[m][1][1] * pt[1] + Tb.dM[m][1][2] * pt[2] + Tb.dt[m][1];
+                    const int dMo = 8 + 6 * m, dto = 26 + 2 * m;
+                    dCx[m] = TB(dMo) * pt[0] + TB(dMo + 1) * pt[1] + TB(dMo + 2) * pt[2] + TB(dto);
+                    dCy[m] = TB(dMo + 3) * pt[0] + TB(dMo + 4) * pt[1] + TB(dMo + 5) * pt[2] + TB(dto + 1);
                 }
-                double dist, jc[10];
+                // jc: [a_x a_y a_th0..2 b_th0..2]; b_x = -a_x, b_y = -a_y
+                double dist, jc[8];
                 if (regular) {
                     const double s = lx * ey - ly * ex;
                     const double sg = s < 0.0 ? -1.0 : 1.0;
@@ -145,9 +169,8 @@ __device__ void laser_group(const LinArgs& A, const DevParams& P, int b, int i, 
 #pragma unroll
                     for (int m = 0; m < 3; ++m) {
                         jc[2 + m] = BOTH ? sg * (dlx[m] * ey - dly[m] * ex - lx * dBy[m] + ly * dBx[m]) : 0.0;
-                        jc[7 + m] = sg * (lx * dCy[m] - ly * dCx[m]);
+                        jc[5 + m] = sg * (lx * dCy[m] - ly * dCx[m]);
                     }
-                    jc[5] = -sg * ly; jc[6] = sg * lx;
                 } else {  // zero-length reference segment: distance to the point B (Jet semantics of normalized(0))
                     dist = sqrt(ex * ex + ey * ey);
                     const double nx = ex / dist, ny = ey / dist;
@@ -155,80 +178,81 @@ __device__ void laser_group(const LinArgs& A, const DevParams& P, int b, int i, 
 #pragma unroll
                     for (int m = 0; m < 3; ++m) {
                         jc[2 + m] = BOTH ? -(nx * dBx[m] + ny * dBy[m]) : 0.0;
-                        jc[7 + m] = nx * dCx[m] + ny * dCy[m];
+                        jc[5 + m] = nx * dCx[m] + ny * dCy[m];
                     }
-                    jc[5] = nx; jc[6] = ny;
                 }
-                const double w = sum * P.laser_sqrt_info;
                 const double res = sum * (P.laser_sqrt_info * dist);
+                double row[NC];
                 if (BOTH) {
 #pragma unroll
-                    for (int c = 0; c < 10; ++c) row[k][c] = w * jc[c];
+                    for (int c = 0; c < 8; ++c) row[c] = w * jc[c];
                 } else {
+                    row[0] = -w * jc[0]; row[1] = -w * jc[1];
 #pragma unroll
-                    for (int c = 0; c < 5; ++c) row[k][c] = w * jc[5 + c];
+                    for (int c = 0; c < 3; ++c) row[2 + c] = w * jc[5 + c];
                 }
-                row[k][NC - 1] = res;
+                row[NC - 1] = res;
+                // pair products into the register accumulators (compile-time indices)
+#pragma unroll
+                for (int c1 = 0; c1 < NC; ++c1)
+#pragma unroll
+                    for (int c2 = c1; c2 < NC; ++c2) acc[c1 * NC - c1 * (c1 - 1) / 2 + (c2 - c1)] += row[c1] * row[c2];
                 if (A.dbg_laser_res) A.dbg_laser_res[(size_t)j * 2 + k] = res;
                 if (A.dbg_laser_jac) {
                     double* dj = A.dbg_laser_jac + ((size_t)j * 2 + k) * 12;
                     dj[0] = w * jc[0]; dj[1] = w * jc[1]; dj[2] = 0.0;
                     dj[3] = w * jc[2]; dj[4] = w * jc[3]; dj[5] = w * jc[4];
-                    dj[6] = w * jc[5]; dj[7] = w * jc[6]; dj[8] = 0.0;
-                    dj[9] = w * jc[7]; dj[10] = w * jc[8]; dj[11] = w * jc[9];
+                    dj[6] = -w * jc[0]; dj[7] = -w * jc[1]; dj[8] = 0.0;
+                    dj[9] = w * jc[5]; dj[10] = w * jc[6]; dj[11] = w * jc[7];
                 }
             }
         }
-        __syncthreads();   // previous pass's readers are done
-#pragma unroll
-        for (int k = 0; k < 2; ++k)
-#pragma unroll
-            for (int c = 0; c < NC; ++c) Y[(2 * lane + k) * NC + c] = row[k][c];
-        __syncthreads();
-#pragma unroll
-        for (int q = 0; q < 2; ++q) {
-            if (lane + 64 * q < NP) {
-                double s = 0.0;
-                const int c1 = pc1[q], c2 = pc2[q];
-#pragma unroll 8
-                for (int r = 0; r < 128; ++r) s += Y[r * NC + c1] * Y[r * NC + c2];
-                acc[q] += s;
-            }
-        }
     }
-    __syncthreads();
+    // totals: pair p < 32 ends up in lanes 2p, 2p+1; pair 32 + p' (BOTH only) in lanes 4p' .. 4p'+3
+    bfly_step<32, 32>(acc, lane);
+    const double tot_lo = acc[0];
+    double tot_hi = 0.0;
+    if constexpr (BOTH) { bfly_step<16, 32>(acc + 32, lane); tot_hi = acc[32]; }
+    (void)NP;
+    // compose the 128-slot record.  unique-column index of a pose entry (0..5 = px py pz th0 th1 th2) and its sign
+    auto pairidx = [](int c1, int c2) { if (c1 > c2) { const int t = c1; c1 = c2; c2 = t; } return c1 * NC - c1 * (c1 - 1) / 2 + (c2 - c1); };
+    auto col_a = [](int idx) { return idx < 2 ? idx : (idx == 2 ? -1 : idx - 1); };                       // a: x y - th0..2 -> 0 1 - 2 3 4
+    auto col_b = [](int idx) { return BOTH ? (idx < 2 ? idx : (idx == 2 ? -1 : idx + 2)) : (idx == 2 ? -1 : (idx < 2 ? idx : idx - 1)); };
+    auto sgn_b = [](int idx) { return (BOTH && idx < 2) ? -1.0 : 1.0; };
+    constexpr int RC = NC - 1;
 #pragma unroll
-    for (int q = 0; q < 2; ++q)
-        if (lane + 64 * q < NP) { G[pc1[q] * NC + pc2[q]] = acc[q]; G[pc2[q] * NC + pc1[q]] = acc[q]; }
-    __syncthreads();
-    // compose the 128-slot record; pose index (0..5 = px py pz th0 th1 th2) -> column (pz has none)
-    auto colof = [](int idx) { return idx < 2 ? idx : (idx == 2 ? -1 : idx - 1); };
-    constexpr int OFFB = BOTH ? 5 : 0;
-#pragma unroll
-    for (int q = 0; q < 2; ++q) {
-        const int s = lane + 64 * q;
-        double v = 0.0;
+    for (int qq = 0; qq < 2; ++qq) {
+        const int s = lane + 64 * qq;
+        int src = -1;
+        double sg = 1.0;
         if (s < 36) {
-            const int ca = colof(s / 6), cb = colof(s % 6);
-            if (BOTH && ca >= 0 && cb >= 0) v = G[ca * NC + cb];
+            const int ca = col_a(s / 6), cb = col_a(s % 6);
+            if (BOTH && ca >= 0 && cb >= 0) src = pairidx(ca, cb);
         } else if (s < 72) {
-            const int ca = colof((s - 36) / 6), cb = colof((s - 36) % 6);
-            if (ca >= 0 && cb >= 0) v = G[(OFFB + ca) * NC + OFFB + cb];
+            const int ia = (s - 36) / 6, ib = (s - 36) % 6;
+            const int ca = col_b(ia), cb = col_b(ib);
+            if (ca >= 0 && cb >= 0) { src = pairidx(ca, cb); sg = sgn_b(ia) * sgn_b(ib); }
         } else if (s < 108) {
-            const int ca = colof((s - 72) / 6), cb = colof((s - 72) % 6);
-            if (BOTH && ca >= 0 && cb >= 0) v = G[ca * NC + OFFB + cb];
+            const int ia = (s - 72) / 6, ib = (s - 72) % 6;
+            const int ca = col_a(ia), cb = col_b(ib);
+            if (BOTH && ca >= 0 && cb >= 0) { src = pairidx(ca, cb); sg = sgn_b(ib); }
         } else if (s < 114) {
-            const int ca = colof(s - 108);
-            if (BOTH && ca >= 0) v = G[ca * NC + NC - 1];
+            const int ca = col_a(s - 108);
+            if (BOTH && ca >= 0) src = pairidx(ca, RC);
         } else if (s < 120) {
-            const int cb = colof(s - 114);
-            if (cb >= 0) v = G[(OFFB + cb) * NC + NC - 1];
+            const int cb = col_b(s - 114);
+            if (cb >= 0) { src = pairidx(cb, RC); sg = sgn_b(s - 114); }
         } else if (s == 120) {
-            v = G[(NC - 1) * NC + NC - 1];
+            src = pairidx(RC, RC);
         }
-        out[s] = v;
+        const int sp = src < 0 ? 0 : src;
+        const double vlo = __shfl(tot_lo, (sp & 31) * 2, 64);
+        const double vhi = __shfl(tot_hi, ((sp - 32) & 15) * 4, 64);
+        out[s] = src < 0 ? 0.0 : sg * (sp < 32 ? vlo : vhi);
     }
 }
+#undef TA
+#undef TB
 
 // ------------------------------------------------------------------------------------------- imu
 // raw (un-whitened) residual of imu_factor::operator(), src/factor/imu_factor.h:41-83
@@ -448,30 +472,24 @@ __device__ void ground_oct(const LinArgs& A, const DevParams& P, int b, int item
 }
 
 // ------------------------------------------------------------------------------------------- dispatch
-__host__ __device__ inline int lin_items_per_window(int n) { return n + (n - 1 + 1) / 2 + (n - 1 + 3) / 4 + (n + 7) / 8; }
-
-__global__ __launch_bounds__(64) void k_linearize(LinArgs A, DevParams P) {
-    __shared__ double lds[128 * 11 + 121 + 7];
-    const int n = A.n;
-    const int items = lin_items_per_window(n);
-    const int b = blockIdx.x / items;
-    int item = blockIdx.x % items;
+__global__ __launch_bounds__(64) void k_lin_imu(LinArgs A, DevParams P) {
+    __shared__ double lds[480 + 2 * 15 * 31 + 2];
+    const int n = A.n, items = (n - 1 + 1) / 2;
+    const int b = blockIdx.x / items, item = blockIdx.x % items;
     if (b >= A.B) return;
     if (A.lm && A.lm[b].done) return;
-    if (item < n) {
-        if (A.mode == LIW_MODE_INIT) laser_group<true>(A, P, b, item, lds);
-        else laser_group<false>(A, P, b, item, lds);
-        return;
-    }
-    if (!A.eval_small) return;
     const int sel = A.lm ? (A.candidate ? 1 - A.lm[b].cur : A.lm[b].cur) : 0;
-    item -= n;
-    const int n_imu = (n - 1 + 1) / 2, n_wheel = (n - 1 + 3) / 4;
-    if (item < n_imu) { imu_pair(A, P, b, item, sel, lds); return; }
-    item -= n_imu;
-    if (item < n_wheel) { wheel_quad(A, P, b, item, sel, lds); return; }
-    item -= n_wheel;
-    ground_oct(A, P, b, item, sel, lds);
+    imu_pair(A, P, b, item, sel, lds);
+}
+__global__ __launch_bounds__(64) void k_lin_small(LinArgs A, DevParams P) {
+    __shared__ double lds[4 * 40 + 8];
+    const int n = A.n, n_wheel = (n - 1 + 3) / 4, items = n_wheel + (n + 7) / 8;
+    const int b = blockIdx.x / items, item = blockIdx.x % items;
+    if (b >= A.B) return;
+    if (A.lm && A.lm[b].done) return;
+    const int sel = A.lm ? (A.candidate ? 1 - A.lm[b].cur : A.lm[b].cur) : 0;
+    if (item < n_wheel) wheel_quad(A, P, b, item, sel, lds);
+    else ground_oct(A, P, b, item - n_wheel, sel, lds);
 }
 
 // laser block range of every (window, frame): first block of window b owned by a frame >= i
@@ -488,8 +506,18 @@ __global__ void k_group_offsets(int B, int n, const int* laser_off, const int* l
 }
 
 void launch_linearize(const LinArgs& A, const DevParams& P, hipStream_t s) {
-    const int items = lin_items_per_window(A.n);
-    hipLaunchKernelGGL(k_linearize, dim3((unsigned)(A.B * items)), dim3(64), 0, s, A, P);
+    const int n = A.n, B = A.B;
+    const int nrec = B * n * 2 * 4;
+    hipLaunchKernelGGL(k_frame_tf, dim3((nrec + 255) / 256), dim3(256), 0, s, B, n, A.x, A.match_pose, A.ftf, P, A.lm);
+    if (A.mode == LIW_MODE_INIT) hipLaunchKernelGGL(k_lin_laser<true>, dim3((unsigned)(B * n)), dim3(64), 0, s, A, P);
+    else hipLaunchKernelGGL(k_lin_laser<false>, dim3((unsigned)(B * n)), dim3(64), 0, s, A, P);
+    if (A.eval_small && n > 1) {
+        hipLaunchKernelGGL(k_lin_imu, dim3((unsigned)(B * ((n - 1 + 1) / 2))), dim3(64), 0, s, A, P);
+    }
+    if (A.eval_small) {
+        const int items = (n - 1 + 3) / 4 + (n + 7) / 8;
+        hipLaunchKernelGGL(k_lin_small, dim3((unsigned)(B * items)), dim3(64), 0, s, A, P);
+    }
 }
 void launch_group_offsets(int B, int n, const int* laser_off, const int* laser_frame, int* group_off, hipStream_t s) {
     const int tot = B * (n + 1);

@@ -19,6 +19,13 @@
 namespace liw {
 
 typedef double d4 __attribute__((ext_vector_type(4)));
+// optional phase timing (tools/clk_probe.py): build with -DLIW_CLK to record s_memtime stamps of window 0
+#ifdef LIW_CLK
+__device__ long long g_clk[8192];
+#define STAMP(id) do { if (b == 0 && lane == 0 && iteration_dbg == 3) g_clk[(id)] = clock64(); } while (0)
+#else
+#define STAMP(id) do { } while (0)
+#endif
 
 struct StepArgs {
     int B, n, mode, max_iters, fast_mode;
@@ -33,6 +40,15 @@ constexpr double kMinDiag = 1e-6, kMaxDiag = 1e32, kMinRelDec = 1e-3, kFuncTol =
 constexpr double kMaxRadius = 1e16, kMinRadius = 1e-32, kInitRadius = 1e4;
 constexpr double kPi = 3.141592653589793238462643383279, kTwoPi = 6.283185307179586476925286766559;
 
+// Work-groups here are ONE wavefront.  DS instructions of a wave execute in order, so a wave's LDS write is visible to
+// its later LDS reads from any lane without s_barrier / vmcnt drains; only compiler reordering has to be fenced.
+// (Global-memory hand-offs between lanes still use __syncthreads(), which drains vmcnt.)
+__device__ __forceinline__ void lds_sync() {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
 __device__ __forceinline__ double wave_sum(double v) {
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
@@ -42,6 +58,13 @@ __device__ __forceinline__ double wave_max(double v) {
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) v = fmax(v, __shfl_xor(v, o, 64));
     return v;
+}
+
+__device__ __forceinline__ double rdlane(double v, int l) {   // v_readlane_b32 x2: broadcast lane l's value (l uniform)
+    int lo = __double2loint(v), hi = __double2hiint(v);
+    lo = __builtin_amdgcn_readlane(lo, l);
+    hi = __builtin_amdgcn_readlane(hi, l);
+    return __hiloint2double(hi, lo);
 }
 
 // so3 Plus and its Jacobian at delta = 0 (factor_common.h:41-53 through AutoDiffLocalParameterization)
@@ -83,7 +106,9 @@ __device__ __forceinline__ double prior_r(const AsmCtx& c, int k) {
 
 // Assemble frame i's blocks (ambient -> tangent, constants masked), UNSCALED, into 16x16 LDS tiles (ld 16):
 //   Dm = H[i,i], Om = H[i-1,i] (rows: frame i-1), Rm rows 0..5 = H[0(pose), i] (init arrow, i >= 2), gv = g_i.
-__device__ void assemble_frame(const AsmCtx& c, int i, double* Dm, double* Om, double* Rm, double* gv, double* tmp) {
+struct FrameExtra { double sc_i, sc_m, dg_i, x_i; };   // per lane v < 15: scale of frame i / i-1, LM diagonal, state entry
+__device__ void assemble_frame(const AsmCtx& c, int i, double* Dm, double* Om, double* Rm, double* gv, double* tmp,
+                               const double* scl = nullptr, const double* dgl = nullptr, FrameExtra* ex = nullptr) {
     const int lane = threadIdx.x & 63;
     const int n = c.n;
     const double* PLb = c.PL + (size_t)c.b * n * LP;
@@ -93,59 +118,103 @@ __device__ void assemble_frame(const AsmCtx& c, int i, double* Dm, double* Om, d
     const bool prior_here = c.prior_on && i == n - 2;
     if (prior_here) {   // stage r_prior
         if (lane < 15) tmp[lane] = prior_r(c, lane);
-        __syncthreads();
+        lds_sync();
     }
-    for (int e = lane; e < 256; e += 64) {
-        const int r = e >> 4, cc = e & 15;
-        double d = 0.0, o = 0.0, rr = 0.0;
-        if (r < 15 && cc < 15) {
-            const bool pose = r < 6 && cc < 6;
-            if (pose) {
-                d += PLb[(size_t)i * LP + 36 + r * 6 + cc];
-                if (i == 0) for (int j = 0; j < n; ++j) d += PLb[(size_t)j * LP + r * 6 + cc];
-                if (i >= 1) d += PWb[(size_t)(i - 1) * PWS + (6 + r) * 13 + 6 + cc];
-                if (i <= n - 2) d += PWb[(size_t)i * PWS + r * 13 + cc];
-                d += PGb[(size_t)i * PGS + r * 7 + cc];
-            }
-            if (i >= 1) d += PIb[(size_t)(i - 1) * PIS + (15 + r) * 31 + 15 + cc];
-            if (i <= n - 2) d += PIb[(size_t)i * PIS + r * 31 + cc];
-            if (prior_here) { double s = 0.0; for (int k = 0; k < 15; ++k) s += c.pJ[k * 15 + r] * c.pJ[k * 15 + cc]; d += s; }
-            if (i >= 1) {
-                o = PIb[(size_t)(i - 1) * PIS + r * 31 + 15 + cc];
-                if (pose) {
-                    o += PWb[(size_t)(i - 1) * PWS + r * 13 + 6 + cc];
-                    if (i == 1) o += PLb[(size_t)1 * LP + 72 + r * 6 + cc];
-                }
-            }
-            if (pose && i >= 2) rr = PLb[(size_t)i * LP + 72 + r * 6 + cc];
+    // All loads of a frame are issued up front, branch-free (masked by select), so the wave pays ONE memory round
+    // trip per frame instead of one per conditional term.
+    const bool hasm = i >= 1, hasp = i <= n - 2;
+    const double* PIm = PIb + (size_t)(hasm ? i - 1 : 0) * PIS;   // IMU block (i-1, i)
+    const double* PIp = PIb + (size_t)(hasp ? i : 0) * PIS;       // IMU block (i, i+1)
+    const double* PWm = PWb + (size_t)(hasm ? i - 1 : 0) * PWS;
+    const double* PWp = PWb + (size_t)(hasp ? i : 0) * PWS;
+    double dI[4], oI[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const int e = lane + 64 * q, r = e >> 4, cc = e & 15;
+        const bool valid = r < 15 && cc < 15;
+        const int rs = valid ? r : 0, cs = valid ? cc : 0;
+        const double v5 = PIm[(15 + rs) * 31 + 15 + cs], v6 = PIp[rs * 31 + cs], v7 = PIm[rs * 31 + 15 + cs];
+        dI[q] = ((valid && hasm) ? v5 : 0.0) + ((valid && hasp) ? v6 : 0.0);
+        oI[q] = (valid && hasm) ? v7 : 0.0;
+    }
+    double dP = 0.0, oP = 0.0, rP = 0.0;
+    {   // the 6x6 pose block terms: one element per lane (lanes 0..35)
+        const bool pl = lane < 36;
+        const int r = pl ? lane / 6 : 0, cc = pl ? lane % 6 : 0;
+        const double t1 = PLb[(size_t)i * LP + 36 + r * 6 + cc];
+        const double t2 = PWm[(6 + r) * 13 + 6 + cc], t3 = PWp[r * 13 + cc];
+        const double t4 = PGb[(size_t)i * PGS + r * 7 + cc];
+        const double t8 = PWm[r * 13 + 6 + cc];
+        const double t9 = PLb[(size_t)(n > 1 ? 1 : 0) * LP + 72 + r * 6 + cc];
+        const double t10 = PLb[(size_t)i * LP + 72 + r * 6 + cc];
+        dP = t1 + (hasm ? t2 : 0.0) + (hasp ? t3 : 0.0) + t4;
+        if (i == 0) for (int j = 0; j < n; ++j) dP += PLb[(size_t)j * LP + r * 6 + cc];
+        oP = hasm ? t8 + (i == 1 ? t9 : 0.0) : 0.0;
+        rP = i >= 2 ? t10 : 0.0;
+        if (!pl) { dP = 0.0; oP = 0.0; rP = 0.0; }
+    }
+    double gg = 0.0;
+    {
+        const int r = lane < 15 ? lane : 0, r6 = r < 6 ? r : 0;
+        const double g1 = PLb[(size_t)i * LP + 114 + r6], g2 = PWm[(6 + r6) * 13 + 12], g3 = PWp[r6 * 13 + 12];
+        const double g4 = PGb[(size_t)i * PGS + r6 * 7 + 6];
+        const double g5 = PIm[(15 + r) * 31 + 30], g6 = PIp[r * 31 + 30];
+        if (r < 6) {
+            gg = g1 + (hasm ? g2 : 0.0) + (hasp ? g3 : 0.0) + g4;
+            if (i == 0) for (int j = 0; j < n; ++j) gg += PLb[(size_t)j * LP + 108 + r];
         }
-        Dm[e] = d; Om[e] = o; Rm[e] = rr;
+        gg += (hasm ? g5 : 0.0) + (hasp ? g6 : 0.0);
+    }
+    // states needed below (rotation vectors of frames i, i-1, 0 for the so3 Plus Jacobian test) and the LM scales,
+    // fetched in the same batch of loads
+    double xq;
+    {
+        int idx = (size_t)i * 15 + (lane < 15 ? lane : 0);
+        if (lane >= 16 && lane < 19) idx = (hasm ? i - 1 : i) * 15 + 3 + (lane - 16);
+        if (lane >= 20 && lane < 23) idx = 3 + (lane - 20);
+        xq = c.x[idx];
+    }
+    if (ex) {
+        const int v = lane < 15 ? lane : 0;
+        ex->sc_i = scl[i * 15 + v];
+        ex->sc_m = scl[(hasm ? i - 1 : i) * 15 + v];
+        ex->dg_i = dgl[i * 15 + v];
+        ex->x_i = xq;
+    }
+    __builtin_amdgcn_sched_barrier(0);   // keep every load above in ONE batch: a single memory round trip per frame
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const int e = lane + 64 * q;
+        const int r = e >> 4, cc = e & 15;
+        double d = dI[q];
+        if (prior_here && r < 15 && cc < 15) { double sp = 0.0; for (int k = 0; k < 15; ++k) sp += c.pJ[k * 15 + r] * c.pJ[k * 15 + cc]; d += sp; }
+        Dm[e] = d; Om[e] = oI[q]; Rm[e] = 0.0;
     }
     if (lane < 16) {
-        const int r = lane;
-        double g = 0.0;
-        if (r < 15) {
-            if (r < 6) {
-                g += PLb[(size_t)i * LP + 114 + r];
-                if (i == 0) for (int j = 0; j < n; ++j) g += PLb[(size_t)j * LP + 108 + r];
-                if (i >= 1) g += PWb[(size_t)(i - 1) * PWS + (6 + r) * 13 + 12];
-                if (i <= n - 2) g += PWb[(size_t)i * PWS + r * 13 + 12];
-                g += PGb[(size_t)i * PGS + r * 7 + 6];
-            }
-            if (i >= 1) g += PIb[(size_t)(i - 1) * PIS + (15 + r) * 31 + 30];
-            if (i <= n - 2) g += PIb[(size_t)i * PIS + r * 31 + 30];
-            if (prior_here) { double s = 0.0; for (int k = 0; k < 15; ++k) s += c.pJ[k * 15 + r] * tmp[k]; g += s; }
-        }
-        gv[r] = g;
+        double g = lane < 15 ? gg : 0.0;
+        if (prior_here && lane < 15) { double sp = 0.0; for (int k = 0; k < 15; ++k) sp += c.pJ[k * 15 + lane] * tmp[k]; g += sp; }
+        gv[lane] = g;
     }
-    __syncthreads();
+    lds_sync();
+    if (lane < 36) {
+        const int r = lane / 6, cc = lane % 6;
+        Dm[r * 16 + cc] += dP; Om[r * 16 + cc] += oP; Rm[r * 16 + cc] = rP;
+    }
+    lds_sync();
     if (c.mode == LIW_MODE_MARG) return;
     // ---- so3 local parameterisation (identity unless |q| > pi) on the q rows/cols (3..5)
     double Pi[9], Pm[9], P0[9];
-    const bool li = so3_plus_jac(c.x + (size_t)i * 15 + 3, Pi);
-    const bool lm = i >= 1 && so3_plus_jac(c.x + (size_t)(i - 1) * 15 + 3, Pm);
-    const bool l0 = i >= 2 && so3_plus_jac(c.x + 3, P0);
-    if (li || lm || l0) {   // rare path, one lane
+    const double qa0 = rdlane(xq, 3), qa1 = rdlane(xq, 4), qa2 = rdlane(xq, 5);
+    const double qb0 = rdlane(xq, 16), qb1 = rdlane(xq, 17), qb2 = rdlane(xq, 18);
+    const double qc0 = rdlane(xq, 20), qc1 = rdlane(xq, 21), qc2 = rdlane(xq, 22);
+    const double pi2 = kPi * kPi;
+    bool li = qa0 * qa0 + qa1 * qa1 + qa2 * qa2 > pi2;
+    bool lm = i >= 1 && qb0 * qb0 + qb1 * qb1 + qb2 * qb2 > pi2;
+    bool l0 = i >= 2 && qc0 * qc0 + qc1 * qc1 + qc2 * qc2 > pi2;
+    if (li || lm || l0) {   // rare path (|q| > pi), one lane
+        li = so3_plus_jac(c.x + (size_t)i * 15 + 3, Pi);
+        lm = i >= 1 && so3_plus_jac(c.x + (size_t)(i - 1) * 15 + 3, Pm);
+        l0 = i >= 2 && so3_plus_jac(c.x + 3, P0);
         if (lane == 0) {
             auto right = [&](double* M, const double* P) {   // M[:,3:6] <- M[:,3:6] P
                 for (int r = 0; r < 15; ++r) {
@@ -170,7 +239,7 @@ __device__ void assemble_frame(const AsmCtx& c, int i, double* Dm, double* Om, d
             if (lm) left(Om, Pm);
             if (l0) left(Rm, P0);
         }
-        __syncthreads();
+        lds_sync();
     }
     // ---- constant parameter blocks (solver.cpp:787-794): drop their rows / columns
     if (c.mode == LIW_MODE_TRACK) {
@@ -183,7 +252,7 @@ __device__ void assemble_frame(const AsmCtx& c, int i, double* Dm, double* Om, d
             }
         }
         if (lane < 15 && var_is_const(c.mode, c.fast, n, i, lane)) gv[lane] = 0.0;
-        __syncthreads();
+        lds_sync();
     }
 }
 
@@ -244,10 +313,29 @@ __device__ __forceinline__ d4 xty16(const double* X, const double* Y) {
 
 struct LdsTiles {
     double D[256], O[256], R[256], W[256], Wa[256], CD[256], CR[256];
-    double g[16], Cg[16], y0[16], yprev[16], tmp[16], D0acc[36], g0acc[8];
+    double g[16], Cg[16], y0[16], yprev[16], tmp[16], D0acc[36], g0acc[8], sci[16], scm[16], sc0[16], dgi[16];
 };
 
 // ---------------------------------------------------------------------------------------------------
+// Right-looking Cholesky of the 15x15 matrix whose column j lives in lane j (a[r] = A[r][j]) fused with the forward
+// substitution of every other lane's column (right-hand sides): step k broadcasts the pivot, every lane forms
+// w_k = a[k]/L_kk (matrix lane j >= k: L[j][k]; rhs lane: (L^-1 b)[k]) and updates a[r] -= L[r][k] w_k with L[r][k]
+// read from lane r.  Afterwards matrix lane j holds row j of L in a[0..j]; rhs lanes hold L^-1 b.  No LDS, no barrier.
+__device__ __forceinline__ bool fused_chol_solve(double (&a)[15]) {
+    bool ok = true;
+#pragma unroll
+    for (int k = 0; k < 15; ++k) {
+        const double piv = rdlane(a[k], k);
+        if (!(piv > 0.0) || !isfinite(piv)) ok = false;
+        const double inv = 1.0 / sqrt(piv);
+        const double wk = a[k] * inv;
+        a[k] = wk;
+#pragma unroll
+        for (int r = k + 1; r < 15; ++r) a[r] -= rdlane(wk, r) * wk;
+    }
+    return ok;
+}
+
 // diag(H) of frame i in tangent space (lane v < 15 returns H_vv), for the Jacobi scaling fixed at iteration 0
 __device__ double frame_diag(const AsmCtx& c, int i, LdsTiles& T) {
     const int lane = threadIdx.x & 63, n = c.n;
@@ -278,9 +366,8 @@ __device__ double frame_diag(const AsmCtx& c, int i, LdsTiles& T) {
     return d;
 }
 
-__global__ __launch_bounds__(64) void k_lm_step(StepArgs a) {
+__global__ __launch_bounds__(64, 2) void k_lm_step(StepArgs a) {
     __shared__ LdsTiles T;
-    __shared__ double Fb[SOLVE_WS + 6];   // one frame's factor record staged for the back substitution
     const int b = blockIdx.x, lane = threadIdx.x & 63;
     if (b >= a.B) return;
     LmState& st = a.w.lm[b];
@@ -381,121 +468,128 @@ __global__ __launch_bounds__(64) void k_lm_step(StepArgs a) {
     double* dgl = st.diagonal;
     double* sws = a.w.solve_ws + (size_t)b * n * SOLVE_WS;
 
-    // ---- single pass: eliminate frames n-1 .. 1, then 0, of (S H S + D^2) y = S g
-    for (int e = lane; e < 256; e += 64) { T.CD[e] = 0.0; T.CR[e] = 0.0; }
+    // ---- single pass: eliminate frames n-1 .. 1, then 0, of (S H S + D^2) y = S g.
+    // Register-resident elimination: lane j < 15 owns column j of the damped diagonal tile, lanes 16..30 the columns of
+    // O^T, lanes 32..37 the columns of R^T, lane 40 the gradient.  One fused pass (fused_chol_solve) turns the matrix
+    // lanes into the rows of L and every right-hand-side lane into L^-1 b, using v_readlane broadcasts only.
+    for (int e = lane; e < 256; e += 64) { T.CD[e] = 0.0; T.CR[e] = 0.0; T.W[e] = 0.0; T.Wa[e] = 0.0; }
     if (lane < 16) T.Cg[lane] = 0.0;
     if (lane < 36) T.D0acc[lane] = 0.0;
     if (lane < 8) T.g0acc[lane] = 0.0;
-    __syncthreads();
+    if (lane < 15) T.sc0[lane] = scl[lane];
+    lds_sync();
     bool solved = true;
     double gmax = 0.0;
+    const int iteration_dbg = iteration; (void)iteration_dbg;
+    STAMP(0);
     for (int i = n - 1; i >= 0; --i) {
-        assemble_frame(c, i, T.D, T.O, T.R, T.g, T.tmp);
-        // LM diagonal of this frame (LevenbergMarquardtStrategy::ComputeStep) and |x - Plus(x,-g)|
-        double myd = 0.0;
+        STAMP(10 + i * 8 + 0);
+        FrameExtra ex;
+        assemble_frame(c, i, T.D, T.O, T.R, T.g, T.tmp, scl, dgl, &ex);
+        STAMP(10 + i * 8 + 1);
+        // LM diagonal of this frame (LevenbergMarquardtStrategy::ComputeStep), |x - Plus(x,-g)|, scales into LDS
         if (lane < 15) {
             const bool cst = var_is_const(a.mode, a.fast_mode, n, i, lane);
-            const double sc = scl[i * 15 + lane];
-            if (!reuse) dgl[i * 15 + lane] = fmin(fmax(T.D[lane * 16 + lane] * sc * sc, kMinDiag), kMaxDiag);
-            myd = dgl[i * 15 + lane];
+            const double sc = ex.sc_i;
+            T.sci[lane] = sc;
+            T.scm[lane] = i >= 1 ? ex.sc_m : 1.0;
+            double dgv = ex.dg_i;
+            if (!reuse) { dgv = fmin(fmax(T.D[lane * 16 + lane] * sc * sc, kMinDiag), kMaxDiag); dgl[i * 15 + lane] = dgv; }
+            T.dgi[lane] = dgv;
             double m = 0.0;
             if (!cst) {
                 if (lane < 3 || lane >= 6) m = fabs(T.g[lane]);
                 else {
-                    const double* xs = xw + (size_t)i * 15;
+                    const double qv[3] = {rdlane(ex.x_i, 3), rdlane(ex.x_i, 4), rdlane(ex.x_i, 5)};
                     double ng[3] = {-T.g[3], -T.g[4], -T.g[5]}, qn[3];
-                    so3_plus(xs + 3, ng, qn);
-                    m = fabs(xs[lane] - qn[lane - 3]);
+                    so3_plus(qv, ng, qn);
+                    m = fabs(ex.x_i - qn[lane - 3]);
                 }
             }
             gmax = fmax(gmax, m);
+            const double gsv = T.g[lane] * sc;
+            sws[(size_t)i * SOLVE_WS + 960 + lane] = gsv;   // original scaled gradient (model decrease)
         }
-        __syncthreads();
-        // scale, damp, add the carried Schur terms
-        for (int e = lane; e < 256; e += 64) {
-            const int r = e >> 4, cc = e & 15;
-            if (r < 15 && cc < 15) {
-                double d = T.D[e] * scl[i * 15 + r] * scl[i * 15 + cc] + T.CD[e];
-                if (r == cc) {
-                    if (var_is_const(a.mode, a.fast_mode, n, i, r)) d = 1.0;
-                    else d += dgl[i * 15 + r] / radius;
-                }
-                T.D[e] = d;
-                if (i >= 1) T.O[e] = T.O[e] * scl[(i - 1) * 15 + r] * scl[i * 15 + cc];
-                double rv = 0.0;
-                if (r < 6) rv = T.R[e] * scl[r] * scl[i * 15 + cc] + T.CR[e];
-                T.R[e] = rv;
-            } else { T.D[e] = 0.0; T.O[e] = 0.0; T.R[e] = 0.0; }
-        }
-        (void)myd;
-        if (lane < 16) {
-            const double gsv = lane < 15 ? T.g[lane] * scl[i * 15 + lane] : 0.0;
-            if (lane < 15) sws[(size_t)i * SOLVE_WS + 225 + 90 + 15 + 225 + lane] = gsv;   // original scaled gradient
-            T.g[lane] = lane < 15 ? gsv + T.Cg[lane] : 0.0;
-        }
-        __syncthreads();
-        if (i == 0) {
-            for (int e = lane; e < 36; e += 64) T.D[(e / 6) * 16 + e % 6] += T.D0acc[e];
-            if (lane < 6) T.g[lane] += T.g0acc[lane];
-            __syncthreads();
-        }
-        if (i == 1) {   // frame 0 is both the chain neighbour and the arrow target
-            for (int e = lane; e < 256; e += 64) { if ((e >> 4) < 6) T.O[e] += T.R[e]; T.R[e] = 0.0; }
-            __syncthreads();
-        }
-        if (!chol15(T.D)) { solved = false; break; }
-        // forward substitutions L w = rhs : lanes 0..14 -> columns of O^T (Wo), 15..20 -> columns of R^T (Wr), 21 -> g (z)
-        if (lane < 22) {
-            double wv[15];
+        lds_sync();
+        STAMP(10 + i * 8 + 2);
+        // load this lane's column: scale (Jacobi), damp (LM), add the carried Schur terms
+        double col[15];
+        if (lane < 15) {
+            const int j = lane;
+            const double sj = T.sci[j];
 #pragma unroll
-            for (int r = 0; r < 15; ++r) {
-                double rhs;
-                if (lane < 15) rhs = T.O[lane * 16 + r];            // O^T[r][lane]
-                else if (lane < 21) rhs = T.R[(lane - 15) * 16 + r];
-                else rhs = T.g[r];
+            for (int r = 0; r < 15; ++r) col[r] = T.D[r * 16 + j] * T.sci[r] * sj + T.CD[r * 16 + j];
+            if (i == 0 && j < 6) {
 #pragma unroll
-                for (int k = 0; k < r; ++k) rhs -= T.D[r * 16 + k] * wv[k];
-                wv[r] = rhs / T.D[r * 16 + r];
+                for (int r = 0; r < 6; ++r) col[r] += T.D0acc[r * 6 + j];
             }
+            const bool cst = var_is_const(a.mode, a.fast_mode, n, i, j);
+            const double dmp = cst ? 0.0 : T.dgi[j] / radius;
 #pragma unroll
-            for (int r = 0; r < 15; ++r) {
-                if (lane < 15) T.W[r * 16 + lane] = wv[r];
-                else if (lane < 21) T.Wa[r * 16 + (lane - 15)] = wv[r];
-                else T.W[r * 16 + 15] = wv[r];
+            for (int r = 0; r < 15; ++r) if (r == j) col[r] = cst ? 1.0 : col[r] + dmp;
+        } else if (lane >= 16 && lane < 31) {
+            const int cc = lane - 16;
+            const double sm = T.scm[cc];
+#pragma unroll
+            for (int r = 0; r < 15; ++r) col[r] = i >= 1 ? T.O[cc * 16 + r] * sm * T.sci[r] : 0.0;
+            if (i == 1 && cc < 6) {   // frame 0 is both the chain neighbour and the arrow target
+#pragma unroll
+                for (int r = 0; r < 15; ++r) col[r] += T.R[cc * 16 + r] * T.sc0[cc] * T.sci[r] + T.CR[cc * 16 + r];
             }
-        } else if (lane < 32) {
-            const int cc = lane - 22 + 6;   // zero the unused columns 6..15 of Wa
-            for (int r = 0; r < 15; ++r) T.Wa[r * 16 + cc] = 0.0;
+        } else if (lane >= 32 && lane < 38) {
+            const int cc = lane - 32;
+#pragma unroll
+            for (int r = 0; r < 15; ++r) col[r] = i >= 2 ? T.R[cc * 16 + r] * T.sc0[cc] * T.sci[r] + T.CR[cc * 16 + r] : 0.0;
+        } else if (lane == 40) {
+#pragma unroll
+            for (int r = 0; r < 15; ++r) col[r] = T.g[r] * T.sci[r] + T.Cg[r] + ((i == 0 && r < 6) ? T.g0acc[r] : 0.0);
+        } else {
+#pragma unroll
+            for (int r = 0; r < 15; ++r) col[r] = 0.0;
         }
-        if (lane < 16) { T.W[15 * 16 + lane] = 0.0; T.Wa[15 * 16 + lane] = 0.0; }
-        __syncthreads();
-        // keep the factor for the back substitution: L (lower 15x15), Wr, z, Wo
+        STAMP(10 + i * 8 + 3);
+        if (!fused_chol_solve(col)) { solved = false; break; }
+        STAMP(10 + i * 8 + 4);
+        // factor record for the back substitution: rec[r][lane] = this lane's entry r (15 coalesced stores);
+        // matrix lane j holds row j of L in entries 0..j (entries above the diagonal are round-off, never read)
         {
             double* f = sws + (size_t)i * SOLVE_WS;
-            for (int e = lane; e < 225; e += 64) { const int r = e / 15, cc = e % 15; f[e] = T.D[r * 16 + cc]; f[225 + 90 + 15 + e] = T.W[r * 16 + cc]; }
-            for (int e = lane; e < 90; e += 64) f[225 + e] = T.Wa[(e / 6) * 16 + e % 6];
-            if (lane < 15) f[225 + 90 + lane] = T.W[lane * 16 + 15];
+#pragma unroll
+            for (int r = 0; r < 15; ++r) f[r * 64 + lane] = col[r];
+            if (lane >= 16 && lane < 31) {
+#pragma unroll
+                for (int r = 0; r < 15; ++r) T.W[r * 16 + (lane - 16)] = col[r];
+            } else if (lane >= 32 && lane < 38) {
+#pragma unroll
+                for (int r = 0; r < 15; ++r) T.Wa[r * 16 + (lane - 32)] = col[r];
+            } else if (lane == 40) {
+#pragma unroll
+                for (int r = 0; r < 15; ++r) T.W[r * 16 + 15] = col[r];
+            }
         }
+        lds_sync();
+        STAMP(10 + i * 8 + 5);
         if (i >= 1) {
             // Schur products on the matrix cores
             const d4 p1 = xty16(T.W, T.W);     // [Wo|z]^T [Wo|z]
             const d4 p2 = xty16(T.Wa, T.W);    // [Wr|0]^T [Wo|z]
             const d4 p3 = xty16(T.Wa, T.Wa);   // [Wr|0]^T [Wr|0]
-            __syncthreads();
+            lds_sync();
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                const int row = (lane >> 4) + 4 * r, col = lane & 15;
-                if (row < 15 && col < 15) T.CD[row * 16 + col] = -p1[r];
-                if (row < 15 && col == 15) T.Cg[row] = -p1[r];
-                if (row < 6 && col < 15) T.CR[row * 16 + col] = -p2[r];
+                const int row = (lane >> 4) + 4 * r, colx = lane & 15;
+                if (row < 15 && colx < 15) T.CD[row * 16 + colx] = -p1[r];
+                if (row < 15 && colx == 15) T.Cg[row] = -p1[r];
+                if (row < 6 && colx < 15) T.CR[row * 16 + colx] = -p2[r];
                 if (i >= 2) {
-                    if (row < 6 && col == 15) T.g0acc[row] -= p2[r];
-                    if (row < 6 && col < 6) T.D0acc[row * 6 + col] -= p3[r];
+                    if (row < 6 && colx == 15) T.g0acc[row] -= p2[r];
+                    if (row < 6 && colx < 6) T.D0acc[row * 6 + colx] -= p3[r];
                 }
             }
-            __syncthreads();
+            lds_sync();
         }
     }
+    STAMP(1);
     gmax = wave_max(gmax);
     // ---- FinalizeIterationAndCheck, part 2
     {
@@ -515,54 +609,68 @@ __global__ __launch_bounds__(64) void k_lm_step(StepArgs a) {
 
     double model_cost_change = 0.0, step_norm = 0.0;
     bool valid = false;
+    __syncthreads();   // factor records (global) written above are read by other lanes below
     if (solved) {
-        // ---- back substitution, frame 0 first; every frame's record is staged in LDS with coalesced loads
+        // ---- back substitution, frame 0 first.  Lane r owns unknown r: row r of Wo / Wr, column r of L.
         double ytg = 0.0, dsum = 0.0, sn2 = 0.0;
+        double yprev = 0.0, y0v = 0.0;   // lane r < 15: y_{i-1}[r], y_0[r]
+        STAMP(2);
         for (int i = 0; i < n; ++i) {
+            STAMP(300 + i * 4);
             const double* f = sws + (size_t)i * SOLVE_WS;
-            for (int e = lane; e < SOLVE_WS; e += 64) Fb[e] = f[e];
-            __syncthreads();
-            // rhs = z - Wo y_{i-1} - Wr y_0[0:6]
-            double t = 0.0;
-            if (lane < 15) {
-                t = Fb[225 + 90 + lane];
-                if (i >= 1) {
+            const int r = lane < 15 ? lane : 0;
+            // one batch of loads per frame: z, column r of L, row r of Wo / Wr, scaled gradient, state, scale, LM diagonal
+            double t = f[r * 64 + 40];                        // z[r]   (lane 40's column)
+            double Lc[15], Wo[15], Wr[6];
 #pragma unroll
-                    for (int k = 0; k < 15; ++k) t -= Fb[225 + 90 + 15 + lane * 15 + k] * T.yprev[k];
-                }
-                if (i >= 2) {
+            for (int k = 0; k < 15; ++k) { Lc[k] = f[r * 64 + k]; Wo[k] = f[r * 64 + 16 + k]; }
 #pragma unroll
-                    for (int k = 0; k < 6; ++k) t -= Fb[225 + lane * 6 + k] * T.y0[k];
-                }
+            for (int k = 0; k < 6; ++k) Wr[k] = f[r * 64 + 32 + k];
+            const double gsv = f[960 + r];
+            const double xold = xw[(size_t)i * 15 + r];
+            const double scv = scl[i * 15 + r];
+            const double dgv = dgl[i * 15 + r];
+            __builtin_amdgcn_sched_barrier(0);
+            double dsel = Lc[0];                               // L[r][r] without a dynamic register index
+#pragma unroll
+            for (int k = 1; k < 15; ++k) dsel = (r == k) ? Lc[k] : dsel;
+            const double dinv = 1.0 / dsel;
+            if (i >= 1) {
+#pragma unroll
+                for (int k = 0; k < 15; ++k) t -= Wo[k] * rdlane(yprev, k);
             }
-            // L^T y = rhs, lanes hold one unknown each
+            if (i >= 2) {
 #pragma unroll
-            for (int r = 14; r >= 0; --r) {
-                const double yr = __shfl(t, r, 64) / Fb[r * 15 + r];
-                if (lane == r) t = yr;
-                else if (lane < r) t -= Fb[r * 15 + lane] * yr;
+                for (int k = 0; k < 6; ++k) t -= Wr[k] * rdlane(y0v, k);
             }
-            __syncthreads();
-            if (lane < 15) { T.yprev[lane] = t; if (i == 0) T.y0[lane] = t; }
+            STAMP(300 + i * 4 + 1);
+            // L^T y = t
+#pragma unroll
+            for (int q = 14; q >= 0; --q) {
+                const double yq = rdlane(t * dinv, q);
+                if (lane == q) t = yq;
+                else if (lane < q) t -= Lc[q] * yq;
+            }
+            yprev = t;
+            if (i == 0) y0v = t;
             // candidate of this frame: delta = -y * scale ; Plus
             const bool cst = lane < 15 && var_is_const(a.mode, a.fast_mode, n, i, lane);
-            const double del = (lane < 15 && !cst) ? -t * scl[i * 15 + lane] : 0.0;
-            const double* xs = xw + (size_t)i * 15;
-            double dq[3] = {__shfl(del, 3, 64), __shfl(del, 4, 64), __shfl(del, 5, 64)}, qn[3];
-            so3_plus(xs + 3, dq, qn);
+            const double del = (lane < 15 && !cst) ? -t * scv : 0.0;
+            const double qv[3] = {rdlane(xold, 3), rdlane(xold, 4), rdlane(xold, 5)};
+            double dq[3] = {rdlane(del, 3), rdlane(del, 4), rdlane(del, 5)}, qn[3];
+            so3_plus(qv, dq, qn);
             if (lane < 15) {
-                const double xold = xs[lane];
                 double xnew = xold + del;
                 if (lane >= 3 && lane < 6) xnew = var_is_const(a.mode, a.fast_mode, n, i, 3) ? xold : qn[lane - 3];
                 xc[(size_t)i * 15 + lane] = xnew;
                 if (!cst) {
                     sn2 += (xold - xnew) * (xold - xnew);
-                    ytg += t * Fb[225 + 90 + 15 + 225 + lane];
-                    dsum += dgl[i * 15 + lane] / radius * t * t;
+                    ytg += t * gsv;
+                    dsum += dgv / radius * t * t;
                 }
             }
-            __syncthreads();
         }
+        STAMP(3);
         step_norm = sqrt(wave_sum(sn2));
         // model cost change -(s'g_s + s'A s/2) with s = -y and (A + D^2) y = g_s  ==  (y'g_s + y'D^2 y)/2
         model_cost_change = 0.5 * (wave_sum(ytg) + wave_sum(dsum));
@@ -785,6 +893,9 @@ __global__ __launch_bounds__(64) void k_marg_schur(MargArgs a) {
     if (lane == 0) a.has_prior[b] = 1;
 }
 
+#ifdef LIW_CLK
+extern "C" void liw_debug_clk(long long* out, int nn) { hipMemcpyFromSymbol(out, HIP_SYMBOL(g_clk), sizeof(long long) * nn); }
+#endif
 void launch_lm_begin(int B, int n, LmState* lm, hipStream_t s) {
     hipLaunchKernelGGL(k_lm_begin, dim3((B + 63) / 64), dim3(64), 0, s, B, n, lm);
 }

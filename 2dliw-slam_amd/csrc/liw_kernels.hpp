@@ -28,6 +28,7 @@ constexpr int LP = LIW_LASER_PARTIAL;
 constexpr int PIS = 964;
 constexpr int PWS = 172;
 constexpr int PGS = 52;
+constexpr int FTF = 32;   // frame transform record (k_frame_tf)
 
 // per-window LM state kept on the device across the launches of one solve
 struct LmState {
@@ -52,14 +53,16 @@ struct WsView {
     liw_summary* info;    // [B]
     double* history;      // [(records)][B][n][15] or null
     int history_records;
-    double* marg;         // [B][...] marginalisation scratch
+    double* ftf;          // [B][n][2][FTF] frame transform records
 };
-constexpr int SOLVE_WS = 15 * 15 + 6 * 15 + 15 + 15 * 15 + 15;  // L, Wr(15x6), z, Wo, spare
+constexpr int SOLVE_WS = 15 * 64 + 16;  // rec[15][64 lanes] (L rows, Wo/Wr/z columns) + scaled gradient
 
 struct LinArgs {
     int B, n, mode, eval_small;
     const double* x;            // states to linearise at [B][n][15]
     const int* group_off;
+    const double* ftf_in_unused;
+    double* ftf;
     const int* laser_off;
     const double* laser_pts; int Ltot;
     const double* match_pose;
