@@ -255,16 +255,17 @@ __global__ __launch_bounds__(64, 2) void k_lin_laser(LinArgs A, DevParams P) {
 #undef TB
 
 // ------------------------------------------------------------------------------------------- imu
-// raw (un-whitened) residual of imu_factor::operator(), src/factor/imu_factor.h:41-83
+// raw (un-whitened) residual of imu_factor::operator(), src/factor/imu_factor.h:41-83; also returns R_i^T
 template <class T>
-__device__ __forceinline__ void imu_raw(const DevParams& P, const double* X, const double* Jp, double Dt_, const T* si, const T* sj, T* raw) {
+__device__ __forceinline__ void imu_raw(const DevParams& P, const double* X, const double* Jp, double Dt_, const T* si, const T* sj, T* raw,
+                                        M3<T>& bk_R_w) {
     V3<T> pi(si[0], si[1], si[2]), thetai(si[3], si[4], si[5]), vi(si[6], si[7], si[8]), bai(si[9], si[10], si[11]), bwi(si[12], si[13], si[14]);
     V3<T> pj(sj[0], sj[1], sj[2]), thetaj(sj[3], sj[4], sj[5]), vj(sj[6], sj[7], sj[8]), baj(sj[9], sj[10], sj[11]), bwj(sj[12], sj[13], sj[14]);
     const T g_norm(P.g), Dt(Dt_);
     V3<T> g(T(0.0), T(0.0), T(1.0));
     V3<T> alpha = cast_v3<T>(X), beta = cast_v3<T>(X + 3), gamma = cast_v3<T>(X + 6);
     V3<T> ba = cast_v3<T>(X + 9), bw = cast_v3<T>(X + 12);
-    M3<T> bk_R_w = exp_so3(-thetai);
+    bk_R_w = exp_so3(-thetai);
     auto blk = [&](int ro, int co) {
         M3<T> m;
 #pragma unroll
@@ -288,62 +289,161 @@ __device__ __forceinline__ void imu_raw(const DevParams& P, const double* X, con
     raw[12] = res_bw.x;   raw[13] = res_bw.y;   raw[14] = res_bw.z;
 }
 
-__device__ void imu_pair(const LinArgs& A, const DevParams& P, int b, int item, int sel, double* lds) {
-    const int lane = threadIdx.x & 63, half = lane >> 5, dir = lane & 31;
-    const int n = A.n, k = 2 * item + half;
-    const bool on = k < n - 1;
-    double* S = lds + half * 240;                 // 15x15 whitening matrix of this half's block
-    double* Y = lds + 480 + half * (15 * 31);     // [15][31]
-    const size_t fk = (size_t)b * (n - 1) + (on ? k : 0);
-    if (on)
-        for (int e = dir; e < 225; e += 32) S[e] = A.imu_sqrtP[fk * 225 + e];
-    double y[15], xc[15];   // xc: this lane's column of [J_raw | r_raw]
+typedef double d4 __attribute__((ext_vector_type(4)));
+constexpr int IMU_PER_WAVE = 6;   // 10 lanes per block: 9 derivative directions (theta_i, theta_j, bw_i) + the value lane
+
+// IMU role.  Only the rotation vectors and the gyro bias enter the residual non-linearly, so the dual-number pass
+// carries 9 directions per block (6 blocks per wave); the remaining 21 Jacobian columns are closed forms of R_i^T,
+// Dt and the pre-integration Jacobian blocks.  The whitening  Y = sqrt_info [J_raw | r_raw]  (imu_factor.h:85-86,
+// dense 15x15) and the normal-equation block  G = Y^T Y  run on the matrix cores: 8 + 12 v_mfma_f64_16x16x4_f64 per
+// block, the accumulator layout of Y being directly the operand layout of Y^T Y.
+__device__ void imu_group(const LinArgs& A, const DevParams& P, int b, int item, int sel, double* lds) {
+    const int lane = threadIdx.x & 63, grp = lane / 10, d = lane % 10;
+    const int n = A.n, k0 = IMU_PER_WAVE * item;
+    const int k = k0 + grp;
+    const bool on = grp < IMU_PER_WAVE && k < n - 1;
+    double* Xg = lds + (grp < IMU_PER_WAVE ? grp : 0) * 512;   // [16][32] per block: [J_raw(15x30) | r_raw | 0]
+    // whitening-matrix operands of every block of this wave, fetched up front (one memory round trip, hidden behind
+    // the dual-number pass):  sop[g][c] = A[i = lane & 15][k = (lane >> 4) + 4c] = sqrt_info_g[i][k]
+    double sop[IMU_PER_WAVE][4];
+    {
+        const int ml = lane & 15, mk = lane >> 4;
 #pragma unroll
-    for (int r = 0; r < 15; ++r) { y[r] = 0.0; xc[r] = 0.0; }
+        for (int g = 0; g < IMU_PER_WAVE; ++g) {
+            const bool gon = k0 + g < n - 1;
+            const double* S = A.imu_sqrtP + ((size_t)b * (n - 1) + (gon ? k0 + g : 0)) * 225;
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                const int kk = mk + 4 * c;
+                const bool in = gon && ml < 15 && kk < 15;
+                const double v = S[in ? ml * 15 + kk : 0];
+                sop[g][c] = in ? v : 0.0;
+            }
+        }
+    }
+    for (int e = lane; e < IMU_PER_WAVE * 512; e += 64) lds[e] = 0.0;
+    __syncthreads();
+    const size_t fk = (size_t)b * (n - 1) + (on ? k : 0);
     if (on) {
         const double* si_ = A.x + ((size_t)b * n + k) * 15;
         const double* sj_ = si_ + 15;
-        LJ si[15], sj[15], raw[15];
+        const double* Jp = A.imu_J + fk * 225;
+        const double Dt = A.imu_Dt[fk];
+        // imu_factor::operator() (imu_factor.h:41-83) evaluated stage by stage; every stage writes its rows of
+        // [J_raw | r_raw] to LDS at once so its temporaries die (keeps the kernel at 2 waves per SIMD)
+        const double* X0 = A.imu_X + fk * 15;
+        const int col = d < 3 ? 3 + d : (d < 6 ? 18 + (d - 3) : (d < 9 ? 12 + (d - 6) : 30));
+        auto put3 = [&](int row0, const V3<LJ>& v) {
+            Xg[(row0 + 0) * 32 + col] = d < 9 ? v.x.d : v.x.v;
+            Xg[(row0 + 1) * 32 + col] = d < 9 ? v.y.d : v.y.v;
+            Xg[(row0 + 2) * 32 + col] = d < 9 ? v.z.d : v.z.v;
+        };
+        auto blk = [&](int ro, int co) {
+            M3<LJ> m;
 #pragma unroll
-        for (int e = 0; e < 15; ++e) {
-            si[e] = LJ(si_[e], dir == e ? 1.0 : 0.0);
-            sj[e] = LJ(sj_[e], dir == 15 + e ? 1.0 : 0.0);
+            for (int r = 0; r < 3; ++r)
+#pragma unroll
+                for (int c = 0; c < 3; ++c) m(r, c) = LJ(Jp[(ro + r) * 15 + co + c]);
+            return m;
+        };
+        const V3<LJ> thetai(LJ(si_[3], d == 0 ? 1.0 : 0.0), LJ(si_[4], d == 1 ? 1.0 : 0.0), LJ(si_[5], d == 2 ? 1.0 : 0.0));
+        const V3<LJ> thetaj(LJ(sj_[3], d == 3 ? 1.0 : 0.0), LJ(sj_[4], d == 4 ? 1.0 : 0.0), LJ(sj_[5], d == 5 ? 1.0 : 0.0));
+        const V3<LJ> bwi(LJ(si_[12], d == 6 ? 1.0 : 0.0), LJ(si_[13], d == 7 ? 1.0 : 0.0), LJ(si_[14], d == 8 ? 1.0 : 0.0));
+        const V3<LJ> dbw = bwi - cast_v3<LJ>(X0 + 12);
+        const V3<LJ> dba = cast_v3<LJ>(si_ + 9) - cast_v3<LJ>(X0 + 9);
+        const LJ g_norm(P.g), DtJ(Dt);
+        const V3<LJ> gdir(LJ(0.0), LJ(0.0), LJ(1.0));
+        const M3<LJ> Rt = exp_so3(-thetai);                                        // bk_R_w
+        {   // alpha, beta rows
+            const V3<LJ> pi = cast_v3<LJ>(si_), vi = cast_v3<LJ>(si_ + 6), pj = cast_v3<LJ>(sj_), vj = cast_v3<LJ>(sj_ + 6);
+            const V3<LJ> alpha = cast_v3<LJ>(X0) + mul(blk(0, 9), dba) + mul(blk(0, 12), dbw);
+            put3(0, alpha - mul(Rt, pj - pi + ((gdir * LJ(0.5)) * g_norm) * DtJ * DtJ - vi * DtJ));
+            const V3<LJ> beta = cast_v3<LJ>(X0 + 3) + mul(blk(3, 9), dba) + mul(blk(3, 12), dbw);
+            put3(3, beta - mul(Rt, vj + (gdir * g_norm) * DtJ - vi));
+            put3(9, cast_v3<LJ>(sj_ + 9) - cast_v3<LJ>(si_ + 9));                  // res_ba
+            put3(12, cast_v3<LJ>(sj_ + 12) - bwi);                                  // res_bw
         }
-        imu_raw<LJ>(P, A.imu_X + fk * 15, A.imu_J + fk * 225, A.imu_Dt[fk], si, sj, raw);
+        // closed-form columns (value parts are uniform over the block's lanes; each lane writes one column group)
+        if (d == 0) {
 #pragma unroll
-        for (int r = 0; r < 15; ++r) xc[r] = dir < 30 ? raw[r].d : (dir == 30 ? raw[r].v : 0.0);
+            for (int r = 0; r < 3; ++r)
+#pragma unroll
+                for (int c = 0; c < 3; ++c) Xg[r * 32 + c] = Rt(r, c).v;                      // d r_alpha / d p_i
+        } else if (d == 1) {
+#pragma unroll
+            for (int r = 0; r < 3; ++r)
+#pragma unroll
+                for (int c = 0; c < 3; ++c) { Xg[r * 32 + 6 + c] = Rt(r, c).v * Dt; Xg[(3 + r) * 32 + 6 + c] = Rt(r, c).v; }   // d/d v_i
+        } else if (d == 2) {
+#pragma unroll
+            for (int r = 0; r < 3; ++r)
+#pragma unroll
+                for (int c = 0; c < 3; ++c) {
+                    Xg[r * 32 + 9 + c] = Jp[r * 15 + 9 + c];               // alpha_J_ba
+                    Xg[(3 + r) * 32 + 9 + c] = Jp[(3 + r) * 15 + 9 + c];   // beta_J_ba
+                    Xg[(9 + r) * 32 + 9 + c] = r == c ? -1.0 : 0.0;        // d r_ba / d ba_i
+                }
+        } else if (d == 3) {
+#pragma unroll
+            for (int r = 0; r < 3; ++r)
+#pragma unroll
+                for (int c = 0; c < 3; ++c) Xg[r * 32 + 15 + c] = -Rt(r, c).v;                // d r_alpha / d p_j
+        } else if (d == 4) {
+#pragma unroll
+            for (int r = 0; r < 3; ++r)
+#pragma unroll
+                for (int c = 0; c < 3; ++c) Xg[(3 + r) * 32 + 21 + c] = -Rt(r, c).v;          // d r_beta / d v_j
+        } else if (d == 5) {
+#pragma unroll
+            for (int r = 0; r < 3; ++r) { Xg[(9 + r) * 32 + 24 + r] = 1.0; Xg[(12 + r) * 32 + 27 + r] = 1.0; }   // d r_ba/d ba_j, d r_bw/d bw_j
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        {   // gamma rows: log( exp(-gamma^) R_i^T R_j )
+            const M3<LJ> RiRj = mul(Rt, exp_so3(thetaj));
+            __builtin_amdgcn_sched_barrier(0);
+            const V3<LJ> gamma = cast_v3<LJ>(X0 + 6) + mul(blk(6, 12), dbw);
+            const M3<LJ> E = mul(exp_so3(-gamma), RiRj);
+            __builtin_amdgcn_sched_barrier(0);
+            put3(6, log_SO3(E));
+        }
     }
     __syncthreads();
-    if (on) {
-        // res_all = sqrt_info * res_all, dense 15x15 (imu_factor.h:85-86), applied to every column
+    // ---- matrix-core part, one block at a time (the whole wave cooperates)
+    const int ml = lane & 15, mk = lane >> 4;
 #pragma unroll
-        for (int r = 0; r < 15; ++r) {
-            double s = S[r * 15] * xc[0];
+    for (int g = 0; g < IMU_PER_WAVE; ++g) {
+        const int kg = k0 + g;
+        if (kg >= n - 1) break;
+        const size_t fg = (size_t)b * (n - 1) + kg;
+        const double* X = lds + g * 512;
+        d4 y0 = {0.0, 0.0, 0.0, 0.0}, y1 = {0.0, 0.0, 0.0, 0.0};
 #pragma unroll
-            for (int c = 1; c < 15; ++c) s += S[r * 15 + c] * xc[c];
-            y[r] = s;
+        for (int c = 0; c < 4; ++c) {
+            const int kk = mk + 4 * c;
+            const double a = sop[g][c];                                        // A[i = ml][k = kk] = sqrt_info
+            y0 = __builtin_amdgcn_mfma_f64_16x16x4f64(a, X[kk * 32 + ml], y0, 0, 0, 0);
+            y1 = __builtin_amdgcn_mfma_f64_16x16x4f64(a, X[kk * 32 + 16 + ml], y1, 0, 0, 0);
         }
-    }
-    if (dir < 31)
+        // y_t[r] = Y[mk + 4r][ml + 16t]  ==  operand chunk r of Y^T Y
+        d4 g00 = {0.0, 0.0, 0.0, 0.0}, g01 = g00, g11 = g00;
 #pragma unroll
-        for (int r = 0; r < 15; ++r) Y[r * 31 + dir] = y[r];
-    if (on && dir == 30 && A.dbg_imu_res)
-        for (int r = 0; r < 15; ++r) A.dbg_imu_res[fk * 15 + r] = y[r];
-    if (on && dir < 30 && A.dbg_imu_jac)
-        for (int r = 0; r < 15; ++r) A.dbg_imu_jac[(fk * 15 + r) * 30 + dir] = y[r];
-    __syncthreads();
-    if (on) {
-        double* out = A.PI[sel] + fk * PIS;
-        // 496 pairs over 32 lanes: pair e = dir + 32*t
-        for (int e = dir; e < 496; e += 32) {
-            int c1 = 0, rem = e;
-            while (rem >= 31 - c1) { rem -= 31 - c1; ++c1; }
-            const int c2 = c1 + rem;
-            double s = 0.0;
+        for (int c = 0; c < 4; ++c) {
+            g00 = __builtin_amdgcn_mfma_f64_16x16x4f64(y0[c], y0[c], g00, 0, 0, 0);
+            g01 = __builtin_amdgcn_mfma_f64_16x16x4f64(y0[c], y1[c], g01, 0, 0, 0);
+            g11 = __builtin_amdgcn_mfma_f64_16x16x4f64(y1[c], y1[c], g11, 0, 0, 0);
+        }
+        double* out = A.PI[sel] + fg * PIS;
 #pragma unroll
-            for (int r = 0; r < 15; ++r) s += Y[r * 31 + c1] * Y[r * 31 + c2];
-            out[c1 * 31 + c2] = s;
-            out[c2 * 31 + c1] = s;
+        for (int r = 0; r < 4; ++r) {
+            const int row = mk + 4 * r;
+            out[row * 31 + ml] = g00[r];                                   // rows 0..15, cols 0..15
+            if (ml < 15) { out[row * 31 + 16 + ml] = g01[r]; out[(16 + ml) * 31 + row] = g01[r]; }
+            if (row < 15 && ml < 15) out[(16 + row) * 31 + 16 + ml] = g11[r];
+            if (A.dbg_imu_res && ml == 14 && row < 15) A.dbg_imu_res[fg * 15 + row] = y1[r];
+            if (A.dbg_imu_jac && row < 15) {
+                A.dbg_imu_jac[(fg * 15 + row) * 30 + ml] = y0[r];
+                if (ml < 14) A.dbg_imu_jac[(fg * 15 + row) * 30 + 16 + ml] = y1[r];
+            }
         }
     }
 }
@@ -472,14 +572,14 @@ __device__ void ground_oct(const LinArgs& A, const DevParams& P, int b, int item
 }
 
 // ------------------------------------------------------------------------------------------- dispatch
-__global__ __launch_bounds__(64) void k_lin_imu(LinArgs A, DevParams P) {
-    __shared__ double lds[480 + 2 * 15 * 31 + 2];
-    const int n = A.n, items = (n - 1 + 1) / 2;
+__global__ __launch_bounds__(64, 2) void k_lin_imu(LinArgs A, DevParams P) {
+    __shared__ double lds[IMU_PER_WAVE * 512];
+    const int n = A.n, items = (n - 1 + IMU_PER_WAVE - 1) / IMU_PER_WAVE;
     const int b = blockIdx.x / items, item = blockIdx.x % items;
     if (b >= A.B) return;
     if (A.lm && A.lm[b].done) return;
     const int sel = A.lm ? (A.candidate ? 1 - A.lm[b].cur : A.lm[b].cur) : 0;
-    imu_pair(A, P, b, item, sel, lds);
+    imu_group(A, P, b, item, sel, lds);
 }
 __global__ __launch_bounds__(64) void k_lin_small(LinArgs A, DevParams P) {
     __shared__ double lds[4 * 40 + 8];
@@ -512,7 +612,7 @@ void launch_linearize(const LinArgs& A, const DevParams& P, hipStream_t s) {
     if (A.mode == LIW_MODE_INIT) hipLaunchKernelGGL(k_lin_laser<true>, dim3((unsigned)(B * n)), dim3(64), 0, s, A, P);
     else hipLaunchKernelGGL(k_lin_laser<false>, dim3((unsigned)(B * n)), dim3(64), 0, s, A, P);
     if (A.eval_small && n > 1) {
-        hipLaunchKernelGGL(k_lin_imu, dim3((unsigned)(B * ((n - 1 + 1) / 2))), dim3(64), 0, s, A, P);
+        hipLaunchKernelGGL(k_lin_imu, dim3((unsigned)(B * ((n - 1 + IMU_PER_WAVE - 1) / IMU_PER_WAVE))), dim3(64), 0, s, A, P);
     }
     if (A.eval_small) {
         const int items = (n - 1 + 3) / 4 + (n + 7) / 8;

@@ -107,7 +107,21 @@ __device__ __forceinline__ double prior_r(const AsmCtx& c, int k) {
 // Assemble frame i's blocks (ambient -> tangent, constants masked), UNSCALED, into 16x16 LDS tiles (ld 16):
 //   Dm = H[i,i], Om = H[i-1,i] (rows: frame i-1), Rm rows 0..5 = H[0(pose), i] (init arrow, i >= 2), gv = g_i.
 struct FrameExtra { double sc_i, sc_m, dg_i, x_i; };   // per lane v < 15: scale of frame i / i-1, LM diagonal, state entry
-__device__ void assemble_frame(const AsmCtx& c, int i, double* Dm, double* Om, double* Rm, double* gv, double* tmp,
+
+// Where assemble_frame puts a frame's blocks.  LAYOUT 0: three 16x16 tiles D = H[i,i], O = H[i-1,i] (rows: frame i-1),
+// R rows 0..5 = H[0(pose), i] and g[16].  LAYOUT 1 ("lane layout", k_lm_step): one [15][64] matrix whose column is the
+// lane that will own it in the elimination — cols 0..14 = D, 16..30 = O^T, 32..37 = R^T, 40 = g.
+template <int LAYOUT> struct Tiles {
+    double* D; double* O; double* R; double* g;
+    __device__ __forceinline__ double& d(int r, int c) const { return LAYOUT ? D[r * 64 + c] : D[r * 16 + c]; }
+    __device__ __forceinline__ double& o(int r, int c) const { return LAYOUT ? D[c * 64 + 16 + r] : O[r * 16 + c]; }
+    __device__ __forceinline__ double& rr(int r, int c) const { return LAYOUT ? D[c * 64 + 32 + r] : R[r * 16 + c]; }
+    __device__ __forceinline__ double& gg(int r) const { return LAYOUT ? D[r * 64 + 40] : g[r]; }
+};
+
+// Assemble frame i's blocks (ambient -> tangent, constants masked), UNSCALED.
+template <int LAYOUT>
+__device__ void assemble_frame(const AsmCtx& c, int i, const Tiles<LAYOUT>& T_, double* tmp,
                                const double* scl = nullptr, const double* dgl = nullptr, FrameExtra* ex = nullptr) {
     const int lane = threadIdx.x & 63;
     const int n = c.n;
@@ -186,19 +200,21 @@ __device__ void assemble_frame(const AsmCtx& c, int i, double* Dm, double* Om, d
     for (int q = 0; q < 4; ++q) {
         const int e = lane + 64 * q;
         const int r = e >> 4, cc = e & 15;
+        const bool valid = r < 15 && cc < 15;
         double d = dI[q];
-        if (prior_here && r < 15 && cc < 15) { double sp = 0.0; for (int k = 0; k < 15; ++k) sp += c.pJ[k * 15 + r] * c.pJ[k * 15 + cc]; d += sp; }
-        Dm[e] = d; Om[e] = oI[q]; Rm[e] = 0.0;
+        if (prior_here && valid) { double sp = 0.0; for (int k = 0; k < 15; ++k) sp += c.pJ[k * 15 + r] * c.pJ[k * 15 + cc]; d += sp; }
+        if (LAYOUT == 0) { T_.D[e] = valid ? d : 0.0; T_.O[e] = valid ? oI[q] : 0.0; T_.R[e] = 0.0; }
+        else if (valid) { T_.d(r, cc) = d; T_.o(r, cc) = oI[q]; if (r < 6) T_.rr(r, cc) = 0.0; }
     }
     if (lane < 16) {
         double g = lane < 15 ? gg : 0.0;
         if (prior_here && lane < 15) { double sp = 0.0; for (int k = 0; k < 15; ++k) sp += c.pJ[k * 15 + lane] * tmp[k]; g += sp; }
-        gv[lane] = g;
+        if (LAYOUT == 0) T_.g[lane] = g; else if (lane < 15) T_.gg(lane) = g;
     }
     lds_sync();
     if (lane < 36) {
         const int r = lane / 6, cc = lane % 6;
-        Dm[r * 16 + cc] += dP; Om[r * 16 + cc] += oP; Rm[r * 16 + cc] = rP;
+        T_.d(r, cc) += dP; T_.o(r, cc) += oP; T_.rr(r, cc) = rP;
     }
     lds_sync();
     if (c.mode == LIW_MODE_MARG) return;
@@ -216,28 +232,30 @@ __device__ void assemble_frame(const AsmCtx& c, int i, double* Dm, double* Om, d
         lm = i >= 1 && so3_plus_jac(c.x + (size_t)(i - 1) * 15 + 3, Pm);
         l0 = i >= 2 && so3_plus_jac(c.x + 3, P0);
         if (lane == 0) {
-            auto right = [&](double* M, const double* P) {   // M[:,3:6] <- M[:,3:6] P
-                for (int r = 0; r < 15; ++r) {
+            // kind: 0 = D, 1 = O, 2 = R (rows 0..5 only)
+            auto at = [&](int kind, int r, int cc) -> double& { return kind == 0 ? T_.d(r, cc) : (kind == 1 ? T_.o(r, cc) : T_.rr(r, cc)); };
+            auto right = [&](int kind, int nrows, const double* P) {   // X[:,3:6] <- X[:,3:6] P
+                for (int r = 0; r < nrows; ++r) {
                     double t[3];
-                    for (int k = 0; k < 3; ++k) t[k] = M[r * 16 + 3] * P[k] + M[r * 16 + 4] * P[3 + k] + M[r * 16 + 5] * P[6 + k];
-                    for (int k = 0; k < 3; ++k) M[r * 16 + 3 + k] = t[k];
+                    for (int k = 0; k < 3; ++k) t[k] = at(kind, r, 3) * P[k] + at(kind, r, 4) * P[3 + k] + at(kind, r, 5) * P[6 + k];
+                    for (int k = 0; k < 3; ++k) at(kind, r, 3 + k) = t[k];
                 }
             };
-            auto left = [&](double* M, const double* P) {    // M[3:6,:] <- P^T M[3:6,:]
+            auto left = [&](int kind, const double* P) {    // X[3:6,:] <- P^T X[3:6,:]
                 for (int cc = 0; cc < 15; ++cc) {
                     double t[3];
-                    for (int k = 0; k < 3; ++k) t[k] = P[k] * M[3 * 16 + cc] + P[3 + k] * M[4 * 16 + cc] + P[6 + k] * M[5 * 16 + cc];
-                    for (int k = 0; k < 3; ++k) M[(3 + k) * 16 + cc] = t[k];
+                    for (int k = 0; k < 3; ++k) t[k] = P[k] * at(kind, 3, cc) + P[3 + k] * at(kind, 4, cc) + P[6 + k] * at(kind, 5, cc);
+                    for (int k = 0; k < 3; ++k) at(kind, 3 + k, cc) = t[k];
                 }
             };
             if (li) {
-                right(Dm, Pi); left(Dm, Pi); right(Om, Pi); right(Rm, Pi);
+                right(0, 15, Pi); left(0, Pi); right(1, 15, Pi); right(2, 6, Pi);
                 double t[3];
-                for (int k = 0; k < 3; ++k) t[k] = Pi[k] * gv[3] + Pi[3 + k] * gv[4] + Pi[6 + k] * gv[5];
-                for (int k = 0; k < 3; ++k) gv[3 + k] = t[k];
+                for (int k = 0; k < 3; ++k) t[k] = Pi[k] * T_.gg(3) + Pi[3 + k] * T_.gg(4) + Pi[6 + k] * T_.gg(5);
+                for (int k = 0; k < 3; ++k) T_.gg(3 + k) = t[k];
             }
-            if (lm) left(Om, Pm);
-            if (l0) left(Rm, P0);
+            if (lm) left(1, Pm);
+            if (l0) left(2, P0);
         }
         lds_sync();
     }
@@ -247,11 +265,11 @@ __device__ void assemble_frame(const AsmCtx& c, int i, double* Dm, double* Om, d
             const int r = e >> 4, cc = e & 15;
             if (r < 15 && cc < 15) {
                 const bool cr = var_is_const(c.mode, c.fast, n, i, r), ccn = var_is_const(c.mode, c.fast, n, i, cc);
-                if (cr || ccn) Dm[e] = 0.0;
-                if ((i >= 1 && var_is_const(c.mode, c.fast, n, i - 1, r)) || ccn) Om[e] = 0.0;
+                if (cr || ccn) T_.d(r, cc) = 0.0;
+                if ((i >= 1 && var_is_const(c.mode, c.fast, n, i - 1, r)) || ccn) T_.o(r, cc) = 0.0;
             }
         }
-        if (lane < 15 && var_is_const(c.mode, c.fast, n, i, lane)) gv[lane] = 0.0;
+        if (lane < 15 && var_is_const(c.mode, c.fast, n, i, lane)) T_.gg(lane) = 0.0;
         lds_sync();
     }
 }
@@ -311,9 +329,13 @@ __device__ __forceinline__ d4 xty16(const double* X, const double* Y) {
     return acc;
 }
 
-struct LdsTiles {
+struct LdsTiles {   // export / marginalisation kernels (tile layout)
     double D[256], O[256], R[256], W[256], Wa[256], CD[256], CR[256];
     double g[16], Cg[16], y0[16], yprev[16], tmp[16], D0acc[36], g0acc[8], sci[16], scm[16], sc0[16], dgi[16];
+};
+struct LdsStep {    // k_lm_step (lane layout): M = assembled frame, C = carried Schur terms, W/Wa = MFMA operand tiles
+    double M[15 * 64], C[15 * 64], W[256], Wa[256];
+    double tmp[16], D0acc[36], g0acc[8];
 };
 
 // ---------------------------------------------------------------------------------------------------
@@ -327,7 +349,7 @@ __device__ __forceinline__ bool fused_chol_solve(double (&a)[15]) {
     for (int k = 0; k < 15; ++k) {
         const double piv = rdlane(a[k], k);
         if (!(piv > 0.0) || !isfinite(piv)) ok = false;
-        const double inv = 1.0 / sqrt(piv);
+        const double inv = rsqrt(piv);
         const double wk = a[k] * inv;
         a[k] = wk;
 #pragma unroll
@@ -337,12 +359,12 @@ __device__ __forceinline__ bool fused_chol_solve(double (&a)[15]) {
 }
 
 // diag(H) of frame i in tangent space (lane v < 15 returns H_vv), for the Jacobi scaling fixed at iteration 0
-__device__ double frame_diag(const AsmCtx& c, int i, LdsTiles& T) {
+__device__ double frame_diag(const AsmCtx& c, int i, LdsStep& T) {
     const int lane = threadIdx.x & 63, n = c.n;
     double Pq[9];
     if (so3_plus_jac(c.x + (size_t)i * 15 + 3, Pq)) {   // rare: |q| > pi -> full tangent assembly
-        assemble_frame(c, i, T.D, T.O, T.R, T.g, T.tmp);
-        const double d = lane < 15 ? T.D[lane * 16 + lane] : 0.0;
+        assemble_frame<1>(c, i, Tiles<1>{T.M, nullptr, nullptr, nullptr}, T.tmp);
+        const double d = lane < 15 ? T.M[lane * 64 + lane] : 0.0;
         __syncthreads();
         return d;
     }
@@ -367,7 +389,7 @@ __device__ double frame_diag(const AsmCtx& c, int i, LdsTiles& T) {
 }
 
 __global__ __launch_bounds__(64, 2) void k_lm_step(StepArgs a) {
-    __shared__ LdsTiles T;
+    __shared__ LdsStep T;
     const int b = blockIdx.x, lane = threadIdx.x & 63;
     if (b >= a.B) return;
     LmState& st = a.w.lm[b];
@@ -472,80 +494,77 @@ __global__ __launch_bounds__(64, 2) void k_lm_step(StepArgs a) {
     // Register-resident elimination: lane j < 15 owns column j of the damped diagonal tile, lanes 16..30 the columns of
     // O^T, lanes 32..37 the columns of R^T, lane 40 the gradient.  One fused pass (fused_chol_solve) turns the matrix
     // lanes into the rows of L and every right-hand-side lane into L^-1 b, using v_readlane broadcasts only.
-    for (int e = lane; e < 256; e += 64) { T.CD[e] = 0.0; T.CR[e] = 0.0; T.W[e] = 0.0; T.Wa[e] = 0.0; }
-    if (lane < 16) T.Cg[lane] = 0.0;
+    for (int e = lane; e < 15 * 64; e += 64) { T.M[e] = 0.0; T.C[e] = 0.0; }
+    for (int e = lane; e < 256; e += 64) { T.W[e] = 0.0; T.Wa[e] = 0.0; }
     if (lane < 36) T.D0acc[lane] = 0.0;
     if (lane < 8) T.g0acc[lane] = 0.0;
-    if (lane < 15) T.sc0[lane] = scl[lane];
+    const double sc0reg = scl[lane < 15 ? lane : 0];           // scale of frame 0 (rows of the arrow block)
     lds_sync();
     bool solved = true;
     double gmax = 0.0;
     const int iteration_dbg = iteration; (void)iteration_dbg;
     STAMP(0);
+    const Tiles<1> TM{T.M, nullptr, nullptr, nullptr};
     for (int i = n - 1; i >= 0; --i) {
         STAMP(10 + i * 8 + 0);
         FrameExtra ex;
-        assemble_frame(c, i, T.D, T.O, T.R, T.g, T.tmp, scl, dgl, &ex);
+        assemble_frame<1>(c, i, TM, T.tmp, scl, dgl, &ex);
         STAMP(10 + i * 8 + 1);
-        // LM diagonal of this frame (LevenbergMarquardtStrategy::ComputeStep), |x - Plus(x,-g)|, scales into LDS
+        // LM diagonal of this frame (LevenbergMarquardtStrategy::ComputeStep), |x - Plus(x,-g)|
+        const bool cstl = lane < 15 && var_is_const(a.mode, a.fast_mode, n, i, lane);
+        const double gl = lane < 15 ? T.M[lane * 64 + 40] : 0.0;          // tangent gradient entry of this lane
+        double dgv = ex.dg_i;
         if (lane < 15) {
-            const bool cst = var_is_const(a.mode, a.fast_mode, n, i, lane);
-            const double sc = ex.sc_i;
-            T.sci[lane] = sc;
-            T.scm[lane] = i >= 1 ? ex.sc_m : 1.0;
-            double dgv = ex.dg_i;
-            if (!reuse) { dgv = fmin(fmax(T.D[lane * 16 + lane] * sc * sc, kMinDiag), kMaxDiag); dgl[i * 15 + lane] = dgv; }
-            T.dgi[lane] = dgv;
-            double m = 0.0;
-            if (!cst) {
-                if (lane < 3 || lane >= 6) m = fabs(T.g[lane]);
-                else {
-                    const double qv[3] = {rdlane(ex.x_i, 3), rdlane(ex.x_i, 4), rdlane(ex.x_i, 5)};
-                    double ng[3] = {-T.g[3], -T.g[4], -T.g[5]}, qn[3];
-                    so3_plus(qv, ng, qn);
-                    m = fabs(ex.x_i - qn[lane - 3]);
-                }
-            }
-            gmax = fmax(gmax, m);
-            const double gsv = T.g[lane] * sc;
-            sws[(size_t)i * SOLVE_WS + 960 + lane] = gsv;   // original scaled gradient (model decrease)
+            if (!reuse) { dgv = fmin(fmax(T.M[lane * 64 + lane] * ex.sc_i * ex.sc_i, kMinDiag), kMaxDiag); dgl[i * 15 + lane] = dgv; }
+            sws[(size_t)i * SOLVE_WS + 960 + lane] = gl * ex.sc_i;          // original scaled gradient (model decrease)
         }
-        lds_sync();
+        {
+            const double qv[3] = {rdlane(ex.x_i, 3), rdlane(ex.x_i, 4), rdlane(ex.x_i, 5)};
+            const double ng[3] = {-rdlane(gl, 3), -rdlane(gl, 4), -rdlane(gl, 5)};
+            double qn[3];
+            so3_plus(qv, ng, qn);                                          // uniform: every lane, no divergence
+            double m = fabs(gl);
+            if (lane >= 3 && lane < 6) m = fabs(ex.x_i - (lane == 3 ? qn[0] : (lane == 4 ? qn[1] : qn[2])));
+            if (lane < 15 && !cstl) gmax = fmax(gmax, m);
+        }
         STAMP(10 + i * 8 + 2);
-        // load this lane's column: scale (Jacobi), damp (LM), add the carried Schur terms
+        // this lane's column: scale (Jacobi), damp (LM), add the carried Schur terms.  Lane roles: j < 15 column j of
+        // the diagonal tile, 16..30 columns of O^T, 32..37 columns of R^T, 40 the gradient.
+        // (shuffles run in uniform control flow: ds_bpermute only sees data of active source lanes)
+        const double s_m = __shfl(ex.sc_m, (lane - 16) & 63, 64), s_0 = __shfl(sc0reg, (lane - 32) & 63, 64);
+        double slane = 0.0;
+        if (lane < 15) slane = ex.sc_i;
+        else if (lane >= 16 && lane < 31) slane = i >= 1 ? s_m : 0.0;
+        else if (lane >= 32 && lane < 38) slane = i >= 2 ? s_0 : 0.0;
+        else if (lane == 40) slane = 1.0;
         double col[15];
+#pragma unroll
+        for (int r = 0; r < 15; ++r) col[r] = T.M[r * 64 + lane] * (rdlane(ex.sc_i, r) * slane) + T.C[r * 64 + lane];
+        if (i == 1) {   // frame 0 is both the chain neighbour and the arrow target: fold R^T into O^T
+            const bool mg = lane >= 16 && lane < 22;
+            const int src = mg ? lane + 16 : lane;
+            const double s0 = __shfl(sc0reg, mg ? lane - 16 : 0, 64);
+#pragma unroll
+            for (int r = 0; r < 15; ++r) {
+                const double v = T.M[r * 64 + src] * (rdlane(ex.sc_i, r) * s0) + T.C[r * 64 + src];
+                if (mg) col[r] += v;
+                if (lane >= 32 && lane < 38) col[r] = 0.0;
+            }
+        }
+        if (i == 0) {
+            if (lane < 6) {
+#pragma unroll
+                for (int r = 0; r < 6; ++r) col[r] += T.D0acc[r * 6 + lane];
+            }
+            if (lane == 40) {
+#pragma unroll
+                for (int r = 0; r < 6; ++r) col[r] += T.g0acc[r];
+            }
+        }
         if (lane < 15) {
-            const int j = lane;
-            const double sj = T.sci[j];
+            const double dmp = cstl ? 0.0 : dgv / radius;
 #pragma unroll
-            for (int r = 0; r < 15; ++r) col[r] = T.D[r * 16 + j] * T.sci[r] * sj + T.CD[r * 16 + j];
-            if (i == 0 && j < 6) {
-#pragma unroll
-                for (int r = 0; r < 6; ++r) col[r] += T.D0acc[r * 6 + j];
-            }
-            const bool cst = var_is_const(a.mode, a.fast_mode, n, i, j);
-            const double dmp = cst ? 0.0 : T.dgi[j] / radius;
-#pragma unroll
-            for (int r = 0; r < 15; ++r) if (r == j) col[r] = cst ? 1.0 : col[r] + dmp;
-        } else if (lane >= 16 && lane < 31) {
-            const int cc = lane - 16;
-            const double sm = T.scm[cc];
-#pragma unroll
-            for (int r = 0; r < 15; ++r) col[r] = i >= 1 ? T.O[cc * 16 + r] * sm * T.sci[r] : 0.0;
-            if (i == 1 && cc < 6) {   // frame 0 is both the chain neighbour and the arrow target
-#pragma unroll
-                for (int r = 0; r < 15; ++r) col[r] += T.R[cc * 16 + r] * T.sc0[cc] * T.sci[r] + T.CR[cc * 16 + r];
-            }
-        } else if (lane >= 32 && lane < 38) {
-            const int cc = lane - 32;
-#pragma unroll
-            for (int r = 0; r < 15; ++r) col[r] = i >= 2 ? T.R[cc * 16 + r] * T.sc0[cc] * T.sci[r] + T.CR[cc * 16 + r] : 0.0;
-        } else if (lane == 40) {
-#pragma unroll
-            for (int r = 0; r < 15; ++r) col[r] = T.g[r] * T.sci[r] + T.Cg[r] + ((i == 0 && r < 6) ? T.g0acc[r] : 0.0);
-        } else {
-#pragma unroll
-            for (int r = 0; r < 15; ++r) col[r] = 0.0;
+            for (int r = 0; r < 15; ++r) if (r == lane) col[r] = cstl ? 1.0 : col[r] + dmp;
         }
         STAMP(10 + i * 8 + 3);
         if (!fused_chol_solve(col)) { solved = false; break; }
@@ -570,7 +589,7 @@ __global__ __launch_bounds__(64, 2) void k_lm_step(StepArgs a) {
         lds_sync();
         STAMP(10 + i * 8 + 5);
         if (i >= 1) {
-            // Schur products on the matrix cores
+            // Schur products on the matrix cores, written back in the lane layout of the next frame
             const d4 p1 = xty16(T.W, T.W);     // [Wo|z]^T [Wo|z]
             const d4 p2 = xty16(T.Wa, T.W);    // [Wr|0]^T [Wo|z]
             const d4 p3 = xty16(T.Wa, T.Wa);   // [Wr|0]^T [Wr|0]
@@ -578,9 +597,9 @@ __global__ __launch_bounds__(64, 2) void k_lm_step(StepArgs a) {
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const int row = (lane >> 4) + 4 * r, colx = lane & 15;
-                if (row < 15 && colx < 15) T.CD[row * 16 + colx] = -p1[r];
-                if (row < 15 && colx == 15) T.Cg[row] = -p1[r];
-                if (row < 6 && colx < 15) T.CR[row * 16 + colx] = -p2[r];
+                if (row < 15 && colx < 15) T.C[row * 64 + colx] = -p1[r];            // diagonal tile of frame i-1
+                if (row < 15 && colx == 15) T.C[row * 64 + 40] = -p1[r];             // gradient of frame i-1
+                if (row < 6 && colx < 15) T.C[colx * 64 + 32 + row] = -p2[r];        // arrow block H[0, i-1] (as R^T)
                 if (i >= 2) {
                     if (row < 6 && colx == 15) T.g0acc[row] -= p2[r];
                     if (row < 6 && colx < 6) T.D0acc[row * 6 + colx] -= p3[r];
@@ -743,7 +762,7 @@ __global__ __launch_bounds__(64) void k_export_dense(ExportArgs a) {
     __syncthreads();
     const double sgn = a.mode == LIW_MODE_MARG ? -1.0 : 1.0;
     for (int i = 0; i < n; ++i) {
-        assemble_frame(c, i, T.D, T.O, T.R, T.g, T.tmp);
+        assemble_frame<0>(c, i, Tiles<0>{T.D, T.O, T.R, T.g}, T.tmp);
         for (int e = lane; e < 256; e += 64) {
             const int r = e >> 4, cc = e & 15;
             if (r < 15 && cc < 15) {
@@ -785,7 +804,7 @@ __global__ __launch_bounds__(64) void k_marg_schur(MargArgs a) {
     // frame i is eliminated using its coupling O_{i+1} = H[i, i+1]; O of frame i+1 is assembled one frame ahead
     for (int i = 0; i < n; ++i) {
         // D_i, g_i  (+ carried Schur terms); O tile of THIS call is H[i-1,i], so fetch H[i,i+1] from the next frame
-        assemble_frame(c, i, T.D, T.O, T.R, T.g, T.tmp);
+        assemble_frame<0>(c, i, Tiles<0>{T.D, T.O, T.R, T.g}, T.tmp);
         for (int e = lane; e < 256; e += 64) {
             const int r = e >> 4, cc = e & 15;
             T.D[e] = (r < 15 && cc < 15) ? T.D[e] + T.CD[e] : 0.0;
@@ -794,7 +813,7 @@ __global__ __launch_bounds__(64) void k_marg_schur(MargArgs a) {
         __syncthreads();
         if (i == n - 1) break;
         // coupling block H[i, i+1]: assemble frame i+1's O tile into T.R (scratch tiles W/Wa used as dummies)
-        assemble_frame(c, i + 1, T.W, T.R, T.Wa, T.y0, T.tmp);   // T.R <- H[i, i+1] (rows: frame i)
+        assemble_frame<0>(c, i + 1, Tiles<0>{T.W, T.R, T.Wa, T.y0}, T.tmp);   // T.R <- H[i, i+1] (rows: frame i)
         if (!chol15(T.D)) { ok = false; break; }
         // W = L^-1 [O | g] : lanes 0..14 columns of O (H[i, i+1][:, col]), lane 15 -> g
         if (lane < 16) {

@@ -160,21 +160,30 @@ template <class T> __host__ __device__ inline V3<T> log_SO3(const M3<T>& mat) {
     } else {
         int i = 0;
         if (mat(1, 1) > mat(0, 0)) i = 1;
-        if (mat(2, 2) > mat(i, i)) i = 2;
-        // branch-free selection of the permuted entries keeps c[] in registers (no dynamic indexing)
+        if (mat(2, 2) > (i == 1 ? mat(1, 1) : mat(0, 0))) i = 2;
+        // the permuted entries are picked with selects on compile-time indices, so nothing is indexed dynamically
         const int j = (i + 1) % 3, k = (j + 1) % 3;
-        auto M = [&](int r, int cc) -> T {
-            T out = mat.m[0];
-#pragma unroll
-            for (int q = 1; q < 9; ++q) if (q == r * 3 + cc) out = mat.m[q];
-            return out;
-        };
-        t = dsqrt(M(i, i) - M(j, j) - M(k, k) + T(1.0));
+        // scalar copies first: selects between array elements would otherwise be folded into a dynamically indexed load
+        const T e0 = mat.m[0], e1 = mat.m[1], e2 = mat.m[2], e3 = mat.m[3], e4 = mat.m[4], e5 = mat.m[5], e6 = mat.m[6], e7 = mat.m[7], e8 = mat.m[8];
+        const T d0 = e0, d1 = e4, d2 = e8;
+        const T mii = i == 0 ? d0 : (i == 1 ? d1 : d2);
+        const T mjj = j == 0 ? d0 : (j == 1 ? d1 : d2);
+        const T mkk = k == 0 ? d0 : (k == 1 ? d1 : d2);
+        // (k,j),(j,k): i=0 -> (2,1),(1,2); i=1 -> (0,2),(2,0); i=2 -> (1,0),(0,1)
+        const T mkj = i == 0 ? e7 : (i == 1 ? e2 : e3);
+        const T mjk = i == 0 ? e5 : (i == 1 ? e6 : e1);
+        // (j,i),(i,j): i=0 -> (1,0),(0,1); i=1 -> (2,1),(1,2); i=2 -> (0,2),(2,0)
+        const T mji = i == 0 ? e3 : (i == 1 ? e7 : e2);
+        const T mij = i == 0 ? e1 : (i == 1 ? e5 : e6);
+        // (k,i),(i,k): i=0 -> (2,0),(0,2); i=1 -> (0,1),(1,0); i=2 -> (1,2),(2,1)
+        const T mki = i == 0 ? e6 : (i == 1 ? e1 : e5);
+        const T mik = i == 0 ? e2 : (i == 1 ? e3 : e7);
+        t = dsqrt(mii - mjj - mkk + T(1.0));
         const T ci = T(0.5) * t;
         t = T(0.5) / t;
-        const T cw = (M(k, j) - M(j, k)) * t;
-        const T cj = (M(j, i) + M(i, j)) * t;
-        const T ck = (M(k, i) + M(i, k)) * t;
+        const T cw = (mkj - mjk) * t;
+        const T cj = (mji + mij) * t;
+        const T ck = (mki + mik) * t;
         c[3] = cw;
         c[0] = (i == 0) ? ci : ((j == 0) ? cj : ck);
         c[1] = (i == 1) ? ci : ((j == 1) ? cj : ck);

@@ -46,3 +46,29 @@ def test_extrinsics_reorthonormalised(liw, synth):
     Tw, Tl = s.extrinsics()
     for T in (Tw, Tl):
         assert np.abs(T[:3, :3] @ T[:3, :3].T - np.eye(3)).max() < 1e-6
+
+
+def test_log_so3_all_quaternion_branches_host(liw, synth, pyoracle):
+    """Large relative rotations between two odometry samples drive lie::log_SO3 through the trace <= 0 branches
+    (arg-max diagonal i = 0, 1, 2) of the shared host/device geometry header; compared with the oracle."""
+    prm = synth.office_params()
+    orc = pyoracle.Oracle(prm)
+    rng = np.random.default_rng(3)
+    hit = set()
+    for trial in range(60):
+        axis = rng.normal(size=3)
+        axis /= np.linalg.norm(axis)
+        if trial < 3:
+            axis = np.eye(3)[trial]
+        ang = rng.uniform(2.2, 3.1)
+        R = synth.exp_so3(axis * ang)
+        hit.add(int(np.argmax(np.diag(R))) if np.trace(R) <= 0 else -1)
+        samples = np.zeros((2, 13))
+        samples[0, 0], samples[1, 0] = 0.0, 0.1
+        samples[0, 1:10] = np.eye(3).reshape(9)
+        samples[1, 1:10] = R.reshape(9)
+        samples[1, 10:13] = [0.1, 0.02, 0.0]
+        Ta, Pa, Da = liw.HostPreint(prm).wheel_preint(samples, 0.0, 0.2)
+        Tb, Pb, Db = orc.wheel_preint(samples, 0.0, 0.2)
+        assert np.abs(Ta - Tb).max() < 1e-12 and np.abs(Pa - Pb).max() <= 1e-10 * np.abs(Pb).max()
+    assert {0, 1, 2} <= hit
