@@ -116,7 +116,18 @@ class BatchSolver:
         """Runs the whole LM loop.  Single rank: one native call (optionally a captured hipGraph).  Factor-sharded:
         the loop is driven here so the all-reduce sits between linearise and step."""
         if self.world == 1:
-            self._chk(self.L.liw_batch_solve(self.h, C.byref(self.b), C.c_int(mode), C.c_int(max_iters), self._wsp(), self._stream(), C.c_int(int(use_graph))))
+            if use_graph:
+                # stream capture is not allowed on the legacy default stream: replay on a dedicated side stream
+                torch = self.torch
+                if getattr(self, "_side", None) is None:
+                    self._side = torch.cuda.Stream(device=self.dev)
+                cur = torch.cuda.current_stream(self.dev)
+                self._side.wait_stream(cur)
+                with torch.cuda.stream(self._side):
+                    self._chk(self.L.liw_batch_solve(self.h, C.byref(self.b), C.c_int(mode), C.c_int(max_iters), self._wsp(), self._stream(), C.c_int(1)))
+                cur.wait_stream(self._side)
+                return
+            self._chk(self.L.liw_batch_solve(self.h, C.byref(self.b), C.c_int(mode), C.c_int(max_iters), self._wsp(), self._stream(), C.c_int(0)))
             return
         K = self._chk(self.L.liw_batch_set_max_iters(self.h, C.c_int(mode), C.c_int(max_iters)))
         s = self._stream()

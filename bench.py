@@ -59,13 +59,14 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--batch", type=int, default=int(os.environ.get("LIW_BENCH_BATCH", 1024)), help="windows per GPU per step")
+    ap.add_argument("--batch", type=int, default=int(os.environ.get("LIW_BENCH_BATCH", 2048)), help="windows per GPU per step")
     ap.add_argument("--frames", type=int, default=30)
     ap.add_argument("--laser", type=int, default=2000)
     ap.add_argument("--iters", type=int, default=50, help="LM iteration cap (Ceres default 50)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-reps", type=int, default=12)
     ap.add_argument("--skip-sharded", action="store_true")
+    ap.add_argument("--no-single", action="store_true", help="skip the B=1 latency measurement (clean per-kernel profiles)")
     args = ap.parse_args()
 
     import torch
@@ -135,14 +136,17 @@ def main():
     alg_bytes_total = args.steps * (lm_window_launches * bytes_init + B * bytes_marg)
     lin_time_s = tm["linearize_ms"] * tm["linearize_launches"] * 1e-3
     achieved = alg_bytes_total / lin_time_s / 1e9 if lin_time_s > 0 else 0.0
+    # HBM traffic per full launch from the rocprofv3 PMC passes (FETCH_SIZE / WRITE_SIZE, separate runs, calibrated as
+    # tools/pmc_traffic.py documents), scaled from the profiled batch to this one: traffic is linear in the windows
     traffic = None
     pmc = os.path.join(ROOT, "profiles", "pmc_traffic.json")
     if os.path.exists(pmc):
         try:
-            traffic = json.load(open(pmc)).get("k_linearize_hbm_bytes_per_launch")
+            traffic = int(json.load(open(pmc))["k_linearize_hbm_bytes_per_window"] * B)
         except Exception:
             traffic = None
-    roofline = {"bound": "hbm", "kernel": "k_linearize", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+    roofline = {"bound": "hbm", "kernel": "linearise = k_frame_tf + k_lin_laser + k_lin_imu + k_lin_small (Jacobian evaluation, one HIP-event bracket)",
+                "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
                 "avg_launch_ms": round(tm["linearize_ms"], 5), "launches": tm["linearize_launches"],
                 "algorithmic_bytes_per_window": bytes_init,
@@ -160,6 +164,25 @@ def main():
                "sample": "%d x (init_solve + marginalization) of window seed 20240 (n=%d, L=%d), %d LM iterations total, %.1f s"
                          % (args.cpu_reps, n, L, it, sec),
                "host_cpu_count": os.cpu_count()}
+
+    # ---- single-window latency (B = 1, the reference's own call pattern), hipGraph-captured launch sequence
+    single = None
+    if rank == 0 and world == 1 and not args.no_single:
+        s1 = liw.BatchSolver(prm, windows[:1], device=dev)
+        x1 = s1.t["x"].clone()
+        reps = 5
+        for rep in range(reps + 1):
+            if rep == 1:
+                torch.cuda.synchronize()
+                ts = time.perf_counter()
+            s1.t["x"].copy_(x1)
+            s1.t["has_prior"].zero_()
+            s1.solve(liw.LIW_MODE_INIT, args.iters, use_graph=True)
+            s1.marginalize()
+        torch.cuda.synchronize()
+        ms1 = 1e3 * (time.perf_counter() - ts) / reps
+        single = {"ms_per_solve": round(ms1, 3), "solves_per_s": round(1e3 / ms1, 1), "lm_iterations": s1.summaries()[0]["iterations"]}
+        s1.close()
 
     # ---- factor-sharded mode (N > 1): C4-shaped window, RCCL all-reduce of the laser partial sums per iteration
     sharded = None
@@ -193,6 +216,8 @@ def main():
                "roofline": roofline, "cpu_baseline": cpu}
         if cpu:
             out["speedup_vs_cpu_1core"] = round(out["value"] / cpu["value"], 1)
+        if single:
+            out["single_window_latency"] = single
         if sharded:
             out["factor_sharded"] = sharded
         print(json.dumps(out))
