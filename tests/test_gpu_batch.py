@@ -1,0 +1,178 @@
+"""GPU tests of the batched / edge-case paths (through the C-ABI): ragged batches, empty inputs, |q| > pi states,
+fast_mode, the hipGraph launch path, run-to-run determinism, full-size (C4 / C5) normal equations."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def rel(a, b):
+    return float(np.abs(np.asarray(a) - np.asarray(b)).max() / max(1.0, np.abs(np.asarray(b)).max()))
+
+
+@pytest.fixture(scope="module")
+def env(liw, synth, pyoracle):
+    prm = synth.office_params()
+    return prm, pyoracle.Oracle(prm)
+
+
+def test_ragged_batch_matches_single_window_and_oracle(liw, synth, pyoracle, env):
+    prm, orc = env
+    shapes = [(6, 60), (6, 0), (6, 7), (6, 131)]          # ragged laser counts inside one batch (uniform n)
+    ws = [synth.make_window(orc, prm, seed=40 + k, n=n, L=L) for k, (n, L) in enumerate(shapes)]
+    bs = liw.BatchSolver(prm, ws, history_records=0)
+    bs.solve(liw.LIW_MODE_INIT, 30)
+    got = bs.states()
+    summ = bs.summaries()
+    for k, w in enumerate(ws):
+        wo = pyoracle.Window(w)
+        orc.set_prior(None)
+        orc.set_max_iterations(30)
+        orc.init_solve(wo)
+        so = orc.summary()
+        assert summ[k]["iterations"] == so["iterations"] and summ[k]["termination"] == so["termination"], k
+        assert rel(got[k], wo["states"].reshape(-1, 15)) <= 1e-6, k
+    orc.set_max_iterations(50)
+
+
+def test_batch_marginalization_matches_oracle(liw, synth, pyoracle, env):
+    prm, orc = env
+    ws = [synth.make_window(orc, prm, seed=60 + k, n=8, L=100 + 13 * k) for k in range(3)]
+    bs = liw.BatchSolver(prm, ws)
+    sH, dH, dg = bs.marginalize()
+    dH, dg = dH.cpu().numpy().reshape(-1, 15, 15), dg.cpu().numpy()
+    for k, w in enumerate(ws):
+        wo = pyoracle.Window(w)
+        orc.set_prior(None)
+        orc.marginalization(wo)
+        m = orc.marg_pieces()
+        assert np.abs(dH[k] - m["Delta_H"]).max() <= 1e-7 * np.abs(m["Delta_H"]).max()
+        assert np.abs(dg[k] - m["Delta_g"]).max() <= 1e-7 * max(1.0, np.abs(m["Delta_g"]).max())
+
+
+def test_marg_topology_normal_equations(liw, synth, pyoracle, env):
+    prm, orc = env
+    d = synth.make_window(orc, prm, seed=77, n=7, L=90)
+    slv = liw.Solver(prm)
+    slv.set_window(liw.Window(d))
+    slv.set_prior(None)
+    H, g, _ = slv.linearize(liw.LIW_MODE_MARG)
+    wo = pyoracle.Window(d)
+    orc.set_prior(None)
+    orc.marginalization(wo)
+    m = orc.marg_pieces()           # dense J^T J and -J^T R of the reference algorithm (solver.cpp:12-13)
+    assert np.abs(H - m["H"]).max() <= 1e-9 * np.abs(m["H"]).max()
+    assert np.abs(g - m["g"]).max() <= 1e-9 * np.abs(m["g"]).max()
+
+
+def test_single_frame_and_two_frame_windows(liw, synth, pyoracle, env):
+    prm, orc = env
+    for n, L in ((2, 0), (2, 5)):
+        d = synth.make_window(orc, prm, seed=5, n=n, L=L)
+        wo, wg = pyoracle.Window(d), liw.Window(d)
+        orc.set_prior(None)
+        orc.init_solve(wo)
+        slv = liw.Solver(prm)
+        slv.set_window(wg)
+        s = slv.init_solve()
+        assert s["iterations"] == orc.summary()["iterations"]
+        assert rel(wg["states"], wo["states"]) <= 1e-6
+    # n = 1 (ground factors only): 13 of 15 states are unobservable and the tilt residual |tilt|/sigma is a cone, so
+    # the LM path is chaotic at round-off level (oracle vs GPU drift apart after ~30 iterations).  The reference
+    # never solves a 1-frame window; only require a finite, cost-decreasing run and parity of the early iterations.
+    d = synth.make_window(orc, prm, seed=5, n=1, L=0)
+    wo, wg = pyoracle.Window(d), liw.Window(d)
+    orc.set_prior(None)
+    orc.init_solve(wo)
+    slv = liw.Solver(prm)
+    slv.set_window(wg)
+    s = slv.init_solve()
+    ho, hg = orc.iterations(), slv.history()
+    for k in range(20):
+        assert np.abs(hg[k] - ho[k]["x"].reshape(1, 15)).max() <= 1e-6
+    assert np.isfinite(wg["states"]).all() and s["final_cost"] < s["initial_cost"]
+
+
+def test_rotation_vectors_beyond_pi(liw, synth, pyoracle, env):
+    """States whose |q| > pi exercise the non-identity Jacobian of the so3 Plus (src/factor/factor_common.h:41-53)."""
+    prm, orc = env
+    d = synth.make_window(orc, prm, seed=9, n=4, L=40)
+    st = d["states"].copy()
+    for k in (0, 2):
+        q = st[k, 3:6]
+        a = np.linalg.norm(q)
+        st[k, 3:6] = q / a * (a - 2 * np.pi)      # same rotation, |q| = 2 pi - a > pi
+    assert np.linalg.norm(st[0, 3:6]) > np.pi
+    d["states"] = st
+    d["match_pose"][:, 0:6] = st[0, 0:6]
+    d["match_pose"][:, 6:12] = st[:, 0:6]
+    slv = liw.Solver(prm)
+    slv.set_window(liw.Window(d))
+    H, g, c = slv.linearize(liw.LIW_MODE_INIT)
+    Ho, go, co = orc.linearize(pyoracle.Window(d), 0)
+    assert abs(c - co) <= 1e-10 * co
+    assert np.abs(H - Ho).max() <= 1e-8 * np.abs(Ho).max() and np.abs(g - go).max() <= 1e-8 * np.abs(go).max()
+    wo, wg = pyoracle.Window(d), liw.Window(d)
+    orc.set_prior(None)
+    orc.init_solve(wo)
+    slv.set_window(wg)
+    s = slv.init_solve()
+    assert s["iterations"] == orc.summary()["iterations"]
+    assert rel(wg["states"], wo["states"]) <= 1e-6
+
+
+def test_fast_mode_tracking(liw, synth, pyoracle):
+    prm = dict(synth.office_params())
+    prm["fast_mode"] = True
+    orc = pyoracle.Oracle(prm)
+    d = synth.make_window(orc, prm, seed=14, n=3, L=50)
+    d["states"][2, 0:3] += 0.01
+    wo, wg = pyoracle.Window(d), liw.Window(d)
+    orc.solve(wo)
+    slv = liw.Solver(prm)
+    slv.set_window(wg)
+    s = slv.solve()
+    so = orc.summary()
+    assert s["iterations"] == so["iterations"] <= 10                 # solver.cpp:800-801
+    assert rel(wg["states"], wo["states"]) <= 1e-6
+    assert np.array_equal(wg["states"].reshape(-1, 15)[:2, 9:15], d["states"][:2, 9:15])   # bs constant too in fast mode
+    assert slv.marginalization()["sqrt_H"].shape == (6, 6)          # no-op (solver.cpp:259-260)
+    assert slv.get_prior() is None
+
+
+def test_graph_launch_and_determinism(liw, synth, env):
+    import torch
+    prm, orc = env
+    ws = [synth.make_window(orc, prm, seed=80 + k, n=10, L=200) for k in range(4)]
+    outs = []
+    for use_graph in (False, True, True):
+        bs = liw.BatchSolver(prm, ws)
+        bs.solve(liw.LIW_MODE_INIT, 20, use_graph=use_graph)
+        torch.cuda.synchronize()
+        outs.append(bs.states().copy())
+    assert np.array_equal(outs[0], outs[1]) and np.array_equal(outs[1], outs[2])   # no atomics: bit-reproducible
+
+
+@pytest.mark.parametrize("n,L", [(30, 20000), (50, 5000)])
+def test_full_size_normal_equations(liw, synth, pyoracle, env, n, L):
+    """BASELINE configs C4 (20 000 laser blocks) and C5 (50 key-frames): H, g, cost against the oracle, plus the
+    size-independent properties (symmetry, PSD, block sparsity pattern)."""
+    prm, orc = env
+    d = synth.make_window(orc, prm, seed=1234, n=n, L=L)
+    slv = liw.Solver(prm)
+    slv.set_window(liw.Window(d))
+    H, g, c = slv.linearize(liw.LIW_MODE_INIT)
+    Ho, go, co = orc.linearize(pyoracle.Window(d), 0)
+    assert abs(c - co) <= 1e-11 * co
+    assert np.abs(H - Ho).max() <= 1e-9 * np.abs(Ho).max() and np.abs(g - go).max() <= 1e-9 * np.abs(go).max()
+    assert np.abs(H - H.T).max() <= 1e-12 * np.abs(H).max()
+    assert np.linalg.eigvalsh(H).min() >= -1e-7 * np.abs(H).max()
+    # only the block tri-diagonal + the frame-0 pose arrow may be non-zero
+    mask = np.zeros_like(H, dtype=bool)
+    for i in range(n):
+        for j in (i - 1, i, i + 1):
+            if 0 <= j < n:
+                mask[i * 15:(i + 1) * 15, j * 15:(j + 1) * 15] = True
+        mask[0:6, i * 15:i * 15 + 6] = True
+        mask[i * 15:i * 15 + 6, 0:6] = True
+    assert np.abs(H[~mask]).max() == 0.0
