@@ -129,17 +129,31 @@ class BatchSolver:
                 return
             self._chk(self.L.liw_batch_solve(self.h, C.byref(self.b), C.c_int(mode), C.c_int(max_iters), self._wsp(), self._stream(), C.c_int(0)))
             return
-        K = self._chk(self.L.liw_batch_set_max_iters(self.h, C.c_int(mode), C.c_int(max_iters)))
-        s = self._stream()
-        self._chk(self.L.liw_batch_lm_begin(self.h, C.byref(self.b), C.c_int(mode), C.c_int(K), self._wsp(), s))
-        self._chk(self.L.liw_batch_lm_linearize(self.h, C.byref(self.b), C.c_int(mode), C.c_int(0), self._wsp(), s))
+        K = self.lm_begin(mode, max_iters)
+        self.lm_linearize(mode, 0)
         allreduce_sum_(self.PL[0], self.group)
         for _ in range(K):
-            self._chk(self.L.liw_batch_lm_step(self.h, C.byref(self.b), C.c_int(mode), self._wsp(), s))
-            self._chk(self.L.liw_batch_lm_linearize(self.h, C.byref(self.b), C.c_int(mode), C.c_int(1), self._wsp(), s))
+            self.lm_step(mode)
+            self.lm_linearize(mode, 1)
             allreduce_sum_(self.PL[1], self.group)
-        self._chk(self.L.liw_batch_lm_step(self.h, C.byref(self.b), C.c_int(mode), self._wsp(), s))
-        self._chk(self.L.liw_batch_lm_finish(self.h, C.byref(self.b), C.c_int(mode), self._wsp(), s))
+        self.lm_step(mode)
+        self.lm_finish(mode)
+
+    # the launch pieces of one solve (what liw_batch_solve chains); a factor-sharded driver puts its exchange of
+    # self.PL[candidate] between lm_linearize and lm_step
+    def lm_begin(self, mode, max_iters=0):
+        K = self._chk(self.L.liw_batch_set_max_iters(self.h, C.c_int(mode), C.c_int(max_iters)))
+        self._chk(self.L.liw_batch_lm_begin(self.h, C.byref(self.b), C.c_int(mode), C.c_int(K), self._wsp(), self._stream()))
+        return K
+
+    def lm_linearize(self, mode, candidate):
+        self._chk(self.L.liw_batch_lm_linearize(self.h, C.byref(self.b), C.c_int(mode), C.c_int(candidate), self._wsp(), self._stream()))
+
+    def lm_step(self, mode):
+        self._chk(self.L.liw_batch_lm_step(self.h, C.byref(self.b), C.c_int(mode), self._wsp(), self._stream()))
+
+    def lm_finish(self, mode):
+        self._chk(self.L.liw_batch_lm_finish(self.h, C.byref(self.b), C.c_int(mode), self._wsp(), self._stream()))
 
     def linearize(self, mode):
         self._chk(self.L.liw_batch_linearize(self.h, C.byref(self.b), C.c_int(mode), self._wsp(), self._stream()))

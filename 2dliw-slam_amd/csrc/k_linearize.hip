@@ -458,8 +458,10 @@ __device__ __forceinline__ void wheel_res(const DevParams& P, const double* T12,
     Iso<T> tf_j = mul(make_tf(pj, thetaj), T_i_w);
     Iso<T> w_tf_ij = mul(inverse(tf_i), tf_j);
     V3<T> p = w_tf_ij.t, q = log_SO3(w_tf_ij.R);
-    Iso<T> od = cast_iso<T>(T12, T12 + 9);
-    V3<T> op = od.t, oq = log_SO3(od.R);
+    // log_SE3 of the constant odometry increment: no parameter enters, so it is evaluated on plain doubles
+    const V3<double> oqd = log_SO3(cast_m3<double>(T12));
+    const V3<T> op = cast_v3<T>(T12 + 9);
+    const V3<T> oq = V3<T>(T(oqd.x), T(oqd.y), T(oqd.z));
     T o_len = dsqrt(op.x * op.x + op.y * op.y);
     T len = dsqrt(p.x * p.x + p.y * p.y);
     V3<T> o_dir(op.x, op.y, T(0.0)), dir(p.x, p.y, T(0.0));

@@ -119,83 +119,113 @@ template <int LAYOUT> struct Tiles {
     __device__ __forceinline__ double& gg(int r) const { return LAYOUT ? D[r * 64 + 40] : g[r]; }
 };
 
-// Assemble frame i's blocks (ambient -> tangent, constants masked), UNSCALED.
-template <int LAYOUT>
-__device__ void assemble_frame(const AsmCtx& c, int i, const Tiles<LAYOUT>& T_, double* tmp,
-                               const double* scl = nullptr, const double* dgl = nullptr, FrameExtra* ex = nullptr) {
+// Raw values of one frame's assembly, as loaded (asm_issue) and before they are combined (asm_commit): splitting the
+// two lets k_lm_step issue frame i-1's loads before it factorises frame i, hiding the memory round trip.
+struct AsmRegs {
+    double v5[4], v6[4], v7[4];             // IMU partial entries: block (i-1,i) jj / block (i,i+1) ii / block (i-1,i) ij
+    double t1, t2, t3, t4, t8, t9, t10;     // 6x6 pose-block terms (laser, wheel, ground)
+    double g1, g2, g3, g4, g5, g6;          // gradient terms
+    double xq, sc_i, sc_m, dg_i;            // state entries, Jacobi scales, LM diagonal
+};
+
+// All loads of a frame are issued up front, branch-free (clamped addresses; masking happens in asm_commit), so the
+// wave pays ONE memory round trip per frame instead of one per conditional term.
+__device__ __forceinline__ AsmRegs asm_issue(const AsmCtx& c, int i, const double* scl, const double* dgl) {
     const int lane = threadIdx.x & 63;
     const int n = c.n;
     const double* PLb = c.PL + (size_t)c.b * n * LP;
     const double* PIb = c.PI + (size_t)c.b * (n - 1) * PIS;
     const double* PWb = c.PW + (size_t)c.b * (n - 1) * PWS;
     const double* PGb = c.PG + (size_t)c.b * n * PGS;
-    const bool prior_here = c.prior_on && i == n - 2;
-    if (prior_here) {   // stage r_prior
-        if (lane < 15) tmp[lane] = prior_r(c, lane);
-        lds_sync();
-    }
-    // All loads of a frame are issued up front, branch-free (masked by select), so the wave pays ONE memory round
-    // trip per frame instead of one per conditional term.
     const bool hasm = i >= 1, hasp = i <= n - 2;
     const double* PIm = PIb + (size_t)(hasm ? i - 1 : 0) * PIS;   // IMU block (i-1, i)
     const double* PIp = PIb + (size_t)(hasp ? i : 0) * PIS;       // IMU block (i, i+1)
     const double* PWm = PWb + (size_t)(hasm ? i - 1 : 0) * PWS;
     const double* PWp = PWb + (size_t)(hasp ? i : 0) * PWS;
-    double dI[4], oI[4];
+    AsmRegs R;
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
         const int e = lane + 64 * q, r = e >> 4, cc = e & 15;
         const bool valid = r < 15 && cc < 15;
         const int rs = valid ? r : 0, cs = valid ? cc : 0;
-        const double v5 = PIm[(15 + rs) * 31 + 15 + cs], v6 = PIp[rs * 31 + cs], v7 = PIm[rs * 31 + 15 + cs];
-        dI[q] = ((valid && hasm) ? v5 : 0.0) + ((valid && hasp) ? v6 : 0.0);
-        oI[q] = (valid && hasm) ? v7 : 0.0;
+        R.v5[q] = PIm[(15 + rs) * 31 + 15 + cs];
+        R.v6[q] = PIp[rs * 31 + cs];
+        R.v7[q] = PIm[rs * 31 + 15 + cs];
     }
-    double dP = 0.0, oP = 0.0, rP = 0.0;
     {   // the 6x6 pose block terms: one element per lane (lanes 0..35)
         const bool pl = lane < 36;
         const int r = pl ? lane / 6 : 0, cc = pl ? lane % 6 : 0;
-        const double t1 = PLb[(size_t)i * LP + 36 + r * 6 + cc];
-        const double t2 = PWm[(6 + r) * 13 + 6 + cc], t3 = PWp[r * 13 + cc];
-        const double t4 = PGb[(size_t)i * PGS + r * 7 + cc];
-        const double t8 = PWm[r * 13 + 6 + cc];
-        const double t9 = PLb[(size_t)(n > 1 ? 1 : 0) * LP + 72 + r * 6 + cc];
-        const double t10 = PLb[(size_t)i * LP + 72 + r * 6 + cc];
-        dP = t1 + (hasm ? t2 : 0.0) + (hasp ? t3 : 0.0) + t4;
+        R.t1 = PLb[(size_t)i * LP + 36 + r * 6 + cc];
+        R.t2 = PWm[(6 + r) * 13 + 6 + cc];
+        R.t3 = PWp[r * 13 + cc];
+        R.t4 = PGb[(size_t)i * PGS + r * 7 + cc];
+        R.t8 = PWm[r * 13 + 6 + cc];
+        R.t9 = PLb[(size_t)(n > 1 ? 1 : 0) * LP + 72 + r * 6 + cc];
+        R.t10 = PLb[(size_t)i * LP + 72 + r * 6 + cc];
+    }
+    {
+        const int r = lane < 15 ? lane : 0, r6 = r < 6 ? r : 0;
+        R.g1 = PLb[(size_t)i * LP + 114 + r6];
+        R.g2 = PWm[(6 + r6) * 13 + 12];
+        R.g3 = PWp[r6 * 13 + 12];
+        R.g4 = PGb[(size_t)i * PGS + r6 * 7 + 6];
+        R.g5 = PIm[(15 + r) * 31 + 30];
+        R.g6 = PIp[r * 31 + 30];
+    }
+    {   // states (rotation vectors of frames i, i-1, 0 for the so3 Plus Jacobian test) and the LM scales
+        int idx = i * 15 + (lane < 15 ? lane : 0);
+        if (lane >= 16 && lane < 19) idx = (hasm ? i - 1 : i) * 15 + 3 + (lane - 16);
+        if (lane >= 20 && lane < 23) idx = 3 + (lane - 20);
+        R.xq = c.x[idx];
+        const int v = lane < 15 ? lane : 0;
+        R.sc_i = scl ? scl[i * 15 + v] : 1.0;
+        R.sc_m = scl ? scl[(hasm ? i - 1 : i) * 15 + v] : 1.0;
+        R.dg_i = dgl ? dgl[i * 15 + v] : 0.0;
+    }
+    return R;
+}
+
+// Combine the loaded values into frame i's blocks (ambient -> tangent, constants masked), UNSCALED.
+template <int LAYOUT>
+__device__ void asm_commit(const AsmCtx& c, int i, const AsmRegs& R, const Tiles<LAYOUT>& T_, double* tmp, FrameExtra* ex = nullptr) {
+    const int lane = threadIdx.x & 63;
+    const int n = c.n;
+    const double* PLb = c.PL + (size_t)c.b * n * LP;
+    const bool hasm = i >= 1, hasp = i <= n - 2;
+    const bool prior_here = c.prior_on && i == n - 2;
+    if (prior_here) {   // stage r_prior
+        if (lane < 15) tmp[lane] = prior_r(c, lane);
+        lds_sync();
+    }
+    double dI[4], oI[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const int e = lane + 64 * q, r = e >> 4, cc = e & 15;
+        const bool valid = r < 15 && cc < 15;
+        dI[q] = ((valid && hasm) ? R.v5[q] : 0.0) + ((valid && hasp) ? R.v6[q] : 0.0);
+        oI[q] = (valid && hasm) ? R.v7[q] : 0.0;
+    }
+    double dP = 0.0, oP = 0.0, rP = 0.0;
+    {
+        const bool pl = lane < 36;
+        const int r = pl ? lane / 6 : 0, cc = pl ? lane % 6 : 0;
+        dP = R.t1 + (hasm ? R.t2 : 0.0) + (hasp ? R.t3 : 0.0) + R.t4;
         if (i == 0) for (int j = 0; j < n; ++j) dP += PLb[(size_t)j * LP + r * 6 + cc];
-        oP = hasm ? t8 + (i == 1 ? t9 : 0.0) : 0.0;
-        rP = i >= 2 ? t10 : 0.0;
+        oP = hasm ? R.t8 + (i == 1 ? R.t9 : 0.0) : 0.0;
+        rP = i >= 2 ? R.t10 : 0.0;
         if (!pl) { dP = 0.0; oP = 0.0; rP = 0.0; }
     }
     double gg = 0.0;
     {
-        const int r = lane < 15 ? lane : 0, r6 = r < 6 ? r : 0;
-        const double g1 = PLb[(size_t)i * LP + 114 + r6], g2 = PWm[(6 + r6) * 13 + 12], g3 = PWp[r6 * 13 + 12];
-        const double g4 = PGb[(size_t)i * PGS + r6 * 7 + 6];
-        const double g5 = PIm[(15 + r) * 31 + 30], g6 = PIp[r * 31 + 30];
+        const int r = lane < 15 ? lane : 0;
         if (r < 6) {
-            gg = g1 + (hasm ? g2 : 0.0) + (hasp ? g3 : 0.0) + g4;
+            gg = R.g1 + (hasm ? R.g2 : 0.0) + (hasp ? R.g3 : 0.0) + R.g4;
             if (i == 0) for (int j = 0; j < n; ++j) gg += PLb[(size_t)j * LP + 108 + r];
         }
-        gg += (hasm ? g5 : 0.0) + (hasp ? g6 : 0.0);
+        gg += (hasm ? R.g5 : 0.0) + (hasp ? R.g6 : 0.0);
     }
-    // states needed below (rotation vectors of frames i, i-1, 0 for the so3 Plus Jacobian test) and the LM scales,
-    // fetched in the same batch of loads
-    double xq;
-    {
-        int idx = (size_t)i * 15 + (lane < 15 ? lane : 0);
-        if (lane >= 16 && lane < 19) idx = (hasm ? i - 1 : i) * 15 + 3 + (lane - 16);
-        if (lane >= 20 && lane < 23) idx = 3 + (lane - 20);
-        xq = c.x[idx];
-    }
-    if (ex) {
-        const int v = lane < 15 ? lane : 0;
-        ex->sc_i = scl[i * 15 + v];
-        ex->sc_m = scl[(hasm ? i - 1 : i) * 15 + v];
-        ex->dg_i = dgl[i * 15 + v];
-        ex->x_i = xq;
-    }
-    __builtin_amdgcn_sched_barrier(0);   // keep every load above in ONE batch: a single memory round trip per frame
+    const double xq = R.xq;
+    if (ex) { ex->sc_i = R.sc_i; ex->sc_m = R.sc_m; ex->dg_i = R.dg_i; ex->x_i = xq; }
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
         const int e = lane + 64 * q;
@@ -272,6 +302,14 @@ __device__ void assemble_frame(const AsmCtx& c, int i, const Tiles<LAYOUT>& T_, 
         if (lane < 15 && var_is_const(c.mode, c.fast, n, i, lane)) T_.gg(lane) = 0.0;
         lds_sync();
     }
+}
+
+template <int LAYOUT>
+__device__ void assemble_frame(const AsmCtx& c, int i, const Tiles<LAYOUT>& T_, double* tmp,
+                               const double* scl = nullptr, const double* dgl = nullptr, FrameExtra* ex = nullptr) {
+    const AsmRegs R = asm_issue(c, i, scl, dgl);
+    __builtin_amdgcn_sched_barrier(0);   // keep every load in ONE batch: a single memory round trip per frame
+    asm_commit<LAYOUT>(c, i, R, T_, tmp, ex);
 }
 
 // cost = 1/2 sum r^2 over the residual blocks ceres keeps (blocks whose parameters are all constant are dropped)
@@ -505,10 +543,11 @@ __global__ __launch_bounds__(64, 2) void k_lm_step(StepArgs a) {
     const int iteration_dbg = iteration; (void)iteration_dbg;
     STAMP(0);
     const Tiles<1> TM{T.M, nullptr, nullptr, nullptr};
+    AsmRegs areg = asm_issue(c, n - 1, scl, dgl);
     for (int i = n - 1; i >= 0; --i) {
         STAMP(10 + i * 8 + 0);
         FrameExtra ex;
-        assemble_frame<1>(c, i, TM, T.tmp, scl, dgl, &ex);
+        asm_commit<1>(c, i, areg, TM, T.tmp, &ex);
         STAMP(10 + i * 8 + 1);
         // LM diagonal of this frame (LevenbergMarquardtStrategy::ComputeStep), |x - Plus(x,-g)|
         const bool cstl = lane < 15 && var_is_const(a.mode, a.fast_mode, n, i, lane);
@@ -516,7 +555,7 @@ __global__ __launch_bounds__(64, 2) void k_lm_step(StepArgs a) {
         double dgv = ex.dg_i;
         if (lane < 15) {
             if (!reuse) { dgv = fmin(fmax(T.M[lane * 64 + lane] * ex.sc_i * ex.sc_i, kMinDiag), kMaxDiag); dgl[i * 15 + lane] = dgv; }
-            sws[(size_t)i * SOLVE_WS + 960 + lane] = gl * ex.sc_i;          // original scaled gradient (model decrease)
+            sws[(size_t)i * SOLVE_WS + 600 + lane] = gl * ex.sc_i;          // original scaled gradient (model decrease)
         }
         {
             const double qv[3] = {rdlane(ex.x_i, 3), rdlane(ex.x_i, 4), rdlane(ex.x_i, 5)};
@@ -567,14 +606,22 @@ __global__ __launch_bounds__(64, 2) void k_lm_step(StepArgs a) {
             for (int r = 0; r < 15; ++r) if (r == lane) col[r] = cstl ? 1.0 : col[r] + dmp;
         }
         STAMP(10 + i * 8 + 3);
+        // software pipeline: the next frame's loads are in flight while this one is factorised
+        __builtin_amdgcn_sched_barrier(0);
+        if (i > 0) areg = asm_issue(c, i - 1, scl, dgl);
+        __builtin_amdgcn_sched_barrier(0);
         if (!fused_chol_solve(col)) { solved = false; break; }
         STAMP(10 + i * 8 + 4);
         // factor record for the back substitution: rec[r][lane] = this lane's entry r (15 coalesced stores);
         // matrix lane j holds row j of L in entries 0..j (entries above the diagonal are round-off, never read)
         {
             double* f = sws + (size_t)i * SOLVE_WS;
+            // packed record rec[r][40]: slots 0..14 rows of L, 15..29 Wo, 30..35 Wr, 36 z
+            const int slot = lane < 15 ? lane : (lane >= 16 && lane < 31 ? lane - 1 : (lane >= 32 && lane < 38 ? lane - 2 : (lane == 40 ? 36 : -1)));
+            if (slot >= 0) {
 #pragma unroll
-            for (int r = 0; r < 15; ++r) f[r * 64 + lane] = col[r];
+                for (int r = 0; r < 15; ++r) f[r * 40 + slot] = col[r];
+            }
             if (lane >= 16 && lane < 31) {
 #pragma unroll
                 for (int r = 0; r < 15; ++r) T.W[r * 16 + (lane - 16)] = col[r];
@@ -634,22 +681,37 @@ __global__ __launch_bounds__(64, 2) void k_lm_step(StepArgs a) {
         double ytg = 0.0, dsum = 0.0, sn2 = 0.0;
         double yprev = 0.0, y0v = 0.0;   // lane r < 15: y_{i-1}[r], y_0[r]
         STAMP(2);
-        for (int i = 0; i < n; ++i) {
-            STAMP(300 + i * 4);
+        struct BsRegs { double t, Lc[15], Wo[15], Wr[6], gsv, xold, scv, dgv; };
+        // one batch of loads per frame: z, column r of L, row r of Wo / Wr, scaled gradient, state, scale, LM diagonal
+        auto bs_issue = [&](int i) {
             const double* f = sws + (size_t)i * SOLVE_WS;
             const int r = lane < 15 ? lane : 0;
-            // one batch of loads per frame: z, column r of L, row r of Wo / Wr, scaled gradient, state, scale, LM diagonal
-            double t = f[r * 64 + 40];                        // z[r]   (lane 40's column)
-            double Lc[15], Wo[15], Wr[6];
+            BsRegs R;
+            R.t = f[r * 40 + 36];
 #pragma unroll
-            for (int k = 0; k < 15; ++k) { Lc[k] = f[r * 64 + k]; Wo[k] = f[r * 64 + 16 + k]; }
+            for (int k = 0; k < 15; ++k) { R.Lc[k] = f[r * 40 + k]; R.Wo[k] = f[r * 40 + 15 + k]; }
 #pragma unroll
-            for (int k = 0; k < 6; ++k) Wr[k] = f[r * 64 + 32 + k];
-            const double gsv = f[960 + r];
-            const double xold = xw[(size_t)i * 15 + r];
-            const double scv = scl[i * 15 + r];
-            const double dgv = dgl[i * 15 + r];
+            for (int k = 0; k < 6; ++k) R.Wr[k] = f[r * 40 + 30 + k];
+            R.gsv = f[600 + r];
+            R.xold = xw[(size_t)i * 15 + r];
+            R.scv = scl[i * 15 + r];
+            R.dgv = dgl[i * 15 + r];
+            return R;
+        };
+        BsRegs cur = bs_issue(0);
+        for (int i = 0; i < n; ++i) {
+            STAMP(300 + i * 4);
+            const int r = lane < 15 ? lane : 0;
+            // software pipeline: frame i+1's record is in flight while frame i is solved
+            BsRegs nxt = cur;
             __builtin_amdgcn_sched_barrier(0);
+            if (i + 1 < n) nxt = bs_issue(i + 1);
+            __builtin_amdgcn_sched_barrier(0);
+            double t = cur.t;
+            const double* Lc = cur.Lc;
+            const double* Wo = cur.Wo;
+            const double* Wr = cur.Wr;
+            const double gsv = cur.gsv, xold = cur.xold, scv = cur.scv, dgv = cur.dgv;
             double dsel = Lc[0];                               // L[r][r] without a dynamic register index
 #pragma unroll
             for (int k = 1; k < 15; ++k) dsel = (r == k) ? Lc[k] : dsel;
@@ -688,6 +750,7 @@ __global__ __launch_bounds__(64, 2) void k_lm_step(StepArgs a) {
                     dsum += dgv / radius * t * t;
                 }
             }
+            cur = nxt;
         }
         STAMP(3);
         step_norm = sqrt(wave_sum(sn2));

@@ -55,7 +55,7 @@ struct WsView {
     int history_records;
     double* ftf;          // [B][n][2][FTF] frame transform records
 };
-constexpr int SOLVE_WS = 15 * 64 + 16;  // rec[15][64 lanes] (L rows, Wo/Wr/z columns) + scaled gradient
+constexpr int SOLVE_WS = 15 * 40 + 16;  // rec[15][40]: L rows (15), Wo (15), Wr (6), z columns + scaled gradient
 
 struct LinArgs {
     int B, n, mode, eval_small;

@@ -176,3 +176,41 @@ def test_full_size_normal_equations(liw, synth, pyoracle, env, n, L):
         mask[0:6, i * 15:i * 15 + 6] = True
         mask[i * 15:i * 15 + 6, 0:6] = True
     assert np.abs(H[~mask]).max() == 0.0
+
+
+def test_factor_sharded_solve_on_one_gpu(liw, synth, pyoracle, env):
+    """The multi-GPU factor-parallel path driven in lock-step on ONE device: two rank objects hold
+    disjoint laser shards of the same windows, the all-reduce of the laser partial sums is emulated by adding the
+    two partial regions, everything else (replicated small factors, identical LM steps) is the real code path.
+    Must reproduce the unsharded solve."""
+    import torch
+    prm, orc = env
+    ws = [synth.make_window(orc, prm, seed=90 + k, n=8, L=150 + 7 * k) for k in range(3)]
+    ref = liw.BatchSolver(prm, ws)
+    ref.solve(liw.LIW_MODE_INIT, 15)
+    ranks = [liw.BatchSolver(prm, ws, rank=r, world=2) for r in range(2)]
+    assert sum(rk.Ltot for rk in ranks) == ref.Ltot
+    mode = liw.LIW_MODE_INIT
+
+    def exchange(which):
+        tot = ranks[0].PL[which] + ranks[1].PL[which]
+        for rk in ranks:
+            rk.PL[which].copy_(tot)
+
+    K = [rk.lm_begin(mode, 15) for rk in ranks][0]
+    for rk in ranks:
+        rk.lm_linearize(mode, 0)
+    exchange(0)
+    for _ in range(K):
+        for rk in ranks:
+            rk.lm_step(mode)
+            rk.lm_linearize(mode, 1)
+        exchange(1)
+    for rk in ranks:
+        rk.lm_step(mode)
+        rk.lm_finish(mode)
+    torch.cuda.synchronize()
+    a, b, r = ranks[0].states(), ranks[1].states(), ref.states()
+    assert np.array_equal(a, b)                         # ranks stay bit-identical
+    assert rel(a, r) <= 1e-9                            # sharded sum == unsharded sum up to summation order
+    assert [s["iterations"] for s in ranks[0].summaries()] == [s["iterations"] for s in ref.summaries()]
