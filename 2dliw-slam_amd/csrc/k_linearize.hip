@@ -607,18 +607,35 @@ __global__ void k_group_offsets(int B, int n, const int* laser_off, const int* l
     group_off[t] = lo;
 }
 
-void launch_linearize(const LinArgs& A, const DevParams& P, hipStream_t s) {
+// Fork/join helper: the laser, IMU and wheel+ground role kernels write disjoint partial-sum slots, so they run
+// concurrently (main stream + two side streams joined by events).  The matrix-core phase of the IMU kernel then
+// overlaps the fp64 VALU work of the laser kernel on the same CUs.
+void launch_linearize(const LinArgs& A, const DevParams& P, hipStream_t s, const LinFork* fk) {
     const int n = A.n, B = A.B;
     const int nrec = B * n * 2 * 4;
+    const bool fork = fk && fk->side[0] && A.eval_small;
+    if (fork) {
+        // the small-factor kernels only need x: fork before the frame-transform kernel
+        hipEventRecord(fk->ev_fork, s);
+        hipStreamWaitEvent(fk->side[0], fk->ev_fork, 0);
+        hipStreamWaitEvent(fk->side[1], fk->ev_fork, 0);
+    }
+    hipStream_t s_imu = fork ? fk->side[0] : s, s_small = fork ? fk->side[1] : s;
     hipLaunchKernelGGL(k_frame_tf, dim3((nrec + 255) / 256), dim3(256), 0, s, B, n, A.x, A.match_pose, A.ftf, P, A.lm);
     if (A.mode == LIW_MODE_INIT) hipLaunchKernelGGL(k_lin_laser<true>, dim3((unsigned)(B * n)), dim3(64), 0, s, A, P);
     else hipLaunchKernelGGL(k_lin_laser<false>, dim3((unsigned)(B * n)), dim3(64), 0, s, A, P);
     if (A.eval_small && n > 1) {
-        hipLaunchKernelGGL(k_lin_imu, dim3((unsigned)(B * ((n - 1 + IMU_PER_WAVE - 1) / IMU_PER_WAVE))), dim3(64), 0, s, A, P);
+        hipLaunchKernelGGL(k_lin_imu, dim3((unsigned)(B * ((n - 1 + IMU_PER_WAVE - 1) / IMU_PER_WAVE))), dim3(64), 0, s_imu, A, P);
     }
     if (A.eval_small) {
         const int items = (n - 1 + 3) / 4 + (n + 7) / 8;
-        hipLaunchKernelGGL(k_lin_small, dim3((unsigned)(B * items)), dim3(64), 0, s, A, P);
+        hipLaunchKernelGGL(k_lin_small, dim3((unsigned)(B * items)), dim3(64), 0, s_small, A, P);
+    }
+    if (fork) {
+        hipEventRecord(fk->ev_join[0], fk->side[0]);
+        hipEventRecord(fk->ev_join[1], fk->side[1]);
+        hipStreamWaitEvent(s, fk->ev_join[0], 0);
+        hipStreamWaitEvent(s, fk->ev_join[1], 0);
     }
 }
 void launch_group_offsets(int B, int n, const int* laser_off, const int* laser_frame, int* group_off, hipStream_t s) {

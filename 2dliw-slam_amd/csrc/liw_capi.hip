@@ -12,7 +12,7 @@
 
 namespace liw {
 // kernel launchers (k_linearize.hip, k_lm.hip)
-void launch_linearize(const LinArgs& A, const DevParams& P, hipStream_t s);
+void launch_linearize(const LinArgs& A, const DevParams& P, hipStream_t s, const LinFork* fk);
 void launch_group_offsets(int B, int n, const int* laser_off, const int* laser_frame, int* group_off, hipStream_t s);
 struct StepArgs {
     int B, n, mode, max_iters, fast_mode;
@@ -76,6 +76,8 @@ struct liw_ctx {
     bool timing = false;
     std::vector<hipEvent_t> ev_lin, ev_step;
     size_t ev_lin_used = 0, ev_step_used = 0;
+    LinFork fork{};
+    bool have_fork = false;
     // graph cache
     hipGraphExec_t gexec = nullptr;
     std::vector<unsigned char> gkey;
@@ -154,6 +156,12 @@ liw_ctx* liw_create(const liw_params* prm) {
         if (hipSetDevice(prm->device) == hipSuccess && hipGetDeviceProperties(&props, prm->device) == hipSuccess) {
             if (std::strstr(props.gcnArchName, "gfx950") != nullptr) {
                 if (hipStreamCreate(&c->stream) == hipSuccess) c->have_device = true;
+                if (c->have_device && hipStreamCreateWithFlags(&c->fork.side[0], hipStreamNonBlocking) == hipSuccess &&
+                    hipStreamCreateWithFlags(&c->fork.side[1], hipStreamNonBlocking) == hipSuccess &&
+                    hipEventCreateWithFlags(&c->fork.ev_fork, hipEventDisableTiming) == hipSuccess &&
+                    hipEventCreateWithFlags(&c->fork.ev_join[0], hipEventDisableTiming) == hipSuccess &&
+                    hipEventCreateWithFlags(&c->fork.ev_join[1], hipEventDisableTiming) == hipSuccess)
+                    c->have_fork = true;
             } else {
                 c->err = std::string("device is ") + props.gcnArchName + ", this library is built for gfx950 only";
             }
@@ -173,6 +181,10 @@ void liw_destroy(liw_ctx* c) {
         for (auto e : c->ev_lin) (void)hipEventDestroy(e);
         for (auto e : c->ev_step) (void)hipEventDestroy(e);
         if (c->gexec) (void)hipGraphExecDestroy(c->gexec);
+        if (c->have_fork) {
+            (void)hipStreamDestroy(c->fork.side[0]); (void)hipStreamDestroy(c->fork.side[1]);
+            (void)hipEventDestroy(c->fork.ev_fork); (void)hipEventDestroy(c->fork.ev_join[0]); (void)hipEventDestroy(c->fork.ev_join[1]);
+        }
         if (c->stream) (void)hipStreamDestroy(c->stream);
     }
     delete c;
@@ -295,7 +307,7 @@ int liw_batch_lm_linearize(liw_ctx* c, const liw_batch* b, int mode, int candida
     if (int r = check_batch(c, b)) return r;
     WsView v = make_view(ws, b->B, b->n, b->history_records);
     LinArgs A = lin_args(b, mode, candidate ? v.x_cand : b->x, v, candidate != 0, true);
-    launch_linearize(A, c->dp, (hipStream_t)stream);
+    launch_linearize(A, c->dp, (hipStream_t)stream, c->have_fork ? &c->fork : nullptr);
     HIPCHK(c, hipGetLastError());
     return LIW_OK;
 }
@@ -337,7 +349,7 @@ static int enqueue_solve(liw_ctx* c, const liw_batch* b, int mode, int K, void* 
     auto lin = [&](int cand) {
         LinArgs A = lin_args(b, mode, cand ? v.x_cand : b->x, v, cand, true);
         if (timed) (void)hipEventRecord(next_event(c->ev_lin, c->ev_lin_used), s);
-        launch_linearize(A, c->dp, s);
+        launch_linearize(A, c->dp, s, c->have_fork ? &c->fork : nullptr);
         if (timed) (void)hipEventRecord(next_event(c->ev_lin, c->ev_lin_used), s);
     };
     auto step = [&]() {
@@ -392,7 +404,7 @@ int liw_batch_marg_linearize(liw_ctx* c, const liw_batch* b, void* ws, void* str
     launch_group_offsets(b->B, b->n, b->laser_off, b->laser_frame, v.group_off, s);
     LinArgs A = lin_args(b, LIW_MODE_MARG, b->x, v, 0, false);
     if (c->timing) (void)hipEventRecord(next_event(c->ev_lin, c->ev_lin_used), s);
-    launch_linearize(A, c->dp, s);
+    launch_linearize(A, c->dp, s, c->have_fork ? &c->fork : nullptr);
     if (c->timing) (void)hipEventRecord(next_event(c->ev_lin, c->ev_lin_used), s);
     HIPCHK(c, hipGetLastError());
     return LIW_OK;
@@ -431,7 +443,7 @@ int liw_batch_linearize(liw_ctx* c, const liw_batch* b, int mode, void* ws, void
     launch_group_offsets(b->B, b->n, b->laser_off, b->laser_frame, v.group_off, s);
     LinArgs A = lin_args(b, mode, b->x, v, 0, false);
     if (c->timing) (void)hipEventRecord(next_event(c->ev_lin, c->ev_lin_used), s);
-    launch_linearize(A, c->dp, s);
+    launch_linearize(A, c->dp, s, c->have_fork ? &c->fork : nullptr);
     if (c->timing) (void)hipEventRecord(next_event(c->ev_lin, c->ev_lin_used), s);
     HIPCHK(c, hipGetLastError());
     return LIW_OK;
@@ -587,7 +599,7 @@ int liw_eval_factors(liw_ctx* c, int mode, double* laser_res, double* laser_jac,
     LinArgs A = lin_args(&c->sb, mode, c->sb.x, v, 0, false);
     A.dbg_laser_res = dptr[0]; A.dbg_laser_jac = dptr[1]; A.dbg_imu_res = dptr[2]; A.dbg_imu_jac = dptr[3];
     A.dbg_wheel_res = dptr[4]; A.dbg_wheel_jac = dptr[5]; A.dbg_ground_res = dptr[6]; A.dbg_ground_jac = dptr[7];
-    launch_linearize(A, c->dp, c->stream);
+    launch_linearize(A, c->dp, c->stream, c->have_fork ? &c->fork : nullptr);
     HIPCHK(c, hipGetLastError());
     double* hptr[8] = {laser_res, laser_jac, imu_res, imu_jac, wheel_res, wheel_jac, ground_res, ground_jac};
     for (int k = 0; k < 8; ++k)

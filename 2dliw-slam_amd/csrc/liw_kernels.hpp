@@ -78,4 +78,10 @@ struct LinArgs {
     double* dbg_wheel_res; double* dbg_wheel_jac; double* dbg_ground_res; double* dbg_ground_jac;
 };
 
+// side streams + events used to run the independent role kernels of one linearisation concurrently
+struct LinFork {
+    hipStream_t side[2];
+    hipEvent_t ev_fork, ev_join[2];
+};
+
 }  // namespace liw
