@@ -1,26 +1,24 @@
 // k_linearize.hip — factor residual/Jacobian evaluation + J^T J block partial sums (gfx950, fp64).
 //
-// One launch evaluates every residual block of every window of a batch.  Work is split into ROLES, one
-// wavefront (64-thread work-group) per work item:
-//   laser  : one (window, owning frame) group; a LANE is one laser_factor block (reference
-//            src/factor/laser_factor.h:45-89, two point-to-line rows), 64 blocks per pass, coalesced reads of
-//            the component-major end-point arrays; the frame transforms and their derivatives w.r.t. the
-//            rotation vector are computed once per wave (dual numbers, direction-per-lane) and broadcast.
-//   imu    : two imu_factor blocks per wave (src/factor/imu_factor.h:13-89), 32 lanes each: lane d < 30 carries
-//            derivative direction d of the 30 parameters, lane 30 carries the value column.
-//   wheel  : four wheel_odom_factor blocks per wave (src/factor/wheel_factor.h:12-73), 16 lanes each.
-//   ground : eight frames per wave, ground_factor_p + ground_factor_q (src/factor/ground_factor.h:27-82), 8 lanes
-//            each; the n-fold duplication of solver.cpp:142-159 is applied as an integer weight n.
-// Every role stacks its rows as Y = [J | r] in LDS and reduces G = Y^T Y with a fixed pair->lane mapping, so
-// the sums are deterministic (no atomics).  G blocks go to the partial-sum slots described in liw_kernels.hpp;
-// k_lm.hip assembles them.  Jacobians here are w.r.t. the AMBIENT parameters, exactly like
-// auto_diff::compute_res_and_jacobi (src/utilies/common.h:201-217); the so3 local parameterisation is applied
-// at assembly.
+// One linearisation = four kernels over every residual block of every window of a batch, one wavefront (64-thread
+// work-group) per work item; the three role kernels write disjoint partial slots and run concurrently:
+//   k_frame_tf  : per (window, frame): rows 0,1 of make_tf(p,theta) * T_imu_to_laser and d/dtheta_k (dual numbers,
+//                 direction-per-lane) — every exp_so3 of the laser path is hoisted here.
+//   k_lin_laser : one (window, owning frame) group per wave; a LANE is one laser_factor block (reference
+//                 src/factor/laser_factor.h:45-89, two point-to-line rows), 64 blocks per pass, coalesced reads of the
+//                 component-major end-point arrays, closed-form Jacobian, register accumulation of the pair products
+//                 and ONE butterfly reduction per group.
+//   k_lin_imu   : six imu_factor blocks per wave (src/factor/imu_factor.h:13-89): 9 dual directions + value lane per
+//                 block, closed forms for the linear columns, whitening and Y^T Y on the fp64 matrix cores.
+//   k_lin_small : wheel_odom_factor (src/factor/wheel_factor.h:12-73, four blocks per wave, 12 dual directions) and
+//                 ground_factor_p/q (src/factor/ground_factor.h:27-82, eight frames per wave); the n-fold duplication
+//                 of solver.cpp:142-159 is applied as an integer weight n.
+// Every role reduces G = Y^T Y with Y = [J | r] deterministically (no atomics).  G blocks go to the partial-sum slots
+// described in liw_kernels.hpp; k_lm.hip assembles them.  Jacobians here are w.r.t. the AMBIENT parameters, exactly like
+// auto_diff::compute_res_and_jacobi (src/utilies/common.h:201-217); the so3 local parameterisation is applied at assembly.
 #include "liw_kernels.hpp"
 
 namespace liw {
-
-__device__ __forceinline__ double bcast(double v, int src_lane) { return __shfl(v, src_lane, 64); }
 
 // ------------------------------------------------------------------------------------------- laser
 // Frame transform record (FTF doubles): rows 0,1 of  make_tf(p,theta) * T_imu_to_laser  and d/dtheta_k, k = 0..2:
@@ -433,12 +431,21 @@ __device__ void imu_group(const LinArgs& A, const DevParams& P, int b, int item,
             g11 = __builtin_amdgcn_mfma_f64_16x16x4f64(y1[c], y1[c], g11, 0, 0, 0);
         }
         double* out = A.PI[sel] + fg * PIS;
+        // G(R, C) over the 31 columns [x_i(15) x_j(15) r]: keep blocks ii, ij, jj, the gradient column and G(30,30)
+        auto put = [&](int R, int C, double v) {
+            if (R < 15 && C < 15) out[PI_II + R * 15 + C] = v;
+            else if (R < 15 && C < 30) out[PI_IJ + R * 15 + (C - 15)] = v;
+            else if (R >= 15 && R < 30 && C >= 15 && C < 30) out[PI_JJ + (R - 15) * 15 + (C - 15)] = v;
+            else if (C == 30 && R < 30) out[PI_G + R] = v;
+            else if (C == 30 && R == 30) out[PI_C] = v;
+        };
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
             const int row = mk + 4 * r;
-            out[row * 31 + ml] = g00[r];                                   // rows 0..15, cols 0..15
-            if (ml < 15) { out[row * 31 + 16 + ml] = g01[r]; out[(16 + ml) * 31 + row] = g01[r]; }
-            if (row < 15 && ml < 15) out[(16 + row) * 31 + 16 + ml] = g11[r];
+            put(row, ml, g00[r]);                                   // tile (0,0): rows 0..15, cols 0..15
+            put(row, 16 + ml, g01[r]);                              // tile (0,1): rows 0..15, cols 16..31
+            if (row == 15 && ml < 14) put(16 + ml, 15, g01[r]);     // mirror of row 15 into column 15 of block jj
+            put(16 + row, 16 + ml, g11[r]);                         // tile (1,1): rows 16..31, cols 16..31
             if (A.dbg_imu_res && ml == 14 && row < 15) A.dbg_imu_res[fg * 15 + row] = y1[r];
             if (A.dbg_imu_jac && row < 15) {
                 A.dbg_imu_jac[(fg * 15 + row) * 30 + ml] = y0[r];

@@ -148,9 +148,9 @@ __device__ __forceinline__ AsmRegs asm_issue(const AsmCtx& c, int i, const doubl
         const int e = lane + 64 * q, r = e >> 4, cc = e & 15;
         const bool valid = r < 15 && cc < 15;
         const int rs = valid ? r : 0, cs = valid ? cc : 0;
-        R.v5[q] = PIm[(15 + rs) * 31 + 15 + cs];
-        R.v6[q] = PIp[rs * 31 + cs];
-        R.v7[q] = PIm[rs * 31 + 15 + cs];
+        R.v5[q] = PIm[PI_JJ + rs * 15 + cs];
+        R.v6[q] = PIp[PI_II + rs * 15 + cs];
+        R.v7[q] = PIm[PI_IJ + rs * 15 + cs];
     }
     {   // the 6x6 pose block terms: one element per lane (lanes 0..35)
         const bool pl = lane < 36;
@@ -169,8 +169,8 @@ __device__ __forceinline__ AsmRegs asm_issue(const AsmCtx& c, int i, const doubl
         R.g2 = PWm[(6 + r6) * 13 + 12];
         R.g3 = PWp[r6 * 13 + 12];
         R.g4 = PGb[(size_t)i * PGS + r6 * 7 + 6];
-        R.g5 = PIm[(15 + r) * 31 + 30];
-        R.g6 = PIp[r * 31 + 30];
+        R.g5 = PIm[PI_G + 15 + r];
+        R.g6 = PIp[PI_G + r];
     }
     {   // states (rotation vectors of frames i, i-1, 0 for the so3 Plus Jacobian test) and the LM scales
         int idx = i * 15 + (lane < 15 ? lane : 0);
@@ -327,7 +327,7 @@ __device__ double window_cost(const AsmCtx& c) {
         if (!(track && i < n - 1)) s += PGb[(size_t)i * PGS + 48];
     }
     for (int k = lane; k < n - 1; k += 64) {
-        s += PIb[(size_t)k * PIS + 30 * 31 + 30];
+        s += PIb[(size_t)k * PIS + PI_C];
         if (!(track && k < n - 2)) s += PWb[(size_t)k * PWS + 12 * 13 + 12];
     }
     if (c.prior_on && lane < 15) { const double r = prior_r(c, lane); s += r * r; }
@@ -420,8 +420,8 @@ __device__ double frame_diag(const AsmCtx& c, int i, LdsStep& T) {
         if (i <= n - 2) d += PWb[(size_t)i * PWS + r * 14];
         d += PGb[(size_t)i * PGS + r * 8];
     }
-    if (i >= 1) d += PIb[(size_t)(i - 1) * PIS + (15 + r) * 32];
-    if (i <= n - 2) d += PIb[(size_t)i * PIS + r * 32];
+    if (i >= 1) d += PIb[(size_t)(i - 1) * PIS + PI_JJ + r * 16];
+    if (i <= n - 2) d += PIb[(size_t)i * PIS + PI_II + r * 16];
     if (c.prior_on && i == n - 2) { double s = 0.0; for (int k = 0; k < 15; ++k) s += c.pJ[k * 15 + r] * c.pJ[k * 15 + r]; d += s; }
     return d;
 }

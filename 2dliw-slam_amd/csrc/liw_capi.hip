@@ -540,6 +540,11 @@ static int download_states(liw_ctx* c) {
 
 int liw_solve(liw_ctx* c, int mode, int max_iters, liw_summary* summary) {
     NEEDWIN(c);
+    if (mode != LIW_MODE_INIT && mode != LIW_MODE_TRACK) return fail(c, LIW_EINVAL, "liw_solve: mode must be LIW_MODE_INIT or LIW_MODE_TRACK");
+    // init topology ties every laser block to (frame 0, owning frame): a block owned by frame 0 would name the same
+    // parameter block twice, which ceres::Problem::AddResidualBlock rejects (solver.cpp:93-106)
+    if (mode == LIW_MODE_INIT && c->L > 0 && c->hw.laser_frame[0] == 0 && c->hw.has_match[0])
+        return fail(c, LIW_EINVAL, "init topology: frame 0 must not own laser blocks (duplicate parameter blocks)");
     int K = resolve_iters(c, mode, max_iters);
     if (K + 1 > c->hist_records) {   // grow the history region
         c->hist_records = K + 1;

@@ -21,11 +21,13 @@ struct DevParams {
 
 // Partial-sum slots written by k_linearize, per buffer (doubles):
 //   PL[B][n][LP]   laser group (window, owning frame): Haa(36) Hbb(36) Hab(36) ga(6) gb(6) sum r^2 (1), pad -> 128
-//   PI[B][n-1][PIS] IMU block k (frames k,k+1): G = Y^T Y, Y = [J(15x30) | r], 31x31 row-major, pad -> 964
+//   PI[B][n-1][PIS] IMU block k (frames k,k+1): G = Y^T Y, Y = [J(15x30) | r]: blocks ii, ij, jj (15x15 each), g(30), sum r^2 -> 708
 //   PW[B][n-1][PWS] wheel block k: G 13x13 (Y = [J(3x12) | r]), pad -> 172
 //   PG[B][n][PGS]   ground of frame i: n * G 7x7 (Y = [J(2x6) | r]), pad -> 52
 constexpr int LP = LIW_LASER_PARTIAL;
-constexpr int PIS = 964;
+constexpr int PIS = 708;
+// compact IMU partial: G = Y^T Y restricted to what the assembly reads
+constexpr int PI_II = 0, PI_IJ = 225, PI_JJ = 450, PI_G = 675, PI_C = 705;   // ii(15x15) ij(15x15) jj(15x15) g(30) sum r^2
 constexpr int PWS = 172;
 constexpr int PGS = 52;
 constexpr int FTF = 32;   // frame transform record (k_frame_tf)
@@ -61,7 +63,6 @@ struct LinArgs {
     int B, n, mode, eval_small;
     const double* x;            // states to linearise at [B][n][15]
     const int* group_off;
-    const double* ftf_in_unused;
     double* ftf;
     const int* laser_off;
     const double* laser_pts; int Ltot;

@@ -214,3 +214,14 @@ def test_factor_sharded_solve_on_one_gpu(liw, synth, pyoracle, env):
     assert np.array_equal(a, b)                         # ranks stay bit-identical
     assert rel(a, r) <= 1e-9                            # sharded sum == unsharded sum up to summation order
     assert [s["iterations"] for s in ranks[0].summaries()] == [s["iterations"] for s in ref.summaries()]
+
+
+def test_init_topology_rejects_blocks_on_frame0(liw, synth, env):
+    prm, orc = env
+    d = synth.make_window(orc, prm, seed=2, n=4, L=12, laser_on_frame0=True)
+    slv = liw.Solver(prm)
+    slv.set_window(liw.Window(d))
+    with pytest.raises(liw.LiwError) as e:
+        slv.init_solve()
+    assert e.value.code == -22
+    slv.solve()        # the tracking topology (constant laser_match pose) accepts it
