@@ -850,7 +850,7 @@ struct MargArgs {
     WsView w;
     double* sqrt_H; double* Delta_H; double* Delta_g; int* status;
 };
-__global__ __launch_bounds__(64) void k_marg_schur(MargArgs a) {
+__global__ __launch_bounds__(64, 2) void k_marg_schur(MargArgs a) {
     __shared__ LdsTiles T;
     __shared__ double V[256], Am[256];
     const int b = blockIdx.x, lane = threadIdx.x & 63, n = a.n;
@@ -860,48 +860,63 @@ __global__ __launch_bounds__(64) void k_marg_schur(MargArgs a) {
     c.x = a.x + (size_t)b * n * 15;
     c.pJ = a.prior_J + (size_t)b * 225; c.pX = a.prior_X + (size_t)b * 15;
     c.prior_on = a.has_prior[b] != 0;
-    for (int e = lane; e < 256; e += 64) T.CD[e] = 0.0;
+    for (int e = lane; e < 256; e += 64) { T.CD[e] = 0.0; T.W[e] = 0.0; }
     if (lane < 16) T.Cg[lane] = 0.0;
-    __syncthreads();
+    lds_sync();
     bool ok = true;
-    // frame i is eliminated using its coupling O_{i+1} = H[i, i+1]; O of frame i+1 is assembled one frame ahead
-    for (int i = 0; i < n; ++i) {
-        // D_i, g_i  (+ carried Schur terms); O tile of THIS call is H[i-1,i], so fetch H[i,i+1] from the next frame
-        assemble_frame<0>(c, i, Tiles<0>{T.D, T.O, T.R, T.g}, T.tmp);
-        for (int e = lane; e < 256; e += 64) {
-            const int r = e >> 4, cc = e & 15;
-            T.D[e] = (r < 15 && cc < 15) ? T.D[e] + T.CD[e] : 0.0;
+    // Chain elimination 0 .. n-2 with the same register-resident fused Cholesky / forward substitution as k_lm_step:
+    // lane j < 15 owns column j of D_i (+ carried Schur term), lanes 16..30 the columns of H[i, i+1], lane 40 g_i.
+    // Two tile sets ping-pong so that every frame is assembled once: set `cur` holds D_i, g_i; assembling frame i+1
+    // into `nxt` yields H[i, i+1] (its O tile) together with D_{i+1}, g_{i+1}.
+    double* Dc = T.D; double* gc = T.g;          // cur
+    double* Dn = T.Wa; double* gn = T.y0;        // nxt   (T.O receives H[i, i+1]; T.R is the unused arrow tile)
+    assemble_frame<0>(c, 0, Tiles<0>{Dc, T.O, T.R, gc}, T.tmp);
+    for (int i = 0; i + 1 < n; ++i) {
+        assemble_frame<0>(c, i + 1, Tiles<0>{Dn, T.O, T.R, gn}, T.tmp);
+        double col[15];
+#pragma unroll
+        for (int r = 0; r < 15; ++r) {
+            double v = 0.0;
+            if (lane < 15) v = Dc[r * 16 + lane] + T.CD[r * 16 + lane];
+            else if (lane >= 16 && lane < 31) v = T.O[r * 16 + (lane - 16)];
+            else if (lane == 40) v = gc[r] + T.Cg[r];
+            col[r] = v;
         }
-        if (lane < 16) T.g[lane] = lane < 15 ? T.g[lane] + T.Cg[lane] : 0.0;
-        __syncthreads();
-        if (i == n - 1) break;
-        // coupling block H[i, i+1]: assemble frame i+1's O tile into T.R (scratch tiles W/Wa used as dummies)
-        assemble_frame<0>(c, i + 1, Tiles<0>{T.W, T.R, T.Wa, T.y0}, T.tmp);   // T.R <- H[i, i+1] (rows: frame i)
-        if (!chol15(T.D)) { ok = false; break; }
-        // W = L^-1 [O | g] : lanes 0..14 columns of O (H[i, i+1][:, col]), lane 15 -> g
-        if (lane < 16) {
-            double wv[15];
+        if (!fused_chol_solve(col)) { ok = false; break; }
+        if (lane >= 16 && lane < 31) {
 #pragma unroll
-            for (int r = 0; r < 15; ++r) {
-                double rhs = lane < 15 ? T.R[r * 16 + lane] : T.g[r];
+            for (int r = 0; r < 15; ++r) T.W[r * 16 + (lane - 16)] = col[r];
+        } else if (lane == 40) {
 #pragma unroll
-                for (int k = 0; k < r; ++k) rhs -= T.D[r * 16 + k] * wv[k];
-                wv[r] = rhs / T.D[r * 16 + r];
-            }
-#pragma unroll
-            for (int r = 0; r < 15; ++r) T.W[r * 16 + lane] = wv[r];
-            T.W[15 * 16 + lane] = 0.0;
+            for (int r = 0; r < 15; ++r) T.W[r * 16 + 15] = col[r];
         }
-        __syncthreads();
-        const d4 p1 = xty16(T.W, T.W);
-        __syncthreads();
+        lds_sync();
+        const d4 p1 = xty16(T.W, T.W);           // [W | z]^T [W | z]: Schur terms for D_{i+1} and g_{i+1}
+        lds_sync();
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-            const int row = (lane >> 4) + 4 * r, col = lane & 15;
-            if (row < 15 && col < 15) T.CD[row * 16 + col] = -p1[r];
-            if (row < 15 && col == 15) T.Cg[row] = -p1[r];
+            const int row = (lane >> 4) + 4 * r, colx = lane & 15;
+            if (row < 15 && colx < 15) T.CD[row * 16 + colx] = -p1[r];
+            if (row < 15 && colx == 15) T.Cg[row] = -p1[r];
         }
-        __syncthreads();
+        lds_sync();
+        double* t1 = Dc; Dc = Dn; Dn = t1;
+        double* t2 = gc; gc = gn; gn = t2;
+    }
+    // Delta_H = D_{n-1} + carried term into T.D, Delta_g(+J^T R convention) into T.g
+    {
+        double dv[4], gv = 0.0;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int e = lane + 64 * q, r = e >> 4, cc = e & 15;
+            dv[q] = (r < 15 && cc < 15) ? Dc[e] + T.CD[e] : 0.0;
+        }
+        if (lane < 15) gv = gc[lane] + T.Cg[lane];
+        lds_sync();
+#pragma unroll
+        for (int q = 0; q < 4; ++q) T.D[lane + 64 * q] = dv[q];
+        if (lane < 16) T.g[lane] = lane < 15 ? gv : 0.0;
+        lds_sync();
     }
     if (a.status && lane == 0) a.status[b] = ok ? 0 : 1;
     if (!ok) return;
