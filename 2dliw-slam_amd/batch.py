@@ -211,3 +211,68 @@ class BatchSolver:
         a, b, c, d = C.c_double(0), C.c_int(0), C.c_double(0), C.c_int(0)
         self._chk(self.L.liw_get_timing(self.h, C.byref(a), C.byref(b), C.byref(c), C.byref(d)))
         return dict(linearize_ms=a.value, linearize_launches=b.value, step_ms=c.value, step_launches=d.value)
+
+
+class BatchPreint:
+    """Batched pre-integration of M independent frame-to-frame intervals on the GPU (`liw_batch_imu_preint`,
+    `liw_batch_wheel_preint`): the batch-replay form of imu_preintegraption / wheel_odom_preintegration.
+    Interval tuples are the ones `HostPreint` takes one at a time: (samples, t_start, t_end[, bias6])."""
+
+    def __init__(self, prm, device="cuda:0"):
+        import torch
+        from . import lib, params_struct, LiwError
+        self.torch, self.LiwError, self.L = torch, LiwError, lib()
+        self.dev = torch.device(device)
+        self._ps = params_struct(prm, self.dev.index if self.dev.index is not None else 0)
+        self.h = C.c_void_p(self.L.liw_create(C.byref(self._ps)))
+
+    def close(self):
+        if self.h:
+            self.L.liw_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _chk(self, r):
+        if r < 0:
+            raise self.LiwError(r, self.L.liw_last_error(self.h).decode())
+
+    def _pack(self, intervals, width):
+        torch = self.torch
+        M = len(intervals)
+        cnt = [int(np.asarray(iv[0]).shape[0]) for iv in intervals]
+        off = np.zeros(M + 1, dtype=np.int32)
+        off[1:] = np.cumsum(cnt)
+        smp = np.concatenate([np.asarray(iv[0], dtype=np.float64).reshape(-1, width) for iv in intervals], axis=0) if M else np.zeros((1, width))
+        ts = np.array([iv[1] for iv in intervals], dtype=np.float64)
+        te = np.array([iv[2] for iv in intervals], dtype=np.float64)
+        d = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(self.dev)
+        return M, d(off), d(smp.reshape(-1)), d(ts), d(te)
+
+    def imu(self, intervals):
+        """-> X [M,15], J [M,15,15], sqrt_inverse_P [M,15,15], Dt [M] (device tensors)"""
+        torch = self.torch
+        M, off, smp, ts, te = self._pack(intervals, 7)
+        bias = torch.from_numpy(np.ascontiguousarray(np.array([iv[3] for iv in intervals], dtype=np.float64).reshape(-1))).to(self.dev)
+        z = lambda *sh: torch.zeros(sh, dtype=torch.float64, device=self.dev)
+        X, J, P, S, Dt = z(M, 15), z(M, 15, 15), z(M, 15, 15), z(M, 15, 15), z(M)
+        p = lambda t: C.c_void_p(t.data_ptr())
+        self._chk(self.L.liw_batch_imu_preint(self.h, C.c_int(M), p(off), p(smp), p(ts), p(te), p(bias), p(X), p(J), p(P), p(S), p(Dt),
+                                              C.c_void_p(torch.cuda.current_stream(self.dev).cuda_stream)))
+        self.last_P = P
+        return X, J, S, Dt
+
+    def wheel(self, intervals):
+        """-> delta_Tij [M,12], sqrt_inverse_P [M,3,3], Dt [M] (device tensors)"""
+        torch = self.torch
+        M, off, smp, ts, te = self._pack(intervals, 13)
+        z = lambda *sh: torch.zeros(sh, dtype=torch.float64, device=self.dev)
+        T, S, Dt = z(M, 12), z(M, 3, 3), z(M)
+        p = lambda t: C.c_void_p(t.data_ptr())
+        self._chk(self.L.liw_batch_wheel_preint(self.h, C.c_int(M), p(off), p(smp), p(ts), p(te), p(T), p(S), p(Dt),
+                                                C.c_void_p(torch.cuda.current_stream(self.dev).cuda_stream)))
+        return T, S, Dt

@@ -449,6 +449,38 @@ int liw_batch_linearize(liw_ctx* c, const liw_batch* b, int mode, void* ws, void
     return LIW_OK;
 }
 
+static PreintNoise preint_noise(const liw_params& prm) {
+    PreintNoise N{};
+    for (int k = 0; k < 3; ++k) {
+        N.q_na[k] = prm.imu_noise_acc_sigma[k] * prm.imu_noise_acc_sigma[k];
+        N.q_nw[k] = prm.imu_noise_gyro_sigma[k] * prm.imu_noise_gyro_sigma[k];
+        N.q_nba[k] = prm.imu_bias_acc_sigma[k] * prm.imu_bias_acc_sigma[k];
+        N.q_nbw[k] = prm.imu_bias_gyro_sigma[k] * prm.imu_bias_gyro_sigma[k];
+        N.wheel_cov[k] = prm.wheel_sigma[k] * prm.wheel_sigma[k];
+    }
+    return N;
+}
+int liw_batch_imu_preint(liw_ctx* c, int M, const int* sample_off, const double* samples, const double* t_start, const double* t_end,
+                         const double* bias6, double* X, double* J, double* P_scratch, double* sqrt_inverse_P, double* Dt, void* stream) {
+    NEEDDEV(c);
+    if (M < 0 || (M > 0 && (!sample_off || !samples || !t_start || !t_end || !bias6 || !X || !J || !P_scratch || !sqrt_inverse_P || !Dt)))
+        return fail(c, LIW_EINVAL, "liw_batch_imu_preint: null argument");
+    if (M == 0) return LIW_OK;
+    launch_preint_imu(M, sample_off, samples, t_start, t_end, bias6, preint_noise(c->prm), X, J, P_scratch, sqrt_inverse_P, Dt, (hipStream_t)stream);
+    HIPCHK(c, hipGetLastError());
+    return LIW_OK;
+}
+int liw_batch_wheel_preint(liw_ctx* c, int M, const int* sample_off, const double* samples, const double* t_start, const double* t_end,
+                           double* delta_Tij, double* sqrt_inverse_P, double* Dt, void* stream) {
+    NEEDDEV(c);
+    if (M < 0 || (M > 0 && (!sample_off || !samples || !t_start || !t_end || !delta_Tij || !sqrt_inverse_P || !Dt)))
+        return fail(c, LIW_EINVAL, "liw_batch_wheel_preint: null argument");
+    if (M == 0) return LIW_OK;
+    launch_preint_wheel(M, sample_off, samples, t_start, t_end, preint_noise(c->prm), delta_Tij, sqrt_inverse_P, Dt, (hipStream_t)stream);
+    HIPCHK(c, hipGetLastError());
+    return LIW_OK;
+}
+
 int liw_set_timing(liw_ctx* c, int enable) {
     if (!c) return LIW_EINVAL;
     c->timing = enable != 0;

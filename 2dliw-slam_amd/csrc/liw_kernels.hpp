@@ -85,4 +85,11 @@ struct LinFork {
     hipEvent_t ev_fork, ev_join[2];
 };
 
+// batched pre-integration (k_preint.hip)
+struct PreintNoise { double q_na[3], q_nw[3], q_nba[3], q_nbw[3], wheel_cov[3]; };
+void launch_preint_imu(int M, const int* sample_off, const double* samples, const double* t_start, const double* t_end, const double* bias6,
+                       const PreintNoise& N, double* X, double* J, double* Pscratch, double* sqrtP, double* Dt, hipStream_t s);
+void launch_preint_wheel(int M, const int* sample_off, const double* samples, const double* t_start, const double* t_end,
+                         const PreintNoise& N, double* T12, double* sq9, double* Dt, hipStream_t s);
+
 }  // namespace liw

@@ -184,6 +184,21 @@ int liw_batch_export_dense(liw_ctx* ctx, const liw_batch* b, int mode, int buf, 
 int liw_set_timing(liw_ctx* ctx, int enable);
 int liw_get_timing(liw_ctx* ctx, double* linearize_ms_avg, int* linearize_launches, double* step_ms_avg, int* step_launches);
 
+/* ---- batched pre-integration on the device ("batch replay" form of the accumulators below): M independent
+ *      intervals, interval m owns samples [sample_off[m], sample_off[m+1]).  Sample 0 of an interval only seeds the
+ *      "previous measurement"; the accumulator is reset at t_start[m] and integrated to t_end[m], i.e. the same
+ *      call sequence as reference src/trajectory/trajectory.cpp:176-184 followed by get_preintegraption_result().
+ *      All pointers are DEVICE pointers.  imu samples [S][7] = t, acc(3), gyro(3); bias6 [M][6] = ba, bw;
+ *      outputs X [M][15], J [M][225], sqrt_inverse_P [M][225], Dt [M]; P_scratch [M][225] receives the raw
+ *      covariance.  wheel samples [S][13] = t, R(9 row-major), t(3); outputs delta_Tij [M][12], sqrt_inverse_P
+ *      [M][9], Dt [M].  Replaces imu_preintegraption::{add_imu_measure, update, get_preintegraption_result}
+ *      (src/factor/imu_preintegraption.h:124-208) and wheel_odom_preintegration::{add_wheel_odom_measure,
+ *      update_by_v, get_preintegraption_result} (src/factor/wheel_odom_preintegration.h:62-152). */
+int liw_batch_imu_preint(liw_ctx* ctx, int M, const int* sample_off, const double* samples, const double* t_start, const double* t_end,
+                         const double* bias6, double* X, double* J, double* P_scratch, double* sqrt_inverse_P, double* Dt, void* stream);
+int liw_batch_wheel_preint(liw_ctx* ctx, int M, const int* sample_off, const double* samples, const double* t_start, const double* t_end,
+                           double* delta_Tij, double* sqrt_inverse_P, double* Dt, void* stream);
+
 /* ---- host pre-integrators (sequential per message; replace imu_preintegraption / wheel_odom_preintegration,
  *      src/factor/imu_preintegraption.h:105-208, src/factor/wheel_odom_preintegration.h:44-152) -------- */
 typedef struct liw_imu_preint liw_imu_preint;
