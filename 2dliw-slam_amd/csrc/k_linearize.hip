@@ -64,53 +64,120 @@ __device__ __forceinline__ void bfly_step(double* v, int lane) {
     }
 }
 
+#ifdef LIW_CLK
+__device__ long long g_clk_lin[512];
+// stamps of one wave in the middle of the grid (so that it runs under load), every memory operation drained first
+#define LSTAMP(id) do { asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory"); if (blockIdx.x == gridDim.x / 2 && lane == 0 && (id) < 512) g_clk_lin[(id)] = clock64(); } while (0)
+#else
+#define LSTAMP(id) do { } while (0)
+#endif
+constexpr int LASER_GMAX = 8;   // (window, frame) groups one wave may own
+
 // Laser group kernel.  Columns of a block's two Jacobian rows: the translation columns of the two poses differ only
 // in sign (d s/d p_b = - d s/d p_a), so the unique columns are  BOTH: [a_x a_y a_th0..2 b_th0..2 r] (9, 45 pairs),
 // one free pose: [b_x b_y b_th0..2 r] (6, 21 pairs).  Every lane accumulates its blocks' pair products in
 // registers over all passes; one butterfly per group reduces them across the wave.
 template <bool BOTH>
-__global__ __launch_bounds__(64, 2) void k_lin_laser(LinArgs A, DevParams P) {
+__global__ __launch_bounds__(64, 2) void k_lin_laser(LinArgs A, DevParams P, int G) {
     constexpr int NC = BOTH ? 9 : 6;
     constexpr int NP = NC * (NC + 1) / 2;
     const int lane = threadIdx.x & 63;
     const int n = A.n;
-    const int b = blockIdx.x / n, i = blockIdx.x % n;
+    const int wpw = (n + G - 1) / G;                     // waves per window
+    const int b = blockIdx.x / wpw, i0 = (blockIdx.x % wpw) * G;
     if (b >= A.B) return;
     if (A.lm && A.lm[b].done) return;
-    double* out = A.PL + ((size_t)b * n + i) * LP;
-    const int j0 = A.group_off[b * (n + 1) + i], j1 = A.group_off[b * (n + 1) + i + 1];
-    const bool on = A.has_match[b * n + i] && j1 > j0 && (A.mode != LIW_MODE_TRACK || i == n - 1);
-    if (!on) { out[lane] = 0.0; out[lane + 64] = 0.0; return; }
+    const int i1 = min(n, i0 + G);                       // this wave owns the groups of frames i0 .. i1-1
 
-    // frame transforms (wave-uniform): a = frame 0 (init) or the constant laser_match pose, b = frame i
-    // staged in LDS (one coalesced load) and read back as broadcasts, which keeps 64 doubles out of the VGPRs
-    __shared__ double tf[2 * FTF];   // re-read (ds_read broadcast) close to each use instead of keeping 64 doubles live
-    {
+    // frame transforms of the wave's frames, staged in LDS (coalesced loads) and re-read close to each use, which keeps
+    // 64 doubles per frame out of the VGPRs.  Per frame: a = frame 0 (init) or the constant laser_match pose, b = own.
+    __shared__ double tf[LASER_GMAX * 2 * FTF];
+    __shared__ int goff[LASER_GMAX + 1];
+    __shared__ double red[24 * 65];      // lane-transpose buffer of the group reduction
+    __shared__ double tl[48];            // pair totals of the group being written
+    __shared__ int slot_src[128];
+    __shared__ int fon_lds[LASER_GMAX];
+    for (int g = 0; g < i1 - i0; ++g) {
+        const int i = i0 + g;
         const double* Tag = A.ftf + (BOTH ? ((size_t)b * n * 2) : (((size_t)b * n + i) * 2 + 1)) * FTF;
         const double* Tbg = A.ftf + (((size_t)b * n + i) * 2) * FTF;
-        tf[lane] = lane < FTF ? Tag[lane] : Tbg[lane - FTF];
+        tf[g * 64 + lane] = lane < FTF ? Tag[lane] : Tbg[lane - FTF];
     }
+    // slot -> (pair index | 64 if negated), -1 = structural zero, of the 128-slot group record.  Unique-column index of a
+    // pose entry (0..5 = px py pz th0 th1 th2) and its sign:
+    {
+        auto pairidx = [](int c1, int c2) { if (c1 > c2) { const int t = c1; c1 = c2; c2 = t; } return c1 * NC - c1 * (c1 - 1) / 2 + (c2 - c1); };
+        auto col_a = [](int idx) { return idx < 2 ? idx : (idx == 2 ? -1 : idx - 1); };                       // a: x y - th0..2 -> 0 1 - 2 3 4
+        auto col_b = [](int idx) { return BOTH ? (idx < 2 ? idx : (idx == 2 ? -1 : idx + 2)) : (idx == 2 ? -1 : (idx < 2 ? idx : idx - 1)); };
+        auto sgn_b = [](int idx) { return (BOTH && idx < 2) ? -1.0 : 1.0; };
+        constexpr int RC = NC - 1;
+#pragma unroll
+        for (int qq = 0; qq < 2; ++qq) {
+            const int s = lane + 64 * qq;
+            int src = -1;
+            double sg = 1.0;
+            if (s < 36) {
+                const int ca = col_a(s / 6), cb = col_a(s % 6);
+                if (BOTH && ca >= 0 && cb >= 0) src = pairidx(ca, cb);
+            } else if (s < 72) {
+                const int ia = (s - 36) / 6, ib = (s - 36) % 6;
+                const int ca = col_b(ia), cb = col_b(ib);
+                if (ca >= 0 && cb >= 0) { src = pairidx(ca, cb); sg = sgn_b(ia) * sgn_b(ib); }
+            } else if (s < 108) {
+                const int ia = (s - 72) / 6, ib = (s - 72) % 6;
+                const int ca = col_a(ia), cb = col_b(ib);
+                if (BOTH && ca >= 0 && cb >= 0) { src = pairidx(ca, cb); sg = sgn_b(ib); }
+            } else if (s < 114) {
+                const int ca = col_a(s - 108);
+                if (BOTH && ca >= 0) src = pairidx(ca, RC);
+            } else if (s < 120) {
+                const int cb = col_b(s - 114);
+                if (cb >= 0) { src = pairidx(cb, RC); sg = sgn_b(s - 114); }
+            } else if (s == 120) {
+                src = pairidx(RC, RC);
+            }
+            slot_src[s] = src < 0 ? -1 : (src | (sg < 0.0 ? 64 : 0));
+        }
+    }
+    LSTAMP(0);
+    if (lane < i1 - i0) fon_lds[lane] = (A.has_match[b * n + i0 + lane] && (A.mode != LIW_MODE_TRACK || i0 + lane == n - 1)) ? 1 : 0;
+    if (lane <= i1 - i0) goff[lane] = A.group_off[b * (n + 1) + i0 + lane];
     __syncthreads();
-#define TA(k) tf[(k)]
-#define TB(k) tf[FTF + (k)]
+    LSTAMP(1);
+    int pass_dbg = 0; (void)pass_dbg;
+    const int J0 = goff[0], J1 = goff[i1 - i0];
 
     constexpr int NACC = BOTH ? 48 : 32;   // 45 / 21 pair accumulators, padded to 32 (+16)
     double acc[NACC];
 #pragma unroll
     for (int e = 0; e < NACC; ++e) acc[e] = 0.0;
     const size_t Lt = (size_t)A.Ltot;
-    for (int base = j0; base < j1; base += 64) {
+    int cf = i0;                           // group being accumulated (uniform)
+    double q[12];                          // this lane's block record (end points of the two matched segments)
+    if (J0 + lane < J1) {
+#pragma unroll
+        for (int c = 0; c < 12; ++c) q[c] = A.laser_pts[c * Lt + J0 + lane];
+    }
+    for (int base = J0;; base += 64) {
         const int j = base + lane;
         asm volatile("" ::: "memory");   // keeps the LDS reads of the transforms inside the pass (no loop-invariant hoisting)
-        if (j < j1) {
-            double q[12];
-#pragma unroll
-            for (int c = 0; c < 12; ++c) q[c] = A.laser_pts[c * Lt + j];
+        // owning frame of this lane's block = number of group boundaries at or below j
+        int fl = i0;
+        for (int g = 1; g < i1 - i0; ++g) fl += (j >= goff[g]) ? 1 : 0;
+        const bool fon = fon_lds[fl - i0] != 0;
+        const bool valid = j < J1 && fon;
+        double rows[2][NC];
+        LSTAMP(8 + pass_dbg * 8 + 0);
+        if (valid) {
+            const double* tfl = tf + (fl - i0) * 64;
+#define TA(k) tfl[(k)]
+#define TB(k) tfl[FTF + (k)]
             // laser_factor ctor: len1, len2, sum   (laser_factor.h:30-43)
             const double d1x = q[0] - q[3], d1y = q[1] - q[4], d1z = q[2] - q[5];
             const double d2x = q[6] - q[9], d2y = q[7] - q[10], d2z = q[8] - q[11];
-            const double len1 = sqrt(d1x * d1x + d1y * d1y + d1z * d1z), len2 = sqrt(d2x * d2x + d2y * d2y + d2z * d2z);
-            const double sum = sqrt(fmin(len1, len2) / 2.0 / 0.02);
+            // min(len1, len2) = sqrt(min(len1^2, len2^2)) exactly (sqrt is monotone and correctly rounded): one sqrt
+            const double lmin = sqrt(fmin(d1x * d1x + d1y * d1y + d1z * d1z, d2x * d2x + d2y * d2y + d2z * d2z));
+            const double sum = sqrt(lmin / 2.0 / 0.02);
             // world points, z dropped (laser_factor.h:67-77)
             double Ap[2], Bp[2], C[2][2];
 #pragma unroll
@@ -123,8 +190,8 @@ __global__ __launch_bounds__(64, 2) void k_lin_laser(LinArgs A, DevParams P) {
             const double ux = Bp[0] - Ap[0], uy = Bp[1] - Ap[1];
             const double zz = ux * ux + uy * uy;
             const bool regular = zz > 0.0;
-            const double len = regular ? sqrt(zz) : 1.0;
-            const double lx = ux / len, ly = uy / len;     // degenerate: stays the (zero) difference vector
+            const double rlen = regular ? 1.0 / sqrt(zz) : 1.0;   // one reciprocal instead of eight divisions by the length
+            const double lx = ux * rlen, ly = uy * rlen;   // degenerate: stays the (zero) difference vector
             double dBx[3], dBy[3], dlx[3], dly[3];
             __builtin_amdgcn_sched_barrier(0);
             if (BOTH) {
@@ -140,8 +207,8 @@ __global__ __launch_bounds__(64, 2) void k_lin_laser(LinArgs A, DevParams P) {
                     dBy[k] = m3 * q[3] + m4 * q[4] + m5 * q[5] + t1;
                     const double dux = dBx[k] - dAx, duy = dBy[k] - dAy;
                     const double pr = lx * dux + ly * duy;
-                    dlx[k] = (dux - lx * pr) / len;
-                    dly[k] = (duy - ly * pr) / len;
+                    dlx[k] = (dux - lx * pr) * rlen;
+                    dly[k] = (duy - ly * pr) * rlen;
                 }
             }
             const double w = sum * P.laser_sqrt_info;
@@ -180,21 +247,15 @@ __global__ __launch_bounds__(64, 2) void k_lin_laser(LinArgs A, DevParams P) {
                     }
                 }
                 const double res = sum * (P.laser_sqrt_info * dist);
-                double row[NC];
                 if (BOTH) {
 #pragma unroll
-                    for (int c = 0; c < 8; ++c) row[c] = w * jc[c];
+                    for (int c = 0; c < 8; ++c) rows[k][c] = w * jc[c];
                 } else {
-                    row[0] = -w * jc[0]; row[1] = -w * jc[1];
+                    rows[k][0] = -w * jc[0]; rows[k][1] = -w * jc[1];
 #pragma unroll
-                    for (int c = 0; c < 3; ++c) row[2 + c] = w * jc[5 + c];
+                    for (int c = 0; c < 3; ++c) rows[k][2 + c] = w * jc[5 + c];
                 }
-                row[NC - 1] = res;
-                // pair products into the register accumulators (compile-time indices)
-#pragma unroll
-                for (int c1 = 0; c1 < NC; ++c1)
-#pragma unroll
-                    for (int c2 = c1; c2 < NC; ++c2) acc[c1 * NC - c1 * (c1 - 1) / 2 + (c2 - c1)] += row[c1] * row[c2];
+                rows[k][NC - 1] = res;
                 if (A.dbg_laser_res) A.dbg_laser_res[(size_t)j * 2 + k] = res;
                 if (A.dbg_laser_jac) {
                     double* dj = A.dbg_laser_jac + ((size_t)j * 2 + k) * 12;
@@ -204,53 +265,77 @@ __global__ __launch_bounds__(64, 2) void k_lin_laser(LinArgs A, DevParams P) {
                     dj[9] = w * jc[5]; dj[10] = w * jc[6]; dj[11] = w * jc[7];
                 }
             }
-        }
-    }
-    // totals: pair p < 32 ends up in lanes 2p, 2p+1; pair 32 + p' (BOTH only) in lanes 4p' .. 4p'+3
-    bfly_step<32, 32>(acc, lane);
-    const double tot_lo = acc[0];
-    double tot_hi = 0.0;
-    if constexpr (BOTH) { bfly_step<16, 32>(acc + 32, lane); tot_hi = acc[32]; }
-    (void)NP;
-    // compose the 128-slot record.  unique-column index of a pose entry (0..5 = px py pz th0 th1 th2) and its sign
-    auto pairidx = [](int c1, int c2) { if (c1 > c2) { const int t = c1; c1 = c2; c2 = t; } return c1 * NC - c1 * (c1 - 1) / 2 + (c2 - c1); };
-    auto col_a = [](int idx) { return idx < 2 ? idx : (idx == 2 ? -1 : idx - 1); };                       // a: x y - th0..2 -> 0 1 - 2 3 4
-    auto col_b = [](int idx) { return BOTH ? (idx < 2 ? idx : (idx == 2 ? -1 : idx + 2)) : (idx == 2 ? -1 : (idx < 2 ? idx : idx - 1)); };
-    auto sgn_b = [](int idx) { return (BOTH && idx < 2) ? -1.0 : 1.0; };
-    constexpr int RC = NC - 1;
-#pragma unroll
-    for (int qq = 0; qq < 2; ++qq) {
-        const int s = lane + 64 * qq;
-        int src = -1;
-        double sg = 1.0;
-        if (s < 36) {
-            const int ca = col_a(s / 6), cb = col_a(s % 6);
-            if (BOTH && ca >= 0 && cb >= 0) src = pairidx(ca, cb);
-        } else if (s < 72) {
-            const int ia = (s - 36) / 6, ib = (s - 36) % 6;
-            const int ca = col_b(ia), cb = col_b(ib);
-            if (ca >= 0 && cb >= 0) { src = pairidx(ca, cb); sg = sgn_b(ia) * sgn_b(ib); }
-        } else if (s < 108) {
-            const int ia = (s - 72) / 6, ib = (s - 72) % 6;
-            const int ca = col_a(ia), cb = col_b(ib);
-            if (BOTH && ca >= 0 && cb >= 0) { src = pairidx(ca, cb); sg = sgn_b(ib); }
-        } else if (s < 114) {
-            const int ca = col_a(s - 108);
-            if (BOTH && ca >= 0) src = pairidx(ca, RC);
-        } else if (s < 120) {
-            const int cb = col_b(s - 114);
-            if (cb >= 0) { src = pairidx(cb, RC); sg = sgn_b(s - 114); }
-        } else if (s == 120) {
-            src = pairidx(RC, RC);
-        }
-        const int sp = src < 0 ? 0 : src;
-        const double vlo = __shfl(tot_lo, (sp & 31) * 2, 64);
-        const double vhi = __shfl(tot_hi, ((sp - 32) & 15) * 4, 64);
-        out[s] = src < 0 ? 0.0 : sg * (sp < 32 ? vlo : vhi);
-    }
-}
 #undef TA
 #undef TB
+        }
+        LSTAMP(8 + pass_dbg * 8 + 1);
+        // software pipeline: the record of the next chunk is in flight during the pair products and the group reduction
+        __builtin_amdgcn_sched_barrier(0);
+        if (j + 64 < J1) {
+#pragma unroll
+            for (int c = 0; c < 12; ++c) q[c] = A.laser_pts[c * Lt + j + 64];
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        // ---- accumulate / flush: a 64-block chunk may straddle group boundaries; the lanes of group cf add their pair
+        //      products, and every group that ends inside (or before) this chunk is reduced and written.  The wave
+        //      therefore makes ceil(blocks/64) passes over its G groups instead of one ceil per group.
+        bool more = true;
+        int fl_dbg = 0; (void)fl_dbg;
+        while (more) {
+            LSTAMP(8 + pass_dbg * 8 + 2 + 2 * fl_dbg);
+            if (valid && fl == cf) {
+#pragma unroll
+                for (int k = 0; k < 2; ++k)
+#pragma unroll
+                    for (int c1 = 0; c1 < NC; ++c1)
+#pragma unroll
+                        for (int c2 = c1; c2 < NC; ++c2) acc[c1 * NC - c1 * (c1 - 1) / 2 + (c2 - c1)] += rows[k][c1] * rows[k][c2];
+            }
+            more = goff[cf + 1 - i0] <= base + 64;       // group cf is complete (uniform)
+            LSTAMP(8 + pass_dbg * 8 + 3 + 2 * fl_dbg);
+            fl_dbg = fl_dbg < 2 ? fl_dbg + 1 : 2;
+            if (more) {
+                double* out = A.PL + ((size_t)b * n + cf) * LP;
+                // totals of the NP pair accumulators over the 64 lanes: transpose through LDS, 24 values per round
+                // (lane (p, h) sums half h of value p's 64 entries), which costs ~50 LDS operations per round instead of
+                // a 49-exchange ds_bpermute butterfly whose latency chain dominated short groups
+#pragma unroll
+                for (int r = 0; r < NACC / 24 + (NACC % 24 ? 1 : 0); ++r) {
+                    if (r * 24 >= NP) break;
+                    __syncthreads();
+#pragma unroll
+                    for (int e = 0; e < 24; ++e)
+                        if (r * 24 + e < NP) red[e * 65 + lane] = acc[r * 24 + e];
+                    __syncthreads();
+                    const int pp = lane % 24, hh = lane < 48 ? lane / 24 : 0;
+                    const double* rp = red + pp * 65 + 32 * hh;
+                    double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
+#pragma unroll
+                    for (int k = 0; k < 32; k += 4) { s0 += rp[k]; s1 += rp[k + 1]; s2 += rp[k + 2]; s3 += rp[k + 3]; }
+                    const double part = (s0 + s1) + (s2 + s3);
+                    const double other = __shfl(part, (lane + 24) & 63, 64);
+                    if (lane < 24) tl[r * 24 + lane] = part + other;
+                }
+                __syncthreads();
+                (void)NP;
+                // compose the 128-slot record from the pair totals (source pair and sign per slot: table built once per wave)
+#pragma unroll
+                for (int qq = 0; qq < 2; ++qq) {
+                    const int s = lane + 64 * qq;
+                    const int src = slot_src[s];
+                    out[s] = src < 0 ? 0.0 : (src & 64 ? -tl[src & 63] : tl[src & 63]);
+                }
+#pragma unroll
+                for (int e = 0; e < NACC; ++e) acc[e] = 0.0;
+                ++cf;
+                more = cf < i1;
+            }
+        }
+        ++pass_dbg;
+        if (cf >= i1) break;
+    }
+    LSTAMP(2);
+}
 
 // ------------------------------------------------------------------------------------------- imu
 // raw (un-whitened) residual of imu_factor::operator(), src/factor/imu_factor.h:41-83; also returns R_i^T
@@ -629,8 +714,12 @@ void launch_linearize(const LinArgs& A, const DevParams& P, hipStream_t s, const
     }
     hipStream_t s_imu = fork ? fk->side[0] : s, s_small = fork ? fk->side[1] : s;
     hipLaunchKernelGGL(k_frame_tf, dim3((nrec + 255) / 256), dim3(256), 0, s, B, n, A.x, A.match_pose, A.ftf, P, A.lm);
-    if (A.mode == LIW_MODE_INIT) hipLaunchKernelGGL(k_lin_laser<true>, dim3((unsigned)(B * n)), dim3(64), 0, s, A, P);
-    else hipLaunchKernelGGL(k_lin_laser<false>, dim3((unsigned)(B * n)), dim3(64), 0, s, A, P);
+    // groups per wave: one for small batches (latency), up to LASER_GMAX for large ones (no ragged last pass per group)
+    int G = 1;
+    if (A.mode != LIW_MODE_TRACK) while (G < LASER_GMAX && (long)B * ((n + 2 * G - 1) / (2 * G)) >= 4096) G *= 2;
+    const unsigned waves = (unsigned)(B * ((n + G - 1) / G));
+    if (A.mode == LIW_MODE_INIT) hipLaunchKernelGGL(k_lin_laser<true>, dim3(waves), dim3(64), 0, s, A, P, G);
+    else hipLaunchKernelGGL(k_lin_laser<false>, dim3(waves), dim3(64), 0, s, A, P, G);
     if (A.eval_small && n > 1) {
         hipLaunchKernelGGL(k_lin_imu, dim3((unsigned)(B * ((n - 1 + IMU_PER_WAVE - 1) / IMU_PER_WAVE))), dim3(64), 0, s_imu, A, P);
     }
@@ -645,6 +734,9 @@ void launch_linearize(const LinArgs& A, const DevParams& P, hipStream_t s, const
         hipStreamWaitEvent(s, fk->ev_join[1], 0);
     }
 }
+#ifdef LIW_CLK
+extern "C" void liw_debug_clk_lin(long long* out, int nn) { hipMemcpyFromSymbol(out, HIP_SYMBOL(g_clk_lin), sizeof(long long) * nn); }
+#endif
 void launch_group_offsets(int B, int n, const int* laser_off, const int* laser_frame, int* group_off, hipStream_t s) {
     const int tot = B * (n + 1);
     hipLaunchKernelGGL(k_group_offsets, dim3((tot + 255) / 256), dim3(256), 0, s, B, n, laser_off, laser_frame, group_off);

@@ -4,6 +4,7 @@
 
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <string>
 #include <vector>
@@ -162,6 +163,7 @@ liw_ctx* liw_create(const liw_params* prm) {
                     hipEventCreateWithFlags(&c->fork.ev_join[0], hipEventDisableTiming) == hipSuccess &&
                     hipEventCreateWithFlags(&c->fork.ev_join[1], hipEventDisableTiming) == hipSuccess)
                     c->have_fork = true;
+                if (std::getenv("LIW_SERIAL_ROLES")) c->have_fork = false;   // profiling aid: role kernels back to back
             } else {
                 c->err = std::string("device is ") + props.gcnArchName + ", this library is built for gfx950 only";
             }
