@@ -404,8 +404,10 @@ __device__ void imu_group(const LinArgs& A, const DevParams& P, int b, int item,
             }
         }
     }
+    LSTAMP(300);
     for (int e = lane; e < IMU_PER_WAVE * 512; e += 64) lds[e] = 0.0;
     __syncthreads();
+    LSTAMP(301);
     const size_t fk = (size_t)b * (n - 1) + (on ? k : 0);
     if (on) {
         const double* si_ = A.x + ((size_t)b * n + k) * 15;
@@ -446,6 +448,7 @@ __device__ void imu_group(const LinArgs& A, const DevParams& P, int b, int item,
             put3(9, cast_v3<LJ>(sj_ + 9) - cast_v3<LJ>(si_ + 9));                  // res_ba
             put3(12, cast_v3<LJ>(sj_ + 12) - bwi);                                  // res_bw
         }
+        LSTAMP(302);
         // closed-form columns (value parts are uniform over the block's lanes; each lane writes one column group)
         if (d == 0) {
 #pragma unroll
@@ -480,6 +483,7 @@ __device__ void imu_group(const LinArgs& A, const DevParams& P, int b, int item,
 #pragma unroll
             for (int r = 0; r < 3; ++r) { Xg[(9 + r) * 32 + 24 + r] = 1.0; Xg[(12 + r) * 32 + 27 + r] = 1.0; }   // d r_ba/d ba_j, d r_bw/d bw_j
         }
+        LSTAMP(303);
         __builtin_amdgcn_sched_barrier(0);
         {   // gamma rows: log( exp(-gamma^) R_i^T R_j )
             const M3<LJ> RiRj = mul(Rt, exp_so3(thetaj));
@@ -491,6 +495,7 @@ __device__ void imu_group(const LinArgs& A, const DevParams& P, int b, int item,
         }
     }
     __syncthreads();
+    LSTAMP(304);
     // ---- matrix-core part, one block at a time (the whole wave cooperates)
     const int ml = lane & 15, mk = lane >> 4;
 #pragma unroll
@@ -515,6 +520,7 @@ __device__ void imu_group(const LinArgs& A, const DevParams& P, int b, int item,
             g01 = __builtin_amdgcn_mfma_f64_16x16x4f64(y0[c], y1[c], g01, 0, 0, 0);
             g11 = __builtin_amdgcn_mfma_f64_16x16x4f64(y1[c], y1[c], g11, 0, 0, 0);
         }
+        LSTAMP(310 + 2 * g);
         double* out = A.PI[sel] + fg * PIS;
         // G(R, C) over the 31 columns [x_i(15) x_j(15) r]: keep blocks ii, ij, jj, the gradient column and G(30,30)
         auto put = [&](int R, int C, double v) {
@@ -537,6 +543,7 @@ __device__ void imu_group(const LinArgs& A, const DevParams& P, int b, int item,
                 if (ml < 14) A.dbg_imu_jac[(fg * 15 + row) * 30 + 16 + ml] = y1[r];
             }
         }
+        LSTAMP(311 + 2 * g);
     }
 }
 

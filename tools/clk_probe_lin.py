@@ -16,3 +16,8 @@ print('total', clk[2]-clk[0], 'stage', clk[1]-clk[0])
 for p in range(10):
     t=clk[8+p*8:8+p*8+8]
     print('pass',p,'wait+rows',t[1]-t[0],'prefetch-issue->prod0',t[2]-t[1],'prod0',t[3]-t[2],'emit0',t[4]-t[3] if t[4] else None,'prod1',t[5]-t[4] if t[5] else None, 'next', clk[8+(p+1)*8]-max(t[3],t[5]))
+
+print('imu: prefetch', clk[300]-0 if False else 0, 'zero+sync', clk[301]-clk[300], 'alpha/beta', clk[302]-clk[301], 'closed', clk[303]-clk[302], 'gamma+sync', clk[304]-clk[303])
+for g in range(6):
+    print(' block', g, 'mfma', clk[310+2*g]-(clk[304] if g==0 else clk[309+2*g]), 'stores', clk[311+2*g]-clk[310+2*g])
+print('imu total from 300', clk[321]-clk[300])
