@@ -87,6 +87,13 @@ def lib():
     if _LIB is None:
         if not os.path.exists(LIB_PATH):
             raise LiwError(-2, "libliw_window.so is not built (run python 2dliw-slam_amd/build.py); there is no CPU fallback")
+        # one HIP runtime per process: PyTorch-ROCm ships its own libamdhip64, and whichever copy is loaded second cannot
+        # initialise the device ("No HIP GPUs are available").  Import torch first when it is installed, so that the
+        # library's HIP calls and torch's device memory / streams share torch's runtime.
+        try:
+            import torch  # noqa: F401
+        except ImportError:
+            pass
         L = C.CDLL(LIB_PATH)
         L.liw_create.restype = C.c_void_p
         L.liw_create.argtypes = [C.POINTER(ParamsC)]
@@ -342,3 +349,4 @@ class HostPreint:
 
 
 from .batch import BatchPreint, BatchSolver, shard_laser  # noqa: E402,F401
+from . import laser  # noqa: E402,F401

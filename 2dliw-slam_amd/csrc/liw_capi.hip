@@ -130,6 +130,8 @@ static void normalize_tf_host(double* R) {
     R[3] = txy + twz;       R[4] = 1 - (txx + tzz); R[5] = tyz - twx;
     R[6] = txz - twy;       R[7] = tyz + twx;       R[8] = 1 - (txx + tyy);
 }
+void liw_normalize_rotation_host(double* R9) { normalize_tf_host(R9); }   // used by liw_laser.cpp
+
 void liw_fill_devparams(const liw_params* prm, DevParams* dp) {
     for (int i = 0; i < 3; ++i) {
         for (int j = 0; j < 3; ++j) { dp->Riw[i * 3 + j] = prm->T_imu_to_wheel[i * 4 + j]; dp->Ril[i * 3 + j] = prm->T_imu_to_laser[i * 4 + j]; }

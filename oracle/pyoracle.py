@@ -241,3 +241,155 @@ class Oracle:
         it = C.c_int(0)
         sec = self.L.oracle_time_solves(self.h, C.byref(w.c), C.c_int(reps), C.c_int(max_iters), C.c_int(int(dense_product)), C.byref(it))
         return sec, it.value
+
+
+# ---------------------------------------------------------------------------------------------------
+# laser front-end restatement (laser_frontend.h / laser_capi.cpp)
+class LaserParamsC(C.Structure):
+    _fields_ = [("w_laser_each_scan", C.c_double), ("h_laser_each_scan", C.c_double), ("laser_resolution", C.c_double),
+                ("line_continuous_threshold", C.c_double), ("line_min_len", C.c_double), ("line_max_dis", C.c_double),
+                ("line_max_tolerance_angle", C.c_double), ("ref_motion_filter_p", C.c_double), ("ref_motion_filter_q", C.c_double),
+                ("ref_n_accumulation", C.c_int), ("T_imu_to_laser", C.c_double * 16), ("normalize_extrinsics", C.c_int)]
+
+
+def _laser_lib():
+    L = lib()
+    if not getattr(L, "_laser_ready", False):
+        for name in ("oracle_laser_create", "oracle_scan_spawn", "oracle_scan_create_empty", "oracle_laser_do_match", "oracle_laser_match_with",
+                     "oracle_laser_ref_scan"):
+            getattr(L, name).restype = C.c_void_p
+        for name in ("oracle_laser_destroy", "oracle_scan_destroy", "oracle_laser_match_destroy"):
+            getattr(L, name).argtypes = [C.c_void_p]
+        L._laser_ready = True
+    return L
+
+
+class OracleScan:
+    def __init__(self, h):
+        self.h = C.c_void_p(h)
+
+    def lines(self):
+        L = _laser_lib()
+        n = L.oracle_scan_num_lines(self.h)
+        out = np.zeros((n, 10))
+        if n:
+            L.oracle_scan_get_lines(self.h, _p(out))
+        return out
+
+    def concers(self):
+        L = _laser_lib()
+        n = L.oracle_scan_num_concers(self.h)
+        out = np.zeros((n, 3))
+        if n:
+            L.oracle_scan_get_concers(self.h, _p(out))
+        return out
+
+    def cell_lines(self, x, y, cap=16):
+        ids = np.zeros(cap, dtype=np.int32)
+        k = _laser_lib().oracle_scan_cell_lines(self.h, C.c_double(x), C.c_double(y), ids.ctypes.data_as(C.POINTER(C.c_int)), C.c_int(cap))
+        return k, ids[:max(0, min(k, cap))].copy()
+
+    def add_segment(self, p1, p2, add_concers=False):
+        a, b = np.ascontiguousarray(p1, dtype=np.float64), np.ascontiguousarray(p2, dtype=np.float64)
+        return _laser_lib().oracle_scan_add_segment(self.h, _p(a), _p(b), C.c_int(int(add_concers)))
+
+    def __del__(self):
+        try:
+            _laser_lib().oracle_scan_destroy(self.h)
+        except Exception:
+            pass
+
+
+class OracleMatch:
+    def __init__(self, h):
+        L = _laser_lib()
+        h = C.c_void_p(h)
+        n = L.oracle_laser_match_size(h)
+        self.pts, self.pose = np.zeros((n, 12)), np.zeros(12)
+        self.idx1, self.idx2 = np.zeros(n, dtype=np.int32), np.zeros(n, dtype=np.int32)
+        ipt = C.POINTER(C.c_int)
+        L.oracle_laser_match_get(h, _p(self.pts), _p(self.pose), self.idx1.ctypes.data_as(ipt), self.idx2.ctypes.data_as(ipt))
+        L.oracle_laser_match_destroy(h)
+
+    def __len__(self):
+        return self.pts.shape[0]
+
+
+class LaserOracle:
+    """laser_manager restatement; lp: dict with the keys of 2dliw-slam_amd.laser.office_laser_params()."""
+
+    def __init__(self, lp):
+        s = LaserParamsC()
+        for k in ("w_laser_each_scan", "h_laser_each_scan", "laser_resolution", "line_continuous_threshold", "line_min_len", "line_max_dis",
+                  "line_max_tolerance_angle", "ref_motion_filter_p", "ref_motion_filter_q"):
+            setattr(s, k, float(lp[k]))
+        s.ref_n_accumulation = int(lp["ref_n_accumulation"])
+        s.T_imu_to_laser[:] = [float(v) for v in np.asarray(lp["T_imu_to_laser"], dtype=np.float64).reshape(16)]
+        s.normalize_extrinsics = int(bool(lp.get("normalize_extrinsics", True)))
+        self._ps = s
+        self.h = C.c_void_p(_laser_lib().oracle_laser_create(C.byref(s)))
+
+    def spawn_scan(self, points, time=0.0):
+        p = np.ascontiguousarray(points, dtype=np.float64).reshape(-1, 3)
+        return OracleScan(_laser_lib().oracle_scan_spawn(self.h, _p(p), C.c_int(p.shape[0]), C.c_double(time)))
+
+    def empty_scan(self, time=0.0):
+        return OracleScan(_laser_lib().oracle_scan_create_empty(self.h, C.c_double(time)))
+
+    def do_match(self, s1, s2, p1, q1, p2, q2, kk=0):
+        a = [np.ascontiguousarray(v, dtype=np.float64) for v in (p1, q1, p2, q2)]
+        return OracleMatch(_laser_lib().oracle_laser_do_match(self.h, s1.h, s2.h, _p(a[0]), _p(a[1]), _p(a[2]), _p(a[3]), C.c_int(kk)))
+
+    def add_scan(self, scan, p, q):
+        a, b = np.ascontiguousarray(p, dtype=np.float64), np.ascontiguousarray(q, dtype=np.float64)
+        _laser_lib().oracle_laser_add_scan(self.h, scan.h, _p(a), _p(b))
+
+    def _match(self, which, scan, p, q):
+        a, b = np.ascontiguousarray(p, dtype=np.float64), np.ascontiguousarray(q, dtype=np.float64)
+        return OracleMatch(_laser_lib().oracle_laser_match_with(self.h, C.c_int(which), scan.h, _p(a), _p(b)))
+
+    def match_with_front(self, scan, p, q):
+        return self._match(0, scan, p, q)
+
+    def match_with_back(self, scan, p, q):
+        return self._match(1, scan, p, q)
+
+    def match_with_ref(self, scan, p, q):
+        return self._match(2, scan, p, q)
+
+    def pop_scan(self):
+        return _laser_lib().oracle_laser_pop_scan(self.h)
+
+    def clear_all_scan(self):
+        _laser_lib().oracle_laser_clear_all_scan(self.h)
+
+    def num_keyframes(self):
+        return _laser_lib().oracle_laser_num_keyframes(self.h)
+
+    def ref_scan(self):
+        p, q = np.zeros(3), np.zeros(3)
+        h = _laser_lib().oracle_laser_ref_scan(self.h, _p(p), _p(q))
+        if not h:
+            return None
+        return OracleScan(h), p, q
+
+    def __del__(self):
+        try:
+            _laser_lib().oracle_laser_destroy(self.h)
+        except Exception:
+            pass
+
+
+def laser_to_points(ranges, angle_min, angle_increment, time_increment, stamp):
+    r = np.ascontiguousarray(ranges, dtype=np.float32)
+    pts, ts = np.zeros((len(r), 3)), np.zeros(len(r))
+    m = _laser_lib().oracle_laser_to_points(r.ctypes.data_as(C.POINTER(C.c_float)), C.c_int(len(r)), C.c_float(angle_min), C.c_float(angle_increment),
+                                            C.c_float(time_increment), C.c_double(stamp), _p(pts), _p(ts))
+    return pts[:m].copy(), ts[:m].copy()
+
+
+def laser_correct(points, times, stamp, linear, angular):
+    p = np.ascontiguousarray(points, dtype=np.float64).copy()
+    t, lin, ang = (np.ascontiguousarray(v, dtype=np.float64) for v in (times, linear, angular))
+    _laser_lib().oracle_laser_correct(_p(p), _p(t), C.c_int(len(t)), C.c_double(stamp), _p(lin), _p(ang))
+    return p

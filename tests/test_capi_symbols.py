@@ -18,6 +18,15 @@ def test_header_symbols_are_exported(liw):
     assert sorted(set(liw.EXPORTS)) == declared
 
 
+def test_laser_header_symbols_are_exported(liw):
+    hdr = open(os.path.join(ROOT, "include", "liw_laser.h")).read()
+    declared = sorted(set(re.findall(r"\b(liw_(?:laser|scan)_[A-Za-z_0-9]+)\s*\(", hdr)))
+    L = liw.lib()
+    missing = [s for s in declared if not hasattr(L, s)]
+    assert not missing, missing
+    assert sorted(set(liw.laser.LASER_EXPORTS)) == declared
+
+
 def test_no_cpu_fallback(liw, synth):
     import torch
     if torch.cuda.is_available():

@@ -70,3 +70,41 @@ def test_cpp_solver_class_matches_oracle(liw, synth, pyoracle, tmp_path):
     assert np.abs(mp[m] - wo["match_pose"].reshape(n, 12)[m]).max() <= 1e-6 * np.abs(wo["match_pose"]).max()
     so = orc.marginalization(wo)
     assert np.abs(sqrt_H.T @ sqrt_H - so.T @ so).max() <= 1e-6 * max(1.0, np.abs(so.T @ so).max())
+
+
+def test_cpp_laser_manager_class_matches_python_binding(liw, synth, tmp_path):
+    """include/lvio_2d_laser.hpp (lvio_2d::laser_manager / scan with the reference's names) against the ctypes binding of the
+    same C ABI and, through tests/test_laser_frontend.py, against the oracle.  CPU: the front-end is host code."""
+    src = os.path.join(ROOT, "tests", "cpp", "laser_api_driver.cpp")
+    exe = os.path.join(ROOT, "tests", "cpp", "laser_api_driver")
+    libdir = os.path.dirname(liw.LIB_PATH)
+    subprocess.check_call(["g++", "-O2", "-std=c++17", "-I", os.path.join(ROOT, "include"), src, "-o", exe,
+                           "-L", libdir, "-lliw_window", "-Wl,-rpath," + libdir, "-Wl,-rpath,/opt/rocm/lib"])
+    prm = synth.office_params()
+    lp = liw.laser.office_laser_params(prm)
+    room = liw.laser.room_segments(4)
+    T_il = np.array(synth.normalize_extrinsic(prm["T_imu_to_laser"])).reshape(4, 4)
+    poses = [np.array([0.1, 0.2, 0.0, 0.0, 0.0, 0.2]), np.array([0.22, 0.25, 0.0, 0.0, 0.0, 0.26])]
+    pts = []
+    for k, x in enumerate(poses):
+        T = np.eye(4)
+        T[:3, :3] = synth.exp_so3(x[3:6])
+        T[:3, 3] = x[0:3]
+        rg, amin, inc = liw.laser.cast_scan(room, T @ T_il, seed=40 + k)
+        pts.append(liw.laser.laser_to_points(rg, amin, inc, 0.0, 0.0)[0])
+    with open(str(tmp_path / "in.bin"), "wb") as f:
+        f.write(struct.pack("<ii", len(pts[0]), len(pts[1])))
+        f.write(np.concatenate(poses).tobytes())
+        f.write(pts[0].tobytes()); f.write(pts[1].tobytes())
+    subprocess.check_call([exe, str(tmp_path / "in.bin"), str(tmp_path / "out.bin")])
+    raw = open(str(tmp_path / "out.bin"), "rb").read()
+    nl1, nl2, nm = struct.unpack("<iii", raw[:12])
+    arr = np.frombuffer(raw[12:], dtype=np.float64)
+    l1, l2 = arr[:nl1 * 6].reshape(nl1, 6), arr[nl1 * 6:(nl1 + nl2) * 6].reshape(nl2, 6)
+    mt, pose = arr[(nl1 + nl2) * 6:(nl1 + nl2) * 6 + nm * 12].reshape(nm, 12), arr[-12:]
+    s1, s2 = liw.laser.Scan.spawn(lp, pts[0], 0.0), liw.laser.Scan.spawn(lp, pts[1], 0.1)
+    mgr = liw.laser.LaserManager(lp)
+    mgr.add_scan(s1, poses[0][0:3], poses[0][3:6])
+    m = mgr.match_with_front(s2, poses[1][0:3], poses[1][3:6])
+    assert np.array_equal(l1, s1.lines()[:, :6]) and np.array_equal(l2, s2.lines()[:, :6])
+    assert nm == len(m) >= 4 and np.array_equal(mt, m.pts) and np.array_equal(pose, m.pose)

@@ -1,0 +1,211 @@
+"""Laser front-end (host C++ behind include/liw_laser.h) against the oracle's restatement of
+reference src/trajectory/laser_manager.cpp on synthetic rooms: LaserScan conversion, line extraction, grid, corners,
+line matching and the key-frame / reference-sub-map bookkeeping.  CPU tests (the front-end is host code).
+
+Tolerances: LaserScan -> points bit-exact (same float arithmetic); line end points / intersections 1e-9 absolute (the
+product diagonalises the 3x3 moment matrix, the oracle runs a one-sided Jacobi SVD of the n x 3 design matrix);
+every discrete output (line counts, cell contents, matched index lists) exact."""
+import numpy as np
+import pytest
+
+
+@pytest.fixture(scope="module")
+def env(liw, synth, pyoracle):
+    prm = synth.office_params()
+    lp = liw.laser.office_laser_params(prm)
+    return prm, lp, pyoracle.LaserOracle(lp)
+
+
+def pose_T(synth, x, y, yaw):
+    T = np.eye(4)
+    T[:3, :3] = synth.exp_so3(np.array([0.0, 0.0, yaw]))
+    T[:2, 3] = [x, y]
+    return T
+
+
+def laser_extrinsic(synth, prm):
+    T = np.array(prm["T_imu_to_laser"], dtype=np.float64).reshape(4, 4)
+    return np.array(synth.normalize_extrinsic(T.reshape(16))).reshape(4, 4) if prm.get("normalize_extrinsics", True) else T
+
+
+def scan_points(liw, synth, prm, room, p, q, seed):
+    """points of a scan taken by the laser of an IMU at world pose (p, q)"""
+    T_il = laser_extrinsic(synth, prm)
+    T_wi = np.eye(4)
+    T_wi[:3, :3] = synth.exp_so3(np.asarray(q, dtype=np.float64))
+    T_wi[:3, 3] = p
+    T_wl = T_wi @ T_il
+    rg, amin, inc = liw.laser.cast_scan(room, T_wl, seed=seed)
+    return liw.laser.laser_to_points(rg, amin, inc, 2e-5, 100.0 + seed)
+
+
+def same_lines(a, b, tol=1e-9):
+    assert a.shape == b.shape, (a.shape, b.shape)
+    if a.shape[0] == 0:
+        return
+    assert np.abs(a[:, :6] - b[:, :6]).max() <= tol
+    sg = np.sign((a[:, 6:9] * b[:, 6:9]).sum(1))          # abc is defined up to its sign
+    assert np.abs(a[:, 6:9] - sg[:, None] * b[:, 6:9]).max() <= 1e-8
+    assert np.abs(a[:, 9] - b[:, 9]).max() <= tol
+
+
+def test_laser_to_points_bit_exact_and_filters(liw, pyoracle):
+    rng = np.random.default_rng(0)
+    r = rng.uniform(0.05, 12.0, 500).astype(np.float32)
+    r[10] = np.nan; r[11] = np.inf; r[12] = -1.0; r[13] = 0.1; r[40:44] = 3.0   # dropped / de-duplicated entries
+    a = liw.laser.laser_to_points(r, -2.35, 0.00436, 3e-5, 1234.5)
+    b = pyoracle.laser_to_points(r, -2.35, 0.00436, 3e-5, 1234.5)
+    assert a[0].shape == b[0].shape and a[0].shape[0] < 500
+    assert np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1])
+    assert np.all(np.linalg.norm(np.diff(a[0], axis=0), axis=1) >= 0.01)
+    with pytest.raises(ValueError):
+        liw.laser.laser_to_points(r, 0.0, -0.01, 0.0, 0.0)
+
+
+def test_laser_correct_matches_oracle(liw, pyoracle):
+    rng = np.random.default_rng(1)
+    pts, ts = rng.normal(0, 4, (200, 3)), 50.0 + np.sort(rng.uniform(0, 0.05, 200))
+    pts[:, 2] = 0.0
+    a = liw.laser.laser_correct(pts, ts, 50.0, [0.4, -0.1, 0.0], [0.0, 0.0, 0.7])
+    b = pyoracle.laser_correct(pts, ts, 50.0, [0.4, -0.1, 0.0], [0.0, 0.0, 0.7])
+    assert np.abs(a - b).max() <= 1e-13
+
+
+@pytest.mark.parametrize("seed", [1, 2, 3, 4, 5, 6])
+def test_spawn_scan_matches_oracle(liw, synth, env, seed):
+    prm, lp, orc = env
+    room = liw.laser.room_segments(seed)
+    rng = np.random.default_rng(100 + seed)
+    p, q = np.array([rng.uniform(-1, 1), rng.uniform(-1, 1), 0.0]), np.array([0.0, 0.0, rng.uniform(-3, 3)])
+    pts, _ = scan_points(liw, synth, prm, room, p, q, seed)
+    s, so = liw.laser.Scan.spawn(lp, pts, 1.0), orc.spawn_scan(pts, 1.0)
+    la, lb = s.lines(), so.lines()
+    assert la.shape[0] >= 4                          # a room has walls
+    same_lines(la, lb)
+    ca, cb = s.concers(), so.concers()
+    assert ca.shape == cb.shape and (ca.shape[0] == 0 or np.abs(ca - cb).max() <= 1e-9)
+    # grid contents at every scan point
+    for x, y, _z in pts[::7]:
+        ka, ia = s.cell_lines(x, y)
+        kb, ib = so.cell_lines(x, y)
+        assert ka == kb and np.array_equal(ia, ib)
+    # every line is at least line_min_len long and its points lie within line_max_dis (checked via end points on the line)
+    assert np.all(la[:, 9] >= lp["line_min_len"])
+    abc = la[:, 6:9]
+    for k in (0, 3):
+        assert np.abs((abc[:, 0] * la[:, k] + abc[:, 1] * la[:, k + 1] + abc[:, 2]) / np.linalg.norm(abc[:, :2], axis=1)).max() <= 1e-9
+
+
+def test_degenerate_scans(liw, env):
+    prm, lp, orc = env
+    for pts in (np.zeros((0, 3)), np.array([[1.0, 0, 0], [1.0, 0.05, 0]]), np.array([[500.0, 0, 0], [500.0, 0.05, 0], [500.0, 0.1, 0], [500.0, 0.15, 0]])):
+        s, so = liw.laser.Scan.spawn(lp, pts, 0.0), orc.spawn_scan(pts, 0.0)
+        assert s.lines().shape == so.lines().shape == (0, 10)       # empty, too short, outside the 100 m grid
+    assert liw.laser.Scan.spawn(lp, np.zeros((0, 3))).cell_lines(1e4, 0.0)[0] == -1
+
+
+def test_segment_rasterisation_matches_oracle(liw, env):
+    prm, lp, orc = env
+    s, so = liw.laser.Scan.empty(lp), orc.empty_scan()
+    rng = np.random.default_rng(5)
+    for _ in range(40):
+        a = np.append(rng.uniform(-8, 8, 2), 0.0)
+        b = a + np.append(rng.uniform(-2, 2, 2), 0.0) * rng.choice([0.01, 1.0])      # some shorter than line_min_len
+        assert s.add_segment(a, b, False) == so.add_segment(a, b, False)
+    same_lines(s.lines(), so.lines())
+    for x, y in rng.uniform(-9, 9, (400, 2)):
+        ka, ia = s.cell_lines(x, y)
+        kb, ib = so.cell_lines(x, y)
+        assert ka == kb and np.array_equal(ia, ib)
+
+
+@pytest.mark.parametrize("seed,kk", [(1, 0), (2, 0), (3, 1), (4, 0)])
+def test_do_match_matches_oracle(liw, synth, env, seed, kk):
+    prm, lp, orc = env
+    room = liw.laser.room_segments(seed)
+    p1, q1 = np.array([0.2, -0.1, 0.0]), np.array([0.0, 0.0, 0.3])
+    p2, q2 = p1 + np.array([0.12, 0.05, 0.0]), q1 + np.array([0.0, 0.0, 0.04])
+    pts1, _ = scan_points(liw, synth, prm, room, p1, q1, 10 + seed)
+    pts2, _ = scan_points(liw, synth, prm, room, p2, q2, 20 + seed)
+    s1, s2 = liw.laser.Scan.spawn(lp, pts1), liw.laser.Scan.spawn(lp, pts2)
+    o1, o2 = orc.spawn_scan(pts1), orc.spawn_scan(pts2)
+    # the initial guess of the second pose is slightly off, as in tracking
+    p2g, q2g = p2 + np.array([0.01, -0.01, 0.0]), q2 + np.array([0.0, 0.0, 0.004])
+    m = liw.laser.do_match(lp, s1, s2, p1, q1, p2g, q2g, kk)
+    mo = orc.do_match(o1, o2, p1, q1, p2g, q2g, kk)
+    assert len(m) == len(mo) and len(m) >= 4
+    assert np.array_equal(m.idx1, mo.idx1) and np.array_equal(m.idx2, mo.idx2)
+    assert np.abs(m.pts - mo.pts).max() <= 1e-9 and np.array_equal(m.pose, mo.pose)
+    # the record is what liw_window.laser_pts expects: lines1 end points come from scan 1, lines2 from scan 2
+    l1, l2 = s1.lines(), s2.lines()
+    assert np.array_equal(m.pts[:, 0:6], l1[m.idx1, 0:6]) and np.array_equal(m.pts[:, 6:12], l2[m.idx2, 0:6])
+    # matched directions agree within 10 degrees after the relative transform T_1_2 (do_match's gate, :283-299)
+    T_il = laser_extrinsic(synth, prm)
+
+    def T_wl(p, q):
+        T = np.eye(4)
+        T[:3, :3] = synth.exp_so3(np.asarray(q, dtype=np.float64))
+        T[:3, 3] = p
+        return T @ T_il
+    R12 = (np.linalg.inv(T_wl(p1, q1)) @ T_wl(p2g, q2g))[:3, :3]
+    d1 = m.pts[:, 3:6] - m.pts[:, 0:3]
+    d2 = (m.pts[:, 9:12] - m.pts[:, 6:9]) @ R12.T
+    cosang = np.abs((d1 * d2).sum(1)) / (np.linalg.norm(d1, axis=1) * np.linalg.norm(d2, axis=1))
+    assert np.degrees(np.arccos(np.clip(cosang, -1, 1))).max() <= 10.0 + 1e-9
+
+
+def test_manager_sequence_matches_oracle(liw, synth, env, pyoracle):
+    prm, lp, _ = env
+    lp = dict(lp, ref_n_accumulation=4)
+    orc = pyoracle.LaserOracle(lp)
+    mgr = liw.laser.LaserManager(lp)
+    room = liw.laser.room_segments(9)
+    # no key frame yet: empty match carrying the query pose twice
+    pts, _ = scan_points(liw, synth, prm, room, [0, 0, 0], [0, 0, 0], 0)
+    s0, o0 = liw.laser.Scan.spawn(lp, pts), orc.spawn_scan(pts)
+    for fn in ("match_with_front", "match_with_back", "match_with_ref"):
+        m, mo = getattr(mgr, fn)(s0, [1, 2, 0], [0, 0, 0.5]), getattr(orc, fn)(o0, [1, 2, 0], [0, 0, 0.5])
+        assert len(m) == len(mo) == 0 and np.array_equal(m.pose, mo.pose) and np.array_equal(m.pose[:6], m.pose[6:])
+    keep = []
+    for k in range(9):
+        p = np.array([0.08 * k, 0.03 * k, 0.0]) if k != 4 else np.array([0.08 * 3 + 0.001, 0.03 * 3, 0.0])   # k = 4 barely moves (motion filter)
+        q = np.array([0.0, 0.0, 0.05 * k]) if k != 4 else np.array([0.0, 0.0, 0.05 * 3 + 0.001])
+        pts, _ = scan_points(liw, synth, prm, room, p, q, 30 + k)
+        s, o = liw.laser.Scan.spawn(lp, pts, float(k)), orc.spawn_scan(pts, float(k))
+        keep.append((s, o))
+        for fn in ("match_with_front", "match_with_back", "match_with_ref"):
+            m, mo = getattr(mgr, fn)(s, p, q), getattr(orc, fn)(o, p, q)
+            assert len(m) == len(mo), (k, fn)
+            assert np.array_equal(m.idx1, mo.idx1) and np.array_equal(m.idx2, mo.idx2), (k, fn)
+            assert len(m) == 0 or np.abs(m.pts - mo.pts).max() <= 1e-9
+            assert np.array_equal(m.pose, mo.pose)
+        mgr.add_scan(s, p, q)
+        orc.add_scan(o, p, q)
+        assert mgr.num_keyframes() == orc.num_keyframes() == k + 1
+        ra, rb = mgr.ref_scan(), orc.ref_scan()
+        assert (ra is None) == (rb is None), k
+        if ra is not None:
+            same_lines(ra[0].lines(), rb[0].lines())
+            assert np.array_equal(ra[1], rb[1]) and np.array_equal(ra[2], rb[2])
+    assert mgr.pop_scan() == orc.pop_scan() == 1 and mgr.num_keyframes() == orc.num_keyframes() == 8
+    mgr.clear_all_scan(); orc.clear_all_scan()
+    assert mgr.num_keyframes() == orc.num_keyframes() == 0 and mgr.pop_scan() == orc.pop_scan() == 0 and mgr.ref_scan() is None
+
+
+def test_reference_quirk_ref_n_accumulation_2(liw, synth, env, pyoracle):
+    """With ref_n_accumulation = 2 (config/office.yaml:122) the second accumulated scan replaces the reference sub-map by
+    the not-yet-created spawning one, i.e. by nothing (laser_manager.cpp:485-494): match_with_ref then returns an empty
+    match until the next add_scan re-initialises it (afterwards a spawning sub-map exists and the hand-over works).
+    Kept, and identical on both sides."""
+    prm, lp, _ = env
+    orc, mgr = pyoracle.LaserOracle(lp), liw.laser.LaserManager(lp)
+    room = liw.laser.room_segments(2)
+    state = []
+    for k in range(4):
+        p, q = np.array([0.1 * k, 0.0, 0.0]), np.array([0.0, 0.0, 0.03 * k])
+        pts, _ = scan_points(liw, synth, prm, room, p, q, 60 + k)
+        s, o = liw.laser.Scan.spawn(lp, pts), orc.spawn_scan(pts)
+        mgr.add_scan(s, p, q); orc.add_scan(o, p, q)
+        assert (mgr.ref_scan() is None) == (orc.ref_scan() is None)
+        state.append(mgr.ref_scan() is None)
+    assert state == [False, True, False, False]
