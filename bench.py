@@ -67,6 +67,8 @@ def main():
     ap.add_argument("--cpu-reps", type=int, default=12)
     ap.add_argument("--skip-sharded", action="store_true")
     ap.add_argument("--no-single", action="store_true", help="skip the B=1 latency measurement (clean per-kernel profiles)")
+    ap.add_argument("--record-md", default=None, help="after the timed region, write a reference-shaped `record` table (labels "
+                    "'solve' / 'marginalization', src/utilies/record.h) of per-batch durations to this path")
     args = ap.parse_args()
 
     import torch
@@ -124,6 +126,17 @@ def main():
         t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
+    if args.record_md and rank == 0:   # outside the timed region: the extra events would serialise solve and marginalisation
+        rec = liw.outputs.Record()
+        for _ in range(max(2, args.steps)):
+            bs.t["x"].copy_(x0); bs.t["match_pose"].copy_(mp0); bs.t["has_prior"].zero_()
+            ev = [torch.cuda.Event(enable_timing=True) for _ in range(3)]
+            ev[0].record(); bs.solve(liw.LIW_MODE_INIT, args.iters); ev[1].record(); bs.marginalize(); ev[2].record()
+            torch.cuda.synchronize()
+            rec.add_time("solve", ev[0].elapsed_time(ev[1]) * 1e3)
+            rec.add_time("marginalization", ev[1].elapsed_time(ev[2]) * 1e3)
+            rec.add_record("windows_per_batch", B)
+        rec.write(args.record_md)
     summ = bs.summaries()
     iters = np.array([s["iterations"] for s in summ])
     term = np.array([s["termination"] for s in summ])

@@ -143,3 +143,25 @@ void oracle_laser_correct(double* points, const double* times, int n, double sta
 }
 
 }  // extern "C"
+
+// ---- on-disk formats (io_formats.h)
+#include "io_formats.h"
+extern "C" {
+int oracle_tum_line(const double* T_iw16, int normalize, double time, const double* p, const double* q, char* buf, int cap) {
+    Iso3<double> T;
+    for (int i = 0; i < 3; ++i) { for (int j = 0; j < 3; ++j) T.R(i, j) = T_iw16[i * 4 + j]; T.t(i) = T_iw16[i * 4 + 3]; }
+    if (normalize) lie::normalize_tf<double>(T);
+    const std::string s = tum_line(T, time, Vec3<double>(p[0], p[1], p[2]), Vec3<double>(q[0], q[1], q[2]));
+    if (buf && cap > 0) { const size_t k = std::min((size_t)cap - 1, s.size()); std::memcpy(buf, s.data(), k); buf[k] = 0; }
+    return (int)s.size();
+}
+void* oracle_record_create() { return new record(); }
+void oracle_record_destroy(void* r) { delete (record*)r; }
+void oracle_record_add_time(void* r, const char* name, unsigned long long us) { ((record*)r)->add_time(name, us); }
+void oracle_record_add(void* r, const char* name, unsigned long long v) { ((record*)r)->add_record(name, v); }
+int oracle_record_dump(void* r, char* buf, int cap) {
+    const std::string s = ((record*)r)->dump();
+    if (buf && cap > 0) { const size_t k = std::min((size_t)cap - 1, s.size()); std::memcpy(buf, s.data(), k); buf[k] = 0; }
+    return (int)s.size();
+}
+}

@@ -393,3 +393,31 @@ def laser_correct(points, times, stamp, linear, angular):
     t, lin, ang = (np.ascontiguousarray(v, dtype=np.float64) for v in (times, linear, angular))
     _laser_lib().oracle_laser_correct(_p(p), _p(t), C.c_int(len(t)), C.c_double(stamp), _p(lin), _p(ang))
     return p
+
+
+# ---------------------------------------------------------------------------------------------------
+# on-disk formats (io_formats.h)
+def tum_line(T_imu_to_wheel16, normalize, time, p, q):
+    buf = C.create_string_buffer(400)
+    T, a, b = (np.ascontiguousarray(v, dtype=np.float64) for v in (T_imu_to_wheel16, p, q))
+    n = lib().oracle_tum_line(_p(T), C.c_int(int(normalize)), C.c_double(time), _p(a), _p(b), buf, C.c_int(400))
+    return buf.raw[:n].decode()
+
+
+class OracleRecord:
+    def __init__(self):
+        L = lib()
+        L.oracle_record_create.restype = C.c_void_p
+        self.h = C.c_void_p(L.oracle_record_create())
+
+    def add_time(self, name, us):
+        lib().oracle_record_add_time(self.h, name.encode(), C.c_ulonglong(int(us)))
+
+    def add_record(self, name, v):
+        lib().oracle_record_add(self.h, name.encode(), C.c_ulonglong(int(v)))
+
+    def dump(self):
+        n = lib().oracle_record_dump(self.h, None, C.c_int(0))
+        buf = C.create_string_buffer(n + 1)
+        lib().oracle_record_dump(self.h, buf, C.c_int(n + 1))
+        return buf.raw[:n].decode()

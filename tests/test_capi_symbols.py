@@ -27,6 +27,15 @@ def test_laser_header_symbols_are_exported(liw):
     assert sorted(set(liw.laser.LASER_EXPORTS)) == declared
 
 
+def test_io_header_symbols_are_exported(liw):
+    hdr = open(os.path.join(ROOT, "include", "liw_io.h")).read()
+    declared = sorted(set(re.findall(r"\b(liw_(?:tum|record)_[A-Za-z_0-9]+)\s*\(", hdr)))
+    L = liw.lib()
+    missing = [s for s in declared if not hasattr(L, s)]
+    assert not missing, missing
+    assert sorted(set(liw.outputs.IO_EXPORTS)) == declared
+
+
 def test_no_cpu_fallback(liw, synth):
     import torch
     if torch.cuda.is_available():
