@@ -852,7 +852,7 @@ struct MargArgs {
 };
 __global__ __launch_bounds__(64, 2) void k_marg_schur(MargArgs a) {
     __shared__ LdsTiles T;
-    __shared__ double V[256], Am[256];
+    __shared__ double V[256], Am[256], rot[32];
     const int b = blockIdx.x, lane = threadIdx.x & 63, n = a.n;
     AsmCtx c;
     c.n = n; c.mode = LIW_MODE_MARG; c.fast = 0; c.b = b; c.buf = 0;
@@ -940,31 +940,47 @@ __global__ __launch_bounds__(64, 2) void k_marg_schur(MargArgs a) {
         }
         off = wave_sum(off); dgn = wave_sum(dgn);
         if (off <= 1e-60 * dgn || off == 0.0) break;
-        for (int p = 0; p < 14; ++p)
-            for (int q = p + 1; q < 15; ++q) {
+        // parallel (round-robin) ordering: 15 rounds of 7 disjoint index pairs; the 7 plane rotations of a round are
+        // computed from the same A and applied together (columns of A and V, then rows of A), 105 independent element
+        // pairs per phase spread over the wave — instead of 105 sequential rotations with three barriers each
+        for (int rnd = 0; rnd < 15; ++rnd) {
+            if (lane < 7) {
+                const int k = lane + 1;
+                int p = (rnd + k) % 15, q = (rnd + 15 - k) % 15;
+                if (p > q) { const int t_ = p; p = q; q = t_; }
                 const double apq = Am[p * 16 + q];
-                if (apq == 0.0) continue;          // uniform: every lane reads the same LDS word
-                const double app = Am[p * 16 + p], aqq = Am[q * 16 + q];
-                const double tau = (aqq - app) / (2.0 * apq);
-                const double t = (tau >= 0.0 ? 1.0 : -1.0) / (fabs(tau) + sqrt(1.0 + tau * tau));
-                const double cs = 1.0 / sqrt(1.0 + t * t), sn = t * cs;
-                __syncthreads();
-                if (lane < 15) {   // columns p,q of A and V
-                    const double akp = Am[lane * 16 + p], akq = Am[lane * 16 + q];
-                    Am[lane * 16 + p] = cs * akp - sn * akq;
-                    Am[lane * 16 + q] = sn * akp + cs * akq;
-                    const double vkp = V[lane * 16 + p], vkq = V[lane * 16 + q];
-                    V[lane * 16 + p] = cs * vkp - sn * vkq;
-                    V[lane * 16 + q] = sn * vkp + cs * vkq;
+                double cs = 1.0, sn = 0.0;
+                if (apq != 0.0) {
+                    const double app = Am[p * 16 + p], aqq = Am[q * 16 + q];
+                    const double tau = (aqq - app) / (2.0 * apq);
+                    const double t = (tau >= 0.0 ? 1.0 : -1.0) / (fabs(tau) + sqrt(1.0 + tau * tau));
+                    cs = 1.0 / sqrt(1.0 + t * t); sn = t * cs;
                 }
-                __syncthreads();
-                if (lane < 15) {   // rows p,q of A
-                    const double apk = Am[p * 16 + lane], aqk = Am[q * 16 + lane];
-                    Am[p * 16 + lane] = cs * apk - sn * aqk;
-                    Am[q * 16 + lane] = sn * apk + cs * aqk;
-                }
-                __syncthreads();
+                rot[lane * 4] = (double)p; rot[lane * 4 + 1] = (double)q; rot[lane * 4 + 2] = cs; rot[lane * 4 + 3] = sn;
             }
+            lds_sync();
+            for (int it = lane; it < 105; it += 64) {   // columns p,q of A and V: (row k, pair i)
+                const int k = it / 7, i = it % 7;
+                const int p = (int)rot[i * 4], q = (int)rot[i * 4 + 1];
+                const double cs = rot[i * 4 + 2], sn = rot[i * 4 + 3];
+                const double akp = Am[k * 16 + p], akq = Am[k * 16 + q];
+                Am[k * 16 + p] = cs * akp - sn * akq;
+                Am[k * 16 + q] = sn * akp + cs * akq;
+                const double vkp = V[k * 16 + p], vkq = V[k * 16 + q];
+                V[k * 16 + p] = cs * vkp - sn * vkq;
+                V[k * 16 + q] = sn * vkp + cs * vkq;
+            }
+            lds_sync();
+            for (int it = lane; it < 105; it += 64) {   // rows p,q of A: (pair i, column k)
+                const int k = it / 7, i = it % 7;
+                const int p = (int)rot[i * 4], q = (int)rot[i * 4 + 1];
+                const double cs = rot[i * 4 + 2], sn = rot[i * 4 + 3];
+                const double apk = Am[p * 16 + k], aqk = Am[q * 16 + k];
+                Am[p * 16 + k] = cs * apk - sn * aqk;
+                Am[q * 16 + k] = sn * apk + cs * aqk;
+            }
+            lds_sync();
+        }
     }
     // sort ascending (rank by counting; ties by index), sign convention: largest |component| positive
     if (lane < 15) {

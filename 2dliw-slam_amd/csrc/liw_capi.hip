@@ -2,6 +2,7 @@
 // No CPU fallback: without a usable gfx950 device every compute entry point returns LIW_ENODEV.
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -67,7 +68,10 @@ struct liw_ctx {
     liw_window hw{};
     bool have_window = false;
     int n = 0, L = 0;
-    DevBuf x, laser_off, laser_frame, laser_pts, match_pose, has_match, imu_X, imu_J, imu_P, imu_Dt, wheel_T, wheel_P;
+    DevBuf arena;                 // every input array of the window, one allocation (one H2D copy per liw_set_window)
+    void* pinned = nullptr;       // page-locked staging image of the arena + read-back slots
+    size_t pinned_cap = 0;
+    size_t off_x = 0, off_mp = 0;
     DevBuf prior_X, prior_J, prior_R, has_prior, ws, scratch;
     liw_batch sb{};
     liw_ws_layout lay{};
@@ -179,8 +183,8 @@ void liw_destroy(liw_ctx* c) {
     if (!c) return;
     if (c->have_device) {
         (void)hipSetDevice(c->prm.device);
-        DevBuf* bufs[] = {&c->x, &c->laser_off, &c->laser_frame, &c->laser_pts, &c->match_pose, &c->has_match, &c->imu_X, &c->imu_J, &c->imu_P,
-                          &c->imu_Dt, &c->wheel_T, &c->wheel_P, &c->prior_X, &c->prior_J, &c->prior_R, &c->has_prior, &c->ws, &c->scratch};
+        DevBuf* bufs[] = {&c->arena, &c->prior_X, &c->prior_J, &c->prior_R, &c->has_prior, &c->ws, &c->scratch};
+        if (c->pinned) (void)hipHostFree(c->pinned);
         for (DevBuf* b : bufs) b->release();
         for (auto e : c->ev_lin) (void)hipEventDestroy(e);
         for (auto e : c->ev_step) (void)hipEventDestroy(e);
@@ -518,22 +522,39 @@ int liw_set_window(liw_ctx* c, const liw_window* w) {
     // laser blocks must be sorted by owning frame
     for (int j = 1; j < L; ++j) if (w->laser_frame[j] < w->laser_frame[j - 1]) return fail(c, LIW_EINVAL, "laser_frame must be ascending");
     for (int j = 0; j < L; ++j) if (w->laser_frame[j] < 0 || w->laser_frame[j] >= n) return fail(c, LIW_EINVAL, "laser_frame out of range");
-    struct Up { DevBuf* d; const void* src; size_t bytes; };
-    std::vector<double> soa((size_t)12 * (L ? L : 1));
-    for (int j = 0; j < L; ++j) for (int k = 0; k < 12; ++k) soa[(size_t)k * L + j] = w->laser_pts[(size_t)j * 12 + k];
-    int off[2] = {0, L};
-    Up ups[] = {
-        {&c->x, w->states, sizeof(double) * n * 15}, {&c->laser_off, off, sizeof(off)},
-        {&c->laser_frame, w->laser_frame, sizeof(int) * (size_t)L}, {&c->laser_pts, soa.data(), sizeof(double) * 12 * (size_t)L},
-        {&c->match_pose, w->match_pose, sizeof(double) * n * 12}, {&c->has_match, w->has_match, (size_t)n},
-        {&c->imu_X, w->imu_X, sizeof(double) * (n - 1) * 15}, {&c->imu_J, w->imu_J, sizeof(double) * (n - 1) * 225},
-        {&c->imu_P, w->imu_sqrtP, sizeof(double) * (n - 1) * 225}, {&c->imu_Dt, w->imu_Dt, sizeof(double) * (n - 1)},
-        {&c->wheel_T, w->wheel_T, sizeof(double) * (n - 1) * 12}, {&c->wheel_P, w->wheel_sqrtP, sizeof(double) * (n - 1) * 9},
+    // one page-locked staging image + ONE host-to-device copy (a tracking window is a dozen arrays of a few hundred
+    // bytes: a dozen pageable copies cost more than the solve)
+    struct Part { const void* src; size_t bytes; size_t off; };
+    int off2[2] = {0, L};
+    Part parts[12] = {
+        {w->states, sizeof(double) * n * 15, 0}, {off2, sizeof(off2), 0}, {w->laser_frame, sizeof(int) * (size_t)L, 0},
+        {nullptr, sizeof(double) * 12 * (size_t)L, 0},   // laser_pts: transposed to component-major below
+        {w->match_pose, sizeof(double) * n * 12, 0}, {w->has_match, (size_t)n, 0},
+        {w->imu_X, sizeof(double) * (n - 1) * 15, 0}, {w->imu_J, sizeof(double) * (n - 1) * 225, 0},
+        {w->imu_sqrtP, sizeof(double) * (n - 1) * 225, 0}, {w->imu_Dt, sizeof(double) * (n - 1), 0},
+        {w->wheel_T, sizeof(double) * (n - 1) * 12, 0}, {w->wheel_sqrtP, sizeof(double) * (n - 1) * 9, 0},
     };
-    for (auto& u : ups) {
-        if (u.d->ensure(u.bytes)) return fail(c, LIW_ENOMEM, "hipMalloc");
-        if (u.bytes) HIPCHK(c, hipMemcpyAsync(u.d->p, u.src, u.bytes, hipMemcpyHostToDevice, c->stream));
+    size_t tot = 0;
+    for (auto& pt : parts) { pt.off = tot; tot = al256(tot + (pt.bytes ? pt.bytes : 8)); }
+    const size_t readback = al256(sizeof(liw_summary)) + al256(sizeof(double) * n * 27) + 256;
+    if (c->arena.ensure(tot)) return fail(c, LIW_ENOMEM, "hipMalloc");
+    if (c->pinned_cap < tot + readback) {
+        if (c->pinned) (void)hipHostFree(c->pinned);
+        c->pinned = nullptr; c->pinned_cap = 0;
+        if (hipHostMalloc(&c->pinned, (tot + readback) * 2, hipHostMallocDefault) != hipSuccess) return fail(c, LIW_ENOMEM, "hipHostMalloc");
+        c->pinned_cap = (tot + readback) * 2;
     }
+    char* stage = (char*)c->pinned;
+    for (int k = 0; k < 12; ++k) {
+        if (k == 3) {
+            double* soa = (double*)(stage + parts[k].off);
+            for (int j = 0; j < L; ++j) for (int q = 0; q < 12; ++q) soa[(size_t)q * L + j] = w->laser_pts[(size_t)j * 12 + q];
+        } else if (parts[k].bytes) {
+            std::memcpy(stage + parts[k].off, parts[k].src, parts[k].bytes);
+        }
+    }
+    HIPCHK(c, hipMemcpyAsync(c->arena.p, stage, tot, hipMemcpyHostToDevice, c->stream));
+    char* dev = (char*)c->arena.p;
     (void)nm;
     bool fresh_prior = c->prior_X.p == nullptr;
     if (c->prior_X.ensure(sizeof(double) * 15) || c->prior_J.ensure(sizeof(double) * 225) || c->prior_R.ensure(sizeof(double) * 15) ||
@@ -552,10 +573,11 @@ int liw_set_window(liw_ctx* c, const liw_window* w) {
     c->hw = *w; c->have_window = true; c->n = n; c->L = L;
     liw_batch& b = c->sb;
     b.B = 1; b.n = n; b.Ltot = L;
-    b.x = c->x.as<double>(); b.laser_off = c->laser_off.as<int>(); b.laser_frame = c->laser_frame.as<int>();
-    b.laser_pts = c->laser_pts.as<double>(); b.match_pose = c->match_pose.as<double>(); b.has_match = c->has_match.as<unsigned char>();
-    b.imu_X = c->imu_X.as<double>(); b.imu_J = c->imu_J.as<double>(); b.imu_sqrtP = c->imu_P.as<double>(); b.imu_Dt = c->imu_Dt.as<double>();
-    b.wheel_T = c->wheel_T.as<double>(); b.wheel_sqrtP = c->wheel_P.as<double>();
+    b.x = (double*)(dev + parts[0].off); b.laser_off = (int*)(dev + parts[1].off); b.laser_frame = (int*)(dev + parts[2].off);
+    b.laser_pts = (double*)(dev + parts[3].off); b.match_pose = (double*)(dev + parts[4].off); b.has_match = (unsigned char*)(dev + parts[5].off);
+    b.imu_X = (double*)(dev + parts[6].off); b.imu_J = (double*)(dev + parts[7].off); b.imu_sqrtP = (double*)(dev + parts[8].off);
+    b.imu_Dt = (double*)(dev + parts[9].off); b.wheel_T = (double*)(dev + parts[10].off); b.wheel_sqrtP = (double*)(dev + parts[11].off);
+    c->off_x = tot; c->off_mp = tot;   // read-back slots live behind the staging image (see download_states)
     b.prior_X = c->prior_X.as<double>(); b.prior_J = c->prior_J.as<double>(); b.prior_R = c->prior_R.as<double>(); b.has_prior = c->has_prior.as<int>();
     b.eval_small = 1; b.history_records = c->hist_records;
     return LIW_OK;
@@ -568,9 +590,13 @@ int liw_set_window(liw_ctx* c, const liw_window* w) {
     } while (0)
 
 static int download_states(liw_ctx* c) {
-    HIPCHK(c, hipMemcpyAsync(c->hw.states, c->x.p, sizeof(double) * c->n * 15, hipMemcpyDeviceToHost, c->stream));
-    HIPCHK(c, hipMemcpyAsync(c->hw.match_pose, c->match_pose.p, sizeof(double) * c->n * 12, hipMemcpyDeviceToHost, c->stream));
+    // page-locked read-back slots behind the staging image: [summary | states | match_pose]
+    char* rb = (char*)c->pinned + c->off_x + al256(sizeof(liw_summary));
+    HIPCHK(c, hipMemcpyAsync(rb, c->sb.x, sizeof(double) * c->n * 15, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipMemcpyAsync(rb + sizeof(double) * c->n * 15, c->sb.match_pose, sizeof(double) * c->n * 12, hipMemcpyDeviceToHost, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
+    std::memcpy(c->hw.states, rb, sizeof(double) * c->n * 15);
+    std::memcpy(c->hw.match_pose, rb + sizeof(double) * c->n * 15, sizeof(double) * c->n * 12);
     return LIW_OK;
 }
 
@@ -588,12 +614,43 @@ int liw_solve(liw_ctx* c, int mode, int max_iters, liw_summary* summary) {
         FullLayout f = full_layout(1, c->n, c->hist_records);
         if (c->ws.ensure(f.bytes)) return fail(c, LIW_ENOMEM, "hipMalloc workspace");
     }
-    if (int r = liw_batch_solve(c, &c->sb, mode, K, c->ws.p, c->stream, 0)) return r;
+    // Same launch sequence as liw_batch_solve (lin, K x [step, lin], step, finish), enqueued in growing chunks with a
+    // 4-byte read-back of the window's `done` flag in between: a tracking solve converges in a few iterations, and 50
+    // iterations' worth of no-op launches would cost milliseconds.  Launches skipped after `done` are exactly the ones
+    // whose kernels return immediately, so the result is identical.
+    {
+        c->last_iters = K;
+        const liw_batch* b = &c->sb;
+        hipStream_t s = c->stream;
+        WsView v = make_view(c->ws.p, 1, c->n, b->history_records);
+        launch_group_offsets(1, c->n, b->laser_off, b->laser_frame, v.group_off, s);
+        launch_lm_begin(1, c->n, v.lm, s);
+        StepArgs st = step_args(c, b, mode, K, v);
+        auto lin = [&](int cand) {
+            LinArgs A = lin_args(b, mode, cand ? v.x_cand : b->x, v, cand, true);
+            launch_linearize(A, c->dp, s, c->have_fork ? &c->fork : nullptr);
+        };
+        int* done_flag = (int*)((char*)c->pinned + c->off_x + al256(sizeof(liw_summary)) + al256(sizeof(double) * c->n * 27));
+        *done_flag = 0;
+        lin(0);
+        int k = 0, chunk = 4;
+        while (k < K && !*done_flag) {
+            const int m = std::min(chunk, K - k);
+            for (int i = 0; i < m; ++i) { launch_lm_step(st, s); lin(1); }
+            k += m;
+            HIPCHK(c, hipMemcpyAsync(done_flag, &v.lm[0].done, sizeof(int), hipMemcpyDeviceToHost, s));
+            HIPCHK(c, hipStreamSynchronize(s));
+            chunk *= 2;
+        }
+        if (!*done_flag) launch_lm_step(st, s);
+        launch_lm_finish(st, s);
+        HIPCHK(c, hipGetLastError());
+    }
     FullLayout f = full_layout(1, c->n, c->hist_records);
-    liw_summary s{};
-    HIPCHK(c, hipMemcpyAsync(&s, (char*)c->ws.p + f.info, sizeof(s), hipMemcpyDeviceToHost, c->stream));
+    liw_summary* sp = (liw_summary*)((char*)c->pinned + c->off_x);
+    HIPCHK(c, hipMemcpyAsync(sp, (char*)c->ws.p + f.info, sizeof(liw_summary), hipMemcpyDeviceToHost, c->stream));
     if (int r = download_states(c)) return r;
-    if (summary) *summary = s;
+    if (summary) *summary = *sp;
     return LIW_OK;
 }
 int liw_get_history(liw_ctx* c, double* x, int max_records) {

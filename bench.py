@@ -198,6 +198,62 @@ def main():
         single = {"ms_per_solve": round(ms1, 3), "solves_per_s": round(1e3 / ms1, 1), "lm_iterations": s1.summaries()[0]["iterations"]}
         s1.close()
 
+    # ---- steady-state tracking frame (the reference keeps a 2-frame window while tracking, trajectory.cpp:525-559):
+    #      solver.solve + solver.marginalization on frames (k-1, k) with the prior of the previous marginalisation,
+    #      through the single-window C ABI with HOST buffers (upload + synchronous calls included), CPU oracle beside it
+    tracking = None
+    if rank == 0 and world == 1 and not args.no_single:
+        try:
+            hp = liw.HostPreint(prm)
+            d3 = synth.make_window(hp, prm, seed=515, n=3, L=120, laser_on_frame0=False)
+
+            def sub(lo):
+                o = dict(d3)
+                o["n"] = 2
+                for k in ("states", "match_pose"):
+                    o[k] = np.asarray(d3[k]).reshape(3, -1)[lo:lo + 2].copy()
+                o["has_match"] = np.asarray(d3["has_match"])[lo:lo + 2].copy()
+                for k in ("imu_X", "imu_J", "imu_sqrtP", "imu_Dt", "wheel_T", "wheel_sqrtP", "wheel_Dt"):
+                    o[k] = np.asarray(d3[k])[lo:lo + 1].copy()
+                m = (np.asarray(d3["laser_frame"]) >= lo) & (np.asarray(d3["laser_frame"]) < lo + 2)
+                o["laser_frame"] = (np.asarray(d3["laser_frame"])[m] - lo).astype(np.int32)
+                o["laser_pts"] = np.asarray(d3["laser_pts"])[m].copy()
+                return o
+            slv = liw.Solver(prm)
+            reps, tg, it_g = 20, 0.0, 0
+            for rep in range(reps + 2):
+                slv.set_prior(None)
+                slv.set_window(liw.Window(sub(0)))
+                slv.solve()
+                slv.marginalization()
+                w12 = liw.Window(sub(1))
+                t0_ = time.perf_counter()
+                slv.set_window(w12)
+                sg = slv.solve()
+                slv.marginalization()
+                if rep >= 2:
+                    tg += time.perf_counter() - t0_
+                    it_g = sg["iterations"]
+            tracking = {"ms_per_frame": round(1e3 * tg / reps, 3), "frames_per_s": round(reps / tg, 1), "lm_iterations": it_g,
+                        "window": "n=2, %d laser blocks on the newest frame, prior on the older one" % int((np.asarray(d3["laser_frame"]) == 2).sum())}
+            if not args.no_cpu_baseline:
+                from oracle import pyoracle
+                orc2 = pyoracle.Oracle(prm)
+                tc = 0.0
+                for rep in range(reps):
+                    orc2.set_prior(None)
+                    w01 = pyoracle.Window(sub(0))
+                    orc2.solve(w01)
+                    orc2.marginalization(w01)
+                    w12o = pyoracle.Window(sub(1))
+                    t0_ = time.perf_counter()
+                    orc2.solve(w12o)
+                    orc2.marginalization(w12o)
+                    tc += time.perf_counter() - t0_
+                tracking["cpu_oracle_ms_per_frame"] = round(1e3 * tc / reps, 3)
+        except Exception as e:   # a latency side-measurement must never take the headline line down
+            tracking = {"error": str(e)[:200]}
+
     # ---- factor-sharded mode (N > 1): C4-shaped window, RCCL all-reduce of the laser partial sums per iteration
     sharded = None
     if world > 1 and not args.skip_sharded:
@@ -238,6 +294,8 @@ def main():
             out["speedup_vs_cpu_1core"] = round(out["value"] / cpu["value"], 1)
         if single:
             out["single_window_latency"] = single
+        if tracking:
+            out["tracking_frame_latency"] = tracking
         if sharded:
             out["factor_sharded"] = sharded
         print(json.dumps(out))
