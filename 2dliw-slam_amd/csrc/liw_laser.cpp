@@ -570,6 +570,12 @@ void liw_laser_manager_clear_all_scan(liw_laser_manager* m) {
     m->spawning.reset();
 }
 int liw_laser_manager_num_keyframes(const liw_laser_manager* m) { return m ? (int)m->key_frame.size() : 0; }
+int liw_laser_manager_set_keyframe_pose(liw_laser_manager* m, int i, const double* p, const double* q) {
+    if (!m || !p || !q || i < 0 || i >= (int)m->key_frame.size()) return LIW_EINVAL;
+    m->key_frame[i].p = liw::cast_v3<double>(p);
+    m->key_frame[i].q = liw::cast_v3<double>(q);
+    return LIW_OK;
+}
 const liw_scan* liw_laser_manager_ref_scan(const liw_laser_manager* m, double* p3, double* q3) {
     if (!m || !m->ref) return nullptr;
     liw_laser_manager* mm = const_cast<liw_laser_manager*>(m);

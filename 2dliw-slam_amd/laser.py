@@ -11,7 +11,7 @@ LASER_EXPORTS = [
     "liw_laser_do_match", "liw_laser_match_destroy", "liw_laser_match_size", "liw_laser_match_get", "liw_laser_manager_create",
     "liw_laser_manager_destroy", "liw_laser_manager_add_scan", "liw_laser_manager_match_with_front", "liw_laser_manager_match_with_back",
     "liw_laser_manager_match_with_ref", "liw_laser_manager_pop_scan", "liw_laser_manager_clear_all_scan", "liw_laser_manager_num_keyframes",
-    "liw_laser_manager_ref_scan",
+    "liw_laser_manager_ref_scan", "liw_laser_manager_set_keyframe_pose",
 ]
 
 

@@ -74,6 +74,8 @@ liw_laser_match* liw_laser_manager_match_with_ref(liw_laser_manager* m, const li
 int liw_laser_manager_pop_scan(liw_laser_manager* m);            /* 1 if a key frame was popped */
 void liw_laser_manager_clear_all_scan(liw_laser_manager* m);
 int liw_laser_manager_num_keyframes(const liw_laser_manager* m);
+/* get_keyframs()[i]->current_p / current_q = p, q (what trajectory.cpp:452-461 does after init_solve) */
+int liw_laser_manager_set_keyframe_pose(liw_laser_manager* m, int i, const double* p, const double* q);
 /* the reference sub-map's scan (NULL before the first add_scan); borrowed, valid until the next add_scan / clear */
 const liw_scan* liw_laser_manager_ref_scan(const liw_laser_manager* m, double* p3, double* q3);
 

@@ -56,20 +56,23 @@ public:
         return s;
     }
     void add_scan(const scan::ptr& s, const double* current_p, const double* current_q) { liw_laser_manager_add_scan(h_, s->handle, current_p, current_q); }
-    laser_match::ptr match_with_front(const scan::ptr& s, const double* p, const double* q) { return take(liw_laser_manager_match_with_front(h_, s->handle, p, q)); }
-    laser_match::ptr match_with_back(const scan::ptr& s, const double* p, const double* q) { return take(liw_laser_manager_match_with_back(h_, s->handle, p, q)); }
-    laser_match::ptr match_with_ref(const scan::ptr& s, const double* p, const double* q) { return take(liw_laser_manager_match_with_ref(h_, s->handle, p, q)); }
+    laser_match::ptr match_with_front(const scan::ptr& s, const double* p, const double* q) { return take(liw_laser_manager_match_with_front(h_, s->handle, p, q), s); }
+    laser_match::ptr match_with_back(const scan::ptr& s, const double* p, const double* q) { return take(liw_laser_manager_match_with_back(h_, s->handle, p, q), s); }
+    laser_match::ptr match_with_ref(const scan::ptr& s, const double* p, const double* q) { return take(liw_laser_manager_match_with_ref(h_, s->handle, p, q), s); }
     static laser_match::ptr do_match(const liw_laser_params& prm, const scan::ptr& scan1, const scan::ptr& scan2, const double* p1, const double* q1,
                                      const double* p2, const double* q2, int kk = 0) {
-        return take(liw_laser_do_match(&prm, scan1->handle, scan2->handle, p1, q1, p2, q2, kk));
+        return take(liw_laser_do_match(&prm, scan1->handle, scan2->handle, p1, q1, p2, q2, kk), scan2);
     }
     bool pop_scan() { return liw_laser_manager_pop_scan(h_) != 0; }
     void clear_all_scan() { liw_laser_manager_clear_all_scan(h_); }
     int num_keyframes() const { return liw_laser_manager_num_keyframes(h_); }
+    // get_keyframs()[i]->current_p / current_q = ... (trajectory.cpp:452-461)
+    void set_keyframe_pose(int i, const double* p, const double* q) { liw_laser_manager_set_keyframe_pose(h_, i, p, q); }
 
 private:
-    static laser_match::ptr take(liw_laser_match* m) {
+    static laser_match::ptr take(liw_laser_match* m, const scan::ptr& scan2) {
         auto r = std::make_shared<laser_match>();
+        r->scan2 = scan2;
         const int n = liw_laser_match_size(m);
         std::vector<double> pts((size_t)n * 12);
         double pose[12];

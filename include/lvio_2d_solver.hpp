@@ -21,10 +21,12 @@ namespace lvio_2d {
 struct line {
     double p1[3], p2[3];
 };
+struct scan;   // lvio_2d_laser.hpp
 struct laser_match {
     using ptr = std::shared_ptr<laser_match>;
     std::vector<line> lines1, lines2;
     double p1[3], q1[3], p2[3], q2[3];
+    std::shared_ptr<scan> scan2;   // the matched scan (set by lvio_2d::laser_manager)
 };
 struct imu_preint_result {
     using ptr = std::shared_ptr<imu_preint_result>;
@@ -49,9 +51,22 @@ struct frame_info {
     laser_match::ptr laser_match_ptr;
     frame_type type = unknow;
     bool is_key_frame = false;
+    std::vector<double> laser_concers;   // [k][3], only carried for key frames
     double sqrt_H[36];
     frame_info() { for (int k = 0; k < 36; ++k) sqrt_H[k] = (k % 7 == 0) ? 1.0 : 0.0; }
     void add_laser_match(const laser_match::ptr& m) { laser_match_ptr = m; type = laser; }
+    void set_key_frame() { is_key_frame = true; }
+    void set_acc_concers(const std::vector<double>& c) { laser_concers = c; }
+    static ptr create(double time_, const double* p_, const double* q_, const double* v_, const double* bs_, const imu_preint_result::ptr& imu_,
+                      const wheel_odom_preint_result::ptr& wheel_) {
+        ptr r = std::make_shared<frame_info>();
+        r->time = time_;
+        for (int k = 0; k < 3; ++k) { r->p[k] = p_[k]; r->q[k] = q_[k]; r->v[k] = v_[k]; }
+        for (int k = 0; k < 6; ++k) r->bs[k] = bs_[k];
+        r->imu_observation_reslut = imu_;
+        r->wheel_observation_reslut = wheel_;
+        return r;
+    }
 };
 
 class solver {

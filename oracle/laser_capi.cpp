@@ -6,6 +6,7 @@
 #include "laser_frontend.h"
 
 using namespace oracle;
+using namespace oracle::lfe;
 
 extern "C" {
 

@@ -107,6 +107,9 @@ inline double clac_cos(const V& point_j, const V& point_i, const V& point_k) {
 inline double clac_angle(const V& j, const V& i, const V& k) { return std::acos(clac_cos(j, i, k)); }
 }  // namespace lf
 
+// the classes below live in oracle::lfe: solver.h has its own plain `line` / `laser_match` (the solver's view of them)
+namespace lfe {
+
 struct line {
     using ptr = std::shared_ptr<line>;
     Vec3<double> p1, p2, abc;
@@ -404,6 +407,8 @@ public:
     Iso3<double> last_add_tf;
     int current_count;
 };
+
+}  // namespace lfe
 
 // convert::laser_to_point_times (src/utilies/common.cpp:5-40): float angles, cosf/sinf
 inline void laser_to_point_times(const float* ranges, int n, float angle_start, float angle_increment, float time_increment, double time,

@@ -449,3 +449,65 @@ double oracle_time_solves(void* hv, oracle_window_c* w, int reps, int max_iters,
 }
 
 }  // extern "C"
+
+// ---------------------------------------------------------------------------------------------------
+// trajectory restatement (trajectory.h): offline replay of a flat sensor log
+#include "trajectory.h"
+extern "C" {
+struct oracle_traj_params_c { int slide_window_size; double p_motion_threshold, q_motion_threshold, key_frame_p_motion_threshold, key_frame_q_motion_threshold, min_delta_t; };
+struct oracle_laser_params_c2 {
+    double w_laser_each_scan, h_laser_each_scan, laser_resolution, line_continuous_threshold, line_min_len, line_max_dis, line_max_tolerance_angle;
+    double ref_motion_filter_p, ref_motion_filter_q;
+    int ref_n_accumulation;
+    double T_imu_to_laser[16];
+    int normalize_extrinsics;
+};
+struct oracle_traj_ctx { params prm; laser_params lprm; trajectory* t; };
+void* oracle_traj_create(const oracle_params_c* c, const oracle_laser_params_c2* l, const oracle_traj_params_c* tp) {
+    oracle_traj_ctx* h = new oracle_traj_ctx();
+    fill_params(c, h->prm);
+    laser_params& p = h->lprm;
+    p.w_laser_each_scan = l->w_laser_each_scan; p.h_laser_each_scan = l->h_laser_each_scan; p.laser_resolution = l->laser_resolution;
+    p.line_continuous_threshold = l->line_continuous_threshold; p.line_min_len = l->line_min_len; p.line_max_dis = l->line_max_dis;
+    p.line_max_tolerance_angle = l->line_max_tolerance_angle; p.ref_motion_filter_p = l->ref_motion_filter_p; p.ref_motion_filter_q = l->ref_motion_filter_q;
+    p.ref_n_accumulation = l->ref_n_accumulation;
+    p.T_imu_to_laser = h->prm.T_imu_to_laser;
+    trajectory_params t;
+    t.slide_window_size = tp->slide_window_size; t.p_motion_threshold = tp->p_motion_threshold; t.q_motion_threshold = tp->q_motion_threshold;
+    t.key_frame_p_motion_threshold = tp->key_frame_p_motion_threshold; t.key_frame_q_motion_threshold = tp->key_frame_q_motion_threshold; t.min_delta_t = tp->min_delta_t;
+    h->t = new trajectory(&h->prm, &h->lprm, t);
+    return h;
+}
+void oracle_traj_destroy(void* hv) { oracle_traj_ctx* h = (oracle_traj_ctx*)hv; delete h->t; delete h; }
+void oracle_traj_add_imu(void* hv, double t, const double* acc, const double* gyro) {
+    imu_sample s; s.time_stamp = t; s.acc = Vec3<double>(acc[0], acc[1], acc[2]); s.gyro = Vec3<double>(gyro[0], gyro[1], gyro[2]);
+    ((oracle_traj_ctx*)hv)->t->add_sensor_data(s);
+}
+void oracle_traj_add_wheel(void* hv, double t, const double* R9, const double* t3) {
+    wheel_sample s; s.time_stamp = t;
+    for (int a = 0; a < 3; ++a) { for (int b = 0; b < 3; ++b) s.pose.R(a, b) = R9[a * 3 + b]; s.pose.t(a) = t3[a]; }
+    ((oracle_traj_ctx*)hv)->t->add_sensor_data(s);
+}
+void oracle_traj_add_laser(void* hv, double t, const double* pts, const double* times, int n) {
+    laser_msg m; m.time_stamp = t;
+    for (int i = 0; i < n; ++i) { m.points.push_back(Vec3<double>(pts[3 * i], pts[3 * i + 1], pts[3 * i + 2])); m.times.push_back(times[i]); }
+    ((oracle_traj_ctx*)hv)->t->add_sensor_data(m);
+}
+// out: status, frames in window, tracked frames, initializations, key frames emitted
+void oracle_traj_counters(void* hv, int* out5) {
+    trajectory* t = ((oracle_traj_ctx*)hv)->t;
+    out5[0] = (int)t->status; out5[1] = (int)t->frame_infos.size(); out5[2] = t->tracked_frames; out5[3] = t->initializations; out5[4] = t->keyframes_out;
+}
+void oracle_traj_current(void* hv, double* time, double* state15) {
+    trajectory* t = ((oracle_traj_ctx*)hv)->t;
+    *time = t->current_time;
+    for (int k = 0; k < 3; ++k) { state15[k] = t->current_p(k); state15[3 + k] = t->current_q(k); state15[6 + k] = t->current_v(k); }
+    for (int k = 0; k < 6; ++k) state15[9 + k] = t->current_bs[k];
+}
+int oracle_traj_tum(void* hv, char* buf, int cap) {
+    const std::string& s = ((oracle_traj_ctx*)hv)->t->tum;
+    if (buf && cap > 0) { const size_t k = std::min((size_t)cap - 1, s.size()); std::memcpy(buf, s.data(), k); buf[k] = 0; }
+    return (int)s.size();
+}
+int oracle_traj_last_iterations(void* hv) { return ((oracle_traj_ctx*)hv)->t->opt_solver.last_summary.num_iterations; }
+}

@@ -421,3 +421,68 @@ class OracleRecord:
         buf = C.create_string_buffer(n + 1)
         lib().oracle_record_dump(self.h, buf, C.c_int(n + 1))
         return buf.raw[:n].decode()
+
+
+# ---------------------------------------------------------------------------------------------------
+# trajectory restatement (trajectory.h)
+class TrajParamsC(C.Structure):
+    _fields_ = [("slide_window_size", C.c_int), ("p_motion_threshold", C.c_double), ("q_motion_threshold", C.c_double),
+                ("key_frame_p_motion_threshold", C.c_double), ("key_frame_q_motion_threshold", C.c_double), ("min_delta_t", C.c_double)]
+
+
+class TrajectoryOracle:
+    """lvio_2d::trajectory restatement; prm / lp dicts as for Oracle / LaserOracle."""
+
+    def __init__(self, prm, lp, slide_window_size=10, p_motion_threshold=0.1, q_motion_threshold=0.05, key_frame_p_motion_threshold=0.05,
+                 key_frame_q_motion_threshold=0.05, min_delta_t=0.001):
+        L = lib()
+        L.oracle_traj_create.restype = C.c_void_p
+        ps = params_struct(prm)
+        ls = LaserOracle.__new__(LaserOracle)   # reuse the struct filling code
+        s = LaserParamsC()
+        for k in ("w_laser_each_scan", "h_laser_each_scan", "laser_resolution", "line_continuous_threshold", "line_min_len", "line_max_dis",
+                  "line_max_tolerance_angle", "ref_motion_filter_p", "ref_motion_filter_q"):
+            setattr(s, k, float(lp[k]))
+        s.ref_n_accumulation = int(lp["ref_n_accumulation"])
+        s.T_imu_to_laser[:] = [float(v) for v in np.asarray(lp["T_imu_to_laser"], dtype=np.float64).reshape(16)]
+        s.normalize_extrinsics = int(bool(lp.get("normalize_extrinsics", True)))
+        del ls
+        tp = TrajParamsC(int(slide_window_size), p_motion_threshold, q_motion_threshold, key_frame_p_motion_threshold, key_frame_q_motion_threshold, min_delta_t)
+        self.h = C.c_void_p(L.oracle_traj_create(C.byref(ps), C.byref(s), C.byref(tp)))
+
+    def add_imu(self, t, acc, gyro):
+        a, b = np.ascontiguousarray(acc, dtype=np.float64), np.ascontiguousarray(gyro, dtype=np.float64)
+        lib().oracle_traj_add_imu(self.h, C.c_double(t), _p(a), _p(b))
+
+    def add_wheel(self, t, R, tr):
+        a, b = np.ascontiguousarray(R, dtype=np.float64).reshape(9), np.ascontiguousarray(tr, dtype=np.float64)
+        lib().oracle_traj_add_wheel(self.h, C.c_double(t), _p(a), _p(b))
+
+    def add_laser(self, t, points, times):
+        p, ts = np.ascontiguousarray(points, dtype=np.float64).reshape(-1, 3), np.ascontiguousarray(times, dtype=np.float64)
+        lib().oracle_traj_add_laser(self.h, C.c_double(t), _p(p), _p(ts), C.c_int(len(ts)))
+
+    def counters(self):
+        out = (C.c_int * 5)()
+        lib().oracle_traj_counters(self.h, out)
+        return dict(status=out[0], frames=out[1], tracked=out[2], initializations=out[3], keyframes=out[4])
+
+    def current(self):
+        t, s = C.c_double(0), np.zeros(15)
+        lib().oracle_traj_current(self.h, C.byref(t), _p(s))
+        return t.value, s
+
+    def tum(self):
+        n = lib().oracle_traj_tum(self.h, None, C.c_int(0))
+        buf = C.create_string_buffer(n + 1)
+        lib().oracle_traj_tum(self.h, buf, C.c_int(n + 1))
+        return buf.raw[:n].decode()
+
+    def last_iterations(self):
+        return lib().oracle_traj_last_iterations(self.h)
+
+    def __del__(self):
+        try:
+            lib().oracle_traj_destroy(self.h)
+        except Exception:
+            pass

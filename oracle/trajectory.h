@@ -1,0 +1,251 @@
+// ORACLE — TEST INFRASTRUCTURE ONLY (see jet.h header).  PARITY UNPINNED.
+//
+// Restatement of lvio_2d::trajectory (src/trajectory/trajectory.h:16-84, trajectory.cpp) for the camera-less
+// configuration (config/office.yaml:6) on top of the other restatements (solver.h, preint.h, laser_frontend.h,
+// io_formats.h), and of the oldest-first merge of lvio_2d::dispatch (src/trajectory/dispatch.h:192-257) in offline form.
+// ROS transport, visualisation, camera branches and keyframe_manager are out of scope (popped key frames are counted).
+#pragma once
+#include <deque>
+#include <limits>
+#include <string>
+
+#include "io_formats.h"
+#include "laser_frontend.h"
+#include "solver.h"
+
+namespace oracle {
+
+struct trajectory_params {
+    int slide_window_size = 10;
+    double p_motion_threshold = 0.1, q_motion_threshold = 0.05;
+    double key_frame_p_motion_threshold = 0.05, key_frame_q_motion_threshold = 0.05;
+    double min_delta_t = 0.001;
+};
+struct laser_msg { double time_stamp; std::vector<Vec3<double>> points; std::vector<double> times; };
+
+class trajectory {
+public:
+    enum TRAJECTORY_STATUS { INITIALIZING = 0, TRACKING = 1 };
+    struct frame {   // frame_info (trajectory_type.h:9-75): the solver's part + what only the trajectory reads
+        frame_info::ptr f;
+        double time;
+        bool is_key_frame = false;
+        lfe::laser_match_lines::ptr match;
+    };
+
+    trajectory(const params* prm_, const laser_params* lprm_, const trajectory_params& tp)
+        : prm(prm_), lprm(lprm_), tprm(tp), imu_preintegraption_(prm_), wheel_odom_preintegration_(prm_), laser_manger_(lprm_), opt_solver(prm_) {
+        init_current_status();
+        wheel_odom_inited = imu_inited = false;
+        current_index = last_laser_index = -1;
+        tum = tum_header();
+    }
+
+    void add_sensor_data(const wheel_sample& d) { if (wheel_odom_preintegration_.add_wheel_odom_measure(d)) wheel_odom_inited = true; }
+    void add_sensor_data(const imu_sample& d) { if (imu_preintegraption_.add_imu_measure(d)) imu_inited = true; }
+    void add_sensor_data(laser_msg& laser_data) {
+        double time = laser_data.time_stamp;
+        if (status == TRACKING) {
+            Iso3<double> T_w_laser = lie::make_tf(current_p, current_q) * prm->T_imu_to_laser;
+            Mat3<double> R_w_laser = T_w_laser.R, R_i_l = prm->T_imu_to_laser.R;
+            Vec3<double> tmp_angular = lie::log_SO3<double>(R_i_l.transpose() * lie::exp_so3(current_angular_local) * R_i_l);
+            laser_correct(laser_data.points, laser_data.times, laser_data.time_stamp, R_w_laser.transpose() * current_v, tmp_angular);
+        }
+        if (!imu_inited) return;
+        if (!wheel_odom_inited) return;
+        auto wheel_result_filter = wheel_odom_preintegration_.get_preintegraption_result();
+        auto laser_delta_filter = wheel_delta_to_laser_delta(wheel_result_filter.delta_Tij);
+        if (status == INITIALIZING && is_static(laser_delta_filter, tprm.p_motion_threshold, tprm.q_motion_threshold)) return;
+        if (status == TRACKING && imu_preintegraption_.Dt < tprm.min_delta_t) return;
+        current_index++;
+        wheel_odom_preintegration_.update_only_t(time);
+        imu_preintegraption_.update_only_t(time);
+        auto wheel_result = std::make_shared<wheel_odom_preint_result>(wheel_odom_preintegration_.get_preintegraption_result());
+        auto imu_reuslt = std::make_shared<imu_preint_result>(imu_preintegraption_.get_preintegraption_result());
+        wheel_odom_preintegration_.reset_wheel_odom_measure(time);
+        imu_preintegraption_.reset_imu_measure(time, current_bs, current_bs + 3);
+        for (int k = 0; k < 3; ++k) current_angular_local(k) = imu_reuslt->X[gamma_index + k] / imu_reuslt->Dt;
+        Iso3<double> delta_tf = wheel_delta_to_imu_delta(wheel_result->delta_Tij);
+        update_current_status(delta_tf, time);
+
+        auto scan_ptr = laser_manger_.spawn_scan(laser_data.points, laser_data.times.empty() ? time : laser_data.times.front());
+        rec.add_record("lines each frame", scan_ptr->lines.size());
+        lfe::laser_match_lines::ptr lm = nullptr;
+        if (status == INITIALIZING) {
+            lm = laser_manger_.match_with_front(scan_ptr, current_p, current_q);
+            laser_manger_.add_scan(scan_ptr, current_p, current_q);
+        } else {
+            lm = laser_manger_.match_with_ref(scan_ptr, current_p, current_q);
+        }
+        frame fr;
+        fr.f = std::make_shared<frame_info>();
+        for (int k = 0; k < 3; ++k) { fr.f->p[k] = current_p(k); fr.f->q[k] = current_q(k); fr.f->v[k] = current_v(k); }
+        for (int k = 0; k < 6; ++k) fr.f->bs[k] = current_bs[k];
+        fr.f->imu_observation_reslut = imu_reuslt;
+        fr.f->wheel_observation_reslut = wheel_result;
+        for (int k = 0; k < 36; ++k) fr.f->sqrt_H[k] = (k % 7 == 0) ? 1.0 : 0.0;
+        fr.time = current_time;
+        fr.match = lm;
+        // add_laser_match: the solver's view of the match
+        fr.f->laser_match_ptr = std::make_shared<laser_match>();
+        for (size_t i = 0; i < lm->lines1.size(); ++i) {
+            fr.f->laser_match_ptr->lines1.push_back(line{lm->lines1[i]->p1, lm->lines1[i]->p2});
+            fr.f->laser_match_ptr->lines2.push_back(line{lm->lines2[i]->p1, lm->lines2[i]->p2});
+        }
+        for (int k = 0; k < 3; ++k) {
+            fr.f->laser_match_ptr->p1[k] = lm->p1(k); fr.f->laser_match_ptr->q1[k] = lm->q1(k);
+            fr.f->laser_match_ptr->p2[k] = lm->p2(k); fr.f->laser_match_ptr->q2[k] = lm->q2(k);
+        }
+        fr.f->type = frame_info::laser;
+        last_laser_index = current_index;
+        frame_infos.push_back(fr);
+        if (status == INITIALIZING) {
+            if (check_and_processing_initialize()) status = TRACKING;
+            return;
+        }
+        do_tracking();
+        {
+            Iso3<double> tf_w_l = lie::make_tf(current_p, current_q) * prm->T_imu_to_laser;
+            for (size_t i = 0; i < lm->scan2->concers.size(); i++) acc_concers.push_back(tf_w_l * lm->scan2->concers[i]);
+        }
+        Iso3<double> current_laser_tf = lie::make_tf(current_p, current_q) * prm->T_imu_to_laser;
+        Iso3<double> delta_laser_tf = last_keyframe_tf.inverse() * current_laser_tf;
+        int n_match_size = 0;
+        if (lm) n_match_size = (int)lm->lines1.size();
+        rec.add_record("match line size", n_match_size);
+        int n_no_match_size = (int)scan_ptr->lines.size() - n_match_size;
+        if (!is_static(delta_laser_tf, tprm.key_frame_p_motion_threshold, tprm.key_frame_q_motion_threshold) || n_match_size < n_no_match_size) {
+            rec.add_record("corner each keyframe", acc_concers.size());
+            frame_infos.back().is_key_frame = true;
+            acc_concers.clear();
+            last_keyframe_tf = current_laser_tf;
+        }
+        laser_manger_.add_scan(scan_ptr, current_p, current_q);
+        last_time = current_time;
+    }
+
+    // state (public: test infrastructure)
+    const params* prm;
+    const laser_params* lprm;
+    trajectory_params tprm;
+    imu_preintegraption imu_preintegraption_;
+    wheel_odom_preintegration wheel_odom_preintegration_;
+    lfe::laser_manager laser_manger_;
+    std::deque<frame> frame_infos;
+    Iso3<double> last_keyframe_tf;
+    double current_time, last_time;
+    int current_index, last_laser_index;
+    Vec3<double> current_p, current_q, current_v, current_angular_local;
+    double current_bs[6];
+    TRAJECTORY_STATUS status;
+    bool wheel_odom_inited, imu_inited;
+    solver opt_solver;
+    std::vector<Vec3<double>> acc_concers;
+    std::string tum;
+    record rec;
+    int tracked_frames = 0, initializations = 0, keyframes_out = 0;
+
+private:
+    static bool is_static(const Iso3<double>& delta_tf, double p_thr, double q_thr) {
+        Vec3<double> dp, dq;
+        lie::log_SE3(delta_tf, dp, dq);
+        return norm(dp) < p_thr && norm(dq) < q_thr;
+    }
+    Iso3<double> wheel_delta_to_imu_delta(const Iso3<double>& wheel_delta) const { return prm->T_imu_to_wheel * wheel_delta * prm->T_imu_to_wheel.inverse(); }
+    Iso3<double> wheel_delta_to_laser_delta(const Iso3<double>& wheel_delta) const {
+        auto T_laser_to_wheel = prm->T_imu_to_laser.inverse() * prm->T_imu_to_wheel;
+        return T_laser_to_wheel * wheel_delta * T_laser_to_wheel.inverse();
+    }
+    void init_current_status() {
+        status = INITIALIZING;
+        last_keyframe_tf = Iso3<double>();
+        last_time = current_time = -std::numeric_limits<double>::max();
+        lie::log_SE3(prm->T_imu_to_wheel.inverse(), current_p, current_q);
+        current_v = Vec3<double>(); current_angular_local = Vec3<double>();
+        for (int k = 0; k < 6; ++k) current_bs[k] = 0.0;
+    }
+    void update_current_status(const Iso3<double>& delta_tf, double time) {
+        Iso3<double> new_tf = lie::make_tf(current_p, current_q) * delta_tf;
+        lie::log_SE3(new_tf, current_p, current_q);
+        current_time = time;
+    }
+    solver::frames solver_frames() const {
+        solver::frames fi;
+        for (const auto& fr : frame_infos) fi.push_back(fr.f);
+        return fi;
+    }
+    void take_back_state() {
+        const frame_info& b = *frame_infos.back().f;
+        for (int k = 0; k < 3; ++k) { current_p(k) = b.p[k]; current_q(k) = b.q[k]; current_v(k) = b.v[k]; }
+        for (int k = 0; k < 6; ++k) current_bs[k] = b.bs[k];
+    }
+    bool check_and_processing_initialize() {
+        if ((int)frame_infos.size() < tprm.slide_window_size) return false;
+        int k = 0;
+        bool is_first_laser = true;
+        for (size_t i = 0; i < frame_infos.size(); i++) {
+            if (frame_infos[i].f->type == frame_info::laser) {
+                if (is_first_laser) { is_first_laser = false; continue; }
+                if (frame_infos[i].f->laser_match_ptr == nullptr) { k = (int)i + 1; break; }
+                if (frame_infos[i].f->laser_match_ptr->lines2.size() < 2) { k = (int)i + 1; break; }
+            }
+        }
+        if (k > 0) {
+            pop_frame((int)frame_infos.size());
+            laser_manger_.clear_all_scan();
+            init_current_status();
+            return false;
+        }
+        ++initializations;
+        solver::frames fi = solver_frames();
+        opt_solver.init_solve(fi);
+        int n_laser = 0;
+        auto& key_frame = laser_manger_.key_frame;
+        for (size_t i = 0; i < frame_infos.size(); i++)
+            if (frame_infos[i].f->type == frame_info::laser) {
+                key_frame[n_laser]->current_p = Vec3<double>(frame_infos[i].f->p[0], frame_infos[i].f->p[1], frame_infos[i].f->p[2]);
+                key_frame[n_laser]->current_q = Vec3<double>(frame_infos[i].f->q[0], frame_infos[i].f->q[1], frame_infos[i].f->q[2]);
+                n_laser++;
+            }
+        take_back_state();
+        laser_manger_.clear_all_scan();
+        for (size_t i = 0; i < frame_infos.size(); i++)
+            if (frame_infos[i].f->type == frame_info::laser && frame_infos[i].match && frame_infos[i].match->scan2)
+                laser_manger_.add_scan(frame_infos[i].match->scan2, Vec3<double>(frame_infos[i].f->p[0], frame_infos[i].f->p[1], frame_infos[i].f->p[2]),
+                                       Vec3<double>(frame_infos[i].f->q[0], frame_infos[i].f->q[1], frame_infos[i].f->q[2]));
+        opt_solver.marginalization(fi);
+        acc_concers.clear();
+        pop_frame_for_tracking();
+        last_keyframe_tf = lie::make_tf(current_p, current_q);
+        return true;
+    }
+    void pop_frame(int k) {
+        if (k <= 0) return;
+        for (int i = 0; i < k; i++) {
+            if (frame_infos.front().is_key_frame) ++keyframes_out;
+            frame_infos.pop_front();
+        }
+        if (last_laser_index > -1) last_laser_index -= k;
+        if (current_index > -1) current_index -= k;
+    }
+    void do_tracking() {
+        if (status != TRACKING) return;
+        solver::frames fi = solver_frames();
+        opt_solver.solve(fi);
+        take_back_state();
+        opt_solver.marginalization(fi);
+        pop_frame_for_tracking();
+        ++tracked_frames;
+        tum += tum_line(prm->T_imu_to_wheel, frame_infos.back().time, current_p, current_q);
+    }
+    void pop_frame_for_tracking() {
+        int n = (int)frame_infos.size();
+        int k = n - 1;
+        for (int i = n - 1; i > -1; i--)
+            if (frame_infos[i].f->type == frame_info::laser) { k = i; break; }
+        pop_frame(k);
+        while (laser_manger_.key_frame.size() > 1) laser_manger_.pop_scan();
+    }
+};
+
+}  // namespace oracle

@@ -108,3 +108,24 @@ def test_cpp_laser_manager_class_matches_python_binding(liw, synth, tmp_path):
     m = mgr.match_with_front(s2, poses[1][0:3], poses[1][3:6])
     assert np.array_equal(l1, s1.lines()[:, :6]) and np.array_equal(l2, s2.lines()[:, :6])
     assert nm == len(m) >= 4 and np.array_equal(mt, m.pts) and np.array_equal(pose, m.pose)
+
+
+def test_replay_tool_builds_and_fails_loudly_without_gpu(liw, synth, tmp_path):
+    """tools/replay_log.cpp (lvio_2d::trajectory + dispatch_queue of include/lvio_2d_trajectory.hpp) compiles against the public
+    headers only; without an MI355X the first solve fails with LIW_ENODEV — the front-end driver has no CPU estimator to fall
+    back to."""
+    import importlib
+    import torch
+    replay = importlib.import_module("2dliw-slam_amd.replay")
+    src = os.path.join(ROOT, "tools", "replay_log.cpp")
+    exe = os.path.join(ROOT, "tools", "replay_log")
+    libdir = os.path.dirname(liw.LIB_PATH)
+    subprocess.check_call(["g++", "-O2", "-std=c++17", "-I", os.path.join(ROOT, "include"), src, "-o", exe,
+                           "-L", libdir, "-lliw_window", "-Wl,-rpath," + libdir, "-Wl,-rpath,/opt/rocm/lib"])
+    if torch.cuda.is_available():
+        pytest.skip("a GPU is present")
+    msgs, _ = replay.make_log(synth.office_params(), duration=2.5, seed=3)
+    replay.write_log(str(tmp_path / "log.bin"), msgs)
+    r = subprocess.run([exe, str(tmp_path / "log.bin"), str(tmp_path) + "/"], capture_output=True)
+    assert r.returncode == 19, (r.returncode, r.stderr.decode())
+    assert b"no usable gfx950 device" in r.stderr or b"no HIP device" in r.stderr
