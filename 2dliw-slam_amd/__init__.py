@@ -349,4 +349,4 @@ class HostPreint:
 
 
 from .batch import BatchPreint, BatchSolver, shard_laser  # noqa: E402,F401
-from . import laser, outputs  # noqa: E402,F401
+from . import laser, outputs, posegraph  # noqa: E402,F401

@@ -1,0 +1,648 @@
+// k_posegraph.hip — back-end pose-graph relinearisation on the MI355X (C ABI include/liw_posegraph.h).
+//
+// keyframe_manager::solve (reference src/trajectory/keyframe_manager.cpp:722-838) = Ceres trust-region LM over the key-frame
+// poses.  Here:
+//   k_pg_linearize   one 16-lane group per edge_factor block (src/factor/edge_factor.h:79-126): 12 dual directions + value,
+//                    so3 local parameterisation applied in the group, Y = [J | r] (6 x 13) per edge to HBM; ground factors
+//                    per key frame the same way (7 lanes, Y 2 x 7).
+//   k_pg_assemble    dense H = sum Y^T Y (6 unknowns per key frame): one wave per key frame gathers its incident edges
+//                    (CSR built on the host) -> deterministic diagonal blocks and gradient; off-diagonal 6x6 blocks are
+//                    written by the edge that owns the pair.
+//   k_pg_scale_damp  A = S H S + diag(D / radius)  (Jacobi scaling, LM diagonal), the matrix that is factorised.
+//   blocked Cholesky k_potrf64 (register-resident, one wave: column per lane, v_readlane broadcasts), k_trsm64 (row per
+//                    lane against the LDS-resident diagonal factor), k_syrk64 (trailing update on the fp64 matrix cores:
+//                    v_mfma_f64_16x16x4_f64, operands staged through LDS), k_trisolve (L y = b, L^T x = y in one launch).
+// The trust-region bookkeeping (radius, step acceptance, the three Ceres tolerances) runs on the host between launches;
+// the per-iteration device->host traffic is the step vector (6N doubles) and two cost scalars.
+#include <algorithm>
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <vector>
+
+#include "../../include/liw_posegraph.h"
+#include "liw_kernels.hpp"
+
+struct liw_ctx;
+hipStream_t liw_ctx_stream(liw_ctx* c);
+const liw::DevParams* liw_ctx_devparams(liw_ctx* c);
+int liw_ctx_device(liw_ctx* c);
+bool liw_ctx_has_device(liw_ctx* c);
+int liw_ctx_fail(liw_ctx* c, int code, const char* what);
+
+namespace liw {
+
+typedef double d4g __attribute__((ext_vector_type(4)));
+constexpr double kPiG = 3.141592653589793238462643383279, kTwoPiG = 6.283185307179586476925286766559;
+
+struct PgNoise { double J[36]; double ground_on_p, ground_on_q; };
+
+__device__ __forceinline__ double rdl64(double v, int l) {
+    int lo = __double2loint(v), hi = __double2hiint(v);
+    lo = __builtin_amdgcn_readlane(lo, l);
+    hi = __builtin_amdgcn_readlane(hi, l);
+    return __hiloint2double(hi, lo);
+}
+// d Plus(x, delta) / d delta at delta = 0 of the so3 parameterisation (src/factor/factor_common.h:37-60): identity unless |x| > pi
+__device__ __forceinline__ bool plus_jac(const double* x, double* P9) {
+    const double a = sqrt(x[0] * x[0] + x[1] * x[1] + x[2] * x[2]);
+    if (!(a > kPiG)) return false;
+    const double k = floor((a + kPiG) / kTwoPiG);
+    const double c = kTwoPiG * k / a;
+    const double u[3] = {x[0] / a, x[1] / a, x[2] / a};
+    for (int i = 0; i < 3; ++i)
+        for (int j = 0; j < 3; ++j) P9[i * 3 + j] = (i == j ? 1.0 : 0.0) - c * ((i == j ? 1.0 : 0.0) - u[i] * u[j]);
+    return true;
+}
+
+// ---- edge_factor::operator() (edge_factor.h:88-117): res = weight * J_noise * log_SE3(tf_j^-1 tf_i tf12)
+template <class T>
+__device__ __forceinline__ void edge_res(const double* tf12, double weight, const double* Jn, const T* pi, const T* qi, const T* pj, const T* qj, T* res) {
+    Iso<T> tf_i = make_tf(V3<T>(pi[0], pi[1], pi[2]), V3<T>(qi[0], qi[1], qi[2]));
+    Iso<T> tf_j = make_tf(V3<T>(pj[0], pj[1], pj[2]), V3<T>(qj[0], qj[1], qj[2]));
+    Iso<T> err = mul(mul(inverse(tf_j), tf_i), cast_iso<T>(tf12, tf12 + 9));
+    V3<T> rq = log_SO3(err.R);
+    T raw[6] = {err.t.x, err.t.y, err.t.z, rq.x, rq.y, rq.z};
+#pragma unroll
+    for (int r = 0; r < 6; ++r) {
+        T s(0.0);
+#pragma unroll
+        for (int c = 0; c < 6; ++c) s = s + T(Jn[r * 6 + c]) * raw[c];
+        res[r] = T(weight) * s;
+    }
+}
+template <class T>
+__device__ __forceinline__ void pg_ground_res(const DevParams& P, const T* p_, const T* q_, T* res) {   // ground_factor.h:27-82
+    Iso<T> tf_w_o = mul(make_tf(V3<T>(p_[0], p_[1], p_[2]), V3<T>(q_[0], q_[1], q_[2])), cast_iso<T>(P.Riw, P.tiw));
+    res[0] = T(P.ground_p_info) * tf_w_o.t.z;
+    V3<T> ABC(T(0.0), T(0.0), T(1.0));
+    V3<T> z_axis(tf_w_o.R(0, 2), tf_w_o.R(1, 2), tf_w_o.R(2, 2));
+    T sinn = norm(cross(z_axis, ABC));
+    res[1] = T(P.ground_q_info) * dasin(sinn);
+}
+
+// Y_edge [E][6][13], Y_ground [N][2][7]; jac = 0: residuals only (column 12 / 6)
+__global__ __launch_bounds__(64) void k_pg_linearize(int N, int E, const double* x, const int* eidx, const double* etf, const double* ew, PgNoise noise,
+                                                     DevParams P, double* Ye, double* Yg, int jac) {
+    __shared__ double Y[4][6 * 13];
+    const int lane = threadIdx.x & 63, grp = lane >> 4, d = lane & 15;
+    const int edge_blocks = (E + 3) / 4;
+    if ((int)blockIdx.x < edge_blocks) {
+        const int e = blockIdx.x * 4 + grp;
+        const bool on = e < E;
+        const int i = on ? eidx[e * 2] : 0, j = on ? eidx[e * 2 + 1] : 0;
+        const double* xi = x + (size_t)i * 6;
+        const double* xj = x + (size_t)j * 6;
+        if (on && (d == 12 || (jac && d < 12))) {
+            LJ pi[3], qi[3], pj[3], qj[3], res[6];
+#pragma unroll
+            for (int k = 0; k < 3; ++k) {
+                pi[k] = LJ(xi[k], d == k ? 1.0 : 0.0);
+                qi[k] = LJ(xi[3 + k], d == 3 + k ? 1.0 : 0.0);
+                pj[k] = LJ(xj[k], d == 6 + k ? 1.0 : 0.0);
+                qj[k] = LJ(xj[3 + k], d == 9 + k ? 1.0 : 0.0);
+            }
+            edge_res<LJ>(etf + (size_t)e * 12, ew[e], noise.J, pi, qi, pj, qj, res);
+#pragma unroll
+            for (int r = 0; r < 6; ++r) Y[grp][r * 13 + d] = d < 12 ? res[r].d : res[r].v;
+        }
+        __syncthreads();
+        if (on && jac && d < 12) {   // local parameterisation: J_theta <- J_theta * dPlus/ddelta  (lane = (row r, pose which))
+            const int r = d % 6, which = d / 6;
+            double Pq[9];
+            if (plus_jac((which ? xj : xi) + 3, Pq)) {
+                double* row = &Y[grp][r * 13 + 6 * which + 3];
+                const double t0 = row[0] * Pq[0] + row[1] * Pq[3] + row[2] * Pq[6];
+                const double t1 = row[0] * Pq[1] + row[1] * Pq[4] + row[2] * Pq[7];
+                const double t2 = row[0] * Pq[2] + row[1] * Pq[5] + row[2] * Pq[8];
+                row[0] = t0; row[1] = t1; row[2] = t2;
+            }
+        }
+        __syncthreads();
+        if (on && d < 13)
+#pragma unroll
+            for (int r = 0; r < 6; ++r) Ye[(size_t)e * 78 + r * 13 + d] = (jac || d == 12) ? Y[grp][r * 13 + d] : 0.0;
+    } else {
+        // ground factors: 8 key frames per wave, 6 dual directions + value
+        const int sub = lane >> 3, dir = lane & 7;
+        const int i = ((int)blockIdx.x - edge_blocks) * 8 + sub;
+        const bool on = i < N;
+        double* Yl = &Y[0][0] + sub * 16;
+        if (on && (dir == 6 || (jac && dir < 6))) {
+            const double* s_ = x + (size_t)i * 6;
+            LJ p[3], q[3], res[2];
+#pragma unroll
+            for (int k = 0; k < 3; ++k) { p[k] = LJ(s_[k], dir == k ? 1.0 : 0.0); q[k] = LJ(s_[3 + k], dir == 3 + k ? 1.0 : 0.0); }
+            pg_ground_res<LJ>(P, p, q, res);
+            Yl[dir] = (dir < 6 ? res[0].d : res[0].v) * noise.ground_on_p;
+            Yl[7 + dir] = (dir < 6 ? res[1].d : res[1].v) * noise.ground_on_q;
+        }
+        __syncthreads();
+        if (on && jac && dir < 2) {
+            double Pq[9];
+            if (plus_jac(x + (size_t)i * 6 + 3, Pq)) {
+                double* row = Yl + dir * 7 + 3;
+                const double t0 = row[0] * Pq[0] + row[1] * Pq[3] + row[2] * Pq[6];
+                const double t1 = row[0] * Pq[1] + row[1] * Pq[4] + row[2] * Pq[7];
+                const double t2 = row[0] * Pq[2] + row[1] * Pq[5] + row[2] * Pq[8];
+                row[0] = t0; row[1] = t1; row[2] = t2;
+            }
+        }
+        __syncthreads();
+        if (on && dir < 7) {
+            Yg[(size_t)i * 14 + dir] = (jac || dir == 6) ? Yl[dir] : 0.0;
+            Yg[(size_t)i * 14 + 7 + dir] = (jac || dir == 6) ? Yl[7 + dir] : 0.0;
+        }
+    }
+}
+
+// cost = 1/2 sum r^2 over all blocks (deterministic two-stage sum)
+__global__ void k_pg_cost(int N, int E, const double* Ye, const double* Yg, int const_pose, double* partial) {
+    __shared__ double red[256];
+    double s = 0.0;
+    for (int t = blockIdx.x * blockDim.x + threadIdx.x; t < E * 6 + N * 2; t += gridDim.x * blockDim.x) {
+        double r;
+        if (t < E * 6) r = Ye[(size_t)(t / 6) * 78 + (t % 6) * 13 + 12];
+        else { const int u = t - E * 6; r = (u / 2 == const_pose) ? 0.0 : Yg[(size_t)(u / 2) * 14 + (u % 2) * 7 + 6]; }   // all-constant blocks are not part of the cost
+        s += r * r;
+    }
+    red[threadIdx.x] = s;
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) { if ((int)threadIdx.x < o) red[threadIdx.x] += red[threadIdx.x + o]; __syncthreads(); }
+    if (threadIdx.x == 0) partial[blockIdx.x] = red[0];
+}
+
+// one wave per key frame: diagonal 6x6 block + gradient from every incident block (CSR: inc_off[N+1], inc[.] = edge*2+side),
+// and the off-diagonal blocks of the edges whose index1 is this key frame.  Constant key frame: identity block, zero gradient.
+__global__ __launch_bounds__(64) void k_pg_assemble(int N, int ld, const int* inc_off, const int* inc, const int* eidx, const double* Ye, const double* Yg,
+                                                    int const_pose, double* H, double* g) {
+    const int i = blockIdx.x, lane = threadIdx.x & 63;
+    if (i >= N) return;
+    const int r = lane / 6, c = lane % 6;     // lanes 0..35: entry (r, c) of the diagonal block; 36..41: gradient entry
+    double acc = 0.0;
+    const bool is_const = i == const_pose;
+    if (!is_const) {
+        if (lane < 36) acc = Yg[(size_t)i * 14 + r] * Yg[(size_t)i * 14 + c] + Yg[(size_t)i * 14 + 7 + r] * Yg[(size_t)i * 14 + 7 + c];
+        else if (lane < 42) acc = Yg[(size_t)i * 14 + (lane - 36)] * Yg[(size_t)i * 14 + 6] + Yg[(size_t)i * 14 + 7 + (lane - 36)] * Yg[(size_t)i * 14 + 13];
+        for (int t = inc_off[i]; t < inc_off[i + 1]; ++t) {
+            const int e = inc[t] >> 1, side = inc[t] & 1;
+            const double* Y = Ye + (size_t)e * 78;
+            double s = 0.0;
+            if (lane < 36) {
+#pragma unroll
+                for (int k = 0; k < 6; ++k) s += Y[k * 13 + 6 * side + r] * Y[k * 13 + 6 * side + c];
+            } else if (lane < 42) {
+#pragma unroll
+                for (int k = 0; k < 6; ++k) s += Y[k * 13 + 6 * side + (lane - 36)] * Y[k * 13 + 12];
+            }
+            acc += s;
+            // off-diagonal block H[j, i] (lower triangle: row index > column index), written by side 0 of the edge
+            if (side == 0) {
+                const int j = eidx[e * 2 + 1];
+                if (j != const_pose && j != i && lane < 36) {
+                    double o = 0.0;   // (J_j^T J_i)(r, c)
+#pragma unroll
+                    for (int k = 0; k < 6; ++k) o += Y[k * 13 + 6 + r] * Y[k * 13 + c];
+                    // two edges between the same pair add commutatively (two terms): atomics keep that deterministic
+                    if (j > i) atomicAdd(&H[(size_t)(j * 6 + r) * ld + i * 6 + c], o);
+                    else atomicAdd(&H[(size_t)(i * 6 + c) * ld + j * 6 + r], o);
+                }
+            }
+        }
+    } else {
+        if (lane < 36) acc = r == c ? 1.0 : 0.0;
+    }
+    if (lane < 36) { if (r >= c) H[(size_t)(i * 6 + r) * ld + i * 6 + c] = acc; }
+    else if (lane < 42) g[i * 6 + (lane - 36)] = acc;
+}
+
+__global__ void k_pg_diag(int n, int ld, const double* H, double* out) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) out[i] = H[(size_t)i * ld + i];
+}
+// A = S H S + diag(D / radius) on the lower triangle; padding rows get the identity
+__global__ void k_pg_scale_damp(int n, int np, int ld, const double* H, const double* scale, const double* dgn, double radius, double* A) {
+    const int col = blockIdx.x * blockDim.x + threadIdx.x, row = blockIdx.y;
+    if (col >= np || row >= np || col > row) return;
+    double v;
+    if (row >= n) v = row == col ? 1.0 : 0.0;
+    else {
+        v = H[(size_t)row * ld + col] * scale[row] * scale[col];
+        if (row == col) { const double lm = sqrt(dgn[row] / radius); v += lm * lm; }
+    }
+    A[(size_t)row * ld + col] = v;
+}
+
+// ---------------------------------------------------------------------------------------------- blocked Cholesky, NB = 64
+// diagonal block: lane j owns column j (a[r] = A[r][j]); step k broadcasts the pivot and column k with v_readlane;
+// afterwards lane j holds row j of L in a[0..j].  status[0] != 0 when a pivot is not positive.
+__global__ __launch_bounds__(64, 1) void k_potrf64(double* A, int ld, int k0, int* status) {
+    const int lane = threadIdx.x & 63;
+    double* B = A + (size_t)k0 * ld + k0;
+    double a[64];
+#pragma unroll
+    for (int r = 0; r < 64; ++r) a[r] = r >= lane ? B[(size_t)r * ld + lane] : B[(size_t)lane * ld + r];   // full symmetric block from the lower triangle
+    bool ok = true;
+#pragma unroll
+    for (int k = 0; k < 64; ++k) {
+        const double piv = rdl64(a[k], k);
+        if (!(piv > 0.0)) ok = false;
+        const double inv = 1.0 / sqrt(piv);
+        const double wk = a[k] * inv;          // lane j >= k: A[k][j] / sqrt(piv) = L[j][k]
+        a[k] = wk;
+#pragma unroll
+        for (int r = k + 1; r < 64; ++r) a[r] -= rdl64(wk, r) * wk;
+    }
+#pragma unroll
+    for (int k = 0; k < 64; ++k) if (k <= lane) B[(size_t)lane * ld + k] = a[k];   // row `lane` of L
+    if (!ok && lane == 0) status[0] = 1;
+}
+
+// panel: X L_kk^T = A_ik  for every block row i > k; one wave per block row, lane = row of the block
+__global__ __launch_bounds__(64) void k_trsm64(double* A, int ld, int k0) {
+    __shared__ double L[64 * 65];
+    const int lane = threadIdx.x & 63;
+    const int i0 = k0 + 64 * (blockIdx.x + 1);
+    const double* D = A + (size_t)k0 * ld + k0;
+    for (int r = 0; r < 64; ++r) L[r * 65 + lane] = lane <= r ? D[(size_t)r * ld + lane] : 0.0;
+    __syncthreads();
+    double* R = A + (size_t)(i0 + lane) * ld + k0;
+    double x[64];
+#pragma unroll
+    for (int c = 0; c < 64; ++c) x[c] = R[c];
+#pragma unroll
+    for (int c = 0; c < 64; ++c) {
+        double s = x[c];
+#pragma unroll
+        for (int m = 0; m < c; ++m) s -= x[m] * L[c * 65 + m];
+        x[c] = s / L[c * 65 + c];
+    }
+#pragma unroll
+    for (int c = 0; c < 64; ++c) R[c] = x[c];
+}
+
+// trailing update A_ij -= A_ik A_jk^T (j <= i), 64x64 tile per work-group of 4 waves, fp64 MFMA 16x16x4
+__global__ __launch_bounds__(256) void k_syrk64(double* A, int ld, int k0, int nb_rem) {
+    __shared__ double Pa[64 * 33], Pb[64 * 33];     // K halves of 32, padded
+    const int ti = blockIdx.y, tj = blockIdx.x;
+    if (tj > ti || ti >= nb_rem) return;
+    const int i0 = k0 + 64 * (ti + 1), j0 = k0 + 64 * (tj + 1);
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    d4g acc[4] = {{0, 0, 0, 0}, {0, 0, 0, 0}, {0, 0, 0, 0}, {0, 0, 0, 0}};
+    for (int kh = 0; kh < 2; ++kh) {
+        __syncthreads();
+        for (int e = tid; e < 64 * 32; e += 256) {
+            const int r = e >> 5, c = e & 31;
+            Pa[r * 33 + c] = A[(size_t)(i0 + r) * ld + k0 + 32 * kh + c];
+            Pb[r * 33 + c] = A[(size_t)(j0 + r) * ld + k0 + 32 * kh + c];
+        }
+        __syncthreads();
+        // wave w: rows 16w..16w+15 of the tile; MFMA operand A[i][k] from lane (i = l & 15, k = l >> 4), B[k][j] likewise
+#pragma unroll
+        for (int ks = 0; ks < 8; ++ks) {
+            const int kk = 4 * ks + (lane >> 4);
+            const double av = Pa[(16 * wave + (lane & 15)) * 33 + kk];
+#pragma unroll
+            for (int ct = 0; ct < 4; ++ct) {
+                const double bv = Pb[(16 * ct + (lane & 15)) * 33 + kk];
+                acc[ct] = __builtin_amdgcn_mfma_f64_16x16x4f64(av, bv, acc[ct], 0, 0, 0);
+            }
+        }
+    }
+    // acc[ct][r] = C[16w + (lane>>4) + 4r][16ct + (lane&15)]
+#pragma unroll
+    for (int ct = 0; ct < 4; ++ct)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int row = 16 * wave + (lane >> 4) + 4 * r, col = 16 * ct + (lane & 15);
+            if (ti != tj || col <= row) A[(size_t)(i0 + row) * ld + j0 + col] -= acc[ct][r];
+        }
+}
+
+// L y = b then L^T x = y, one work-group (1024 threads), blocks of 64 unknowns; the 64x64 diagonal block of each step is
+// held in registers by wave 0 (row per lane going forward, column per lane going back), its unknowns are exchanged with
+// v_readlane, and all 16 waves apply the solved block to the remaining right-hand side
+__global__ __launch_bounds__(1024) void k_trisolve(const double* L, int ld, int np, double* b) {
+    __shared__ double xs[64];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int nb = np / 64;
+    for (int k = 0; k < nb; ++k) {   // forward
+        const int k0 = 64 * k;
+        if (wave == 0) {
+            double Lr[64];
+#pragma unroll
+            for (int m = 0; m < 64; ++m) Lr[m] = L[(size_t)(k0 + lane) * ld + k0 + m];
+            double v = b[k0 + lane];
+#pragma unroll
+            for (int m = 0; m < 64; ++m) {
+                const double ym = rdl64(v, m) / rdl64(Lr[m], m);
+                if (lane == m) v = ym;
+                else if (lane > m) v -= Lr[m] * ym;
+            }
+            xs[lane] = v;
+            b[k0 + lane] = v;
+        }
+        __syncthreads();
+        for (int r = k0 + 64 + tid; r < np; r += 1024) {
+            double s = 0.0;
+            const double* row = L + (size_t)r * ld + k0;
+#pragma unroll 8
+            for (int m = 0; m < 64; ++m) s += row[m] * xs[m];
+            b[r] -= s;
+        }
+        __syncthreads();
+    }
+    for (int k = nb - 1; k >= 0; --k) {   // backward with L^T
+        const int k0 = 64 * k;
+        if (wave == 0) {
+            double Lc[64];
+#pragma unroll
+            for (int m = 0; m < 64; ++m) Lc[m] = L[(size_t)(k0 + m) * ld + k0 + lane];   // column `lane`
+            double v = b[k0 + lane];
+#pragma unroll
+            for (int m = 63; m >= 0; --m) {
+                const double xm = rdl64(v, m) / rdl64(Lc[m], m);
+                if (lane == m) v = xm;
+                else if (lane < m) v -= Lc[m] * xm;
+            }
+            xs[lane] = v;
+            b[k0 + lane] = v;
+        }
+        __syncthreads();
+        for (int r = tid; r < k0; r += 1024) {     // b_r -= sum_m L[k0+m][r] x_m
+            double s = 0.0;
+#pragma unroll 8
+            for (int m = 0; m < 64; ++m) s += L[(size_t)(k0 + m) * ld + r] * xs[m];
+            b[r] -= s;
+        }
+        __syncthreads();
+    }
+}
+
+static int dense_cholesky_solve(liw_ctx* c, double* dA, int np, double* db, int* dstatus, hipStream_t s) {
+    const int nb = np / 64;
+    (void)hipMemsetAsync(dstatus, 0, sizeof(int), s);
+    for (int k = 0; k < nb; ++k) {
+        hipLaunchKernelGGL(k_potrf64, dim3(1), dim3(64), 0, s, dA, np, 64 * k, dstatus);
+        const int rem = nb - k - 1;
+        if (rem > 0) {
+            hipLaunchKernelGGL(k_trsm64, dim3(rem), dim3(64), 0, s, dA, np, 64 * k);
+            hipLaunchKernelGGL(k_syrk64, dim3(rem, rem), dim3(256), 0, s, dA, np, 64 * k, rem);
+        }
+    }
+    hipLaunchKernelGGL(k_trisolve, dim3(1), dim3(1024), 0, s, dA, np, np, db);
+    if (hipGetLastError() != hipSuccess) return liw_ctx_fail(c, LIW_EHIP, "dense Cholesky launch");
+    return LIW_OK;
+}
+
+}  // namespace liw
+
+using namespace liw;
+
+namespace {
+struct DBuf {
+    void* p = nullptr;
+    ~DBuf() { if (p) (void)hipFree(p); }
+    int alloc(size_t bytes) { return hipMalloc(&p, bytes ? bytes : 8) == hipSuccess ? 0 : -1; }
+    template <class T> T* as() { return (T*)p; }
+};
+// Plus of the so3 parameterisation on the host (src/factor/factor_common.h:41-53: the rotation VECTORS add, then wrap)
+void so3_plus_host(const double* x, const double* d, double* out) {
+    V3<double> r = normalize_so3(V3<double>(x[0] + d[0], x[1] + d[1], x[2] + d[2]));
+    out[0] = r.x; out[1] = r.y; out[2] = r.z;
+}
+}  // namespace
+
+extern "C" {
+
+int liw_dense_spd_solve(liw_ctx* c, int n, const double* A, const double* b, double* x) {
+    if (!liw_ctx_has_device(c)) return liw_ctx_fail(c, LIW_ENODEV, "no usable gfx950 device (this library has no CPU fallback)");
+    if (n < 1 || !A || !b || !x) return liw_ctx_fail(c, LIW_EINVAL, "liw_dense_spd_solve: bad argument");
+    (void)hipSetDevice(liw_ctx_device(c));
+    hipStream_t s = liw_ctx_stream(c);
+    const int np = (n + 63) / 64 * 64;
+    std::vector<double> Ap((size_t)np * np, 0.0), bp(np, 0.0);
+    for (int i = 0; i < np; ++i) {
+        if (i < n) { for (int j = 0; j <= i; ++j) Ap[(size_t)i * np + j] = A[(size_t)i * n + j]; bp[i] = b[i]; }
+        else Ap[(size_t)i * np + i] = 1.0;
+    }
+    DBuf dA, db, dst;
+    if (dA.alloc(sizeof(double) * (size_t)np * np) || db.alloc(sizeof(double) * np) || dst.alloc(sizeof(int))) return liw_ctx_fail(c, LIW_ENOMEM, "hipMalloc");
+    (void)hipMemcpyAsync(dA.p, Ap.data(), sizeof(double) * (size_t)np * np, hipMemcpyHostToDevice, s);
+    (void)hipMemcpyAsync(db.p, bp.data(), sizeof(double) * np, hipMemcpyHostToDevice, s);
+    if (int r = dense_cholesky_solve(c, dA.as<double>(), np, db.as<double>(), dst.as<int>(), s)) return r;
+    int st = 0;
+    (void)hipMemcpyAsync(bp.data(), db.p, sizeof(double) * np, hipMemcpyDeviceToHost, s);
+    (void)hipMemcpyAsync(&st, dst.p, sizeof(int), hipMemcpyDeviceToHost, s);
+    if (hipStreamSynchronize(s) != hipSuccess) return liw_ctx_fail(c, LIW_EHIP, "hipStreamSynchronize");
+    if (st) return liw_ctx_fail(c, LIW_ESTATE, "matrix is not positive definite");
+    std::memcpy(x, bp.data(), sizeof(double) * n);
+    return LIW_OK;
+}
+
+struct PgCall {
+    liw_ctx* c; const liw_pg_params* pg; int N; double* poses; int n_seq; const int* seq_idx; const double* seq_tf12; int n_loop; const int* loop_idx;
+    const double* loop_tf12; int max_iters; liw_summary* summary; double* H_out; double* g_out; double* cost_out;
+};
+static int pg_run(const PgCall& q);
+
+int liw_posegraph_solve(liw_ctx* c, const liw_pg_params* pg, int N, double* poses, int n_seq, const int* seq_idx, const double* seq_tf12, int n_loop,
+                        const int* loop_idx, const double* loop_tf12, int max_iters, liw_summary* summary) {
+    return pg_run(PgCall{c, pg, N, poses, n_seq, seq_idx, seq_tf12, n_loop, loop_idx, loop_tf12, max_iters, summary, nullptr, nullptr, nullptr});
+}
+int liw_posegraph_linearize(liw_ctx* c, const liw_pg_params* pg, int N, const double* poses, int n_seq, const int* seq_idx, const double* seq_tf12, int n_loop,
+                            const int* loop_idx, const double* loop_tf12, double* H, double* g, double* cost) {
+    return pg_run(PgCall{c, pg, N, const_cast<double*>(poses), n_seq, seq_idx, seq_tf12, n_loop, loop_idx, loop_tf12, 0, nullptr, H, g, cost ? cost : (double*)nullptr});
+}
+
+static int pg_run(const PgCall& q) {
+    liw_ctx* c = q.c; const liw_pg_params* pg = q.pg; const int N = q.N; double* poses = q.poses; const int n_seq = q.n_seq; const int* seq_idx = q.seq_idx;
+    const double* seq_tf12 = q.seq_tf12; const int n_loop = q.n_loop; const int* loop_idx = q.loop_idx; const double* loop_tf12 = q.loop_tf12;
+    const int max_iters = q.max_iters; liw_summary* summary = q.summary;
+    const bool linearize_only = q.H_out || q.g_out || q.cost_out;
+    if (!liw_ctx_has_device(c)) return liw_ctx_fail(c, LIW_ENODEV, "no usable gfx950 device (this library has no CPU fallback)");
+    if (!pg || N < 2 || !poses || n_seq < 1 || !seq_idx || !seq_tf12 || n_loop < 0 || (n_loop && (!loop_idx || !loop_tf12)))
+        return liw_ctx_fail(c, LIW_EINVAL, "liw_posegraph_solve: bad argument");
+    const int E = n_seq + n_loop;
+    std::vector<int> eidx((size_t)E * 2);
+    std::vector<double> etf((size_t)E * 12), ew(E);
+    for (int e = 0; e < E; ++e) {
+        const int* id = e < n_seq ? seq_idx + 2 * e : loop_idx + 2 * (e - n_seq);
+        if (id[0] < 0 || id[0] >= N || id[1] < 0 || id[1] >= N || id[0] == id[1]) return liw_ctx_fail(c, LIW_EINVAL, "liw_posegraph_solve: edge index out of range");
+        eidx[2 * e] = id[0]; eidx[2 * e + 1] = id[1];
+        std::memcpy(&etf[(size_t)e * 12], e < n_seq ? seq_tf12 + 12 * (size_t)e : loop_tf12 + 12 * (size_t)(e - n_seq), sizeof(double) * 12);
+        ew[e] = e < n_seq ? 1.0 : pg->loop_edge_k;
+    }
+    const int const_pose = seq_idx[0];   // keyframe_manager.cpp:745-749
+    // incidence CSR
+    std::vector<int> inc_off(N + 1, 0), inc((size_t)E * 2);
+    for (int e = 0; e < E; ++e) { ++inc_off[eidx[2 * e] + 1]; ++inc_off[eidx[2 * e + 1] + 1]; }
+    for (int i = 0; i < N; ++i) inc_off[i + 1] += inc_off[i];
+    {
+        std::vector<int> fill(inc_off.begin(), inc_off.end() - 1);
+        for (int e = 0; e < E; ++e) { inc[fill[eidx[2 * e]]++] = e * 2; inc[fill[eidx[2 * e + 1]]++] = e * 2 + 1; }
+    }
+    PgNoise noise{};
+    for (int k = 0; k < 36; ++k) noise.J[k] = (k % 7 == 0) ? 1.0 : 0.0;   // edge_noise (edge_factor.h:15-25), J(1,2) as written there
+    noise.J[0] = 1.0 / pg->loop_sigma_p[0]; noise.J[1 * 6 + 2] = 1.0 / pg->loop_sigma_p[1]; noise.J[2 * 6 + 2] = 1.0 / pg->loop_sigma_p[2];
+    noise.J[3 * 6 + 3] = 1.0 / pg->loop_sigma_q[0]; noise.J[4 * 6 + 4] = 1.0 / pg->loop_sigma_q[1]; noise.J[5 * 6 + 5] = 1.0 / pg->loop_sigma_q[2];
+    noise.ground_on_p = pg->use_ground_p_factor ? 1.0 : 0.0;
+    noise.ground_on_q = pg->use_ground_q_factor ? 1.0 : 0.0;
+
+    (void)hipSetDevice(liw_ctx_device(c));
+    hipStream_t s = liw_ctx_stream(c);
+    const DevParams P = *liw_ctx_devparams(c);
+    const int n = 6 * N, np = (n + 63) / 64 * 64;
+    DBuf dx, dxc, deidx, detf, dew, dinc_off, dinc, dYe, dYg, dH, dA, dg, dscale, ddgn, drhs, dpart, dst;
+    const int cost_blocks = 64;
+    if (dx.alloc(sizeof(double) * n) || dxc.alloc(sizeof(double) * n) || deidx.alloc(sizeof(int) * 2 * (size_t)E) || detf.alloc(sizeof(double) * 12 * (size_t)E) ||
+        dew.alloc(sizeof(double) * E) || dinc_off.alloc(sizeof(int) * (N + 1)) || dinc.alloc(sizeof(int) * 2 * (size_t)E) || dYe.alloc(sizeof(double) * 78 * (size_t)E) ||
+        dYg.alloc(sizeof(double) * 14 * (size_t)N) || dH.alloc(sizeof(double) * (size_t)np * np) || dA.alloc(sizeof(double) * (size_t)np * np) ||
+        dg.alloc(sizeof(double) * np) || dscale.alloc(sizeof(double) * np) || ddgn.alloc(sizeof(double) * np) || drhs.alloc(sizeof(double) * np) ||
+        dpart.alloc(sizeof(double) * cost_blocks) || dst.alloc(sizeof(int)))
+        return liw_ctx_fail(c, LIW_ENOMEM, "hipMalloc");
+    auto up = [&](DBuf& d, const void* src, size_t bytes) { (void)hipMemcpyAsync(d.p, src, bytes, hipMemcpyHostToDevice, s); };
+    up(deidx, eidx.data(), sizeof(int) * eidx.size()); up(detf, etf.data(), sizeof(double) * etf.size()); up(dew, ew.data(), sizeof(double) * E);
+    up(dinc_off, inc_off.data(), sizeof(int) * (N + 1)); up(dinc, inc.data(), sizeof(int) * inc.size());
+
+    std::vector<double> x(poses, poses + n), cand(n), g(n), scale(n, 1.0), dgn(n, 0.0), gs(n), y(np), Hdiag(n), part(cost_blocks);
+    const unsigned lin_blocks = (unsigned)((E + 3) / 4 + (N + 7) / 8);
+    auto evaluate = [&](const std::vector<double>& xv, DBuf& dxx, bool with_jac, double* cost) -> int {
+        up(dxx, xv.data(), sizeof(double) * n);
+        hipLaunchKernelGGL(k_pg_linearize, dim3(lin_blocks), dim3(64), 0, s, N, E, dxx.as<double>(), deidx.as<int>(), detf.as<double>(), dew.as<double>(), noise, P,
+                           dYe.as<double>(), dYg.as<double>(), with_jac ? 1 : 0);
+        hipLaunchKernelGGL(k_pg_cost, dim3(cost_blocks), dim3(256), 0, s, N, E, dYe.as<double>(), dYg.as<double>(), const_pose, dpart.as<double>());
+        if (with_jac) {
+            (void)hipMemsetAsync(dH.p, 0, sizeof(double) * (size_t)np * np, s);
+            hipLaunchKernelGGL(k_pg_assemble, dim3(N), dim3(64), 0, s, N, np, dinc_off.as<int>(), dinc.as<int>(), deidx.as<int>(), dYe.as<double>(), dYg.as<double>(),
+                               const_pose, dH.as<double>(), dg.as<double>());
+            (void)hipMemcpyAsync(g.data(), dg.p, sizeof(double) * n, hipMemcpyDeviceToHost, s);
+            hipLaunchKernelGGL(k_pg_diag, dim3((n + 255) / 256), dim3(256), 0, s, n, np, dH.as<double>(), drhs.as<double>());
+            (void)hipMemcpyAsync(Hdiag.data(), drhs.p, sizeof(double) * n, hipMemcpyDeviceToHost, s);
+        }
+        (void)hipMemcpyAsync(part.data(), dpart.p, sizeof(double) * cost_blocks, hipMemcpyDeviceToHost, s);
+        if (hipStreamSynchronize(s) != hipSuccess || hipGetLastError() != hipSuccess) return liw_ctx_fail(c, LIW_EHIP, "pose graph evaluate");
+        double t = 0.0;
+        for (double v : part) t += v;
+        *cost = 0.5 * t;
+        return LIW_OK;
+    };
+    auto is_const = [&](int i) { return i / 6 == const_pose; };
+    auto plus = [&](const std::vector<double>& xin, const std::vector<double>& delta, std::vector<double>& xout) {
+        xout = xin;
+        for (int i = 0; i < N; ++i) {
+            if (i == const_pose) continue;
+            for (int k = 0; k < 3; ++k) xout[i * 6 + k] = xin[i * 6 + k] + delta[i * 6 + k];
+            so3_plus_host(&xin[i * 6 + 3], &delta[i * 6 + 3], &xout[i * 6 + 3]);
+        }
+    };
+    auto gradient_max_norm = [&]() {
+        std::vector<double> ng(n), xp;
+        for (int i = 0; i < n; ++i) ng[i] = -g[i];
+        plus(x, ng, xp);
+        double m = 0.0;
+        for (int i = 0; i < n; ++i) if (!is_const(i)) m = std::max(m, std::fabs(x[i] - xp[i]));
+        return m;
+    };
+
+    // ---- Ceres trust-region Levenberg-Marquardt (defaults)
+    const int K = max_iters > 0 ? max_iters : 50;
+    const double kMinDiagH = 1e-6, kMaxDiagH = 1e32, kMinRelDecH = 1e-3, kFuncTolH = 1e-6, kGradTolH = 1e-10, kParamTolH = 1e-8;
+    double radius = 1e4, decrease_factor = 2.0, x_cost = 0.0;
+    bool reuse_diagonal = false;
+    liw_summary sum{};
+    if (int r = evaluate(x, dx, true, &x_cost)) return r;
+    if (linearize_only) {   // dense tangent-space normal equations (lower triangle mirrored), constant key frame = identity block
+        if (q.cost_out) *q.cost_out = x_cost;
+        if (q.g_out) std::memcpy(q.g_out, g.data(), sizeof(double) * n);
+        if (q.H_out) {
+            std::vector<double> Hp((size_t)np * np);
+            if (hipMemcpy(Hp.data(), dH.p, sizeof(double) * (size_t)np * np, hipMemcpyDeviceToHost) != hipSuccess) return liw_ctx_fail(c, LIW_EHIP, "hipMemcpy");
+            for (int i = 0; i < n; ++i) for (int j = 0; j <= i; ++j) q.H_out[(size_t)i * n + j] = q.H_out[(size_t)j * n + i] = Hp[(size_t)i * np + j];
+        }
+        return LIW_OK;
+    }
+    sum.initial_cost = x_cost;
+    for (int i = 0; i < n; ++i) scale[i] = is_const(i) ? 1.0 : 1.0 / (1.0 + std::sqrt(Hdiag[i]));
+    double x_norm = 0.0;
+    for (int i = 0; i < n; ++i) if (!is_const(i)) x_norm += x[i] * x[i];
+    x_norm = std::sqrt(x_norm);
+    double gmax = gradient_max_norm();
+    int iteration = 0, invalid_steps = 0, termination = 0, successful = 0;
+    bool last_successful = true;
+    if (gmax <= kGradTolH) termination = 1;
+    while (!termination) {
+        if (iteration >= K) { termination = 4; break; }
+        if (iteration > 0 && last_successful && gmax <= kGradTolH) { termination = 1; break; }
+        if (!(radius > 1e-32)) { termination = 5; break; }
+        ++iteration;
+        for (int i = 0; i < n; ++i) gs[i] = is_const(i) ? 0.0 : g[i] * scale[i];
+        if (!reuse_diagonal)
+            for (int i = 0; i < n; ++i) dgn[i] = is_const(i) ? 0.0 : std::min(std::max(Hdiag[i] * scale[i] * scale[i], kMinDiagH), kMaxDiagH);
+        reuse_diagonal = true;
+        up(dscale, scale.data(), sizeof(double) * n); up(ddgn, dgn.data(), sizeof(double) * n);
+        std::fill(y.begin(), y.end(), 0.0);
+        std::memcpy(y.data(), gs.data(), sizeof(double) * n);
+        up(drhs, y.data(), sizeof(double) * np);
+        hipLaunchKernelGGL(k_pg_scale_damp, dim3((np + 255) / 256, np), dim3(256), 0, s, n, np, np, dH.as<double>(), dscale.as<double>(), ddgn.as<double>(), radius,
+                           dA.as<double>());
+        if (int r = dense_cholesky_solve(c, dA.as<double>(), np, drhs.as<double>(), dst.as<int>(), s)) return r;
+        int st = 0;
+        (void)hipMemcpyAsync(y.data(), drhs.p, sizeof(double) * np, hipMemcpyDeviceToHost, s);
+        (void)hipMemcpyAsync(&st, dst.p, sizeof(int), hipMemcpyDeviceToHost, s);
+        if (hipStreamSynchronize(s) != hipSuccess) return liw_ctx_fail(c, LIW_EHIP, "pose graph solve");
+        bool solved = st == 0;
+        for (int i = 0; i < n && solved; ++i) if (!std::isfinite(y[i])) solved = false;
+        // model cost change with (A + D^2) y = g_s, step = -y:  (y'g_s + y'D^2 y) / 2
+        double model_cost_change = 0.0;
+        bool valid = false;
+        if (solved) {
+            double ytg = 0.0, dsum = 0.0;
+            for (int i = 0; i < n; ++i) if (!is_const(i)) { ytg += y[i] * gs[i]; dsum += dgn[i] / radius * y[i] * y[i]; }
+            model_cost_change = 0.5 * (ytg + dsum);
+            valid = model_cost_change > 0.0 && std::isfinite(model_cost_change);
+        }
+        if (!valid) {
+            if (++invalid_steps >= 5) { termination = 6; --iteration; break; }
+            radius /= decrease_factor; decrease_factor *= 2.0; reuse_diagonal = true;
+            last_successful = false;
+            continue;
+        }
+        invalid_steps = 0;
+        std::vector<double> delta(n, 0.0);
+        for (int i = 0; i < n; ++i) if (!is_const(i)) delta[i] = -y[i] * scale[i];
+        plus(x, delta, cand);
+        double candidate_cost = 0.0;
+        if (int r = evaluate(cand, dxc, false, &candidate_cost)) return r;
+        if (!std::isfinite(candidate_cost)) candidate_cost = 1.7976931348623157e308;
+        if (getenv("LIW_PG_DEBUG")) { double yn = 0, gn = 0; for (int i = 0; i < n; ++i) { yn += y[i] * y[i]; gn += gs[i] * gs[i]; } fprintf(stderr, "[pg] it %d x_cost %.6f model %.6f cand %.6f |y| %.6g |gs| %.6g radius %.3g y0..: %g %g %g %g\n", iteration, x_cost, model_cost_change, candidate_cost, std::sqrt(yn), std::sqrt(gn), radius, y[6], y[7], y[8], y[9]); }
+        double step_norm = 0.0;
+        for (int i = 0; i < n; ++i) if (!is_const(i)) step_norm += (x[i] - cand[i]) * (x[i] - cand[i]);
+        step_norm = std::sqrt(step_norm);
+        if (step_norm <= kParamTolH * (x_norm + kParamTolH)) { termination = 3; break; }
+        if (std::fabs(x_cost - candidate_cost) <= kFuncTolH * x_cost) { termination = 2; break; }
+        const double rho = (x_cost - candidate_cost) / model_cost_change;
+        if (rho > kMinRelDecH) {
+            x = cand;
+            if (int r = evaluate(x, dx, true, &x_cost)) return r;
+            x_norm = 0.0;
+            for (int i = 0; i < n; ++i) if (!is_const(i)) x_norm += x[i] * x[i];
+            x_norm = std::sqrt(x_norm);
+            gmax = gradient_max_norm();
+            radius = std::min(1e16, radius / std::max(1.0 / 3.0, 1.0 - std::pow(2.0 * rho - 1.0, 3.0)));
+            decrease_factor = 2.0; reuse_diagonal = false;
+            ++successful;
+            last_successful = true;
+        } else {
+            radius /= decrease_factor; decrease_factor *= 2.0; reuse_diagonal = true;
+            last_successful = false;
+        }
+    }
+    std::memcpy(poses, x.data(), sizeof(double) * n);
+    sum.iterations = iteration; sum.successful_steps = successful; sum.termination = termination; sum.final_cost = x_cost;
+    if (summary) *summary = sum;
+    return LIW_OK;
+}
+
+}  // extern "C"

@@ -135,6 +135,12 @@ static void normalize_tf_host(double* R) {
     R[6] = txz - twy;       R[7] = tyz + twx;       R[8] = 1 - (txx + tyy);
 }
 void liw_normalize_rotation_host(double* R9) { normalize_tf_host(R9); }   // used by liw_laser.cpp
+// context accessors for the other translation units of the library (k_posegraph.hip)
+hipStream_t liw_ctx_stream(liw_ctx* c) { return c->stream; }
+const DevParams* liw_ctx_devparams(liw_ctx* c) { return &c->dp; }
+int liw_ctx_device(liw_ctx* c) { return c->prm.device; }
+bool liw_ctx_has_device(liw_ctx* c) { return c && c->have_device; }
+int liw_ctx_fail(liw_ctx* c, int code, const char* what) { return fail(c, code, what); }
 
 void liw_fill_devparams(const liw_params* prm, DevParams* dp) {
     for (int i = 0; i < 3; ++i) {

@@ -511,3 +511,53 @@ int oracle_traj_tum(void* hv, char* buf, int cap) {
 }
 int oracle_traj_last_iterations(void* hv) { return ((oracle_traj_ctx*)hv)->t->opt_solver.last_summary.num_iterations; }
 }
+
+// ---------------------------------------------------------------------------------------------------
+// pose-graph restatement (posegraph.h)
+#include "posegraph.h"
+extern "C" {
+struct oracle_pg_params_c { double loop_sigma_p[3], loop_sigma_q[3]; double loop_edge_k; int use_ground_p_factor, use_ground_q_factor; };
+// out5: iterations, successful steps, termination, then initial_cost / final_cost in cost2
+int oracle_posegraph_solve(void* hv, const oracle_pg_params_c* pc, int N, double* poses, int n_seq, const int* seq_idx, const double* seq_tf12, int n_loop,
+                           const int* loop_idx, const double* loop_tf12, int max_iters, int* out3, double* cost2) {
+    oracle_ctx* h = (oracle_ctx*)hv;
+    pg_params P;
+    for (int k = 0; k < 3; ++k) { P.loop_sigma_p[k] = pc->loop_sigma_p[k]; P.loop_sigma_q[k] = pc->loop_sigma_q[k]; }
+    P.loop_edge_k = pc->loop_edge_k; P.use_ground_p_factor = pc->use_ground_p_factor != 0; P.use_ground_q_factor = pc->use_ground_q_factor != 0;
+    auto tf = [](const double* t) { Iso3<double> T; for (int a = 0; a < 3; ++a) { for (int b = 0; b < 3; ++b) T.R(a, b) = t[a * 3 + b]; T.t(a) = t[9 + a]; } return T; };
+    std::vector<std::pair<int, int>> si, li;
+    std::vector<Iso3<double>> st, lt;
+    for (int e = 0; e < n_seq; ++e) { si.emplace_back(seq_idx[2 * e], seq_idx[2 * e + 1]); st.push_back(tf(seq_tf12 + 12 * e)); }
+    for (int e = 0; e < n_loop; ++e) { li.emplace_back(loop_idx[2 * e], loop_idx[2 * e + 1]); lt.push_back(tf(loop_tf12 + 12 * e)); }
+    miniceres::Summary sum;
+    keyframe_manager_solve(&h->prm, P, N, poses, si, st, li, lt, max_iters, &sum);
+    int succ = 0;
+    for (auto& r : sum.iterations) if (r.iteration > 0 && r.step_is_successful) ++succ;
+    out3[0] = sum.num_iterations; out3[1] = succ; out3[2] = sum.termination;
+    cost2[0] = sum.initial_cost; cost2[1] = sum.final_cost;
+    return 0;
+}
+// normal equations of the pose graph over the non-constant entries; idx[k] = index into the [N][6] pose array of tangent entry k.
+// Returns nt (call with H = NULL first to size the buffers).
+int oracle_posegraph_linearize(void* hv, const oracle_pg_params_c* pc, int N, const double* poses_in, int n_seq, const int* seq_idx, const double* seq_tf12,
+                               int n_loop, const int* loop_idx, const double* loop_tf12, double* H, double* g, double* cost, int* idx) {
+    oracle_ctx* h = (oracle_ctx*)hv;
+    pg_params P;
+    for (int k = 0; k < 3; ++k) { P.loop_sigma_p[k] = pc->loop_sigma_p[k]; P.loop_sigma_q[k] = pc->loop_sigma_q[k]; }
+    P.loop_edge_k = pc->loop_edge_k; P.use_ground_p_factor = pc->use_ground_p_factor != 0; P.use_ground_q_factor = pc->use_ground_q_factor != 0;
+    auto tf = [](const double* t) { Iso3<double> T; for (int a = 0; a < 3; ++a) { for (int b = 0; b < 3; ++b) T.R(a, b) = t[a * 3 + b]; T.t(a) = t[9 + a]; } return T; };
+    std::vector<std::pair<int, int>> si, li;
+    std::vector<Iso3<double>> st, lt;
+    for (int e = 0; e < n_seq; ++e) { si.emplace_back(seq_idx[2 * e], seq_idx[2 * e + 1]); st.push_back(tf(seq_tf12 + 12 * e)); }
+    for (int e = 0; e < n_loop; ++e) { li.emplace_back(loop_idx[2 * e], loop_idx[2 * e + 1]); lt.push_back(tf(loop_tf12 + 12 * e)); }
+    std::vector<double> poses(poses_in, poses_in + 6 * N), Hv, gv;
+    std::vector<int> pot;
+    double c = 0.0;
+    const int nt = keyframe_manager_linearize(&h->prm, P, N, poses.data(), si, st, li, lt, Hv, gv, c, pot);
+    if (H) std::memcpy(H, Hv.data(), sizeof(double) * (size_t)nt * nt);
+    if (g) std::memcpy(g, gv.data(), sizeof(double) * nt);
+    if (cost) *cost = c;
+    if (idx) std::memcpy(idx, pot.data(), sizeof(int) * nt);
+    return nt;
+}
+}

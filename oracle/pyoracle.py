@@ -486,3 +486,51 @@ class TrajectoryOracle:
             lib().oracle_traj_destroy(self.h)
         except Exception:
             pass
+
+
+# ---------------------------------------------------------------------------------------------------
+# pose-graph restatement (posegraph.h)
+class PgParamsC(C.Structure):
+    _fields_ = [("loop_sigma_p", C.c_double * 3), ("loop_sigma_q", C.c_double * 3), ("loop_edge_k", C.c_double),
+                ("use_ground_p_factor", C.c_int), ("use_ground_q_factor", C.c_int)]
+
+
+def posegraph_solve(orc, pg, poses, seq_idx, seq_tf12, loop_idx=None, loop_tf12=None, max_iters=0):
+    """orc: Oracle (extrinsics / ground sigmas); pg: dict as 2dliw-slam_amd.posegraph.office_pg_params()."""
+    s = PgParamsC()
+    s.loop_sigma_p[:] = [float(v) for v in pg["loop_sigma_p"]]
+    s.loop_sigma_q[:] = [float(v) for v in pg["loop_sigma_q"]]
+    s.loop_edge_k = float(pg["loop_edge_k"])
+    s.use_ground_p_factor = int(bool(pg["use_ground_p_factor"]))
+    s.use_ground_q_factor = int(bool(pg["use_ground_q_factor"]))
+    x = np.ascontiguousarray(poses, dtype=np.float64).reshape(-1, 6).copy()
+    si, st = np.ascontiguousarray(seq_idx, dtype=np.int32).reshape(-1, 2), np.ascontiguousarray(seq_tf12, dtype=np.float64).reshape(-1, 12)
+    nl = 0 if loop_idx is None else len(loop_idx)
+    li = np.ascontiguousarray(loop_idx if nl else np.zeros((1, 2)), dtype=np.int32).reshape(-1, 2)
+    lt = np.ascontiguousarray(loop_tf12 if nl else np.zeros((1, 12)), dtype=np.float64).reshape(-1, 12)
+    out3, cost2 = (C.c_int * 3)(), (C.c_double * 2)()
+    ipt = C.POINTER(C.c_int)
+    lib().oracle_posegraph_solve(orc.h, C.byref(s), C.c_int(x.shape[0]), _p(x), C.c_int(si.shape[0]), si.ctypes.data_as(ipt), _p(st), C.c_int(nl),
+                                 li.ctypes.data_as(ipt), _p(lt), C.c_int(max_iters), out3, cost2)
+    return x, dict(iterations=out3[0], successful=out3[1], termination=out3[2], initial_cost=cost2[0], final_cost=cost2[1])
+
+
+def posegraph_linearize(orc, pg, poses, seq_idx, seq_tf12, loop_idx=None, loop_tf12=None):
+    """-> H [nt, nt], g [nt], cost, idx [nt] (flat index into the [N, 6] pose array of every tangent entry)"""
+    s = PgParamsC()
+    s.loop_sigma_p[:] = [float(v) for v in pg["loop_sigma_p"]]
+    s.loop_sigma_q[:] = [float(v) for v in pg["loop_sigma_q"]]
+    s.loop_edge_k = float(pg["loop_edge_k"])
+    s.use_ground_p_factor = int(bool(pg["use_ground_p_factor"]))
+    s.use_ground_q_factor = int(bool(pg["use_ground_q_factor"]))
+    x = np.ascontiguousarray(poses, dtype=np.float64).reshape(-1, 6)
+    si, st = np.ascontiguousarray(seq_idx, dtype=np.int32).reshape(-1, 2), np.ascontiguousarray(seq_tf12, dtype=np.float64).reshape(-1, 12)
+    nl = 0 if loop_idx is None else len(loop_idx)
+    li = np.ascontiguousarray(loop_idx if nl else np.zeros((1, 2)), dtype=np.int32).reshape(-1, 2)
+    lt = np.ascontiguousarray(loop_tf12 if nl else np.zeros((1, 12)), dtype=np.float64).reshape(-1, 12)
+    ipt = C.POINTER(C.c_int)
+    n = 6 * x.shape[0]
+    H, g, cost, idx = np.zeros((n, n)), np.zeros(n), C.c_double(0), np.zeros(n, dtype=np.int32)
+    nt = lib().oracle_posegraph_linearize(orc.h, C.byref(s), C.c_int(x.shape[0]), _p(x), C.c_int(si.shape[0]), si.ctypes.data_as(ipt), _p(st), C.c_int(nl),
+                                          li.ctypes.data_as(ipt), _p(lt), _p(H), _p(g), C.byref(cost), idx.ctypes.data_as(ipt))
+    return H.reshape(-1)[:nt * nt].reshape(nt, nt).copy(), g[:nt].copy(), cost.value, idx[:nt].copy()

@@ -36,6 +36,16 @@ def test_io_header_symbols_are_exported(liw):
     assert sorted(set(liw.outputs.IO_EXPORTS)) == declared
 
 
+def test_posegraph_header_symbols_are_exported(liw):
+    hdr = open(os.path.join(ROOT, "include", "liw_posegraph.h")).read()
+    declared = sorted(set(re.findall(r"\b(liw_(?:posegraph|dense)_[A-Za-z_0-9]+)\s*\(", hdr)))
+    L = liw.lib()
+    assert not [s for s in declared if not hasattr(L, s)]
+    assert sorted(set(liw.posegraph.PG_EXPORTS)) == declared
+    lie = sorted(set(re.findall(r"\b(liw_lie_[A-Za-z_0-9]+)\s*\(", open(os.path.join(ROOT, "include", "liw_lie.h")).read())))
+    assert lie and not [s for s in lie if not hasattr(L, s)]
+
+
 def test_no_cpu_fallback(liw, synth):
     import torch
     if torch.cuda.is_available():
