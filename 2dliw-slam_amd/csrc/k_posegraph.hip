@@ -11,7 +11,7 @@
 //   k_pg_scale_damp  A = S H S + diag(D / radius)  (Jacobi scaling, LM diagonal), the matrix that is factorised.
 //   blocked Cholesky k_potrf64 (register-resident, one wave: column per lane, v_readlane broadcasts), k_trsm64 (row per
 //                    lane against the LDS-resident diagonal factor), k_syrk64 (trailing update on the fp64 matrix cores:
-//                    v_mfma_f64_16x16x4_f64, operands staged through LDS), k_trisolve (L y = b, L^T x = y in one launch).
+//                    v_mfma_f64_16x16x4_f64, operands staged through LDS), k_trisolve_pipe (L y = b, L^T x = y as a flag-synchronised pipeline over the blocks).
 // The trust-region bookkeeping (radius, step acceptance, the three Ceres tolerances) runs on the host between launches;
 // the per-iteration device->host traffic is the step vector (6N doubles) and two cost scalars.
 #include <algorithm>
@@ -320,69 +320,70 @@ __global__ __launch_bounds__(256) void k_syrk64(double* A, int ld, int k0, int n
         }
 }
 
-// L y = b then L^T x = y, one work-group (1024 threads), blocks of 64 unknowns; the 64x64 diagonal block of each step is
-// held in registers by wave 0 (row per lane going forward, column per lane going back), its unknowns are exchanged with
-// v_readlane, and all 16 waves apply the solved block to the remaining right-hand side
-__global__ __launch_bounds__(1024) void k_trisolve(const double* L, int ld, int np, double* b) {
-    __shared__ double xs[64];
+// Triangular solves L y = b (DIR = 0) and L^T x = y (DIR = 1) as a pipeline over the 64-unknown blocks: work-group i owns
+// block i, consumes the solved blocks it depends on as soon as their flag is published (tile of L through LDS, 64x64
+// mat-vec), then solves its diagonal block in one wave (row / column per lane, v_readlane exchange) and publishes its own
+// flag.  Work-groups are dispatched in index order and only wait on blocks that were dispatched before them (forward: lower
+// indices; backward: the grid is reversed), so the spin-waits cannot deadlock even when not all groups are resident.
+template <int DIR>
+__global__ __launch_bounds__(256) void k_trisolve_pipe(const double* L, int ld, int nb, double* b, int* flags) {
+    __shared__ double tile[64 * 65];
+    __shared__ double xs[64], part[4][64];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int nb = np / 64;
-    for (int k = 0; k < nb; ++k) {   // forward
+    const int i = DIR == 0 ? (int)blockIdx.x : nb - 1 - (int)blockIdx.x;
+    const int i0 = 64 * i;
+    double acc = 0.0;   // thread (wave, lane): partial sum of unknown `lane` over the 16 tile rows / columns of its quarter
+    const int kbeg = DIR == 0 ? 0 : nb - 1, kend = i, kstep = DIR == 0 ? 1 : -1;
+    for (int k = kbeg; k != kend; k += kstep) {
         const int k0 = 64 * k;
-        if (wave == 0) {
-            double Lr[64];
-#pragma unroll
-            for (int m = 0; m < 64; ++m) Lr[m] = L[(size_t)(k0 + lane) * ld + k0 + m];
-            double v = b[k0 + lane];
-#pragma unroll
-            for (int m = 0; m < 64; ++m) {
-                const double ym = rdl64(v, m) / rdl64(Lr[m], m);
-                if (lane == m) v = ym;
-                else if (lane > m) v -= Lr[m] * ym;
-            }
-            xs[lane] = v;
-            b[k0 + lane] = v;
-        }
+        if (tid == 0) { while (__atomic_load_n(&flags[k], __ATOMIC_ACQUIRE) == 0) __builtin_amdgcn_s_sleep(1); }
         __syncthreads();
-        for (int r = k0 + 64 + tid; r < np; r += 1024) {
-            double s = 0.0;
-            const double* row = L + (size_t)r * ld + k0;
-#pragma unroll 8
-            for (int m = 0; m < 64; ++m) s += row[m] * xs[m];
-            b[r] -= s;
+        // forward: tile = L[i-block rows][k-block cols]; backward: tile = L[k-block rows][i-block cols] (used transposed)
+        const double* T = DIR == 0 ? L + (size_t)i0 * ld + k0 : L + (size_t)k0 * ld + i0;
+        for (int e = tid; e < 64 * 64; e += 256) { const int r = e >> 6, c = e & 63; tile[r * 65 + c] = T[(size_t)r * ld + c]; }
+        if (tid < 64) xs[tid] = __builtin_nontemporal_load(&b[k0 + tid]);
+        __syncthreads();
+        double s = 0.0;
+#pragma unroll
+        for (int m = 0; m < 16; ++m) {
+            const int q = 16 * wave + m;
+            s += (DIR == 0 ? tile[lane * 65 + q] : tile[q * 65 + lane]) * xs[q];
         }
+        acc += s;
         __syncthreads();
     }
-    for (int k = nb - 1; k >= 0; --k) {   // backward with L^T
-        const int k0 = 64 * k;
-        if (wave == 0) {
-            double Lc[64];
+    part[wave][lane] = acc;
+    __syncthreads();
+    if (wave == 0) {
+        double v = b[i0 + lane] - ((part[0][lane] + part[1][lane]) + (part[2][lane] + part[3][lane]));
+        double Ld[64];   // forward: row `lane` of the diagonal block; backward: column `lane`
 #pragma unroll
-            for (int m = 0; m < 64; ++m) Lc[m] = L[(size_t)(k0 + m) * ld + k0 + lane];   // column `lane`
-            double v = b[k0 + lane];
+        for (int m = 0; m < 64; ++m) Ld[m] = DIR == 0 ? L[(size_t)(i0 + lane) * ld + i0 + m] : L[(size_t)(i0 + m) * ld + i0 + lane];
+        if (DIR == 0) {
+#pragma unroll
+            for (int m = 0; m < 64; ++m) {
+                const double ym = rdl64(v, m) / rdl64(Ld[m], m);
+                if (lane == m) v = ym;
+                else if (lane > m) v -= Ld[m] * ym;
+            }
+        } else {
 #pragma unroll
             for (int m = 63; m >= 0; --m) {
-                const double xm = rdl64(v, m) / rdl64(Lc[m], m);
+                const double xm = rdl64(v, m) / rdl64(Ld[m], m);
                 if (lane == m) v = xm;
-                else if (lane < m) v -= Lc[m] * xm;
+                else if (lane < m) v -= Ld[m] * xm;
             }
-            xs[lane] = v;
-            b[k0 + lane] = v;
         }
-        __syncthreads();
-        for (int r = tid; r < k0; r += 1024) {     // b_r -= sum_m L[k0+m][r] x_m
-            double s = 0.0;
-#pragma unroll 8
-            for (int m = 0; m < 64; ++m) s += L[(size_t)(k0 + m) * ld + r] * xs[m];
-            b[r] -= s;
-        }
-        __syncthreads();
+        b[i0 + lane] = v;
+        __threadfence();
+        if (lane == 0) __atomic_store_n(&flags[i], 1, __ATOMIC_RELEASE);
     }
 }
 
 static int dense_cholesky_solve(liw_ctx* c, double* dA, int np, double* db, int* dstatus, hipStream_t s) {
+    // dstatus: [0] = not-positive-definite flag, [1 .. nb] forward flags, [1 + nb .. 2 nb] backward flags
     const int nb = np / 64;
-    (void)hipMemsetAsync(dstatus, 0, sizeof(int), s);
+    (void)hipMemsetAsync(dstatus, 0, sizeof(int) * (1 + 2 * (size_t)nb), s);
     for (int k = 0; k < nb; ++k) {
         hipLaunchKernelGGL(k_potrf64, dim3(1), dim3(64), 0, s, dA, np, 64 * k, dstatus);
         const int rem = nb - k - 1;
@@ -391,7 +392,8 @@ static int dense_cholesky_solve(liw_ctx* c, double* dA, int np, double* db, int*
             hipLaunchKernelGGL(k_syrk64, dim3(rem, rem), dim3(256), 0, s, dA, np, 64 * k, rem);
         }
     }
-    hipLaunchKernelGGL(k_trisolve, dim3(1), dim3(1024), 0, s, dA, np, np, db);
+    hipLaunchKernelGGL(k_trisolve_pipe<0>, dim3(nb), dim3(256), 0, s, dA, np, nb, db, dstatus + 1);
+    hipLaunchKernelGGL(k_trisolve_pipe<1>, dim3(nb), dim3(256), 0, s, dA, np, nb, db, dstatus + 1 + nb);
     if (hipGetLastError() != hipSuccess) return liw_ctx_fail(c, LIW_EHIP, "dense Cholesky launch");
     return LIW_OK;
 }
@@ -428,7 +430,7 @@ int liw_dense_spd_solve(liw_ctx* c, int n, const double* A, const double* b, dou
         else Ap[(size_t)i * np + i] = 1.0;
     }
     DBuf dA, db, dst;
-    if (dA.alloc(sizeof(double) * (size_t)np * np) || db.alloc(sizeof(double) * np) || dst.alloc(sizeof(int))) return liw_ctx_fail(c, LIW_ENOMEM, "hipMalloc");
+    if (dA.alloc(sizeof(double) * (size_t)np * np) || db.alloc(sizeof(double) * np) || dst.alloc(sizeof(int) * (1 + 2 * (size_t)(np / 64)))) return liw_ctx_fail(c, LIW_ENOMEM, "hipMalloc");
     (void)hipMemcpyAsync(dA.p, Ap.data(), sizeof(double) * (size_t)np * np, hipMemcpyHostToDevice, s);
     (void)hipMemcpyAsync(db.p, bp.data(), sizeof(double) * np, hipMemcpyHostToDevice, s);
     if (int r = dense_cholesky_solve(c, dA.as<double>(), np, db.as<double>(), dst.as<int>(), s)) return r;
@@ -500,7 +502,7 @@ static int pg_run(const PgCall& q) {
         dew.alloc(sizeof(double) * E) || dinc_off.alloc(sizeof(int) * (N + 1)) || dinc.alloc(sizeof(int) * 2 * (size_t)E) || dYe.alloc(sizeof(double) * 78 * (size_t)E) ||
         dYg.alloc(sizeof(double) * 14 * (size_t)N) || dH.alloc(sizeof(double) * (size_t)np * np) || dA.alloc(sizeof(double) * (size_t)np * np) ||
         dg.alloc(sizeof(double) * np) || dscale.alloc(sizeof(double) * np) || ddgn.alloc(sizeof(double) * np) || drhs.alloc(sizeof(double) * np) ||
-        dpart.alloc(sizeof(double) * cost_blocks) || dst.alloc(sizeof(int)))
+        dpart.alloc(sizeof(double) * cost_blocks) || dst.alloc(sizeof(int) * (1 + 2 * (size_t)(np / 64))))
         return liw_ctx_fail(c, LIW_ENOMEM, "hipMalloc");
     auto up = [&](DBuf& d, const void* src, size_t bytes) { (void)hipMemcpyAsync(d.p, src, bytes, hipMemcpyHostToDevice, s); };
     up(deidx, eidx.data(), sizeof(int) * eidx.size()); up(detf, etf.data(), sizeof(double) * etf.size()); up(dew, ew.data(), sizeof(double) * E);
