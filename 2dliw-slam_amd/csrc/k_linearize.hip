@@ -1,10 +1,11 @@
 // k_linearize.hip — factor residual/Jacobian evaluation + J^T J block partial sums (gfx950, fp64).
 //
-// One linearisation = four kernels over every residual block of every window of a batch, one wavefront (64-thread
-// work-group) per work item; the three role kernels write disjoint partial slots and run concurrently:
+// One linearisation = three role kernels over every residual block of every window of a batch (or ONE kernel for small
+// batches), one wavefront (64-thread work-group) per work item; the roles write disjoint partial slots and run concurrently:
 //   k_frame_tf  : per (window, frame): rows 0,1 of make_tf(p,theta) * T_imu_to_laser and d/dtheta_k (dual numbers,
-//                 direction-per-lane) — every exp_so3 of the laser path is hoisted here.
-//   k_lin_laser : one (window, owning frame) group per wave; a LANE is one laser_factor block (reference
+//                 direction-per-lane) — every exp_so3 of the laser path is hoisted out of the blocks (k_lin_all: done by
+//                 the laser waves themselves).
+//   k_lin_laser : G (window, owning frame) groups per wave; a LANE is one laser_factor block (reference
 //                 src/factor/laser_factor.h:45-89, two point-to-line rows), 64 blocks per pass, coalesced reads of the
 //                 component-major end-point arrays, closed-form Jacobian, register accumulation of the pair products
 //                 and ONE butterfly reduction per group.
@@ -23,25 +24,27 @@ namespace liw {
 // ------------------------------------------------------------------------------------------- laser
 // Frame transform record (FTF doubles): rows 0,1 of  make_tf(p,theta) * T_imu_to_laser  and d/dtheta_k, k = 0..2:
 //   [0..5] M[2][3]   [6..7] t[2]   [8+6k .. 8+6k+5] dM_k[2][3]   [26+2k .. 26+2k+1] dt_k[2]
-// k_frame_tf writes two records per (window, frame): slot 0 at the frame's own pose, slot 1 at the constant
-// laser_match pose (p1,q1) the tracking / marginalisation topologies tie the frame to.
-__global__ void k_frame_tf(int B, int n, const double* x, const double* match_pose, double* ftf, DevParams P, const LmState* lm) {
-    const int t = blockIdx.x * blockDim.x + threadIdx.x;
-    const int dir = t & 3, rec = t >> 2;           // 4 lanes per record: 3 derivative directions + value
-    if (rec >= B * n * 2) return;
-    const int slot = rec & 1, fi = rec >> 1;
-    if (lm && lm[fi / n].done) return;
-    const double* pose6 = slot ? (match_pose + (size_t)fi * 12) : (x + (size_t)fi * 15);
+// Two records per (window, frame): slot 0 at the frame's own pose, slot 1 at the constant laser_match pose (p1,q1) the
+// tracking / marginalisation topologies tie the frame to.  4 lanes per record: 3 derivative directions + the value.
+__device__ __forceinline__ void frame_tf_record(const DevParams& P, const double* pose6, int dir, double* o) {
     V3<LJ> p = cast_v3<LJ>(pose6);
     V3<LJ> th(LJ(pose6[3], dir == 0 ? 1.0 : 0.0), LJ(pose6[4], dir == 1 ? 1.0 : 0.0), LJ(pose6[5], dir == 2 ? 1.0 : 0.0));
     Iso<LJ> Twl = mul(make_tf(p, th), cast_iso<LJ>(P.Ril, P.til));
-    double* o = ftf + (size_t)rec * FTF;
     const LJ tt[2] = {Twl.t.x, Twl.t.y};
     if (dir == 3) {
         for (int r = 0; r < 2; ++r) { for (int c = 0; c < 3; ++c) o[r * 3 + c] = Twl.R(r, c).v; o[6 + r] = tt[r].v; }
     } else {
         for (int r = 0; r < 2; ++r) { for (int c = 0; c < 3; ++c) o[8 + 6 * dir + r * 3 + c] = Twl.R(r, c).d; o[26 + 2 * dir + r] = tt[r].d; }
     }
+}
+// large batches: every record once, ahead of the laser kernel (k_lin_all computes its records in the laser waves instead)
+__global__ void k_frame_tf(int B, int n, const double* x, const double* match_pose, double* ftf, DevParams P, const LmState* lm) {
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    const int dir = t & 3, rec = t >> 2;
+    if (rec >= B * n * 2) return;
+    const int slot = rec & 1, fi = rec >> 1;
+    if (lm && lm[fi / n].done) return;
+    frame_tf_record(P, slot ? (match_pose + (size_t)fi * 12) : (x + (size_t)fi * 15), dir, ftf + (size_t)rec * FTF);
 }
 
 // Wave-wide sums of V per-lane values (V = 32 or 16) in V-1 pair exchanges + log2(64/V) plain steps: each step pairs
@@ -78,263 +81,17 @@ constexpr int LASER_GMAX = 8;   // (window, frame) groups one wave may own
 // one free pose: [b_x b_y b_th0..2 r] (6, 21 pairs).  Every lane accumulates its blocks' pair products in
 // registers over all passes; one butterfly per group reduces them across the wave.
 template <bool BOTH>
+__device__ void laser_wave_local(const LinArgs& A, const DevParams& P, int G, int vblock) {
+#define LASER_LOCAL_TF 1
+#include "k_lin_laser_body.inc"
+#undef LASER_LOCAL_TF
+}
+template <bool BOTH>
 __global__ __launch_bounds__(64, 2) void k_lin_laser(LinArgs A, DevParams P, int G) {
-    constexpr int NC = BOTH ? 9 : 6;
-    constexpr int NP = NC * (NC + 1) / 2;
-    const int lane = threadIdx.x & 63;
-    const int n = A.n;
-    const int wpw = (n + G - 1) / G;                     // waves per window
-    const int b = blockIdx.x / wpw, i0 = (blockIdx.x % wpw) * G;
-    if (b >= A.B) return;
-    if (A.lm && A.lm[b].done) return;
-    const int i1 = min(n, i0 + G);                       // this wave owns the groups of frames i0 .. i1-1
-
-    // frame transforms of the wave's frames, staged in LDS (coalesced loads) and re-read close to each use, which keeps
-    // 64 doubles per frame out of the VGPRs.  Per frame: a = frame 0 (init) or the constant laser_match pose, b = own.
-    __shared__ double tf[LASER_GMAX * 2 * FTF];
-    __shared__ int goff[LASER_GMAX + 1];
-    __shared__ double red[24 * 65];      // lane-transpose buffer of the group reduction
-    __shared__ double tl[48];            // pair totals of the group being written
-    __shared__ int slot_src[128];
-    __shared__ int fon_lds[LASER_GMAX];
-    for (int g = 0; g < i1 - i0; ++g) {
-        const int i = i0 + g;
-        const double* Tag = A.ftf + (BOTH ? ((size_t)b * n * 2) : (((size_t)b * n + i) * 2 + 1)) * FTF;
-        const double* Tbg = A.ftf + (((size_t)b * n + i) * 2) * FTF;
-        tf[g * 64 + lane] = lane < FTF ? Tag[lane] : Tbg[lane - FTF];
-    }
-    // slot -> (pair index | 64 if negated), -1 = structural zero, of the 128-slot group record.  Unique-column index of a
-    // pose entry (0..5 = px py pz th0 th1 th2) and its sign:
-    {
-        auto pairidx = [](int c1, int c2) { if (c1 > c2) { const int t = c1; c1 = c2; c2 = t; } return c1 * NC - c1 * (c1 - 1) / 2 + (c2 - c1); };
-        auto col_a = [](int idx) { return idx < 2 ? idx : (idx == 2 ? -1 : idx - 1); };                       // a: x y - th0..2 -> 0 1 - 2 3 4
-        auto col_b = [](int idx) { return BOTH ? (idx < 2 ? idx : (idx == 2 ? -1 : idx + 2)) : (idx == 2 ? -1 : (idx < 2 ? idx : idx - 1)); };
-        auto sgn_b = [](int idx) { return (BOTH && idx < 2) ? -1.0 : 1.0; };
-        constexpr int RC = NC - 1;
-#pragma unroll
-        for (int qq = 0; qq < 2; ++qq) {
-            const int s = lane + 64 * qq;
-            int src = -1;
-            double sg = 1.0;
-            if (s < 36) {
-                const int ca = col_a(s / 6), cb = col_a(s % 6);
-                if (BOTH && ca >= 0 && cb >= 0) src = pairidx(ca, cb);
-            } else if (s < 72) {
-                const int ia = (s - 36) / 6, ib = (s - 36) % 6;
-                const int ca = col_b(ia), cb = col_b(ib);
-                if (ca >= 0 && cb >= 0) { src = pairidx(ca, cb); sg = sgn_b(ia) * sgn_b(ib); }
-            } else if (s < 108) {
-                const int ia = (s - 72) / 6, ib = (s - 72) % 6;
-                const int ca = col_a(ia), cb = col_b(ib);
-                if (BOTH && ca >= 0 && cb >= 0) { src = pairidx(ca, cb); sg = sgn_b(ib); }
-            } else if (s < 114) {
-                const int ca = col_a(s - 108);
-                if (BOTH && ca >= 0) src = pairidx(ca, RC);
-            } else if (s < 120) {
-                const int cb = col_b(s - 114);
-                if (cb >= 0) { src = pairidx(cb, RC); sg = sgn_b(s - 114); }
-            } else if (s == 120) {
-                src = pairidx(RC, RC);
-            }
-            slot_src[s] = src < 0 ? -1 : (src | (sg < 0.0 ? 64 : 0));
-        }
-    }
-    LSTAMP(0);
-    if (lane < i1 - i0) fon_lds[lane] = (A.has_match[b * n + i0 + lane] && (A.mode != LIW_MODE_TRACK || i0 + lane == n - 1)) ? 1 : 0;
-    if (lane <= i1 - i0) goff[lane] = A.group_off[b * (n + 1) + i0 + lane];
-    __syncthreads();
-    LSTAMP(1);
-    int pass_dbg = 0; (void)pass_dbg;
-    const int J0 = goff[0], J1 = goff[i1 - i0];
-
-    constexpr int NACC = BOTH ? 48 : 32;   // 45 / 21 pair accumulators, padded to 32 (+16)
-    double acc[NACC];
-#pragma unroll
-    for (int e = 0; e < NACC; ++e) acc[e] = 0.0;
-    const size_t Lt = (size_t)A.Ltot;
-    int cf = i0;                           // group being accumulated (uniform)
-    double q[12];                          // this lane's block record (end points of the two matched segments)
-    if (J0 + lane < J1) {
-#pragma unroll
-        for (int c = 0; c < 12; ++c) q[c] = A.laser_pts[c * Lt + J0 + lane];
-    }
-    for (int base = J0;; base += 64) {
-        const int j = base + lane;
-        asm volatile("" ::: "memory");   // keeps the LDS reads of the transforms inside the pass (no loop-invariant hoisting)
-        // owning frame of this lane's block = number of group boundaries at or below j
-        int fl = i0;
-        for (int g = 1; g < i1 - i0; ++g) fl += (j >= goff[g]) ? 1 : 0;
-        const bool fon = fon_lds[fl - i0] != 0;
-        const bool valid = j < J1 && fon;
-        double rows[2][NC];
-        LSTAMP(8 + pass_dbg * 8 + 0);
-        if (valid) {
-            const double* tfl = tf + (fl - i0) * 64;
-#define TA(k) tfl[(k)]
-#define TB(k) tfl[FTF + (k)]
-            // laser_factor ctor: len1, len2, sum   (laser_factor.h:30-43)
-            const double d1x = q[0] - q[3], d1y = q[1] - q[4], d1z = q[2] - q[5];
-            const double d2x = q[6] - q[9], d2y = q[7] - q[10], d2z = q[8] - q[11];
-            // min(len1, len2) = sqrt(min(len1^2, len2^2)) exactly (sqrt is monotone and correctly rounded): one sqrt
-            const double lmin = sqrt(fmin(d1x * d1x + d1y * d1y + d1z * d1z, d2x * d2x + d2y * d2y + d2z * d2z));
-            const double sum = sqrt(lmin / 2.0 / 0.02);
-            // world points, z dropped (laser_factor.h:67-77)
-            double Ap[2], Bp[2], C[2][2];
-#pragma unroll
-            for (int r = 0; r < 2; ++r) {
-                Ap[r] = TA(r * 3) * q[0] + TA(r * 3 + 1) * q[1] + TA(r * 3 + 2) * q[2] + TA(6 + r);
-                Bp[r] = TA(r * 3) * q[3] + TA(r * 3 + 1) * q[4] + TA(r * 3 + 2) * q[5] + TA(6 + r);
-                C[0][r] = TB(r * 3) * q[6] + TB(r * 3 + 1) * q[7] + TB(r * 3 + 2) * q[8] + TB(6 + r);
-                C[1][r] = TB(r * 3) * q[9] + TB(r * 3 + 1) * q[10] + TB(r * 3 + 2) * q[11] + TB(6 + r);
-            }
-            const double ux = Bp[0] - Ap[0], uy = Bp[1] - Ap[1];
-            const double zz = ux * ux + uy * uy;
-            const bool regular = zz > 0.0;
-            const double rlen = regular ? 1.0 / sqrt(zz) : 1.0;   // one reciprocal instead of eight divisions by the length
-            const double lx = ux * rlen, ly = uy * rlen;   // degenerate: stays the (zero) difference vector
-            double dBx[3], dBy[3], dlx[3], dly[3];
-            __builtin_amdgcn_sched_barrier(0);
-            if (BOTH) {
-#pragma unroll
-                for (int k = 0; k < 3; ++k) {
-                    __builtin_amdgcn_sched_barrier(0);
-                    const int dMo = 8 + 6 * k, dto = 26 + 2 * k;
-                    const double m0 = TA(dMo), m1 = TA(dMo + 1), m2 = TA(dMo + 2), m3 = TA(dMo + 3), m4 = TA(dMo + 4), m5 = TA(dMo + 5);
-                    const double t0 = TA(dto), t1 = TA(dto + 1);
-                    const double dAx = m0 * q[0] + m1 * q[1] + m2 * q[2] + t0;
-                    const double dAy = m3 * q[0] + m4 * q[1] + m5 * q[2] + t1;
-                    dBx[k] = m0 * q[3] + m1 * q[4] + m2 * q[5] + t0;
-                    dBy[k] = m3 * q[3] + m4 * q[4] + m5 * q[5] + t1;
-                    const double dux = dBx[k] - dAx, duy = dBy[k] - dAy;
-                    const double pr = lx * dux + ly * duy;
-                    dlx[k] = (dux - lx * pr) * rlen;
-                    dly[k] = (duy - ly * pr) * rlen;
-                }
-            }
-            const double w = sum * P.laser_sqrt_info;
-#pragma unroll
-            for (int k = 0; k < 2; ++k) {
-                __builtin_amdgcn_sched_barrier(0);
-                const double* pt = q + 6 + 3 * k;
-                const double ex = C[k][0] - Bp[0], ey = C[k][1] - Bp[1];
-                double dCx[3], dCy[3];
-#pragma unroll
-                for (int m = 0; m < 3; ++m) {
-                    const int dMo = 8 + 6 * m, dto = 26 + 2 * m;
-                    dCx[m] = TB(dMo) * pt[0] + TB(dMo + 1) * pt[1] + TB(dMo + 2) * pt[2] + TB(dto);
-                    dCy[m] = TB(dMo + 3) * pt[0] + TB(dMo + 4) * pt[1] + TB(dMo + 5) * pt[2] + TB(dto + 1);
-                }
-                // jc: [a_x a_y a_th0..2 b_th0..2]; b_x = -a_x, b_y = -a_y
-                double dist, jc[8];
-                if (regular) {
-                    const double s = lx * ey - ly * ex;
-                    const double sg = s < 0.0 ? -1.0 : 1.0;
-                    dist = fabs(s);
-                    jc[0] = sg * ly; jc[1] = -sg * lx;
-#pragma unroll
-                    for (int m = 0; m < 3; ++m) {
-                        jc[2 + m] = BOTH ? sg * (dlx[m] * ey - dly[m] * ex - lx * dBy[m] + ly * dBx[m]) : 0.0;
-                        jc[5 + m] = sg * (lx * dCy[m] - ly * dCx[m]);
-                    }
-                } else {  // zero-length reference segment: distance to the point B (Jet semantics of normalized(0))
-                    dist = sqrt(ex * ex + ey * ey);
-                    const double nx = ex / dist, ny = ey / dist;
-                    jc[0] = -nx; jc[1] = -ny;
-#pragma unroll
-                    for (int m = 0; m < 3; ++m) {
-                        jc[2 + m] = BOTH ? -(nx * dBx[m] + ny * dBy[m]) : 0.0;
-                        jc[5 + m] = nx * dCx[m] + ny * dCy[m];
-                    }
-                }
-                const double res = sum * (P.laser_sqrt_info * dist);
-                if (BOTH) {
-#pragma unroll
-                    for (int c = 0; c < 8; ++c) rows[k][c] = w * jc[c];
-                } else {
-                    rows[k][0] = -w * jc[0]; rows[k][1] = -w * jc[1];
-#pragma unroll
-                    for (int c = 0; c < 3; ++c) rows[k][2 + c] = w * jc[5 + c];
-                }
-                rows[k][NC - 1] = res;
-                if (A.dbg_laser_res) A.dbg_laser_res[(size_t)j * 2 + k] = res;
-                if (A.dbg_laser_jac) {
-                    double* dj = A.dbg_laser_jac + ((size_t)j * 2 + k) * 12;
-                    dj[0] = w * jc[0]; dj[1] = w * jc[1]; dj[2] = 0.0;
-                    dj[3] = w * jc[2]; dj[4] = w * jc[3]; dj[5] = w * jc[4];
-                    dj[6] = -w * jc[0]; dj[7] = -w * jc[1]; dj[8] = 0.0;
-                    dj[9] = w * jc[5]; dj[10] = w * jc[6]; dj[11] = w * jc[7];
-                }
-            }
-#undef TA
-#undef TB
-        }
-        LSTAMP(8 + pass_dbg * 8 + 1);
-        // software pipeline: the record of the next chunk is in flight during the pair products and the group reduction
-        __builtin_amdgcn_sched_barrier(0);
-        if (j + 64 < J1) {
-#pragma unroll
-            for (int c = 0; c < 12; ++c) q[c] = A.laser_pts[c * Lt + j + 64];
-        }
-        __builtin_amdgcn_sched_barrier(0);
-        // ---- accumulate / flush: a 64-block chunk may straddle group boundaries; the lanes of group cf add their pair
-        //      products, and every group that ends inside (or before) this chunk is reduced and written.  The wave
-        //      therefore makes ceil(blocks/64) passes over its G groups instead of one ceil per group.
-        bool more = true;
-        int fl_dbg = 0; (void)fl_dbg;
-        while (more) {
-            LSTAMP(8 + pass_dbg * 8 + 2 + 2 * fl_dbg);
-            if (valid && fl == cf) {
-#pragma unroll
-                for (int k = 0; k < 2; ++k)
-#pragma unroll
-                    for (int c1 = 0; c1 < NC; ++c1)
-#pragma unroll
-                        for (int c2 = c1; c2 < NC; ++c2) acc[c1 * NC - c1 * (c1 - 1) / 2 + (c2 - c1)] += rows[k][c1] * rows[k][c2];
-            }
-            more = goff[cf + 1 - i0] <= base + 64;       // group cf is complete (uniform)
-            LSTAMP(8 + pass_dbg * 8 + 3 + 2 * fl_dbg);
-            fl_dbg = fl_dbg < 2 ? fl_dbg + 1 : 2;
-            if (more) {
-                double* out = A.PL + ((size_t)b * n + cf) * LP;
-                // totals of the NP pair accumulators over the 64 lanes: transpose through LDS, 24 values per round
-                // (lane (p, h) sums half h of value p's 64 entries), which costs ~50 LDS operations per round instead of
-                // a 49-exchange ds_bpermute butterfly whose latency chain dominated short groups
-#pragma unroll
-                for (int r = 0; r < NACC / 24 + (NACC % 24 ? 1 : 0); ++r) {
-                    if (r * 24 >= NP) break;
-                    __syncthreads();
-#pragma unroll
-                    for (int e = 0; e < 24; ++e)
-                        if (r * 24 + e < NP) red[e * 65 + lane] = acc[r * 24 + e];
-                    __syncthreads();
-                    const int pp = lane % 24, hh = lane < 48 ? lane / 24 : 0;
-                    const double* rp = red + pp * 65 + 32 * hh;
-                    double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
-#pragma unroll
-                    for (int k = 0; k < 32; k += 4) { s0 += rp[k]; s1 += rp[k + 1]; s2 += rp[k + 2]; s3 += rp[k + 3]; }
-                    const double part = (s0 + s1) + (s2 + s3);
-                    const double other = __shfl(part, (lane + 24) & 63, 64);
-                    if (lane < 24) tl[r * 24 + lane] = part + other;
-                }
-                __syncthreads();
-                (void)NP;
-                // compose the 128-slot record from the pair totals (source pair and sign per slot: table built once per wave)
-#pragma unroll
-                for (int qq = 0; qq < 2; ++qq) {
-                    const int s = lane + 64 * qq;
-                    const int src = slot_src[s];
-                    out[s] = src < 0 ? 0.0 : (src & 64 ? -tl[src & 63] : tl[src & 63]);
-                }
-#pragma unroll
-                for (int e = 0; e < NACC; ++e) acc[e] = 0.0;
-                ++cf;
-                more = cf < i1;
-            }
-        }
-        ++pass_dbg;
-        if (cf >= i1) break;
-    }
-    LSTAMP(2);
+    const int vblock = (int)blockIdx.x;
+#define LASER_LOCAL_TF 0
+#include "k_lin_laser_body.inc"
+#undef LASER_LOCAL_TF
 }
 
 // ------------------------------------------------------------------------------------------- imu
@@ -673,24 +430,40 @@ __device__ void ground_oct(const LinArgs& A, const DevParams& P, int b, int item
 }
 
 // ------------------------------------------------------------------------------------------- dispatch
-__global__ __launch_bounds__(64, 2) void k_lin_imu(LinArgs A, DevParams P) {
-    __shared__ double lds[IMU_PER_WAVE * 512];
+__device__ void imu_role(const LinArgs& A, const DevParams& P, int vblock, double* lds) {
     const int n = A.n, items = (n - 1 + IMU_PER_WAVE - 1) / IMU_PER_WAVE;
-    const int b = blockIdx.x / items, item = blockIdx.x % items;
+    const int b = vblock / items, item = vblock % items;
     if (b >= A.B) return;
     if (A.lm && A.lm[b].done) return;
     const int sel = A.lm ? (A.candidate ? 1 - A.lm[b].cur : A.lm[b].cur) : 0;
     imu_group(A, P, b, item, sel, lds);
 }
-__global__ __launch_bounds__(64) void k_lin_small(LinArgs A, DevParams P) {
-    __shared__ double lds[4 * 40 + 8];
+__device__ void small_role(const LinArgs& A, const DevParams& P, int vblock, double* lds) {
     const int n = A.n, n_wheel = (n - 1 + 3) / 4, items = n_wheel + (n + 7) / 8;
-    const int b = blockIdx.x / items, item = blockIdx.x % items;
+    const int b = vblock / items, item = vblock % items;
     if (b >= A.B) return;
     if (A.lm && A.lm[b].done) return;
     const int sel = A.lm ? (A.candidate ? 1 - A.lm[b].cur : A.lm[b].cur) : 0;
     if (item < n_wheel) wheel_quad(A, P, b, item, sel, lds);
     else ground_oct(A, P, b, item - n_wheel, sel, lds);
+}
+__global__ __launch_bounds__(64, 2) void k_lin_imu(LinArgs A, DevParams P) {
+    __shared__ double lds[IMU_PER_WAVE * 512];
+    imu_role(A, P, (int)blockIdx.x, lds);
+}
+__global__ __launch_bounds__(64) void k_lin_small(LinArgs A, DevParams P) {
+    __shared__ double lds[4 * 40 + 8];
+    small_role(A, P, (int)blockIdx.x, lds);
+}
+// Small batches (a single tracking window): every role in ONE launch, the role of a wave follows from its block index —
+// one kernel and no fork / join events per linearisation, which is what a latency-bound 2-frame window pays for.
+template <bool BOTH>
+__global__ __launch_bounds__(64, 2) void k_lin_all(LinArgs A, DevParams P, int G, int n_laser, int n_imu) {
+    __shared__ double lds[IMU_PER_WAVE * 512];   // IMU / small roles; the laser role brings its own static LDS
+    const int v = (int)blockIdx.x;
+    if (v < n_laser) laser_wave_local<BOTH>(A, P, G, v);
+    else if (v < n_laser + n_imu) imu_role(A, P, v - n_laser, lds);
+    else small_role(A, P, v - n_laser - n_imu, lds);
 }
 
 // laser block range of every (window, frame): first block of window b owned by a frame >= i
@@ -706,34 +479,35 @@ __global__ void k_group_offsets(int B, int n, const int* laser_off, const int* l
     group_off[t] = lo;
 }
 
-// Fork/join helper: the laser, IMU and wheel+ground role kernels write disjoint partial-sum slots, so they run
-// concurrently (main stream + two side streams joined by events).  The matrix-core phase of the IMU kernel then
-// overlaps the fp64 VALU work of the laser kernel on the same CUs.
+// One linearisation.  Large batches: the laser, IMU and wheel+ground role kernels write disjoint partial-sum slots, so
+// they run concurrently (main stream + two side streams joined by events); the matrix-core phase of the IMU kernel then
+// overlaps the fp64 VALU work of the laser kernel on the same CUs.  Small batches: one launch for everything (k_lin_all).
 void launch_linearize(const LinArgs& A, const DevParams& P, hipStream_t s, const LinFork* fk) {
     const int n = A.n, B = A.B;
-    const int nrec = B * n * 2 * 4;
+    // groups per wave: one for small batches (latency), up to LASER_GMAX for large ones (no ragged last pass per group)
+    int G = 1;
+    if (A.mode != LIW_MODE_TRACK) while (G < LASER_GMAX && (long)B * ((n + 2 * G - 1) / (2 * G)) >= 4096) G *= 2;
+    const int laser_waves = B * ((n + G - 1) / G);
+    const int imu_waves = (A.eval_small && n > 1) ? B * ((n - 1 + IMU_PER_WAVE - 1) / IMU_PER_WAVE) : 0;
+    const int small_waves = A.eval_small ? B * ((n - 1 + 3) / 4 + (n + 7) / 8) : 0;
+    if (A.eval_small && laser_waves + imu_waves + small_waves <= 256) {
+        const unsigned tot = (unsigned)(laser_waves + imu_waves + small_waves);
+        if (A.mode == LIW_MODE_INIT) hipLaunchKernelGGL(k_lin_all<true>, dim3(tot), dim3(64), 0, s, A, P, G, laser_waves, imu_waves);
+        else hipLaunchKernelGGL(k_lin_all<false>, dim3(tot), dim3(64), 0, s, A, P, G, laser_waves, imu_waves);
+        return;
+    }
     const bool fork = fk && fk->side[0] && A.eval_small;
     if (fork) {
-        // the small-factor kernels only need x: fork before the frame-transform kernel
         hipEventRecord(fk->ev_fork, s);
         hipStreamWaitEvent(fk->side[0], fk->ev_fork, 0);
         hipStreamWaitEvent(fk->side[1], fk->ev_fork, 0);
     }
     hipStream_t s_imu = fork ? fk->side[0] : s, s_small = fork ? fk->side[1] : s;
-    hipLaunchKernelGGL(k_frame_tf, dim3((nrec + 255) / 256), dim3(256), 0, s, B, n, A.x, A.match_pose, A.ftf, P, A.lm);
-    // groups per wave: one for small batches (latency), up to LASER_GMAX for large ones (no ragged last pass per group)
-    int G = 1;
-    if (A.mode != LIW_MODE_TRACK) while (G < LASER_GMAX && (long)B * ((n + 2 * G - 1) / (2 * G)) >= 4096) G *= 2;
-    const unsigned waves = (unsigned)(B * ((n + G - 1) / G));
-    if (A.mode == LIW_MODE_INIT) hipLaunchKernelGGL(k_lin_laser<true>, dim3(waves), dim3(64), 0, s, A, P, G);
-    else hipLaunchKernelGGL(k_lin_laser<false>, dim3(waves), dim3(64), 0, s, A, P, G);
-    if (A.eval_small && n > 1) {
-        hipLaunchKernelGGL(k_lin_imu, dim3((unsigned)(B * ((n - 1 + IMU_PER_WAVE - 1) / IMU_PER_WAVE))), dim3(64), 0, s_imu, A, P);
-    }
-    if (A.eval_small) {
-        const int items = (n - 1 + 3) / 4 + (n + 7) / 8;
-        hipLaunchKernelGGL(k_lin_small, dim3((unsigned)(B * items)), dim3(64), 0, s_small, A, P);
-    }
+    hipLaunchKernelGGL(k_frame_tf, dim3((B * n * 2 * 4 + 255) / 256), dim3(256), 0, s, B, n, A.x, A.match_pose, A.ftf, P, A.lm);
+    if (A.mode == LIW_MODE_INIT) hipLaunchKernelGGL(k_lin_laser<true>, dim3((unsigned)laser_waves), dim3(64), 0, s, A, P, G);
+    else hipLaunchKernelGGL(k_lin_laser<false>, dim3((unsigned)laser_waves), dim3(64), 0, s, A, P, G);
+    if (imu_waves) hipLaunchKernelGGL(k_lin_imu, dim3((unsigned)imu_waves), dim3(64), 0, s_imu, A, P);
+    if (small_waves) hipLaunchKernelGGL(k_lin_small, dim3((unsigned)small_waves), dim3(64), 0, s_small, A, P);
     if (fork) {
         hipEventRecord(fk->ev_join[0], fk->side[0]);
         hipEventRecord(fk->ev_join[1], fk->side[1]);
