@@ -80,3 +80,19 @@ def test_posegraph_ground_gates_and_iteration_cap(liw, synth, pyoracle):
         assert np.abs(xg - xo).max() <= 1e-6 * max(1.0, np.abs(xo).max())
     with pytest.raises(liw.LiwError):
         pgs.solve(liw.posegraph.office_pg_params(), G["poses"], [[0, 99]], G["seq_tf12"][:1])
+
+
+def test_posegraph_cost_vs_cpu_restatement(liw, synth, pyoracle):
+    """Measurement row of f2: 200 key frames, GPU solve against the oracle's dense CPU minimizer, same graph."""
+    import time
+    prm = synth.office_params()
+    pg = dict(liw.posegraph.office_pg_params(), use_ground_q_factor=False)
+    G = liw.posegraph.make_pose_graph(prm, N=200, seed=200, n_loop=5, laps=2.2)
+    args = (G["poses"], G["seq_idx"], G["seq_tf12"], G["loop_idx"], G["loop_tf12"])
+    pgs, orc = liw.posegraph.PoseGraph(prm), pyoracle.Oracle(prm)
+    pgs.solve(pg, *args, max_iters=1)
+    t0 = time.perf_counter(); xg, sg = pgs.solve(pg, *args); tg = time.perf_counter() - t0
+    t0 = time.perf_counter(); xo, so = pyoracle.posegraph_solve(orc, pg, *args); to = time.perf_counter() - t0
+    print("pose graph 200 key frames: GPU %.1f ms, CPU oracle %.1f ms" % (tg * 1e3, to * 1e3))
+    assert sg["iterations"] == so["iterations"] and np.abs(xg - xo).max() <= 1e-6 * max(1.0, np.abs(xo).max())
+    assert tg < to

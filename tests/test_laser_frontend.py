@@ -209,3 +209,21 @@ def test_reference_quirk_ref_n_accumulation_2(liw, synth, env, pyoracle):
         assert (mgr.ref_scan() is None) == (orc.ref_scan() is None)
         state.append(mgr.ref_scan() is None)
     assert state == [False, True, False, False]
+
+
+def test_spawn_scan_cost_vs_restatement(liw, synth, env):
+    """Measurement row of the front-end: the sparse-grid / moment-matrix implementation against the oracle's
+    literal restatement (std::map grid, shared_ptr lines, one-sided Jacobi SVD) on the same scan; both through ctypes."""
+    import time
+    prm, lp, orc = env
+    pts, _ = scan_points(liw, synth, prm, liw.laser.room_segments(1), [0.2, -0.1, 0.0], [0.0, 0.0, 0.3], 1)
+    lps = liw.laser.laser_params_struct(lp)
+    t = []
+    for fn in (lambda: liw.laser.Scan.spawn(lps, pts), lambda: orc.spawn_scan(pts)):
+        fn()
+        t0 = time.perf_counter()
+        for _ in range(30):
+            fn()
+        t.append((time.perf_counter() - t0) / 30)
+    print("spawn_scan: product %.0f us, oracle restatement %.0f us" % (t[0] * 1e6, t[1] * 1e6))
+    assert t[0] < t[1]

@@ -1,5 +1,5 @@
-"""CPU timing of the laser front-end (host C++ of libliw_window.so) next to the oracle's restatement: spawn_scan on a
-1080-ray synthetic scan and do_match between two consecutive scans.  usage: python tools/bench_laser.py [reps]"""
+"""CPU timing of the laser front-end (host C++ of libliw_window.so): spawn_scan on a synthetic scan and do_match between two
+consecutive scans (ctypes binding included).  usage: python tools/bench_laser.py [reps]"""
 import importlib
 import json
 import os
@@ -11,7 +11,6 @@ import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 liw = importlib.import_module("2dliw-slam_amd")
 synth = importlib.import_module("2dliw-slam_amd.synth")
-from oracle import pyoracle as po  # noqa: E402  (baseline leg only)
 
 
 def main():
@@ -28,27 +27,17 @@ def main():
         T[:2, 3] = [0.2 + 0.1 * k, -0.1]
         rg, amin, inc = liw.laser.cast_scan(room, T @ T_il, seed=k)
         pts.append(liw.laser.laser_to_points(rg, amin, inc, 0.0, 0.0)[0])
-    orc = po.LaserOracle(lp_dict)
     out = {"points_per_scan": int(len(pts[0])), "reps": reps}
     t0 = time.perf_counter()
     for _ in range(reps):
         s = liw.laser.Scan.spawn(lp, pts[0])
     out["spawn_scan_us"] = (time.perf_counter() - t0) / reps * 1e6
-    t0 = time.perf_counter()
-    for _ in range(reps):
-        so = orc.spawn_scan(pts[0])
-    out["oracle_spawn_scan_us"] = (time.perf_counter() - t0) / reps * 1e6
     s1, s2 = liw.laser.Scan.spawn(lp, pts[0]), liw.laser.Scan.spawn(lp, pts[1])
-    o1, o2 = orc.spawn_scan(pts[0]), orc.spawn_scan(pts[1])
     p1, q1, p2, q2 = [0.2, -0.1, 0], [0, 0, 0.3], [0.3, -0.1, 0], [0, 0, 0.34]
     t0 = time.perf_counter()
     for _ in range(reps):
         m = liw.laser.do_match(lp, s1, s2, p1, q1, p2, q2)
     out["do_match_us"] = (time.perf_counter() - t0) / reps * 1e6
-    t0 = time.perf_counter()
-    for _ in range(reps):
-        mo = orc.do_match(o1, o2, p1, q1, p2, q2)
-    out["oracle_do_match_us"] = (time.perf_counter() - t0) / reps * 1e6
     out["lines"], out["matches"] = int(s.lines().shape[0]), int(len(m))
     print(json.dumps(out))
 

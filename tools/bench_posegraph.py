@@ -35,12 +35,6 @@ def main():
                "cholesky_gflop_per_factorisation": round(np_ ** 3 / 3 / 1e9, 2),
                "end_error_before_m": round(float(np.linalg.norm(G["poses"][-1, :3] - G["truth"][-1, :3])), 3),
                "end_error_after_m": round(float(np.linalg.norm(x[-1, :3] - G["truth"][-1, :3])), 3)}
-        if "--oracle" in sys.argv and N <= 300:
-            from oracle import pyoracle as po
-            orc = po.Oracle(prm)
-            t0 = time.perf_counter()
-            po.posegraph_solve(orc, pg, *args)
-            out["cpu_oracle_dense_s"] = round(time.perf_counter() - t0, 3)
         print(json.dumps(out))
 
 
