@@ -11,7 +11,7 @@
 //                 and ONE butterfly reduction per group.
 //   k_lin_imu   : six imu_factor blocks per wave (src/factor/imu_factor.h:13-89): 9 dual directions + value lane per
 //                 block, closed forms for the linear columns, whitening and Y^T Y on the fp64 matrix cores.
-//   k_lin_small : wheel_odom_factor (src/factor/wheel_factor.h:12-73, four blocks per wave, 12 dual directions) and
+//   k_lin_small : wheel_odom_factor (src/factor/wheel_factor.h:12-73, six blocks per wave, 9 dual directions) and
 //                 ground_factor_p/q (src/factor/ground_factor.h:27-82, eight frames per wave); the n-fold duplication
 //                 of solver.cpp:142-159 is applied as an integer weight n.
 // Every role reduces G = Y^T Y with Y = [J | r] deterministically (no atomics).  G blocks go to the partial-sum slots
@@ -307,13 +307,16 @@ __device__ void imu_group(const LinArgs& A, const DevParams& P, int b, int item,
 // ------------------------------------------------------------------------------------------- wheel
 // wheel_odom_factor::operator(), src/factor/wheel_factor.h:12-73
 template <class T>
-__device__ __forceinline__ void wheel_res(const DevParams& P, const double* T12, const double* sq9, const T* pi_, const T* qi_, const T* pj_, const T* qj_, T* res) {
+__device__ __forceinline__ void wheel_res(const DevParams& P, const double* T12, const double* sq9, const T* pi_, const T* qi_, const T* pj_, const T* qj_, T* res,
+                                          const T* dp, M3<T>* R_w_wheel_i) {
     V3<T> pi(pi_[0], pi_[1], pi_[2]), thetai(qi_[0], qi_[1], qi_[2]), pj(pj_[0], pj_[1], pj_[2]), thetaj(qj_[0], qj_[1], qj_[2]);
     Iso<T> T_i_w = cast_iso<T>(P.Riw, P.tiw);
     Iso<T> tf_i = mul(make_tf(pi, thetai), T_i_w);
     Iso<T> tf_j = mul(make_tf(pj, thetaj), T_i_w);
     Iso<T> w_tf_ij = mul(inverse(tf_i), tf_j);
-    V3<T> p = w_tf_ij.t, q = log_SO3(w_tf_ij.R);
+    // dp: perturbation of the relative translation (the positions enter only through R_wi^T (p_j - p_i), see wheel_hex)
+    V3<T> p = w_tf_ij.t + V3<T>(dp[0], dp[1], dp[2]), q = log_SO3(w_tf_ij.R);
+    *R_w_wheel_i = tf_i.R;
     // log_SE3 of the constant odometry increment: no parameter enters, so it is evaluated on plain doubles
     const V3<double> oqd = log_SO3(cast_m3<double>(T12));
     const V3<T> op = cast_v3<T>(T12 + 9);
@@ -337,39 +340,53 @@ __device__ __forceinline__ void wheel_res(const DevParams& P, const double* T12,
     else res[2] = T(sq9[8]) * (norm(oq) - norm(q));
 }
 
-__device__ void wheel_quad(const LinArgs& A, const DevParams& P, int b, int item, int sel, double* lds) {
-    const int lane = threadIdx.x & 63, sub = lane >> 4, dir = lane & 15;
-    const int n = A.n, k = 4 * item + sub;
-    const bool on = k < n - 1;
-    double* Y = lds + sub * 40;   // [3][13]
+// Six blocks per wave, ten lanes each: 6 dual directions for theta_i, theta_j, 3 for the RELATIVE translation, the value.
+// The positions enter the residual only through p = R_wi^T (p_j - p_i) + c(theta), R_wi = R_i R_imu_to_wheel, so
+// d res / d p_j = (d res / d p) R_wi^T and d res / d p_i = -(d res / d p_j): three directions instead of six.
+constexpr int WHEEL_PER_WAVE = 6;
+__device__ void wheel_hex(const LinArgs& A, const DevParams& P, int b, int item, int sel, double* lds) {
+    const int lane = threadIdx.x & 63, sub = lane / 10, dir = lane % 10;
+    const int n = A.n, k = WHEEL_PER_WAVE * item + sub;
+    const bool on = sub < WHEEL_PER_WAVE && k < n - 1;
+    double* Y = lds + (sub < WHEEL_PER_WAVE ? sub : 0) * 64;   // [3][13] then Dp [3][3] at 40, R_wi [3][3] at 49
     const size_t fk = (size_t)b * (n - 1) + (on ? k : 0);
-    double y[3] = {0.0, 0.0, 0.0};
     if (on) {
         const double* si_ = A.x + ((size_t)b * n + k) * 15;
         const double* sj_ = si_ + 15;
-        LJ pi[3], qi[3], pj[3], qj[3], res[3];
+        LJ pi[3], qi[3], pj[3], qj[3], dp[3], res[3];
+        M3<LJ> Rwi;
 #pragma unroll
         for (int e = 0; e < 3; ++e) {
-            pi[e] = LJ(si_[e], dir == e ? 1.0 : 0.0);
-            qi[e] = LJ(si_[3 + e], dir == 3 + e ? 1.0 : 0.0);
-            pj[e] = LJ(sj_[e], dir == 6 + e ? 1.0 : 0.0);
-            qj[e] = LJ(sj_[3 + e], dir == 9 + e ? 1.0 : 0.0);
+            pi[e] = LJ(si_[e]);
+            qi[e] = LJ(si_[3 + e], dir == e ? 1.0 : 0.0);
+            pj[e] = LJ(sj_[e]);
+            qj[e] = LJ(sj_[3 + e], dir == 3 + e ? 1.0 : 0.0);
+            dp[e] = LJ(0.0, dir == 6 + e ? 1.0 : 0.0);
         }
-        wheel_res<LJ>(P, A.wheel_T + fk * 12, A.wheel_sqrtP + fk * 9, pi, qi, pj, qj, res);
-#pragma unroll
-        for (int r = 0; r < 3; ++r) y[r] = dir < 12 ? res[r].d : (dir == 12 ? res[r].v : 0.0);
+        wheel_res<LJ>(P, A.wheel_T + fk * 12, A.wheel_sqrtP + fk * 9, pi, qi, pj, qj, res, dp, &Rwi);
+        if (dir < 3) { for (int r = 0; r < 3; ++r) Y[r * 13 + 3 + dir] = res[r].d; }
+        else if (dir < 6) { for (int r = 0; r < 3; ++r) Y[r * 13 + 6 + dir] = res[r].d; }
+        else if (dir < 9) { for (int r = 0; r < 3; ++r) Y[40 + r * 3 + (dir - 6)] = res[r].d; }
+        else {
+            for (int r = 0; r < 3; ++r) Y[r * 13 + 12] = res[r].v;
+            for (int r = 0; r < 3; ++r) for (int c = 0; c < 3; ++c) Y[49 + r * 3 + c] = Rwi(r, c).v;
+        }
     }
-    if (dir < 13)
-#pragma unroll
-        for (int r = 0; r < 3; ++r) Y[r * 13 + dir] = y[r];
-    if (on && dir == 12 && A.dbg_wheel_res)
-        for (int r = 0; r < 3; ++r) A.dbg_wheel_res[fk * 3 + r] = y[r];
-    if (on && dir < 12 && A.dbg_wheel_jac)
-        for (int r = 0; r < 3; ++r) A.dbg_wheel_jac[(fk * 3 + r) * 12 + dir] = y[r];
     __syncthreads();
+    if (on && dir < 9) {   // position columns: Y[r][p_j c] = sum_k Dp[r][k] R_wi[c][k],  Y[r][p_i c] = -Y[r][p_j c]
+        const int r = dir / 3, c = dir % 3;
+        const double v = Y[40 + r * 3] * Y[49 + c * 3] + Y[40 + r * 3 + 1] * Y[49 + c * 3 + 1] + Y[40 + r * 3 + 2] * Y[49 + c * 3 + 2];
+        Y[r * 13 + 6 + c] = v;
+        Y[r * 13 + c] = -v;
+    }
+    __syncthreads();
+    if (on && dir == 9 && A.dbg_wheel_res)
+        for (int r = 0; r < 3; ++r) A.dbg_wheel_res[fk * 3 + r] = Y[r * 13 + 12];
+    if (on && A.dbg_wheel_jac)
+        for (int e = dir; e < 36; e += 10) A.dbg_wheel_jac[fk * 36 + e] = Y[(e / 12) * 13 + e % 12];
     if (on) {
         double* out = A.PW[sel] + fk * PWS;
-        for (int e = dir; e < 91; e += 16) {
+        for (int e = dir; e < 91; e += 10) {
             int c1 = 0, rem = e;
             while (rem >= 13 - c1) { rem -= 13 - c1; ++c1; }
             const int c2 = c1 + rem;
@@ -439,12 +456,12 @@ __device__ void imu_role(const LinArgs& A, const DevParams& P, int vblock, doubl
     imu_group(A, P, b, item, sel, lds);
 }
 __device__ void small_role(const LinArgs& A, const DevParams& P, int vblock, double* lds) {
-    const int n = A.n, n_wheel = (n - 1 + 3) / 4, items = n_wheel + (n + 7) / 8;
+    const int n = A.n, n_wheel = (n - 1 + WHEEL_PER_WAVE - 1) / WHEEL_PER_WAVE, items = n_wheel + (n + 7) / 8;
     const int b = vblock / items, item = vblock % items;
     if (b >= A.B) return;
     if (A.lm && A.lm[b].done) return;
     const int sel = A.lm ? (A.candidate ? 1 - A.lm[b].cur : A.lm[b].cur) : 0;
-    if (item < n_wheel) wheel_quad(A, P, b, item, sel, lds);
+    if (item < n_wheel) wheel_hex(A, P, b, item, sel, lds);
     else ground_oct(A, P, b, item - n_wheel, sel, lds);
 }
 __global__ __launch_bounds__(64, 2) void k_lin_imu(LinArgs A, DevParams P) {
@@ -452,7 +469,7 @@ __global__ __launch_bounds__(64, 2) void k_lin_imu(LinArgs A, DevParams P) {
     imu_role(A, P, (int)blockIdx.x, lds);
 }
 __global__ __launch_bounds__(64) void k_lin_small(LinArgs A, DevParams P) {
-    __shared__ double lds[4 * 40 + 8];
+    __shared__ double lds[WHEEL_PER_WAVE * 64];
     small_role(A, P, (int)blockIdx.x, lds);
 }
 // Small batches (a single tracking window): every role in ONE launch, the role of a wave follows from its block index —
@@ -489,7 +506,7 @@ void launch_linearize(const LinArgs& A, const DevParams& P, hipStream_t s, const
     if (A.mode != LIW_MODE_TRACK) while (G < LASER_GMAX && (long)B * ((n + 2 * G - 1) / (2 * G)) >= 4096) G *= 2;
     const int laser_waves = B * ((n + G - 1) / G);
     const int imu_waves = (A.eval_small && n > 1) ? B * ((n - 1 + IMU_PER_WAVE - 1) / IMU_PER_WAVE) : 0;
-    const int small_waves = A.eval_small ? B * ((n - 1 + 3) / 4 + (n + 7) / 8) : 0;
+    const int small_waves = A.eval_small ? B * ((n - 1 + WHEEL_PER_WAVE - 1) / WHEEL_PER_WAVE + (n + 7) / 8) : 0;
     if (A.eval_small && laser_waves + imu_waves + small_waves <= 256) {
         const unsigned tot = (unsigned)(laser_waves + imu_waves + small_waves);
         if (A.mode == LIW_MODE_INIT) hipLaunchKernelGGL(k_lin_all<true>, dim3(tot), dim3(64), 0, s, A, P, G, laser_waves, imu_waves);
