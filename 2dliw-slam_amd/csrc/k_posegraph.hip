@@ -383,6 +383,9 @@ __global__ __launch_bounds__(256) void k_trisolve_pipe(const double* L, int ld, 
 static int dense_cholesky_solve(liw_ctx* c, double* dA, int np, double* db, int* dstatus, hipStream_t s) {
     // dstatus: [0] = not-positive-definite flag, [1 .. nb] forward flags, [1 + nb .. 2 nb] backward flags
     const int nb = np / 64;
+    // the pipelined triangular solves spin on flags of earlier blocks: keep every work-group co-resident (256 CUs x 8 groups of
+    // 256 threads) so that the scheme does not depend on the dispatch order
+    if (nb > 2048) return liw_ctx_fail(c, LIW_EINVAL, "dense solver: more than 131072 unknowns");
     (void)hipMemsetAsync(dstatus, 0, sizeof(int) * (1 + 2 * (size_t)nb), s);
     for (int k = 0; k < nb; ++k) {
         hipLaunchKernelGGL(k_potrf64, dim3(1), dim3(64), 0, s, dA, np, 64 * k, dstatus);
