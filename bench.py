@@ -209,7 +209,8 @@ def main():
             import resource
             ru0 = resource.getrusage(resource.RUSAGE_CHILDREN)
             t0_ = time.perf_counter()
-            with cf.ProcessPoolExecutor(max_workers=ncpu) as ex:
+            import multiprocessing as mp
+            with cf.ProcessPoolExecutor(max_workers=ncpu, mp_context=mp.get_context("spawn")) as ex:   # spawn: children never see the HIP runtime
                 secs = list(ex.map(_cpu_worker, jobs))
             wall = time.perf_counter() - t0_
             ru1 = resource.getrusage(resource.RUSAGE_CHILDREN)
