@@ -1,0 +1,63 @@
+"""The launch configurations only large batches reach — several (window, frame) groups per laser wave with chunks that
+straddle group boundaries, empty groups in the middle of a wave, role kernels on forked streams — checked against the
+single-window path (one group per wave, single-launch k_lin_all) and against the oracle, window by window."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def rel(a, b):
+    return float(np.abs(np.asarray(a) - np.asarray(b)).max() / max(1.0, np.abs(np.asarray(b)).max()))
+
+
+@pytest.mark.parametrize("n,mode_name", [(9, "init"), (30, "init"), (13, "marg")])
+def test_multi_group_laser_waves_match_single_window_path(liw, synth, pyoracle, n, mode_name):
+    prm = synth.office_params()
+    orc = pyoracle.Oracle(prm)
+    rng = np.random.default_rng(n)
+    B = 1200 if n == 9 else (600 if n == 13 else 324)         # enough windows for G = 8 groups per wave
+    base = []
+    for k in range(6):
+        L = int(rng.integers(0, 260))
+        w = synth.make_window(orc, prm, seed=700 + 10 * n + k, n=n, L=L)
+        if k % 2 == 1 and L > 10:                                # knock out every block of two frames: empty groups inside a wave
+            keep = ~np.isin(w["laser_frame"], [2, n - 2])
+            w["laser_frame"], w["laser_pts"] = w["laser_frame"][keep], w["laser_pts"][keep]
+        base.append(w)
+    windows = [base[b % 6] for b in range(B)]
+    mode = liw.LIW_MODE_INIT if mode_name == "init" else liw.LIW_MODE_MARG
+    big = liw.BatchSolver(prm, windows)
+    big.linearize(mode)
+    Hb, gb, cb = [t.cpu().numpy() for t in big.export_dense(mode)]
+    for k in range(6):
+        one = liw.BatchSolver(prm, [base[k]])
+        one.linearize(mode)
+        H1, g1, c1 = [t.cpu().numpy() for t in one.export_dense(mode)]
+        for b in (k, k + 6 * 7, B - 6 + k):                      # first, middle and last copies of this window in the batch
+            assert rel(Hb[b], H1[0]) <= 1e-12 and rel(gb[b], g1[0]) <= 1e-12 and abs(cb[b] - c1[0]) <= 1e-12 * max(1.0, abs(c1[0])), (k, b)
+        if mode_name == "init":                                  # (the marginalisation topology is compared with the oracle in test_gpu_batch.py)
+            wo = pyoracle.Window(base[k])
+            orc.set_prior(None)
+            Ho, go, co = orc.linearize(wo, 0)
+            assert rel(H1[0], Ho) <= 1e-9 and rel(g1[0], go) <= 1e-9, k
+
+
+def test_large_batch_solve_matches_oracle_on_sampled_windows(liw, synth, pyoracle):
+    prm = synth.office_params()
+    orc = pyoracle.Oracle(prm)
+    n, B = 7, 1600
+    base = [synth.make_window(orc, prm, seed=910 + k, n=n, L=30 + 41 * k) for k in range(5)]
+    bs = liw.BatchSolver(prm, [base[b % 5] for b in range(B)])
+    bs.solve(liw.LIW_MODE_INIT, 12)
+    got, summ = bs.states(), bs.summaries()
+    orc.set_max_iterations(12)
+    for k in range(5):
+        wo = pyoracle.Window(base[k])
+        orc.set_prior(None)
+        orc.init_solve(wo)
+        so = orc.summary()
+        for b in (k, B - 5 + k):
+            assert summ[b]["iterations"] == so["iterations"] and summ[b]["termination"] == so["termination"], (k, b)
+            assert rel(got[b], wo["states"].reshape(n, 15)) <= 1e-6, (k, b)
+    orc.set_max_iterations(50)
