@@ -95,40 +95,6 @@ __global__ __launch_bounds__(64, 2) void k_lin_laser(LinArgs A, DevParams P, int
 }
 
 // ------------------------------------------------------------------------------------------- imu
-// raw (un-whitened) residual of imu_factor::operator(), src/factor/imu_factor.h:41-83; also returns R_i^T
-template <class T>
-__device__ __forceinline__ void imu_raw(const DevParams& P, const double* X, const double* Jp, double Dt_, const T* si, const T* sj, T* raw,
-                                        M3<T>& bk_R_w) {
-    V3<T> pi(si[0], si[1], si[2]), thetai(si[3], si[4], si[5]), vi(si[6], si[7], si[8]), bai(si[9], si[10], si[11]), bwi(si[12], si[13], si[14]);
-    V3<T> pj(sj[0], sj[1], sj[2]), thetaj(sj[3], sj[4], sj[5]), vj(sj[6], sj[7], sj[8]), baj(sj[9], sj[10], sj[11]), bwj(sj[12], sj[13], sj[14]);
-    const T g_norm(P.g), Dt(Dt_);
-    V3<T> g(T(0.0), T(0.0), T(1.0));
-    V3<T> alpha = cast_v3<T>(X), beta = cast_v3<T>(X + 3), gamma = cast_v3<T>(X + 6);
-    V3<T> ba = cast_v3<T>(X + 9), bw = cast_v3<T>(X + 12);
-    bk_R_w = exp_so3(-thetai);
-    auto blk = [&](int ro, int co) {
-        M3<T> m;
-#pragma unroll
-        for (int r = 0; r < 3; ++r)
-#pragma unroll
-            for (int c = 0; c < 3; ++c) m(r, c) = T(Jp[(ro + r) * 15 + co + c]);
-        return m;
-    };
-    const V3<T> dba = bai - ba, dbw = bwi - bw;
-    alpha = alpha + mul(blk(0, 9), dba) + mul(blk(0, 12), dbw);
-    beta = beta + mul(blk(3, 9), dba) + mul(blk(3, 12), dbw);
-    gamma = gamma + mul(blk(6, 12), dbw);
-    V3<T> res_alpha = alpha - mul(bk_R_w, pj - pi + ((g * T(0.5)) * g_norm) * Dt * Dt - vi * Dt);
-    V3<T> res_beta = beta - mul(bk_R_w, vj + (g * g_norm) * Dt - vi);
-    V3<T> res_gamma = log_SO3(mul(exp_so3(-gamma), mul(bk_R_w, exp_so3(thetaj))));
-    V3<T> res_ba = baj - bai, res_bw = bwj - bwi;
-    raw[0] = res_alpha.x; raw[1] = res_alpha.y; raw[2] = res_alpha.z;
-    raw[3] = res_beta.x;  raw[4] = res_beta.y;  raw[5] = res_beta.z;
-    raw[6] = res_gamma.x; raw[7] = res_gamma.y; raw[8] = res_gamma.z;
-    raw[9] = res_ba.x;    raw[10] = res_ba.y;   raw[11] = res_ba.z;
-    raw[12] = res_bw.x;   raw[13] = res_bw.y;   raw[14] = res_bw.z;
-}
-
 typedef double d4 __attribute__((ext_vector_type(4)));
 constexpr int IMU_PER_WAVE = 6;   // 10 lanes per block: 9 derivative directions (theta_i, theta_j, bw_i) + the value lane
 

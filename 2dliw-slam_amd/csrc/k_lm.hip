@@ -334,27 +334,6 @@ __device__ double window_cost(const AsmCtx& c) {
     return 0.5 * wave_sum(s);
 }
 
-// in-place Cholesky of the leading 15x15 of a 16x16 LDS tile (lower), one wave.  returns false on a bad pivot
-__device__ bool chol15(double* A) {
-    const int lane = threadIdx.x & 63;
-    bool ok = true;
-    for (int j = 0; j < 15; ++j) {
-        const double piv = A[j * 16 + j];
-        if (!(piv > 0.0) || !isfinite(piv)) { ok = false; break; }
-        const double dj = sqrt(piv);
-        __syncthreads();
-        if (lane >= j && lane < 15) A[lane * 16 + j] = (lane == j) ? dj : A[lane * 16 + j] / dj;
-        __syncthreads();
-        // trailing update A[r][c] -= L[r][j] L[c][j], r,c > j  (lower part only needed)
-        for (int e = lane; e < 225; e += 64) {
-            const int r = e / 15, cc = e % 15;
-            if (r > j && cc > j && cc <= r) A[r * 16 + cc] -= A[r * 16 + j] * A[cc * 16 + j];
-        }
-        __syncthreads();
-    }
-    return ok;
-}
-
 // P = X^T Y for two [16(k)][16] LDS tiles with fp64 MFMA 16x16x4; lane l gets P[(l>>4)+4r][l&15] in acc[r]
 __device__ __forceinline__ d4 xty16(const double* X, const double* Y) {
     const int lane = threadIdx.x & 63;
