@@ -90,13 +90,21 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", 0))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (the estimator has no CPU fallback)")
-    torch.cuda.set_device(local_rank)
-    dev = "cuda:%d" % local_rank
+    # LIW_BENCH_SHARE_GPU=1 (testing aid on a 1-GPU box): every rank on cuda:0 with the gloo backend, which exercises the
+    # multi-rank control flow of this script (barriers, max-over-ranks timing, the factor-sharded loop) without RCCL
+    share = os.environ.get("LIW_BENCH_SHARE_GPU") == "1"
+    dev_index = 0 if share else local_rank
+    torch.cuda.set_device(dev_index)
+    dev = "cuda:%d" % dev_index
     if world > 1:
+        import datetime
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29500")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        dist.init_process_group(backend="nccl", rank=rank, world_size=world, device_id=torch.device(dev))
+        if share:
+            dist.init_process_group(backend="gloo", rank=rank, world_size=world, timeout=datetime.timedelta(minutes=5))
+        else:
+            dist.init_process_group(backend="nccl", rank=rank, world_size=world, device_id=torch.device(dev), timeout=datetime.timedelta(minutes=5))
 
     liw = importlib.import_module("2dliw-slam_amd")
     synth = importlib.import_module("2dliw-slam_amd.synth")
