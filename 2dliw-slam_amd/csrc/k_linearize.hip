@@ -96,6 +96,7 @@ __global__ __launch_bounds__(64, 2) void k_lin_laser(LinArgs A, DevParams P, int
 
 // ------------------------------------------------------------------------------------------- imu
 typedef double d4 __attribute__((ext_vector_type(4)));
+constexpr int IMU_XS = 31, IMU_X = 15 * IMU_XS;   // LDS tile of one block: [J_raw | r_raw], 15 rows x 31 columns
 constexpr int IMU_PER_WAVE = 6;   // 10 lanes per block: 9 derivative directions (theta_i, theta_j, bw_i) + the value lane
 
 // IMU role.  Only the rotation vectors and the gyro bias enter the residual non-linearly, so the dual-number pass
@@ -108,7 +109,7 @@ __device__ void imu_group(const LinArgs& A, const DevParams& P, int b, int item,
     const int n = A.n, k0 = IMU_PER_WAVE * item;
     const int k = k0 + grp;
     const bool on = grp < IMU_PER_WAVE && k < n - 1;
-    double* Xg = lds + (grp < IMU_PER_WAVE ? grp : 0) * 512;   // [16][32] per block: [J_raw(15x30) | r_raw | 0]
+    double* Xg = lds + (grp < IMU_PER_WAVE ? grp : 0) * IMU_X;   // [15][31] per block: [J_raw(15x30) | r_raw]
     // whitening-matrix operands of every block of this wave, fetched up front (one memory round trip, hidden behind
     // the dual-number pass):  sop[g][c] = A[i = lane & 15][k = (lane >> 4) + 4c] = sqrt_info_g[i][k]
     double sop[IMU_PER_WAVE][4];
@@ -128,7 +129,7 @@ __device__ void imu_group(const LinArgs& A, const DevParams& P, int b, int item,
         }
     }
     LSTAMP(300);
-    for (int e = lane; e < IMU_PER_WAVE * 512; e += 64) lds[e] = 0.0;
+    for (int e = lane; e < IMU_PER_WAVE * IMU_X; e += 64) lds[e] = 0.0;
     __syncthreads();
     LSTAMP(301);
     const size_t fk = (size_t)b * (n - 1) + (on ? k : 0);
@@ -142,9 +143,9 @@ __device__ void imu_group(const LinArgs& A, const DevParams& P, int b, int item,
         const double* X0 = A.imu_X + fk * 15;
         const int col = d < 3 ? 3 + d : (d < 6 ? 18 + (d - 3) : (d < 9 ? 12 + (d - 6) : 30));
         auto put3 = [&](int row0, const V3<LJ>& v) {
-            Xg[(row0 + 0) * 32 + col] = d < 9 ? v.x.d : v.x.v;
-            Xg[(row0 + 1) * 32 + col] = d < 9 ? v.y.d : v.y.v;
-            Xg[(row0 + 2) * 32 + col] = d < 9 ? v.z.d : v.z.v;
+            Xg[(row0 + 0) * IMU_XS + col] = d < 9 ? v.x.d : v.x.v;
+            Xg[(row0 + 1) * IMU_XS + col] = d < 9 ? v.y.d : v.y.v;
+            Xg[(row0 + 2) * IMU_XS + col] = d < 9 ? v.z.d : v.z.v;
         };
         auto blk = [&](int ro, int co) {
             M3<LJ> m;
@@ -177,34 +178,34 @@ __device__ void imu_group(const LinArgs& A, const DevParams& P, int b, int item,
 #pragma unroll
             for (int r = 0; r < 3; ++r)
 #pragma unroll
-                for (int c = 0; c < 3; ++c) Xg[r * 32 + c] = Rt(r, c).v;                      // d r_alpha / d p_i
+                for (int c = 0; c < 3; ++c) Xg[r * IMU_XS + c] = Rt(r, c).v;                      // d r_alpha / d p_i
         } else if (d == 1) {
 #pragma unroll
             for (int r = 0; r < 3; ++r)
 #pragma unroll
-                for (int c = 0; c < 3; ++c) { Xg[r * 32 + 6 + c] = Rt(r, c).v * Dt; Xg[(3 + r) * 32 + 6 + c] = Rt(r, c).v; }   // d/d v_i
+                for (int c = 0; c < 3; ++c) { Xg[r * IMU_XS + 6 + c] = Rt(r, c).v * Dt; Xg[(3 + r) * IMU_XS + 6 + c] = Rt(r, c).v; }   // d/d v_i
         } else if (d == 2) {
 #pragma unroll
             for (int r = 0; r < 3; ++r)
 #pragma unroll
                 for (int c = 0; c < 3; ++c) {
-                    Xg[r * 32 + 9 + c] = Jp[r * 15 + 9 + c];               // alpha_J_ba
-                    Xg[(3 + r) * 32 + 9 + c] = Jp[(3 + r) * 15 + 9 + c];   // beta_J_ba
-                    Xg[(9 + r) * 32 + 9 + c] = r == c ? -1.0 : 0.0;        // d r_ba / d ba_i
+                    Xg[r * IMU_XS + 9 + c] = Jp[r * 15 + 9 + c];               // alpha_J_ba
+                    Xg[(3 + r) * IMU_XS + 9 + c] = Jp[(3 + r) * 15 + 9 + c];   // beta_J_ba
+                    Xg[(9 + r) * IMU_XS + 9 + c] = r == c ? -1.0 : 0.0;        // d r_ba / d ba_i
                 }
         } else if (d == 3) {
 #pragma unroll
             for (int r = 0; r < 3; ++r)
 #pragma unroll
-                for (int c = 0; c < 3; ++c) Xg[r * 32 + 15 + c] = -Rt(r, c).v;                // d r_alpha / d p_j
+                for (int c = 0; c < 3; ++c) Xg[r * IMU_XS + 15 + c] = -Rt(r, c).v;                // d r_alpha / d p_j
         } else if (d == 4) {
 #pragma unroll
             for (int r = 0; r < 3; ++r)
 #pragma unroll
-                for (int c = 0; c < 3; ++c) Xg[(3 + r) * 32 + 21 + c] = -Rt(r, c).v;          // d r_beta / d v_j
+                for (int c = 0; c < 3; ++c) Xg[(3 + r) * IMU_XS + 21 + c] = -Rt(r, c).v;          // d r_beta / d v_j
         } else if (d == 5) {
 #pragma unroll
-            for (int r = 0; r < 3; ++r) { Xg[(9 + r) * 32 + 24 + r] = 1.0; Xg[(12 + r) * 32 + 27 + r] = 1.0; }   // d r_ba/d ba_j, d r_bw/d bw_j
+            for (int r = 0; r < 3; ++r) { Xg[(9 + r) * IMU_XS + 24 + r] = 1.0; Xg[(12 + r) * IMU_XS + 27 + r] = 1.0; }   // d r_ba/d ba_j, d r_bw/d bw_j
         }
         LSTAMP(303);
         __builtin_amdgcn_sched_barrier(0);
@@ -226,14 +227,17 @@ __device__ void imu_group(const LinArgs& A, const DevParams& P, int b, int item,
         const int kg = k0 + g;
         if (kg >= n - 1) break;
         const size_t fg = (size_t)b * (n - 1) + kg;
-        const double* X = lds + g * 512;
+        const double* X = lds + g * IMU_X;
         d4 y0 = {0.0, 0.0, 0.0, 0.0}, y1 = {0.0, 0.0, 0.0, 0.0};
 #pragma unroll
         for (int c = 0; c < 4; ++c) {
             const int kk = mk + 4 * c;
             const double a = sop[g][c];                                        // A[i = ml][k = kk] = sqrt_info
-            y0 = __builtin_amdgcn_mfma_f64_16x16x4f64(a, X[kk * 32 + ml], y0, 0, 0, 0);
-            y1 = __builtin_amdgcn_mfma_f64_16x16x4f64(a, X[kk * 32 + 16 + ml], y1, 0, 0, 0);
+            // row 15 and column 31 of the 16x32 operand are zero padding: not stored (15 x 31 doubles per block keep 7 waves per CU in LDS)
+            const double x0v = kk < 15 ? X[kk * IMU_XS + ml] : 0.0;
+            const double x1v = (kk < 15 && ml < 15) ? X[kk * IMU_XS + 16 + ml] : 0.0;
+            y0 = __builtin_amdgcn_mfma_f64_16x16x4f64(a, x0v, y0, 0, 0, 0);
+            y1 = __builtin_amdgcn_mfma_f64_16x16x4f64(a, x1v, y1, 0, 0, 0);
         }
         // y_t[r] = Y[mk + 4r][ml + 16t]  ==  operand chunk r of Y^T Y
         d4 g00 = {0.0, 0.0, 0.0, 0.0}, g01 = g00, g11 = g00;
@@ -431,7 +435,7 @@ __device__ void small_role(const LinArgs& A, const DevParams& P, int vblock, dou
     else ground_oct(A, P, b, item - n_wheel, sel, lds);
 }
 __global__ __launch_bounds__(64, 2) void k_lin_imu(LinArgs A, DevParams P) {
-    __shared__ double lds[IMU_PER_WAVE * 512];
+    __shared__ double lds[IMU_PER_WAVE * IMU_X];
     imu_role(A, P, (int)blockIdx.x, lds);
 }
 __global__ __launch_bounds__(64) void k_lin_small(LinArgs A, DevParams P) {
@@ -442,7 +446,7 @@ __global__ __launch_bounds__(64) void k_lin_small(LinArgs A, DevParams P) {
 // one kernel and no fork / join events per linearisation, which is what a latency-bound 2-frame window pays for.
 template <bool BOTH>
 __global__ __launch_bounds__(64, 2) void k_lin_all(LinArgs A, DevParams P, int G, int n_laser, int n_imu) {
-    __shared__ double lds[IMU_PER_WAVE * 512];   // IMU / small roles; the laser role brings its own static LDS
+    __shared__ double lds[IMU_PER_WAVE * IMU_X];   // IMU / small roles; the laser role brings its own static LDS
     const int v = (int)blockIdx.x;
     if (v < n_laser) laser_wave_local<BOTH>(A, P, G, v);
     else if (v < n_laser + n_imu) imu_role(A, P, v - n_laser, lds);
