@@ -111,12 +111,13 @@ struct FrameExtra { double sc_i, sc_m, dg_i, x_i; };   // per lane v < 15: scale
 // Where assemble_frame puts a frame's blocks.  LAYOUT 0: three 16x16 tiles D = H[i,i], O = H[i-1,i] (rows: frame i-1),
 // R rows 0..5 = H[0(pose), i] and g[16].  LAYOUT 1 ("lane layout", k_lm_step): one [15][64] matrix whose column is the
 // lane that will own it in the elimination — cols 0..14 = D, 16..30 = O^T, 32..37 = R^T, 40 = g.
+constexpr int MS = 41;   // row stride of the lane-layout tiles of k_lm_step: lanes 0..40 carry columns (D 0-14, O^T 16-30, R^T 32-37, g 40)
 template <int LAYOUT> struct Tiles {
     double* D; double* O; double* R; double* g;
-    __device__ __forceinline__ double& d(int r, int c) const { return LAYOUT ? D[r * 64 + c] : D[r * 16 + c]; }
-    __device__ __forceinline__ double& o(int r, int c) const { return LAYOUT ? D[c * 64 + 16 + r] : O[r * 16 + c]; }
-    __device__ __forceinline__ double& rr(int r, int c) const { return LAYOUT ? D[c * 64 + 32 + r] : R[r * 16 + c]; }
-    __device__ __forceinline__ double& gg(int r) const { return LAYOUT ? D[r * 64 + 40] : g[r]; }
+    __device__ __forceinline__ double& d(int r, int c) const { return LAYOUT ? D[r * MS + c] : D[r * 16 + c]; }
+    __device__ __forceinline__ double& o(int r, int c) const { return LAYOUT ? D[c * MS + 16 + r] : O[r * 16 + c]; }
+    __device__ __forceinline__ double& rr(int r, int c) const { return LAYOUT ? D[c * MS + 32 + r] : R[r * 16 + c]; }
+    __device__ __forceinline__ double& gg(int r) const { return LAYOUT ? D[r * MS + 40] : g[r]; }
 };
 
 // Raw values of one frame's assembly, as loaded (asm_issue) and before they are combined (asm_commit): splitting the
@@ -351,7 +352,7 @@ struct LdsTiles {   // export / marginalisation kernels (tile layout)
     double g[16], Cg[16], y0[16], yprev[16], tmp[16], D0acc[36], g0acc[8], sci[16], scm[16], sc0[16], dgi[16];
 };
 struct LdsStep {    // k_lm_step (lane layout): M = assembled frame, C = carried Schur terms, W/Wa = MFMA operand tiles
-    double M[15 * 64], C[15 * 64], W[256], Wa[256];
+    double M[15 * MS], C[15 * MS], W[256], Wa[256];
     double tmp[16], D0acc[36], g0acc[8];
 };
 
@@ -381,7 +382,7 @@ __device__ double frame_diag(const AsmCtx& c, int i, LdsStep& T) {
     double Pq[9];
     if (so3_plus_jac(c.x + (size_t)i * 15 + 3, Pq)) {   // rare: |q| > pi -> full tangent assembly
         assemble_frame<1>(c, i, Tiles<1>{T.M, nullptr, nullptr, nullptr}, T.tmp);
-        const double d = lane < 15 ? T.M[lane * 64 + lane] : 0.0;
+        const double d = lane < 15 ? T.M[lane * MS + lane] : 0.0;
         __syncthreads();
         return d;
     }
@@ -511,7 +512,7 @@ __global__ __launch_bounds__(64, 2) void k_lm_step(StepArgs a) {
     // Register-resident elimination: lane j < 15 owns column j of the damped diagonal tile, lanes 16..30 the columns of
     // O^T, lanes 32..37 the columns of R^T, lane 40 the gradient.  One fused pass (fused_chol_solve) turns the matrix
     // lanes into the rows of L and every right-hand-side lane into L^-1 b, using v_readlane broadcasts only.
-    for (int e = lane; e < 15 * 64; e += 64) { T.M[e] = 0.0; T.C[e] = 0.0; }
+    for (int e = lane; e < 15 * MS; e += 64) { T.M[e] = 0.0; T.C[e] = 0.0; }
     for (int e = lane; e < 256; e += 64) { T.W[e] = 0.0; T.Wa[e] = 0.0; }
     if (lane < 36) T.D0acc[lane] = 0.0;
     if (lane < 8) T.g0acc[lane] = 0.0;
@@ -530,10 +531,10 @@ __global__ __launch_bounds__(64, 2) void k_lm_step(StepArgs a) {
         STAMP(10 + i * 8 + 1);
         // LM diagonal of this frame (LevenbergMarquardtStrategy::ComputeStep), |x - Plus(x,-g)|
         const bool cstl = lane < 15 && var_is_const(a.mode, a.fast_mode, n, i, lane);
-        const double gl = lane < 15 ? T.M[lane * 64 + 40] : 0.0;          // tangent gradient entry of this lane
+        const double gl = lane < 15 ? T.M[lane * MS + 40] : 0.0;          // tangent gradient entry of this lane
         double dgv = ex.dg_i;
         if (lane < 15) {
-            if (!reuse) { dgv = fmin(fmax(T.M[lane * 64 + lane] * ex.sc_i * ex.sc_i, kMinDiag), kMaxDiag); dgl[i * 15 + lane] = dgv; }
+            if (!reuse) { dgv = fmin(fmax(T.M[lane * MS + lane] * ex.sc_i * ex.sc_i, kMinDiag), kMaxDiag); dgl[i * 15 + lane] = dgv; }
             sws[(size_t)i * SOLVE_WS + 600 + lane] = gl * ex.sc_i;          // original scaled gradient (model decrease)
         }
         {
@@ -556,15 +557,16 @@ __global__ __launch_bounds__(64, 2) void k_lm_step(StepArgs a) {
         else if (lane >= 32 && lane < 38) slane = i >= 2 ? s_0 : 0.0;
         else if (lane == 40) slane = 1.0;
         double col[15];
+        const int lc = lane < MS ? lane : MS - 1;   // lanes beyond the last column read a valid word they never use
 #pragma unroll
-        for (int r = 0; r < 15; ++r) col[r] = T.M[r * 64 + lane] * (rdlane(ex.sc_i, r) * slane) + T.C[r * 64 + lane];
+        for (int r = 0; r < 15; ++r) col[r] = T.M[r * MS + lc] * (rdlane(ex.sc_i, r) * slane) + T.C[r * MS + lc];
         if (i == 1) {   // frame 0 is both the chain neighbour and the arrow target: fold R^T into O^T
             const bool mg = lane >= 16 && lane < 22;
-            const int src = mg ? lane + 16 : lane;
+            const int src = mg ? lane + 16 : lc;
             const double s0 = __shfl(sc0reg, mg ? lane - 16 : 0, 64);
 #pragma unroll
             for (int r = 0; r < 15; ++r) {
-                const double v = T.M[r * 64 + src] * (rdlane(ex.sc_i, r) * s0) + T.C[r * 64 + src];
+                const double v = T.M[r * MS + src] * (rdlane(ex.sc_i, r) * s0) + T.C[r * MS + src];
                 if (mg) col[r] += v;
                 if (lane >= 32 && lane < 38) col[r] = 0.0;
             }
@@ -623,9 +625,9 @@ __global__ __launch_bounds__(64, 2) void k_lm_step(StepArgs a) {
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const int row = (lane >> 4) + 4 * r, colx = lane & 15;
-                if (row < 15 && colx < 15) T.C[row * 64 + colx] = -p1[r];            // diagonal tile of frame i-1
-                if (row < 15 && colx == 15) T.C[row * 64 + 40] = -p1[r];             // gradient of frame i-1
-                if (row < 6 && colx < 15) T.C[colx * 64 + 32 + row] = -p2[r];        // arrow block H[0, i-1] (as R^T)
+                if (row < 15 && colx < 15) T.C[row * MS + colx] = -p1[r];            // diagonal tile of frame i-1
+                if (row < 15 && colx == 15) T.C[row * MS + 40] = -p1[r];             // gradient of frame i-1
+                if (row < 6 && colx < 15) T.C[colx * MS + 32 + row] = -p2[r];        // arrow block H[0, i-1] (as R^T)
                 if (i >= 2) {
                     if (row < 6 && colx == 15) T.g0acc[row] -= p2[r];
                     if (row < 6 && colx < 6) T.D0acc[row * 6 + colx] -= p3[r];
