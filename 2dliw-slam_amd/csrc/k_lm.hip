@@ -22,9 +22,13 @@ typedef double d4 __attribute__((ext_vector_type(4)));
 // optional phase timing (tools/clk_probe.py): build with -DLIW_CLK to record s_memtime stamps of window 0
 #ifdef LIW_CLK
 __device__ long long g_clk[8192];
+__device__ long long g_span[3 * 16384];   // per window: start, end (s_memtime), hardware id of the wave
 #define STAMP(id) do { if (b == 0 && lane == 0 && iteration_dbg == 3) g_clk[(id)] = clock64(); } while (0)
+#define SPAN(k) do { if (lane == 0 && iteration_dbg == 3 && b < 16384) { g_span[3 * b + (k)] = clock64(); \
+                     if ((k) == 0) g_span[3 * b + 2] = __builtin_amdgcn_s_getreg((4 << 0) | (0 << 6) | (31 << 11)); } } while (0)
 #else
 #define STAMP(id) do { } while (0)
+#define SPAN(k) do { } while (0)
 #endif
 
 struct StepArgs {
@@ -131,8 +135,7 @@ struct AsmRegs {
 
 // All loads of a frame are issued up front, branch-free (clamped addresses; masking happens in asm_commit), so the
 // wave pays ONE memory round trip per frame instead of one per conditional term.
-__device__ __forceinline__ AsmRegs asm_issue(const AsmCtx& c, int i, const double* scl, const double* dgl) {
-    const int lane = threadIdx.x & 63;
+__device__ __forceinline__ AsmRegs asm_issue(const AsmCtx& c, int i, const double* scl, const double* dgl, int lane = threadIdx.x & 63) {
     const int n = c.n;
     const double* PLb = c.PL + (size_t)c.b * n * LP;
     const double* PIb = c.PI + (size_t)c.b * (n - 1) * PIS;
@@ -188,8 +191,8 @@ __device__ __forceinline__ AsmRegs asm_issue(const AsmCtx& c, int i, const doubl
 
 // Combine the loaded values into frame i's blocks (ambient -> tangent, constants masked), UNSCALED.
 template <int LAYOUT>
-__device__ void asm_commit(const AsmCtx& c, int i, const AsmRegs& R, const Tiles<LAYOUT>& T_, double* tmp, FrameExtra* ex = nullptr) {
-    const int lane = threadIdx.x & 63;
+__device__ void asm_commit(const AsmCtx& c, int i, const AsmRegs& R, const Tiles<LAYOUT>& T_, double* tmp, FrameExtra* ex = nullptr,
+                           int lane = threadIdx.x & 63) {
     const int n = c.n;
     const double* PLb = c.PL + (size_t)c.b * n * LP;
     const bool hasm = i >= 1, hasp = i <= n - 2;
@@ -347,14 +350,34 @@ __device__ __forceinline__ d4 xty16(const double* X, const double* Y) {
     return acc;
 }
 
+// the same product for 15-row tiles with row strides XS / YS whose k = 15 row is the shared zero row Z
+template <int XS, int YS>
+__device__ __forceinline__ d4 xty15(const double* X, const double* Y, const double* Z) {
+    const int lane = threadIdx.x & 63, m = lane & 15;
+    d4 acc = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+        const int k = (lane >> 4) + 4 * c;
+        const double* xr = X + k * XS;
+        const double* yr = Y + k * YS;
+        if (c == 3) { const bool z = (lane >> 4) == 3; xr = z ? Z : xr; yr = z ? Z : yr; }
+        acc = __builtin_amdgcn_mfma_f64_16x16x4f64(xr[m], yr[m], acc, 0, 0, 0);
+    }
+    return acc;
+}
+
 struct LdsTiles {   // export / marginalisation kernels (tile layout)
     double D[256], O[256], R[256], W[256], Wa[256], CD[256], CR[256];
     double g[16], Cg[16], y0[16], yprev[16], tmp[16], D0acc[36], g0acc[8], sci[16], scm[16], sc0[16], dgi[16];
 };
-struct LdsStep {    // k_lm_step (lane layout): M = assembled frame, C = carried Schur terms, W/Wa = MFMA operand tiles
-    double M[15 * MS], C[15 * MS], W[256], Wa[256];
+struct LdsStep {    // k_lm_step (lane layout): M = assembled frame, C = carried Schur terms
+    // The MFMA operand tiles live in M's storage (M is dead once the lanes hold their columns): W = L^-1 [O^T | g] (15 rows,
+    // stride 16), Li = L^-1 (stride 16), Wa = L^-1 R^T (stride 8).  Their 16th row (k = 15) is the shared zero row Z;
+    // columns a product does not use may hold stale words (each output depends on one column of either operand only).
+    double M[640], C[15 * MS], Z[16];
     double tmp[16], D0acc[36], g0acc[8];
 };
+constexpr int LW = 0, LLI = 240, LWA = 480;   // offsets of W / Li / Wa inside LdsStep::M
 
 // ---------------------------------------------------------------------------------------------------
 // Right-looking Cholesky of the 15x15 matrix whose column j lives in lane j (a[r] = A[r][j]) fused with the forward
@@ -406,7 +429,12 @@ __device__ double frame_diag(const AsmCtx& c, int i, LdsStep& T) {
     return d;
 }
 
-__global__ __launch_bounds__(64, 2) void k_lm_step(StepArgs a) {
+// THROUGHPUT = false: 2 waves per SIMD, the next frame's loads are issued one frame ahead in the elimination sweep (lowest
+// latency of one window).  THROUGHPUT = true: 3 waves per SIMD (<= 168 VGPRs, no look-ahead there): the other waves hide
+// the round trip instead (large batches).
+template <bool THROUGHPUT>
+__global__ __launch_bounds__(64, THROUGHPUT ? 3 : 2) void k_lm_step(StepArgs a) {
+    constexpr bool LIW_PF1 = !THROUGHPUT, LIW_PF2 = true;
     __shared__ LdsStep T;
     const int b = blockIdx.x, lane = threadIdx.x & 63;
     if (b >= a.B) return;
@@ -512,8 +540,8 @@ __global__ __launch_bounds__(64, 2) void k_lm_step(StepArgs a) {
     // Register-resident elimination: lane j < 15 owns column j of the damped diagonal tile, lanes 16..30 the columns of
     // O^T, lanes 32..37 the columns of R^T, lane 40 the gradient.  One fused pass (fused_chol_solve) turns the matrix
     // lanes into the rows of L and every right-hand-side lane into L^-1 b, using v_readlane broadcasts only.
-    for (int e = lane; e < 15 * MS; e += 64) { T.M[e] = 0.0; T.C[e] = 0.0; }
-    for (int e = lane; e < 256; e += 64) { T.W[e] = 0.0; T.Wa[e] = 0.0; }
+    for (int e = lane; e < 640; e += 64) { T.M[e] = 0.0; if (e < 15 * MS) T.C[e] = 0.0; }
+    if (lane < 16) T.Z[lane] = 0.0;
     if (lane < 36) T.D0acc[lane] = 0.0;
     if (lane < 8) T.g0acc[lane] = 0.0;
     const double sc0reg = scl[lane < 15 ? lane : 0];           // scale of frame 0 (rows of the arrow block)
@@ -521,21 +549,27 @@ __global__ __launch_bounds__(64, 2) void k_lm_step(StepArgs a) {
     bool solved = true;
     double gmax = 0.0;
     const int iteration_dbg = iteration; (void)iteration_dbg;
-    STAMP(0);
+    STAMP(0); SPAN(0);
     const Tiles<1> TM{T.M, nullptr, nullptr, nullptr};
-    AsmRegs areg = asm_issue(c, n - 1, scl, dgl);
+    AsmRegs areg;
+    if constexpr (LIW_PF1) areg = asm_issue(c, n - 1, scl, dgl);
     for (int i = n - 1; i >= 0; --i) {
         STAMP(10 + i * 8 + 0);
+        // the lane id is laundered once per frame: lane-derived addresses and masks are recomputed (a few integer ops)
+        // instead of being hoisted out of the loop into registers that then spill
+        int ln = lane;
+        asm volatile("" : "+v"(ln));
         FrameExtra ex;
-        asm_commit<1>(c, i, areg, TM, T.tmp, &ex);
+        if constexpr (!LIW_PF1) areg = asm_issue(c, i, scl, dgl, ln);
+        asm_commit<1>(c, i, areg, TM, T.tmp, &ex, ln);
         STAMP(10 + i * 8 + 1);
         // LM diagonal of this frame (LevenbergMarquardtStrategy::ComputeStep), |x - Plus(x,-g)|
-        const bool cstl = lane < 15 && var_is_const(a.mode, a.fast_mode, n, i, lane);
-        const double gl = lane < 15 ? T.M[lane * MS + 40] : 0.0;          // tangent gradient entry of this lane
+        const bool cstl = ln < 15 && var_is_const(a.mode, a.fast_mode, n, i, ln);
+        const double gl = ln < 15 ? T.M[ln * MS + 40] : 0.0;          // tangent gradient entry of this lane
         double dgv = ex.dg_i;
-        if (lane < 15) {
-            if (!reuse) { dgv = fmin(fmax(T.M[lane * MS + lane] * ex.sc_i * ex.sc_i, kMinDiag), kMaxDiag); dgl[i * 15 + lane] = dgv; }
-            sws[(size_t)i * SOLVE_WS + 600 + lane] = gl * ex.sc_i;          // original scaled gradient (model decrease)
+        if (ln < 15) {
+            if (!reuse) { dgv = fmin(fmax(T.M[ln * MS + ln] * ex.sc_i * ex.sc_i, kMinDiag), kMaxDiag); dgl[i * 15 + ln] = dgv; }
+            sws[(size_t)i * SOLVE_WS + REC_GS + ln] = gl * ex.sc_i;          // original scaled gradient (model decrease)
         }
         {
             const double qv[3] = {rdlane(ex.x_i, 3), rdlane(ex.x_i, 4), rdlane(ex.x_i, 5)};
@@ -543,88 +577,107 @@ __global__ __launch_bounds__(64, 2) void k_lm_step(StepArgs a) {
             double qn[3];
             so3_plus(qv, ng, qn);                                          // uniform: every lane, no divergence
             double m = fabs(gl);
-            if (lane >= 3 && lane < 6) m = fabs(ex.x_i - (lane == 3 ? qn[0] : (lane == 4 ? qn[1] : qn[2])));
-            if (lane < 15 && !cstl) gmax = fmax(gmax, m);
+            if (ln >= 3 && ln < 6) m = fabs(ex.x_i - (ln == 3 ? qn[0] : (ln == 4 ? qn[1] : qn[2])));
+            if (ln < 15 && !cstl) gmax = fmax(gmax, m);
         }
         STAMP(10 + i * 8 + 2);
         // this lane's column: scale (Jacobi), damp (LM), add the carried Schur terms.  Lane roles: j < 15 column j of
         // the diagonal tile, 16..30 columns of O^T, 32..37 columns of R^T, 40 the gradient.
         // (shuffles run in uniform control flow: ds_bpermute only sees data of active source lanes)
-        const double s_m = __shfl(ex.sc_m, (lane - 16) & 63, 64), s_0 = __shfl(sc0reg, (lane - 32) & 63, 64);
+        const double s_m = __shfl(ex.sc_m, (ln - 16) & 63, 64), s_0 = __shfl(sc0reg, (ln - 32) & 63, 64);
         double slane = 0.0;
-        if (lane < 15) slane = ex.sc_i;
-        else if (lane >= 16 && lane < 31) slane = i >= 1 ? s_m : 0.0;
-        else if (lane >= 32 && lane < 38) slane = i >= 2 ? s_0 : 0.0;
-        else if (lane == 40) slane = 1.0;
+        if (ln < 15) slane = ex.sc_i;
+        else if (ln >= 16 && ln < 31) slane = i >= 1 ? s_m : 0.0;
+        else if (ln >= 32 && ln < 38) slane = i >= 2 ? s_0 : 0.0;
+        else if (ln == 40) slane = 1.0;
         double col[15];
-        const int lc = lane < MS ? lane : MS - 1;   // lanes beyond the last column read a valid word they never use
+        const int lc = ln < MS ? ln : MS - 1;   // lanes beyond the last column read a valid word they never use
 #pragma unroll
         for (int r = 0; r < 15; ++r) col[r] = T.M[r * MS + lc] * (rdlane(ex.sc_i, r) * slane) + T.C[r * MS + lc];
         if (i == 1) {   // frame 0 is both the chain neighbour and the arrow target: fold R^T into O^T
-            const bool mg = lane >= 16 && lane < 22;
-            const int src = mg ? lane + 16 : lc;
-            const double s0 = __shfl(sc0reg, mg ? lane - 16 : 0, 64);
+            const bool mg = ln >= 16 && ln < 22;
+            const int src = mg ? ln + 16 : lc;
+            const double s0 = __shfl(sc0reg, mg ? ln - 16 : 0, 64);
 #pragma unroll
             for (int r = 0; r < 15; ++r) {
                 const double v = T.M[r * MS + src] * (rdlane(ex.sc_i, r) * s0) + T.C[r * MS + src];
                 if (mg) col[r] += v;
-                if (lane >= 32 && lane < 38) col[r] = 0.0;
+                if (ln >= 32 && ln < 38) col[r] = 0.0;
             }
         }
         if (i == 0) {
-            if (lane < 6) {
+            if (ln < 6) {
 #pragma unroll
-                for (int r = 0; r < 6; ++r) col[r] += T.D0acc[r * 6 + lane];
+                for (int r = 0; r < 6; ++r) col[r] += T.D0acc[r * 6 + ln];
             }
-            if (lane == 40) {
+            if (ln == 40) {
 #pragma unroll
                 for (int r = 0; r < 6; ++r) col[r] += T.g0acc[r];
             }
         }
-        if (lane < 15) {
+        if (ln < 15) {
             const double dmp = cstl ? 0.0 : dgv / radius;
 #pragma unroll
-            for (int r = 0; r < 15; ++r) if (r == lane) col[r] = cstl ? 1.0 : col[r] + dmp;
+            for (int r = 0; r < 15; ++r) if (r == ln) col[r] = cstl ? 1.0 : col[r] + dmp;
         }
         STAMP(10 + i * 8 + 3);
         // software pipeline: the next frame's loads are in flight while this one is factorised
+        if constexpr (LIW_PF1) {
         __builtin_amdgcn_sched_barrier(0);
-        if (i > 0) areg = asm_issue(c, i - 1, scl, dgl);
+        if (i > 0) areg = asm_issue(c, i - 1, scl, dgl, ln);
         __builtin_amdgcn_sched_barrier(0);
+        }
+        // lanes 41..55 carry the unit vectors: the fused pass leaves the columns of L^-1 in them
+        if (ln >= 41 && ln < 56) {
+#pragma unroll
+            for (int r = 0; r < 15; ++r) col[r] = (r == ln - 41) ? 1.0 : 0.0;
+        }
         if (!fused_chol_solve(col)) { solved = false; break; }
         STAMP(10 + i * 8 + 4);
-        // factor record for the back substitution: rec[r][lane] = this lane's entry r (15 coalesced stores);
-        // matrix lane j holds row j of L in entries 0..j (entries above the diagonal are round-off, never read)
-        {
-            double* f = sws + (size_t)i * SOLVE_WS;
-            // packed record rec[r][40]: slots 0..14 rows of L, 15..29 Wo, 30..35 Wr, 36 z
-            const int slot = lane < 15 ? lane : (lane >= 16 && lane < 31 ? lane - 1 : (lane >= 32 && lane < 38 ? lane - 2 : (lane == 40 ? 36 : -1)));
-            if (slot >= 0) {
+        // MFMA operand tiles: W = L^-1 [O^T | g], Wa = L^-1 R^T, Li = L^-1
+        if (ln >= 16 && ln < 31) {
 #pragma unroll
-                for (int r = 0; r < 15; ++r) f[r * 40 + slot] = col[r];
-            }
-            if (lane >= 16 && lane < 31) {
+            for (int r = 0; r < 15; ++r) T.M[LW + r * 16 + (ln - 16)] = col[r];
+        } else if (ln >= 32 && ln < 38) {
 #pragma unroll
-                for (int r = 0; r < 15; ++r) T.W[r * 16 + (lane - 16)] = col[r];
-            } else if (lane >= 32 && lane < 38) {
+            for (int r = 0; r < 15; ++r) T.M[LWA + r * 8 + (ln - 32)] = col[r];
+        } else if (ln == 40) {
 #pragma unroll
-                for (int r = 0; r < 15; ++r) T.Wa[r * 16 + (lane - 32)] = col[r];
-            } else if (lane == 40) {
+            for (int r = 0; r < 15; ++r) T.M[LW + r * 16 + 15] = col[r];
+        } else if (ln >= 41 && ln < 56) {
 #pragma unroll
-                for (int r = 0; r < 15; ++r) T.W[r * 16 + 15] = col[r];
-            }
+            for (int r = 0; r < 15; ++r) T.M[LLI + r * 16 + (ln - 41)] = col[r];
         }
         lds_sync();
         STAMP(10 + i * 8 + 5);
+        // Back-substitution operators of this frame, y_i = yz - Yo y_{i-1} - Yr y_0 with [Yo | Yr | yz] = D^-1 [O^T | R^T | g]
+        // = L^-T (L^-1 [..]): two more products on the matrix cores instead of a second triangular solve, so the record is
+        // 22 columns (not L + W: 37) and the second sweep is a matrix-vector product.  rec[r][22]: 0..14 Yo, 15..20 Yr, 21 yz.
+        {
+            const d4 y1 = xty15<16, 16>(T.M + LLI, T.M + LW, T.Z), y2 = xty15<16, 8>(T.M + LLI, T.M + LWA, T.Z);
+            double* f = sws + (size_t)i * SOLVE_WS;
+            const int colx = ln & 15;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int row = (ln >> 4) + 4 * r;
+                if (row < 15) {
+                    f[row * REC_LD + (colx < 15 ? colx : 21)] = y1[r];
+                    if (colx < 6) f[row * REC_LD + 15 + colx] = y2[r];
+                }
+            }
+        }
+        d4 p1 = {0.0, 0.0, 0.0, 0.0}, p2 = p1, p3 = p1;
+        if (i >= 1) {   // Schur products on the matrix cores
+            p1 = xty15<16, 16>(T.M + LW, T.M + LW, T.Z);      // [Wo|z]^T [Wo|z]
+            p2 = xty15<8, 16>(T.M + LWA, T.M + LW, T.Z);      // Wr^T [Wo|z]   (rows < 6)
+            p3 = xty15<8, 8>(T.M + LWA, T.M + LWA, T.Z);      // Wr^T Wr       (rows, cols < 6)
+        }
         if (i >= 1) {
-            // Schur products on the matrix cores, written back in the lane layout of the next frame
-            const d4 p1 = xty16(T.W, T.W);     // [Wo|z]^T [Wo|z]
-            const d4 p2 = xty16(T.Wa, T.W);    // [Wr|0]^T [Wo|z]
-            const d4 p3 = xty16(T.Wa, T.Wa);   // [Wr|0]^T [Wr|0]
+            // written back in the lane layout of the next frame
             lds_sync();
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                const int row = (lane >> 4) + 4 * r, colx = lane & 15;
+                const int row = (ln >> 4) + 4 * r, colx = ln & 15;
                 if (row < 15 && colx < 15) T.C[row * MS + colx] = -p1[r];            // diagonal tile of frame i-1
                 if (row < 15 && colx == 15) T.C[row * MS + 40] = -p1[r];             // gradient of frame i-1
                 if (row < 6 && colx < 15) T.C[colx * MS + 32 + row] = -p2[r];        // arrow block H[0, i-1] (as R^T)
@@ -658,61 +711,53 @@ __global__ __launch_bounds__(64, 2) void k_lm_step(StepArgs a) {
     bool valid = false;
     __syncthreads();   // factor records (global) written above are read by other lanes below
     if (solved) {
-        // ---- back substitution, frame 0 first.  Lane r owns unknown r: row r of Wo / Wr, column r of L.
+        // ---- back substitution, frame 0 first.  Lane r owns unknown r: row r of Yo / Yr.
         double ytg = 0.0, dsum = 0.0, sn2 = 0.0;
         double yprev = 0.0, y0v = 0.0;   // lane r < 15: y_{i-1}[r], y_0[r]
         STAMP(2);
-        struct BsRegs { double t, Lc[15], Wo[15], Wr[6], gsv, xold, scv, dgv; };
-        // one batch of loads per frame: z, column r of L, row r of Wo / Wr, scaled gradient, state, scale, LM diagonal
+        struct BsRegs { double t, Yo[15], Yr[6], gsv, xold, scv, dgv; };
+        // one batch of loads per frame: yz, row r of Yo / Yr, scaled gradient, state, scale, LM diagonal
         auto bs_issue = [&](int i) {
             const double* f = sws + (size_t)i * SOLVE_WS;
             const int r = lane < 15 ? lane : 0;
             BsRegs R;
-            R.t = f[r * 40 + 36];
+            R.t = f[r * REC_LD + 21];
 #pragma unroll
-            for (int k = 0; k < 15; ++k) { R.Lc[k] = f[r * 40 + k]; R.Wo[k] = f[r * 40 + 15 + k]; }
+            for (int k = 0; k < 15; ++k) R.Yo[k] = f[r * REC_LD + k];
 #pragma unroll
-            for (int k = 0; k < 6; ++k) R.Wr[k] = f[r * 40 + 30 + k];
-            R.gsv = f[600 + r];
+            for (int k = 0; k < 6; ++k) R.Yr[k] = f[r * REC_LD + 15 + k];
+            R.gsv = f[REC_GS + r];
             R.xold = xw[(size_t)i * 15 + r];
             R.scv = scl[i * 15 + r];
             R.dgv = dgl[i * 15 + r];
             return R;
         };
-        BsRegs cur = bs_issue(0);
+        BsRegs cur;
+        if (LIW_PF2) cur = bs_issue(0);
         for (int i = 0; i < n; ++i) {
+            if (!LIW_PF2) cur = bs_issue(i);
             STAMP(300 + i * 4);
-            const int r = lane < 15 ? lane : 0;
             // software pipeline: frame i+1's record is in flight while frame i is solved
-            BsRegs nxt = cur;
+            BsRegs nxt;
+            if (LIW_PF2) {
+            nxt = cur;
             __builtin_amdgcn_sched_barrier(0);
             if (i + 1 < n) nxt = bs_issue(i + 1);
             __builtin_amdgcn_sched_barrier(0);
+            }
             double t = cur.t;
-            const double* Lc = cur.Lc;
-            const double* Wo = cur.Wo;
-            const double* Wr = cur.Wr;
+            const double* Yo = cur.Yo;
+            const double* Yr = cur.Yr;
             const double gsv = cur.gsv, xold = cur.xold, scv = cur.scv, dgv = cur.dgv;
-            double dsel = Lc[0];                               // L[r][r] without a dynamic register index
-#pragma unroll
-            for (int k = 1; k < 15; ++k) dsel = (r == k) ? Lc[k] : dsel;
-            const double dinv = 1.0 / dsel;
             if (i >= 1) {
 #pragma unroll
-                for (int k = 0; k < 15; ++k) t -= Wo[k] * rdlane(yprev, k);
+                for (int k = 0; k < 15; ++k) t -= Yo[k] * rdlane(yprev, k);
             }
             if (i >= 2) {
 #pragma unroll
-                for (int k = 0; k < 6; ++k) t -= Wr[k] * rdlane(y0v, k);
+                for (int k = 0; k < 6; ++k) t -= Yr[k] * rdlane(y0v, k);
             }
             STAMP(300 + i * 4 + 1);
-            // L^T y = t
-#pragma unroll
-            for (int q = 14; q >= 0; --q) {
-                const double yq = rdlane(t * dinv, q);
-                if (lane == q) t = yq;
-                else if (lane < q) t -= Lc[q] * yq;
-            }
             yprev = t;
             if (i == 0) y0v = t;
             // candidate of this frame: delta = -y * scale ; Plus
@@ -731,9 +776,9 @@ __global__ __launch_bounds__(64, 2) void k_lm_step(StepArgs a) {
                     dsum += dgv / radius * t * t;
                 }
             }
-            cur = nxt;
+            if (LIW_PF2) cur = nxt;
         }
-        STAMP(3);
+        STAMP(3); SPAN(1);
         step_norm = sqrt(wave_sum(sn2));
         // model cost change -(s'g_s + s'A s/2) with s = -y and (A + D^2) y = g_s  ==  (y'g_s + y'D^2 y)/2
         model_cost_change = 0.5 * (wave_sum(ytg) + wave_sum(dsum));
@@ -989,11 +1034,17 @@ __global__ __launch_bounds__(64, 2) void k_marg_schur(MargArgs a) {
 
 #ifdef LIW_CLK
 extern "C" void liw_debug_clk(long long* out, int nn) { hipMemcpyFromSymbol(out, HIP_SYMBOL(g_clk), sizeof(long long) * nn); }
+extern "C" void liw_debug_span(long long* out, int nn) { hipMemcpyFromSymbol(out, HIP_SYMBOL(g_span), sizeof(long long) * nn); }
 #endif
 void launch_lm_begin(int B, int n, LmState* lm, hipStream_t s) {
     hipLaunchKernelGGL(k_lm_begin, dim3((B + 63) / 64), dim3(64), 0, s, B, n, lm);
 }
-void launch_lm_step(const StepArgs& a, hipStream_t s) { hipLaunchKernelGGL(k_lm_step, dim3(a.B), dim3(64), 0, s, a); }
+void launch_lm_step(const StepArgs& a, hipStream_t s) {
+    static const char* env = getenv("LIW_STEP_VARIANT");   // 0 / 1: force the latency / throughput variant (profiling aid)
+    const bool tp = env ? env[0] == '1' : a.B > 2048;
+    if (tp) hipLaunchKernelGGL(k_lm_step<true>, dim3(a.B), dim3(64), 0, s, a);
+    else hipLaunchKernelGGL(k_lm_step<false>, dim3(a.B), dim3(64), 0, s, a);
+}
 void launch_lm_finish(const StepArgs& a, hipStream_t s) { hipLaunchKernelGGL(k_lm_finish, dim3((a.B + 63) / 64), dim3(64), 0, s, a); }
 void launch_export_dense(const ExportArgs& a, hipStream_t s) { hipLaunchKernelGGL(k_export_dense, dim3(a.B), dim3(64), 0, s, a); }
 void launch_marg_schur(const MargArgs& a, hipStream_t s) { hipLaunchKernelGGL(k_marg_schur, dim3(a.B), dim3(64), 0, s, a); }

@@ -57,7 +57,9 @@ struct WsView {
     int history_records;
     double* ftf;          // [B][n][2][FTF] frame transform records
 };
-constexpr int SOLVE_WS = 15 * 40 + 16;  // rec[15][40]: L rows (15), Wo (15), Wr (6), z columns + scaled gradient
+constexpr int REC_LD = 22;                 // rec[15][22]: back-substitution operators Yo (15), Yr (6), yz columns of a frame
+constexpr int REC_GS = 15 * REC_LD;       // + the scaled gradient (model decrease)
+constexpr int SOLVE_WS = REC_GS + 16;
 
 struct LinArgs {
     int B, n, mode, eval_small;

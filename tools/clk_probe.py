@@ -13,7 +13,7 @@ liw.lib().liw_debug_clk(clk.ctypes.data_as(C.c_void_p), C.c_int(8192))
 print('sweep1 total', clk[1]-clk[0], 'gap', clk[2]-clk[1], 'sweep2 total', clk[3]-clk[2])
 for i in (29,15,1):
     t=clk[10+i*8:10+i*8+6]
-    print('frame',i,'assemble',t[1]-t[0],'diag/gmax',t[2]-t[1],'colload',t[3]-t[2],'chol',t[4]-t[3],'store+ldsW',t[5]-t[4],'mfma+next', clk[10+(i-1)*8]-t[5])
+    print('frame',i,'assemble',t[1]-t[0],'diag/gmax',t[2]-t[1],'colload',t[3]-t[2],'chol',t[4]-t[3],'ldsW',t[5]-t[4],'mfma+record+C', clk[10+(i-1)*8]-t[5])
 print('assemble stamps', [int(clk[2000+k+1]-clk[2000+k]) for k in range(4)])
 for i in (1,15,29):
-    print('bs frame',i,'loads+rhs',clk[300+i*4+1]-clk[300+i*4],'LTy+emit',clk[300+(i+1)*4]-clk[300+i*4+1] if i<29 else clk[3]-clk[300+i*4+1])
+    print('bs frame',i,'loads+matvec',clk[300+i*4+1]-clk[300+i*4],'emit',clk[300+(i+1)*4]-clk[300+i*4+1] if i<29 else clk[3]-clk[300+i*4+1])
