@@ -61,3 +61,38 @@ def test_large_batch_solve_matches_oracle_on_sampled_windows(liw, synth, pyoracl
             assert summ[b]["iterations"] == so["iterations"] and summ[b]["termination"] == so["termination"], (k, b)
             assert rel(got[b], wo["states"].reshape(n, 15)) <= 1e-6, (k, b)
     orc.set_max_iterations(50)
+
+
+def test_throughput_step_kernel_variant_matches_latency_variant_and_oracle(liw, synth, pyoracle):
+    """Batches above 2 048 windows run k_lm_step<true> (3 waves per SIMD, no look-ahead in the elimination sweep); smaller
+    ones k_lm_step<false>.  Same arithmetic, different load schedule: states must agree window by window — init topology
+    (arrow) and, after the on-device marginalisation, tracking topology with the stored prior — and follow the oracle."""
+    prm = synth.office_params()
+    orc = pyoracle.Oracle(prm)
+    n, B, K = 6, 2100, 10
+    base = [synth.make_window(orc, prm, seed=1310 + k, n=n, L=25 + 30 * k) for k in range(4)]
+    big = liw.BatchSolver(prm, [base[b % 4] for b in range(B)])
+    small = liw.BatchSolver(prm, base)
+    picks = [(k, b) for k in range(4) for b in (k, 4 * 300 + k, B - 4 + k)]
+    big.solve(liw.LIW_MODE_INIT, K)
+    small.solve(liw.LIW_MODE_INIT, K)
+    gb, gs, sb, ss = big.states(), small.states(), big.summaries(), small.summaries()
+    orc.set_max_iterations(K)
+    for k, b in picks:
+        assert sb[b]["iterations"] == ss[k]["iterations"] and sb[b]["termination"] == ss[k]["termination"], (k, b)
+        assert rel(gb[b], gs[k]) <= 1e-10, (k, b)
+    for k in range(4):
+        wo = pyoracle.Window(base[k])
+        orc.set_prior(None)
+        orc.init_solve(wo)
+        assert ss[k]["iterations"] == orc.summary()["iterations"], k
+        assert rel(gs[k], wo["states"].reshape(n, 15)) <= 1e-6, k
+    orc.set_max_iterations(50)
+    big.marginalize()
+    small.marginalize()
+    big.solve(liw.LIW_MODE_TRACK, K)
+    small.solve(liw.LIW_MODE_TRACK, K)
+    gb, gs, sb, ss = big.states(), small.states(), big.summaries(), small.summaries()
+    for k, b in picks:
+        assert sb[b]["iterations"] == ss[k]["iterations"] and sb[b]["termination"] == ss[k]["termination"], (k, b)
+        assert rel(gb[b], gs[k]) <= 1e-9, (k, b)
