@@ -965,7 +965,7 @@ __global__ __launch_bounds__(64, 2) void k_marg_schur(MargArgs a) {
             if (cc == r) dgn += v * v;
         }
         off = wave_sum(off); dgn = wave_sum(dgn);
-        if (off <= 1e-60 * dgn || off == 0.0) break;
+        if (off <= 1e-34 * dgn || off == 0.0) break;   // sums of squares: off-diagonal below 1e-17 of the diagonal
         // parallel (round-robin) ordering: 15 rounds of 7 disjoint index pairs; the 7 plane rotations of a round are
         // computed from the same A and applied together (columns of A and V, then rows of A), 105 independent element
         // pairs per phase spread over the wave — instead of 105 sequential rotations with three barriers each
@@ -977,10 +977,11 @@ __global__ __launch_bounds__(64, 2) void k_marg_schur(MargArgs a) {
                 const double apq = Am[p * 16 + q];
                 double cs = 1.0, sn = 0.0;
                 if (apq != 0.0) {
-                    const double app = Am[p * 16 + p], aqq = Am[q * 16 + q];
-                    const double tau = (aqq - app) / (2.0 * apq);
-                    const double t = (tau >= 0.0 ? 1.0 : -1.0) / (fabs(tau) + sqrt(1.0 + tau * tau));
-                    cs = 1.0 / sqrt(1.0 + t * t); sn = t * cs;
+                    // t = sgn(tau) / (|tau| + sqrt(1 + tau^2)) with tau = (aqq - app) / (2 apq), written without the division
+                    // by apq: one sqrt, one division and one rsqrt on the dependent chain instead of three and two
+                    const double d = Am[q * 16 + q] - Am[p * 16 + p], h = 2.0 * apq;
+                    const double t = (d >= 0.0 ? h : -h) / (fabs(d) + sqrt(d * d + h * h));
+                    cs = rsqrt(1.0 + t * t); sn = t * cs;
                 }
                 rot[lane * 4] = (double)p; rot[lane * 4 + 1] = (double)q; rot[lane * 4 + 2] = cs; rot[lane * 4 + 3] = sn;
             }
