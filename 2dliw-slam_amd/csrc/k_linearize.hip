@@ -109,7 +109,10 @@ __device__ void imu_group(const LinArgs& A, const DevParams& P, int b, int item,
     const int n = A.n, k0 = IMU_PER_WAVE * item;
     const int k = k0 + grp;
     const bool on = grp < IMU_PER_WAVE && k < n - 1;
-    double* Xg = lds + (grp < IMU_PER_WAVE ? grp : 0) * IMU_X;   // [15][31] per block: [J_raw(15x30) | r_raw]
+    // [15][31] per block: [J_raw wrt x_i (15) | r_raw | J_raw wrt x_j (15)] — the residual sits in column 15 so that the three
+    // 16x16 tiles of G = Y^T Y are exactly the blocks ii (+ gradient_i, cost), ij (+ gradient_j) and jj
+    constexpr int XR = 15, XJ = 16;
+    double* Xg = lds + (grp < IMU_PER_WAVE ? grp : 0) * IMU_X;
     // whitening-matrix operands of every block of this wave, fetched up front (one memory round trip, hidden behind
     // the dual-number pass):  sop[g][c] = A[i = lane & 15][k = (lane >> 4) + 4c] = sqrt_info_g[i][k]
     double sop[IMU_PER_WAVE][4];
@@ -141,7 +144,7 @@ __device__ void imu_group(const LinArgs& A, const DevParams& P, int b, int item,
         // imu_factor::operator() (imu_factor.h:41-83) evaluated stage by stage; every stage writes its rows of
         // [J_raw | r_raw] to LDS at once so its temporaries die (keeps the kernel at 2 waves per SIMD)
         const double* X0 = A.imu_X + fk * 15;
-        const int col = d < 3 ? 3 + d : (d < 6 ? 18 + (d - 3) : (d < 9 ? 12 + (d - 6) : 30));
+        const int col = d < 3 ? 3 + d : (d < 6 ? XJ + 3 + (d - 3) : (d < 9 ? 12 + (d - 6) : XR));
         auto put3 = [&](int row0, const V3<LJ>& v) {
             Xg[(row0 + 0) * IMU_XS + col] = d < 9 ? v.x.d : v.x.v;
             Xg[(row0 + 1) * IMU_XS + col] = d < 9 ? v.y.d : v.y.v;
@@ -197,15 +200,15 @@ __device__ void imu_group(const LinArgs& A, const DevParams& P, int b, int item,
 #pragma unroll
             for (int r = 0; r < 3; ++r)
 #pragma unroll
-                for (int c = 0; c < 3; ++c) Xg[r * IMU_XS + 15 + c] = -Rt(r, c).v;                // d r_alpha / d p_j
+                for (int c = 0; c < 3; ++c) Xg[r * IMU_XS + XJ + c] = -Rt(r, c).v;                // d r_alpha / d p_j
         } else if (d == 4) {
 #pragma unroll
             for (int r = 0; r < 3; ++r)
 #pragma unroll
-                for (int c = 0; c < 3; ++c) Xg[(3 + r) * IMU_XS + 21 + c] = -Rt(r, c).v;          // d r_beta / d v_j
+                for (int c = 0; c < 3; ++c) Xg[(3 + r) * IMU_XS + XJ + 6 + c] = -Rt(r, c).v;      // d r_beta / d v_j
         } else if (d == 5) {
 #pragma unroll
-            for (int r = 0; r < 3; ++r) { Xg[(9 + r) * IMU_XS + 24 + r] = 1.0; Xg[(12 + r) * IMU_XS + 27 + r] = 1.0; }   // d r_ba/d ba_j, d r_bw/d bw_j
+            for (int r = 0; r < 3; ++r) { Xg[(9 + r) * IMU_XS + XJ + 9 + r] = 1.0; Xg[(12 + r) * IMU_XS + XJ + 12 + r] = 1.0; }   // d r_ba/d ba_j, d r_bw/d bw_j
         }
         LSTAMP(303);
         __builtin_amdgcn_sched_barrier(0);
@@ -249,25 +252,24 @@ __device__ void imu_group(const LinArgs& A, const DevParams& P, int b, int item,
         }
         LSTAMP(310 + 2 * g);
         double* out = A.PI[sel] + fg * PIS;
-        // G(R, C) over the 31 columns [x_i(15) x_j(15) r]: keep blocks ii, ij, jj, the gradient column and G(30,30)
-        auto put = [&](int R, int C, double v) {
-            if (R < 15 && C < 15) out[PI_II + R * 15 + C] = v;
-            else if (R < 15 && C < 30) out[PI_IJ + R * 15 + (C - 15)] = v;
-            else if (R >= 15 && R < 30 && C >= 15 && C < 30) out[PI_JJ + (R - 15) * 15 + (C - 15)] = v;
-            else if (C == 30 && R < 30) out[PI_G + R] = v;
-            else if (C == 30 && R == 30) out[PI_C] = v;
-        };
+        // tile (0,0) = [ii | gradient_i ; . | cost], tile (0,1) = [ij ; gradient_j], tile (1,1) = jj: one masked store per tile row group
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
             const int row = mk + 4 * r;
-            put(row, ml, g00[r]);                                   // tile (0,0): rows 0..15, cols 0..15
-            put(row, 16 + ml, g01[r]);                              // tile (0,1): rows 0..15, cols 16..31
-            if (row == 15 && ml < 14) put(16 + ml, 15, g01[r]);     // mirror of row 15 into column 15 of block jj
-            put(16 + row, 16 + ml, g11[r]);                         // tile (1,1): rows 16..31, cols 16..31
-            if (A.dbg_imu_res && ml == 14 && row < 15) A.dbg_imu_res[fg * 15 + row] = y1[r];
-            if (A.dbg_imu_jac && row < 15) {
+            if (row < 15 && ml < 15) {
+                out[PI_II + row * 15 + ml] = g00[r];
+                out[PI_IJ + row * 15 + ml] = g01[r];
+                out[PI_JJ + row * 15 + ml] = g11[r];
+            }
+            if (row < 15 && ml == 15) out[PI_G + row] = g00[r];
+            if (r == 3) {
+                if (row == 15 && ml < 15) out[PI_G + 15 + ml] = g01[r];
+                if (row == 15 && ml == 15) out[PI_C] = g00[r];
+            }
+            if (A.dbg_imu_res && ml == 15 && row < 15) A.dbg_imu_res[fg * 15 + row] = y0[r];
+            if (A.dbg_imu_jac && row < 15 && ml < 15) {
                 A.dbg_imu_jac[(fg * 15 + row) * 30 + ml] = y0[r];
-                if (ml < 14) A.dbg_imu_jac[(fg * 15 + row) * 30 + 16 + ml] = y1[r];
+                A.dbg_imu_jac[(fg * 15 + row) * 30 + 15 + ml] = y1[r];
             }
         }
         LSTAMP(311 + 2 * g);
