@@ -621,7 +621,6 @@ static int pg_run(const PgCall& q) {
         double candidate_cost = 0.0;
         if (int r = evaluate(cand, dxc, false, &candidate_cost)) return r;
         if (!std::isfinite(candidate_cost)) candidate_cost = 1.7976931348623157e308;
-        if (getenv("LIW_PG_DEBUG")) { double yn = 0, gn = 0; for (int i = 0; i < n; ++i) { yn += y[i] * y[i]; gn += gs[i] * gs[i]; } fprintf(stderr, "[pg] it %d x_cost %.6f model %.6f cand %.6f |y| %.6g |gs| %.6g radius %.3g y0..: %g %g %g %g\n", iteration, x_cost, model_cost_change, candidate_cost, std::sqrt(yn), std::sqrt(gn), radius, y[6], y[7], y[8], y[9]); }
         double step_norm = 0.0;
         for (int i = 0; i < n; ++i) if (!is_const(i)) step_norm += (x[i] - cand[i]) * (x[i] - cand[i]);
         step_norm = std::sqrt(step_norm);
