@@ -16,14 +16,20 @@ n = int(rng.integers(2, 31)); nd = int(rng.integers(2, 7))
 B = int(rng.choice([nd, 97, 1500, 2100, 2500])) if n <= 12 else int(rng.choice([nd, 97, 700]))
 cap = int(rng.choice([1, 2, 5, 12]))
 base = [synth.make_window(orc, prm, seed=88000 + 10 * seed + k, n=n, L=int(rng.integers(0, 260)), state_noise=float(rng.choice([0.2, 1.0]))) for k in range(nd)]
+orc.set_max_iterations(cap)
+wos = []
+for k in range(nd):
+    wo = pyoracle.Window(base[k]); orc.set_prior(None); orc.init_solve(wo); wos.append(wo)
 bs = liw.BatchSolver(prm, base)
 bs.solve(liw.LIW_MODE_INIT, cap)
+# marginalise at the oracle's linearisation point (states and laser_match poses), as soak_batch.py does
+bs.set_states(np.stack([np.asarray(w["states"]).reshape(n, 15) for w in wos]))
+bs.t["match_pose"].copy_(bs.torch.from_numpy(np.concatenate([np.asarray(w["match_pose"]).reshape(-1) for w in wos])).to(bs.dev))
 sH, dH, dg = bs.marginalize()
 dH, dg = dH.cpu().numpy().reshape(-1, 15, 15), dg.cpu().numpy()
-orc.set_max_iterations(cap)
 print("seed", seed, "n", n, "cap", cap)
 for k in range(nd):
-    wo = pyoracle.Window(base[k]); orc.set_prior(None); orc.init_solve(wo); orc.marginalization(wo); m = orc.marg_pieces()
+    wo = wos[k]; orc.set_prior(None); orc.marginalization(wo); m = orc.marg_pieces()
     H, g = m["H"], m["g"]
     N = H.shape[0]
     Hmm, Hrm, gm = H[:N - 15, :N - 15], H[N - 15:, :N - 15], g[:N - 15]
