@@ -10,7 +10,8 @@ trajectory (src/trajectory/trajectory.cpp:446,479).  Inputs are resident in HBM 
 N > 1 (launched by torch.distributed.run, one rank per GPU): windows are independent, so ranks hold disjoint
 window batches (replicas, weak scaling, no data-path collective); the factor-sharded mode (laser blocks of each
 window split across ranks, RCCL all-reduce of the laser partial sums per LM iteration) is measured separately on
-the C4-shaped window and reported under "factor_sharded".
+the C4-shaped window and reported under "factor_sharded" at EVERY N (same total work: strong scaling; N = 1 is the
+un-sharded reference point of that curve).
 """
 import argparse
 import importlib
@@ -305,11 +306,12 @@ def main():
         except Exception as e:   # a latency side-measurement must never take the headline line down
             tracking = {"error": str(e)[:200]}
 
-    # ---- factor-sharded mode (N > 1): C4-shaped window, RCCL all-reduce of the laser partial sums per iteration
+    # ---- factor-sharded mode: C4-shaped windows, the laser blocks of every window split over the ranks, RCCL all-reduce of the
+    #      laser partial sums per iteration.  Same total work at every N (strong scaling); at N = 1 it is the un-sharded reference point
     sharded = None
-    if world > 1 and not args.skip_sharded:
+    if not args.skip_sharded:
         try:
-            Bs, Ls, Ks = 64, 20000, 10
+            Bs, Ls, Ks = 256, 20000, 10
             hp = liw.HostPreint(prm)
             wfull = [synth.make_window(hp, prm, seed=4242 + k, n=n, L=Ls) for k in range(2)]   # same seeds on every rank
             wl = [wfull[k % 2] for k in range(Bs)]
@@ -323,8 +325,9 @@ def main():
                 sb.solve(liw.LIW_MODE_INIT, Ks)
                 barrier()
                 te = time.perf_counter()
-            sharded = {"workload": "C4: %d windows x (n=%d, L=%d) laser blocks split over %d ranks, %d LM iterations, RCCL all-reduce of "
-                                   "the laser partial sums per iteration" % (Bs, n, Ls, world, Ks),
+            sharded = {"workload": "C4: %d windows x (n=%d, L=%d) laser blocks split over %d rank(s), %d LM iterations, RCCL all-reduce of "
+                                   "the laser partial sums per iteration%s" % (Bs, n, Ls, world, Ks, "" if world > 1 else " (none at 1 rank)"),
+                       "scaling": "strong", "ranks": world,
                        "solves_per_s": round(Bs / (te - ts), 3), "ms_per_lm_iteration": round(1e3 * (te - ts) / (Ks + 1), 3),
                        "allreduce_bytes_per_iteration": int(sb.lay.laser_partial_bytes)}
             sb.close()
