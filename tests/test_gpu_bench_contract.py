@@ -28,6 +28,8 @@ def test_single_rank_line():
     assert set(d["roofline"]) >= {"bound", "achieved", "peak", "unit", "frac", "traffic"} and d["roofline"]["bound"] == "hbm"
     assert set(d["cpu_baseline"]) >= {"value", "unit", "cores", "kind", "sample"} and d["cpu_baseline"]["kind"] == "port"
     assert "workload" in d["config"] and "model" not in d["config"]
+    fs = d["factor_sharded"]                                     # N = 1: the un-sharded reference point of the factor-parallel curve
+    assert "error" not in fs and fs["ranks"] == 1 and fs["scaling"] == "strong" and fs["solves_per_s"] > 0
 
 
 def test_two_rank_control_flow_on_one_gpu():
@@ -39,4 +41,5 @@ def test_two_rank_control_flow_on_one_gpu():
     d = last_json(r.stdout)
     assert d["n_gpus"] == 2 and d["cpu_baseline"] is None and d["value"] > 0
     fs = d["factor_sharded"]
-    assert "error" not in fs and fs["solves_per_s"] > 0 and fs["allreduce_bytes_per_iteration"] == 64 * 30 * 128 * 8
+    assert "error" not in fs and fs["ranks"] == 2 and fs["scaling"] == "strong" and fs["solves_per_s"] > 0
+    assert fs["allreduce_bytes_per_iteration"] == 256 * 30 * 128 * 8    # the laser partial region of the 256 C4 windows
