@@ -73,7 +73,11 @@ __device__ __forceinline__ double rdlane(double v, int l) {   // v_readlane_b32 
 
 // so3 Plus and its Jacobian at delta = 0 (factor_common.h:41-53 through AutoDiffLocalParameterization)
 __device__ __forceinline__ void so3_plus(const double* x, const double* d, double* out) {
-    V3<double> r = normalize_so3(V3<double>(x[0] + d[0], x[1] + d[1], x[2] + d[2]));
+    const double a0 = x[0] + d[0], a1 = x[1] + d[1], a2 = x[2] + d[2];
+    // normalize_so3 returns its argument unchanged unless |a| > pi: clearly below that (|a|^2 < 9.8 < pi^2 = 9.8696) the
+    // square root of the norm is skipped; the callers pass wave-uniform values, so the branch does not diverge
+    if (a0 * a0 + a1 * a1 + a2 * a2 < 9.8) { out[0] = a0; out[1] = a1; out[2] = a2; return; }
+    V3<double> r = normalize_so3(V3<double>(a0, a1, a2));
     out[0] = r.x; out[1] = r.y; out[2] = r.z;
 }
 __device__ __forceinline__ bool so3_plus_jac(const double* x, double* P9) {
