@@ -376,9 +376,10 @@ struct LdsTiles {   // export / marginalisation kernels (tile layout)
 };
 struct LdsStep {    // k_lm_step (lane layout): M = assembled frame, C = carried Schur terms
     // The MFMA operand tiles live in M's storage (M is dead once the lanes hold their columns): W = L^-1 [O^T | g] (15 rows,
-    // stride 16), Li = L^-1 (stride 16), Wa = L^-1 R^T (stride 8).  Their 16th row (k = 15) is the shared zero row Z;
-    // columns a product does not use may hold stale words (each output depends on one column of either operand only).
-    double M[640], C[15 * MS], Z[16];
+    // stride 16), Li = L^-1, Wa = L^-1 R^T (6 columns), all with row stride 16 so that every lane writes its column with the same
+    // 15 immediate offsets (ONE masked store per row).  Their 16th row (k = 15) is the shared zero row Z; columns a product does
+    // not use may hold stale words (each output depends on one column of either operand only).
+    double M[720], C[15 * MS], Z[16];
     double tmp[16], D0acc[36], g0acc[8];
 };
 constexpr int LW = 0, LLI = 240, LWA = 480;   // offsets of W / Li / Wa inside LdsStep::M
@@ -544,7 +545,7 @@ __global__ __launch_bounds__(64, THROUGHPUT ? 3 : 2) void k_lm_step(StepArgs a) 
     // Register-resident elimination: lane j < 15 owns column j of the damped diagonal tile, lanes 16..30 the columns of
     // O^T, lanes 32..37 the columns of R^T, lane 40 the gradient.  One fused pass (fused_chol_solve) turns the matrix
     // lanes into the rows of L and every right-hand-side lane into L^-1 b, using v_readlane broadcasts only.
-    for (int e = lane; e < 640; e += 64) { T.M[e] = 0.0; if (e < 15 * MS) T.C[e] = 0.0; }
+    for (int e = lane; e < 720; e += 64) { T.M[e] = 0.0; if (e < 15 * MS) T.C[e] = 0.0; }
     if (lane < 16) T.Z[lane] = 0.0;
     if (lane < 36) T.D0acc[lane] = 0.0;
     if (lane < 8) T.g0acc[lane] = 0.0;
@@ -639,18 +640,12 @@ __global__ __launch_bounds__(64, THROUGHPUT ? 3 : 2) void k_lm_step(StepArgs a) 
         if (!fused_chol_solve(col)) { solved = false; break; }
         STAMP(10 + i * 8 + 4);
         // MFMA operand tiles: W = L^-1 [O^T | g], Wa = L^-1 R^T, Li = L^-1
-        if (ln >= 16 && ln < 31) {
+        {
+            const int toff = (ln >= 16 && ln < 31) ? LW + (ln - 16) : ((ln >= 32 && ln < 38) ? LWA + (ln - 32) : (ln == 40 ? LW + 15 : ((ln >= 41 && ln < 56) ? LLI + (ln - 41) : -1)));
+            if (toff >= 0) {
 #pragma unroll
-            for (int r = 0; r < 15; ++r) T.M[LW + r * 16 + (ln - 16)] = col[r];
-        } else if (ln >= 32 && ln < 38) {
-#pragma unroll
-            for (int r = 0; r < 15; ++r) T.M[LWA + r * 8 + (ln - 32)] = col[r];
-        } else if (ln == 40) {
-#pragma unroll
-            for (int r = 0; r < 15; ++r) T.M[LW + r * 16 + 15] = col[r];
-        } else if (ln >= 41 && ln < 56) {
-#pragma unroll
-            for (int r = 0; r < 15; ++r) T.M[LLI + r * 16 + (ln - 41)] = col[r];
+                for (int r = 0; r < 15; ++r) T.M[toff + r * 16] = col[r];
+            }
         }
         lds_sync();
         STAMP(10 + i * 8 + 5);
@@ -658,7 +653,7 @@ __global__ __launch_bounds__(64, THROUGHPUT ? 3 : 2) void k_lm_step(StepArgs a) 
         // = L^-T (L^-1 [..]): two more products on the matrix cores instead of a second triangular solve, so the record is
         // 22 columns (not L + W: 37) and the second sweep is a matrix-vector product.  rec[r][22]: 0..14 Yo, 15..20 Yr, 21 yz.
         {
-            const d4 y1 = xty15<16, 16>(T.M + LLI, T.M + LW, T.Z), y2 = xty15<16, 8>(T.M + LLI, T.M + LWA, T.Z);
+            const d4 y1 = xty15<16, 16>(T.M + LLI, T.M + LW, T.Z), y2 = xty15<16, 16>(T.M + LLI, T.M + LWA, T.Z);
             double* f = sws + (size_t)i * SOLVE_WS;
             const int colx = ln & 15;
 #pragma unroll
@@ -673,8 +668,8 @@ __global__ __launch_bounds__(64, THROUGHPUT ? 3 : 2) void k_lm_step(StepArgs a) 
         d4 p1 = {0.0, 0.0, 0.0, 0.0}, p2 = p1, p3 = p1;
         if (i >= 1) {   // Schur products on the matrix cores
             p1 = xty15<16, 16>(T.M + LW, T.M + LW, T.Z);      // [Wo|z]^T [Wo|z]
-            p2 = xty15<8, 16>(T.M + LWA, T.M + LW, T.Z);      // Wr^T [Wo|z]   (rows < 6)
-            p3 = xty15<8, 8>(T.M + LWA, T.M + LWA, T.Z);      // Wr^T Wr       (rows, cols < 6)
+            p2 = xty15<16, 16>(T.M + LWA, T.M + LW, T.Z);     // Wr^T [Wo|z]   (rows < 6)
+            p3 = xty15<16, 16>(T.M + LWA, T.M + LWA, T.Z);    // Wr^T Wr       (rows, cols < 6)
         }
         if (i >= 1) {
             // written back in the lane layout of the next frame
