@@ -720,11 +720,18 @@ __global__ __launch_bounds__(64, THROUGHPUT ? 3 : 2) void k_lm_step(StepArgs a) 
             const double* f = sws + (size_t)i * SOLVE_WS;
             const int r = lane < 15 ? lane : 0;
             BsRegs R;
-            R.t = f[r * REC_LD + 21];
+            // a record row is 22 consecutive doubles on a 16-byte boundary (REC_LD and SOLVE_WS are even, the workspace is 256-byte
+            // aligned): 11 128-bit loads instead of 22 64-bit ones
+            static_assert(REC_LD % 2 == 0 && SOLVE_WS % 2 == 0, "16-byte aligned record rows");
+            const double2* f2 = reinterpret_cast<const double2*>(f + r * REC_LD);
+            double row[22];
 #pragma unroll
-            for (int k = 0; k < 15; ++k) R.Yo[k] = f[r * REC_LD + k];
+            for (int k = 0; k < 11; ++k) { const double2 v = f2[k]; row[2 * k] = v.x; row[2 * k + 1] = v.y; }
+            R.t = row[21];
 #pragma unroll
-            for (int k = 0; k < 6; ++k) R.Yr[k] = f[r * REC_LD + 15 + k];
+            for (int k = 0; k < 15; ++k) R.Yo[k] = row[k];
+#pragma unroll
+            for (int k = 0; k < 6; ++k) R.Yr[k] = row[15 + k];
             R.gsv = f[REC_GS + r];
             R.xold = xw[(size_t)i * 15 + r];
             R.scv = scl[i * 15 + r];
