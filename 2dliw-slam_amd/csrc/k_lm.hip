@@ -677,8 +677,7 @@ __global__ __launch_bounds__(64, THROUGHPUT ? 3 : 2) void k_lm_step(StepArgs a) 
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const int row = (ln >> 4) + 4 * r, colx = ln & 15;
-                if (row < 15 && colx < 15) T.C[row * MS + colx] = -p1[r];            // diagonal tile of frame i-1
-                if (row < 15 && colx == 15) T.C[row * MS + 40] = -p1[r];             // gradient of frame i-1
+                if (row < 15) T.C[row * MS + (colx < 15 ? colx : 40)] = -p1[r];      // diagonal tile (+ gradient, column 15 -> lane 40) of frame i-1
                 if (row < 6 && colx < 15) T.C[colx * MS + 32 + row] = -p2[r];        // arrow block H[0, i-1] (as R^T)
                 if (i >= 2) {
                     if (row < 6 && colx == 15) T.g0acc[row] -= p2[r];
