@@ -27,6 +27,76 @@ def allreduce_sum_(t, group=None):
     return t
 
 
+def allgather_(out, t, group=None):
+    """One-shot exchange: every rank's image of `t` lands in out[rank] on every rank (no reduction on the wire; the caller
+    sums the images in rank order, which is deterministic and identical on all ranks)."""
+    import torch.distributed as dist
+    if dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1:
+        if t.is_cuda and dist.get_backend(group) == "gloo":
+            # gloo has no device all-gather (single-GPU testing aid of bench.py / the tests): stage through the host
+            import torch
+            host = torch.empty(out.shape, dtype=out.dtype)
+            dist.all_gather_into_tensor(host.view(-1), t.cpu(), group=group)
+            out.copy_(host)
+        else:
+            dist.all_gather_into_tensor(out.view(-1), t, group=group)
+    else:
+        out.view(-1)[:t.numel()].copy_(t)
+    return out
+
+
+EXCHANGES = ("allreduce", "oneshot")
+
+
+class TorchComm:
+    """The production transport: torch.distributed over the given process group (RCCL on GPUs)."""
+
+    def __init__(self, group=None):
+        self.group = group
+
+    def all_reduce_sum_(self, t):
+        return allreduce_sum_(t, self.group)
+
+    def all_gather_(self, out, t):
+        return allgather_(out, t, self.group)
+
+
+class LockstepComm:
+    """Testing aid for 1-GPU boxes: `world` rank objects of ONE process, each driven by its own Python thread, exchange through
+    shared slots and a barrier.  All ranks enqueue on the same HIP stream, so stream order makes every rank's image complete
+    before any rank's sum runs.  One instance per rank: LockstepComm.make(world) -> [comm_0, .., comm_{world-1}]."""
+
+    def __init__(self, shared, rank):
+        self.sh, self.rank = shared, rank
+
+    @staticmethod
+    def make(world):
+        import threading
+        shared = {"slots": [None] * world, "bar": threading.Barrier(world), "world": world}
+        return [LockstepComm(shared, r) for r in range(world)]
+
+    def _deposit(self, t):
+        self.sh["slots"][self.rank] = t
+        self.sh["bar"].wait()
+
+    def all_reduce_sum_(self, t):
+        self._deposit(t)
+        tot = self.sh["slots"][0].clone()
+        for r in range(1, self.sh["world"]):
+            tot += self.sh["slots"][r]
+        self.sh["bar"].wait()          # every rank has enqueued its read of the images before any image is overwritten
+        t.copy_(tot)
+        self.sh["bar"].wait()
+        return t
+
+    def all_gather_(self, out, t):
+        self._deposit(t)
+        for r in range(self.sh["world"]):
+            out[r].copy_(self.sh["slots"][r])
+        self.sh["bar"].wait()
+        return out
+
+
 class BatchSolver:
     """B independent windows (uniform n) resident on one GPU.
 
@@ -34,7 +104,7 @@ class BatchSolver:
     sharded across ranks (`shard_laser`), the small factors are evaluated on every rank, and `solve` all-reduces
     the laser partial sums after every linearisation (one exchange per LM iteration)."""
 
-    def __init__(self, prm, windows, device="cuda:0", history_records=0, rank=0, world=1, group=None):
+    def __init__(self, prm, windows, device="cuda:0", history_records=0, rank=0, world=1, group=None, exchange="allreduce", force_exchange=False, comm=None):
         import torch
         from . import BatchC, WsLayoutC, lib, params_struct, LiwError
         self.torch = torch
@@ -45,6 +115,15 @@ class BatchSolver:
         self._ps = params_struct(prm, dev_index)
         self.h = C.c_void_p(self.L.liw_create(C.byref(self._ps)))
         self.rank, self.world, self.group = rank, world, group
+        assert exchange in EXCHANGES, exchange
+        # exchange: how the ranks of a factor-sharded run combine their laser partial sums:
+        #   "allreduce": RCCL all-reduce(SUM) of the compact record; "oneshot": all-gather of every rank's compact record
+        #   (each GPU pushes its image to all peers once) + local sum in rank order.  force_exchange runs the pack / exchange /
+        #   unpack path even with one rank (tests).
+        self.exchange, self.sharded = exchange, (world > 1 or force_exchange)
+        self.comm = comm if comm is not None else TorchComm(group)
+        self.exchange_ms, self.exchange_calls, self._xev, self._xbuf = 0.0, 0, [], {}
+        self.time_exchange = False
         if world > 1:
             windows = [shard_laser(w, rank, world) for w in windows]
         self.B = len(windows)
@@ -115,7 +194,7 @@ class BatchSolver:
     def solve(self, mode, max_iters=0, use_graph=False):
         """Runs the whole LM loop.  Single rank: one native call (optionally a captured hipGraph).  Factor-sharded:
         the loop is driven here so the all-reduce sits between linearise and step."""
-        if self.world == 1:
+        if not self.sharded:
             if use_graph:
                 # stream capture is not allowed on the legacy default stream: replay on a dedicated side stream
                 torch = self.torch
@@ -129,15 +208,79 @@ class BatchSolver:
                 return
             self._chk(self.L.liw_batch_solve(self.h, C.byref(self.b), C.c_int(mode), C.c_int(max_iters), self._wsp(), self._stream(), C.c_int(0)))
             return
+        # factor-sharded loop.  Per LM iteration: step -> linearise (laser role on this stream, small roles on the ctx's side
+        # streams) -> exchange of the compact laser record on this stream, overlapping the small roles -> join.  Every rank holds
+        # bit-identical sums, so states and `done` flags stay identical across ranks; the number of windows still iterating rides
+        # in the exchanged buffer (identical everywhere by construction) and is read back between growing chunks for the early exit.
         K = self.lm_begin(mode, max_iters)
-        self.lm_linearize(mode, 0)
-        allreduce_sum_(self.PL[0], self.group)
-        for _ in range(K):
-            self.lm_step(mode)
-            self.lm_linearize(mode, 1)
-            allreduce_sum_(self.PL[1], self.group)
+        self._lin_exchange(mode, 0)
+        k, chunk = 0, 4
+        while k < K:
+            m = min(chunk, K - k)
+            for _ in range(m):
+                self.lm_step(mode)
+                self._lin_exchange(mode, 1)
+            k += m
+            if k < K and self.active_windows(mode) == 0:
+                break
+            chunk *= 2
         self.lm_step(mode)
         self.lm_finish(mode)
+
+    def _xbuffers(self, mode):
+        nd = int(self.L.liw_batch_exchange_doubles(C.c_int(self.B), C.c_int(self.n), C.c_int(mode)))
+        if (mode, "buf") not in self._xbuf:
+            t = self.torch
+            self._xbuf[(mode, "buf")] = t.zeros(nd, dtype=t.float64, device=self.dev)
+            self._xbuf[(mode, "all")] = t.zeros((max(self.world, 1), nd), dtype=t.float64, device=self.dev) if self.exchange == "oneshot" else None
+        return self._xbuf[(mode, "buf")], self._xbuf[(mode, "all")], nd
+
+    def exchange_bytes(self, mode):
+        """bytes one rank contributes to one exchange (what crosses xGMI per rank: x 2(P-1)/P for a ring all-reduce, x (P-1) pushes
+        for the one-shot variant)"""
+        return 8 * int(self.L.liw_batch_exchange_doubles(C.c_int(self.B), C.c_int(self.n), C.c_int(mode)))
+
+    def _exchange(self, mode, candidate):
+        """pack -> all-reduce | all-gather -> unpack (sum in rank order) of the laser partial sums of buffer `candidate`"""
+        buf, allb, nd = self._xbuffers(mode)
+        s = self._stream()
+        ev = None
+        if self.time_exchange:
+            ev = (self.torch.cuda.Event(enable_timing=True), self.torch.cuda.Event(enable_timing=True))
+            ev[0].record()
+        self._chk(self.L.liw_batch_exchange_pack(self.h, C.byref(self.b), C.c_int(mode), C.c_int(candidate), self._wsp(), C.c_void_p(buf.data_ptr()), s))
+        if self.exchange == "oneshot":
+            self.comm.all_gather_(allb, buf)
+            self._chk(self.L.liw_batch_exchange_unpack(self.h, C.byref(self.b), C.c_int(mode), C.c_int(candidate), self._wsp(),
+                                                       C.c_void_p(allb.data_ptr()), C.c_int(max(self.world, 1)), s))
+            self._last_x = allb[0]
+        else:
+            self.comm.all_reduce_sum_(buf)
+            self._chk(self.L.liw_batch_exchange_unpack(self.h, C.byref(self.b), C.c_int(mode), C.c_int(candidate), self._wsp(),
+                                                       C.c_void_p(buf.data_ptr()), C.c_int(1), s))
+            self._last_x = buf
+        if ev:
+            ev[1].record()
+            self._xev.append(ev)
+
+    def _lin_exchange(self, mode, candidate):
+        self._chk(self.L.liw_batch_lm_linearize_async(self.h, C.byref(self.b), C.c_int(mode), C.c_int(candidate), self._wsp(), self._stream()))
+        self._exchange(mode, candidate)
+        self._chk(self.L.liw_batch_lm_join(self.h, self._stream()))
+
+    def active_windows(self, mode):
+        """windows still iterating at the last exchange (trailer of the exchanged buffer; blocking 8-byte read-back)"""
+        buf, allb, nd = self._xbuffers(mode)
+        if self.exchange == "oneshot":
+            return int(round(float(allb[:, nd - 1].sum().item()))) // max(self.world, 1)
+        return int(round(float(buf[nd - 1].item()))) // max(self.world, 1)
+
+    def exchange_timing(self):
+        """average device time (ms) of one exchange (pack + collective + unpack) since the last call, and the count"""
+        self.torch.cuda.synchronize(self.dev)
+        ms = [a.elapsed_time(b) for a, b in self._xev]
+        self._xev = []
+        return (sum(ms) / len(ms) if ms else 0.0), len(ms)
 
     # the launch pieces of one solve (what liw_batch_solve chains); a factor-sharded driver puts its exchange of
     # self.PL[candidate] between lm_linearize and lm_step
@@ -157,8 +300,12 @@ class BatchSolver:
 
     def linearize(self, mode):
         self._chk(self.L.liw_batch_linearize(self.h, C.byref(self.b), C.c_int(mode), self._wsp(), self._stream()))
-        if self.world > 1:
-            allreduce_sum_(self.PL[0], self.group)
+        if self.sharded:
+            self._exchange_plain(mode)
+
+    def _exchange_plain(self, mode):
+        # stand-alone linearisations carry no LM state: exchange the full record region (rare path: tests, liw_linearize)
+        self.comm.all_reduce_sum_(self.PL[0])
 
     def export_dense(self, mode):
         N = 15 * self.n
@@ -177,8 +324,9 @@ class BatchSolver:
         dg = torch.zeros((self.B, 15), dtype=torch.float64, device=self.dev)
         s = self._stream()
         self._chk(self.L.liw_batch_marg_linearize(self.h, C.byref(self.b), self._wsp(), s))
-        if self.world > 1:
-            allreduce_sum_(self.PL[0], self.group)
+        if self.sharded:
+            from . import LIW_MODE_MARG
+            self._exchange(LIW_MODE_MARG, 0)
         self._chk(self.L.liw_batch_marg_schur(self.h, C.byref(self.b), self._wsp(), C.c_void_p(sH.data_ptr()), C.c_void_p(dH.data_ptr()),
                                               C.c_void_p(dg.data_ptr()), s))
         return sH, dH, dg

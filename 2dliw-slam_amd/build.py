@@ -20,12 +20,26 @@ def _hipcc():
     return "hipcc"
 
 
+STAMP = LIB + ".srchash"   # content hash of every source / header / flag the library was built from (git-ignored, travels with the .so)
+
+
+def source_hash():
+    import hashlib
+    h = hashlib.sha256(" ".join(FLAGS).encode())
+    for d in [os.path.join(CSRC, s) for s in SOURCES + HEADERS] + [os.path.abspath(__file__)]:
+        h.update(os.path.basename(d).encode())
+        with open(d, "rb") as f:
+            h.update(f.read())
+    return h.hexdigest()
+
+
 def needs_build():
-    if not os.path.exists(LIB):
+    """Content-based, not mtime-based: a snapshot copied to another box (fresh mtimes) is rebuilt exactly when its sources differ
+    from the ones the shipped library was compiled from."""
+    if not os.path.exists(LIB) or not os.path.exists(STAMP):
         return True
-    t = os.path.getmtime(LIB)
-    deps = [os.path.join(CSRC, s) for s in SOURCES + HEADERS] + [os.path.abspath(__file__)]
-    return any(os.path.getmtime(d) > t for d in deps if os.path.exists(d))
+    with open(STAMP) as f:
+        return f.read().strip() != source_hash()
 
 
 def build(force=False, verbose=False):
@@ -51,6 +65,8 @@ def build(force=False, verbose=False):
     r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT)
     if r.returncode != 0:
         raise RuntimeError("link failed: %s\n%s" % (" ".join(cmd), r.stdout.decode(errors="replace")))
+    with open(STAMP, "w") as f:
+        f.write(source_hash() + "\n")
     return LIB
 
 

@@ -471,7 +471,9 @@ __global__ void k_group_offsets(int B, int n, const int* laser_off, const int* l
 // One linearisation.  Large batches: the laser, IMU and wheel+ground role kernels write disjoint partial-sum slots, so
 // they run concurrently (main stream + two side streams joined by events); the matrix-core phase of the IMU kernel then
 // overlaps the fp64 VALU work of the laser kernel on the same CUs.  Small batches: one launch for everything (k_lin_all).
-void launch_linearize(const LinArgs& A, const DevParams& P, hipStream_t s, const LinFork* fk) {
+// defer_join: the laser role stays on `s`, the IMU / small roles on the side streams, and the join is left to launch_linearize_join —
+// a factor-sharded driver puts its exchange of the laser partial sums on `s` in between, so that it overlaps the small roles.
+void launch_linearize(const LinArgs& A, const DevParams& P, hipStream_t s, const LinFork* fk, bool defer_join) {
     const int n = A.n, B = A.B;
     // groups per wave: one for small batches (latency), up to LASER_GMAX for large ones (no ragged last pass per group)
     int G = 1;
@@ -500,9 +502,69 @@ void launch_linearize(const LinArgs& A, const DevParams& P, hipStream_t s, const
     if (fork) {
         hipEventRecord(fk->ev_join[0], fk->side[0]);
         hipEventRecord(fk->ev_join[1], fk->side[1]);
-        hipStreamWaitEvent(s, fk->ev_join[0], 0);
-        hipStreamWaitEvent(s, fk->ev_join[1], 0);
+        if (!defer_join) {
+            hipStreamWaitEvent(s, fk->ev_join[0], 0);
+            hipStreamWaitEvent(s, fk->ev_join[1], 0);
+        }
     }
+}
+void launch_linearize_join(hipStream_t s, const LinFork* fk) {
+    if (!fk || !fk->side[0]) return;
+    hipStreamWaitEvent(s, fk->ev_join[0], 0);   // events never recorded count as complete
+    hipStreamWaitEvent(s, fk->ev_join[1], 0);
+}
+
+// ------------------------------------------------------------------------------------------- factor-sharded exchange
+// A laser group record (LP = 128 slots) is a signed expansion of NP pair totals (45 with both poses free, 21 with one): the
+// exchange between ranks moves the NP totals only.  pack: record -> totals (representative slot and sign per total, table built on
+// the host with the same slot map the laser kernel uses); unpack: sum over `world` gathered copies in rank order -> record.
+__global__ void k_exchange_pack(int groups, int n, int np, LaserPackTable tb, const double* PL, const LmState* lm, double* buf) {
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= groups * np) return;
+    const int grp = t / np, p = t % np;
+    const bool dead = lm && lm[grp / n].done;   // finished windows are not re-linearised: their stale sums must not accumulate
+    const double v = PL[(size_t)grp * LP + tb.slot[p]];
+    buf[t] = dead ? 0.0 : (tb.neg[p] ? -v : v);
+}
+template <bool BOTH>
+__global__ void k_exchange_unpack(int groups, int np, int world, size_t stride, const double* buf, double* PL) {
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= groups * LP) return;
+    const int grp = t / LP, s = t % LP;
+    const int code = laser_slot_code<BOTH>(s);
+    double v = 0.0;
+    if (code >= 0) {
+        const double* src = buf + (size_t)grp * np + (code & 63);
+        for (int r = 0; r < world; ++r) v += src[(size_t)r * stride];   // fixed rank order: every rank forms the same bits
+        if (code & 64) v = -v;
+    }
+    PL[t] = v;
+}
+__global__ void k_count_active(int B, const LmState* lm, double* out) {
+    __shared__ int cnt;
+    if (threadIdx.x == 0) cnt = 0;
+    __syncthreads();
+    int c = 0;
+    for (int b = threadIdx.x; b < B; b += blockDim.x) c += lm[b].done ? 0 : 1;
+    atomicAdd(&cnt, c);   // integer: order-independent
+    __syncthreads();
+    if (threadIdx.x == 0) out[0] = (double)cnt;
+}
+void launch_exchange_pack(int B, int n, bool both, const double* PL, const LmState* lm, double* buf, hipStream_t s) {
+    const int np = both ? 45 : 21, groups = B * n;
+    LaserPackTable tb{};
+    for (int p = 0; p < np; ++p) tb.slot[p] = -1;
+    for (int sl = 0; sl < LP; ++sl) {
+        const int code = both ? laser_slot_code<true>(sl) : laser_slot_code<false>(sl);
+        if (code >= 0 && tb.slot[code & 63] < 0) { tb.slot[code & 63] = sl; tb.neg[code & 63] = (code & 64) ? 1 : 0; }
+    }
+    hipLaunchKernelGGL(k_exchange_pack, dim3((groups * np + 255) / 256), dim3(256), 0, s, groups, n, np, tb, PL, lm, buf);
+    if (lm) hipLaunchKernelGGL(k_count_active, dim3(1), dim3(256), 0, s, B, lm, buf + (size_t)groups * np);
+}
+void launch_exchange_unpack(int B, int n, bool both, int world, size_t stride, const double* buf, double* PL, hipStream_t s) {
+    const int np = both ? 45 : 21, groups = B * n;
+    if (both) hipLaunchKernelGGL(k_exchange_unpack<true>, dim3((groups * LP + 255) / 256), dim3(256), 0, s, groups, np, world, stride, buf, PL);
+    else hipLaunchKernelGGL(k_exchange_unpack<false>, dim3((groups * LP + 255) / 256), dim3(256), 0, s, groups, np, world, stride, buf, PL);
 }
 #ifdef LIW_CLK
 extern "C" void liw_debug_clk_lin(long long* out, int nn) { hipMemcpyFromSymbol(out, HIP_SYMBOL(g_clk_lin), sizeof(long long) * nn); }

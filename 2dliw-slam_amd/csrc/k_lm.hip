@@ -518,7 +518,7 @@ __global__ __launch_bounds__(64, THROUGHPUT ? 3 : 2) void k_lm_step(StepArgs a) 
 
     // ---- FinalizeIterationAndCheckIfMinimizerCanContinue, part 1 (the gradient test needs the assembled g and is
     //      applied after the pass below; it can only pre-empt the min-radius exit, never the iteration cap)
-    if (iteration >= a.max_iters && !(iteration == 0 && fresh)) {
+    if (iteration >= st.max_iters && !(iteration == 0 && fresh)) {
         if (lane == 0) {
             st.done = 1; st.termination = 4; st.radius = radius; st.decrease_factor = dec; st.x_cost = x_cost; st.x_norm = x_norm;
             st.reuse_diagonal = reuse; st.cur = cur; st.have_candidate = 0;
@@ -803,13 +803,13 @@ __global__ __launch_bounds__(64, THROUGHPUT ? 3 : 2) void k_lm_step(StepArgs a) 
     }
 }
 
-__global__ void k_lm_begin(int B, int n, LmState* lm) {
+__global__ void k_lm_begin(int B, int n, LmState* lm, int max_iters) {
     const int b = blockIdx.x * blockDim.x + threadIdx.x;
     if (b >= B) return;
     LmState& s = lm[b];
     s.radius = kInitRadius; s.decrease_factor = 2.0; s.x_cost = 0.0; s.x_norm = 0.0; s.minimum_cost = 0.0;
     s.cand_step_norm = 0.0; s.model_cost_change = 0.0; s.reuse_diagonal = 0; s.iteration = 0; s.done = 0; s.termination = 0;
-    s.successful = 0; s.cur = 0; s.invalid_steps = 0; s.have_candidate = 0; s.initial_cost = 0.0;
+    s.successful = 0; s.cur = 0; s.invalid_steps = 0; s.have_candidate = 0; s.initial_cost = 0.0; s.max_iters = max_iters; s.pad_ = 0;
 }
 
 // write-backs the reference does after ceres::Solve (solver.cpp:176-190 init, :804-814 tracking) + summaries
@@ -1042,8 +1042,8 @@ __global__ __launch_bounds__(64, 2) void k_marg_schur(MargArgs a) {
 extern "C" void liw_debug_clk(long long* out, int nn) { hipMemcpyFromSymbol(out, HIP_SYMBOL(g_clk), sizeof(long long) * nn); }
 extern "C" void liw_debug_span(long long* out, int nn) { hipMemcpyFromSymbol(out, HIP_SYMBOL(g_span), sizeof(long long) * nn); }
 #endif
-void launch_lm_begin(int B, int n, LmState* lm, hipStream_t s) {
-    hipLaunchKernelGGL(k_lm_begin, dim3((B + 63) / 64), dim3(64), 0, s, B, n, lm);
+void launch_lm_begin(int B, int n, LmState* lm, int max_iters, hipStream_t s) {
+    hipLaunchKernelGGL(k_lm_begin, dim3((B + 63) / 64), dim3(64), 0, s, B, n, lm, max_iters);
 }
 void launch_lm_step(const StepArgs& a, hipStream_t s) {
     static const char* env = getenv("LIW_STEP_VARIANT");   // 0 / 1: force the latency / throughput variant (profiling aid)

@@ -14,7 +14,10 @@
 
 namespace liw {
 // kernel launchers (k_linearize.hip, k_lm.hip)
-void launch_linearize(const LinArgs& A, const DevParams& P, hipStream_t s, const LinFork* fk);
+void launch_linearize(const LinArgs& A, const DevParams& P, hipStream_t s, const LinFork* fk, bool defer_join = false);
+void launch_linearize_join(hipStream_t s, const LinFork* fk);
+void launch_exchange_pack(int B, int n, bool both, const double* PL, const LmState* lm, double* buf, hipStream_t s);
+void launch_exchange_unpack(int B, int n, bool both, int world, size_t stride, const double* buf, double* PL, hipStream_t s);
 void launch_group_offsets(int B, int n, const int* laser_off, const int* laser_frame, int* group_off, hipStream_t s);
 struct StepArgs {
     int B, n, mode, max_iters, fast_mode;
@@ -34,7 +37,7 @@ struct MargArgs {
     WsView w;
     double* sqrt_H; double* Delta_H; double* Delta_g; int* status;
 };
-void launch_lm_begin(int B, int n, LmState* lm, hipStream_t s);
+void launch_lm_begin(int B, int n, LmState* lm, int max_iters, hipStream_t s);
 void launch_lm_step(const StepArgs& a, hipStream_t s);
 void launch_lm_finish(const StepArgs& a, hipStream_t s);
 void launch_export_dense(const ExportArgs& a, hipStream_t s);
@@ -77,6 +80,7 @@ struct liw_ctx {
     liw_ws_layout lay{};
     int hist_records = 0;
     int last_iters = 0;
+    int solved_records = 0;       // history records of the last completed liw_solve on the current window (0: none)
     // timing
     bool timing = false;
     std::vector<hipEvent_t> ev_lin, ev_step;
@@ -273,10 +277,14 @@ int liw_batch_ws_layout(int B, int n, int history_records, liw_ws_layout* out) {
 }
 
 // ------------------------------------------------------------------------------------------ batch API
-static int check_batch(liw_ctx* c, const liw_batch* b) {
+// min_n = 2 for the TRACK / MARG topologies: their prior block sits on frame n-2 (solver.cpp:234-254, :282-306), which does
+// not exist in a 1-frame window (the reference never builds one: trajectory.cpp:525-560 always has the previous frame)
+static int check_batch(liw_ctx* c, const liw_batch* b, int min_n = 1) {
     if (!b || b->B <= 0 || b->n <= 0 || b->n > 64) return fail(c, LIW_EINVAL, "bad batch (need 1 <= n <= 64, B >= 1)");
+    if (b->n < min_n) return fail(c, LIW_EINVAL, "TRACK / MARG topology needs n >= 2 (the prior block is tied to frame n-2)");
     return LIW_OK;
 }
+static int min_frames(int mode) { return mode == LIW_MODE_INIT ? 1 : 2; }
 static LinArgs lin_args(const liw_batch* b, int mode, const double* x, const WsView& v, int candidate, bool use_lm) {
     LinArgs A{};
     A.B = b->B; A.n = b->n; A.mode = mode; A.eval_small = b->eval_small;
@@ -307,27 +315,67 @@ static int resolve_iters(liw_ctx* c, int mode, int max_iters) {
 
 int liw_batch_lm_begin(liw_ctx* c, const liw_batch* b, int mode, int max_iters, void* ws, void* stream) {
     NEEDDEV(c);
-    if (int r = check_batch(c, b)) return r;
-    (void)mode; (void)max_iters;
+    if (int r = check_batch(c, b, min_frames(mode))) return r;
+    // the cap lives in the device-side LmState from here on: liw_batch_lm_step / _finish do not depend on host ctx state
+    c->last_iters = resolve_iters(c, mode, max_iters);
     WsView v = make_view(ws, b->B, b->n, b->history_records);
     hipStream_t s = (hipStream_t)stream;
     launch_group_offsets(b->B, b->n, b->laser_off, b->laser_frame, v.group_off, s);
-    launch_lm_begin(b->B, b->n, v.lm, s);
+    launch_lm_begin(b->B, b->n, v.lm, c->last_iters, s);
     HIPCHK(c, hipGetLastError());
     return LIW_OK;
 }
 int liw_batch_lm_linearize(liw_ctx* c, const liw_batch* b, int mode, int candidate, void* ws, void* stream) {
     NEEDDEV(c);
-    if (int r = check_batch(c, b)) return r;
+    if (int r = check_batch(c, b, min_frames(mode))) return r;
     WsView v = make_view(ws, b->B, b->n, b->history_records);
     LinArgs A = lin_args(b, mode, candidate ? v.x_cand : b->x, v, candidate != 0, true);
     launch_linearize(A, c->dp, (hipStream_t)stream, c->have_fork ? &c->fork : nullptr);
     HIPCHK(c, hipGetLastError());
     return LIW_OK;
 }
+/* linearisation without the final join of the role streams (see liw_window.h, factor-sharded exchange) */
+int liw_batch_lm_linearize_async(liw_ctx* c, const liw_batch* b, int mode, int candidate, void* ws, void* stream) {
+    NEEDDEV(c);
+    if (int r = check_batch(c, b, min_frames(mode))) return r;
+    WsView v = make_view(ws, b->B, b->n, b->history_records);
+    LinArgs A = lin_args(b, mode, candidate ? v.x_cand : b->x, v, candidate != 0, true);
+    launch_linearize(A, c->dp, (hipStream_t)stream, c->have_fork ? &c->fork : nullptr, true);
+    HIPCHK(c, hipGetLastError());
+    return LIW_OK;
+}
+int liw_batch_lm_join(liw_ctx* c, void* stream) {
+    NEEDDEV(c);
+    launch_linearize_join((hipStream_t)stream, c->have_fork ? &c->fork : nullptr);
+    HIPCHK(c, hipGetLastError());
+    return LIW_OK;
+}
+int liw_batch_exchange_doubles(int B, int n, int mode) {
+    if (B <= 0 || n <= 0 || n > 64) return LIW_EINVAL;
+    return B * n * (mode == LIW_MODE_INIT ? 45 : 21) + 1;
+}
+int liw_batch_exchange_pack(liw_ctx* c, const liw_batch* b, int mode, int candidate, void* ws, double* buf, void* stream) {
+    NEEDDEV(c);
+    if (int r = check_batch(c, b, min_frames(mode))) return r;
+    if (!buf) return fail(c, LIW_EINVAL, "liw_batch_exchange_pack: null buffer");
+    WsView v = make_view(ws, b->B, b->n, b->history_records);
+    launch_exchange_pack(b->B, b->n, mode == LIW_MODE_INIT, v.PL[candidate ? 1 : 0], mode == LIW_MODE_MARG ? nullptr : v.lm, buf, (hipStream_t)stream);
+    HIPCHK(c, hipGetLastError());
+    return LIW_OK;
+}
+int liw_batch_exchange_unpack(liw_ctx* c, const liw_batch* b, int mode, int candidate, void* ws, const double* buf, int copies, void* stream) {
+    NEEDDEV(c);
+    if (int r = check_batch(c, b, min_frames(mode))) return r;
+    if (!buf || copies < 1) return fail(c, LIW_EINVAL, "liw_batch_exchange_unpack: null buffer / copies < 1");
+    WsView v = make_view(ws, b->B, b->n, b->history_records);
+    const size_t stride = (size_t)liw_batch_exchange_doubles(b->B, b->n, mode);
+    launch_exchange_unpack(b->B, b->n, mode == LIW_MODE_INIT, copies, stride, buf, v.PL[candidate ? 1 : 0], (hipStream_t)stream);
+    HIPCHK(c, hipGetLastError());
+    return LIW_OK;
+}
 int liw_batch_lm_step(liw_ctx* c, const liw_batch* b, int mode, void* ws, void* stream) {
     NEEDDEV(c);
-    if (int r = check_batch(c, b)) return r;
+    if (int r = check_batch(c, b, min_frames(mode))) return r;
     WsView v = make_view(ws, b->B, b->n, b->history_records);
     StepArgs a = step_args(c, b, mode, c->last_iters, v);
     launch_lm_step(a, (hipStream_t)stream);
@@ -336,7 +384,7 @@ int liw_batch_lm_step(liw_ctx* c, const liw_batch* b, int mode, void* ws, void* 
 }
 int liw_batch_lm_finish(liw_ctx* c, const liw_batch* b, int mode, void* ws, void* stream) {
     NEEDDEV(c);
-    if (int r = check_batch(c, b)) return r;
+    if (int r = check_batch(c, b, min_frames(mode))) return r;
     WsView v = make_view(ws, b->B, b->n, b->history_records);
     StepArgs a = step_args(c, b, mode, c->last_iters, v);
     launch_lm_finish(a, (hipStream_t)stream);
@@ -358,7 +406,7 @@ static hipEvent_t next_event(std::vector<hipEvent_t>& pool, size_t& used) {
 static int enqueue_solve(liw_ctx* c, const liw_batch* b, int mode, int K, void* ws, hipStream_t s, bool timed) {
     WsView v = make_view(ws, b->B, b->n, b->history_records);
     launch_group_offsets(b->B, b->n, b->laser_off, b->laser_frame, v.group_off, s);
-    launch_lm_begin(b->B, b->n, v.lm, s);
+    launch_lm_begin(b->B, b->n, v.lm, K, s);
     StepArgs st = step_args(c, b, mode, K, v);
     auto lin = [&](int cand) {
         LinArgs A = lin_args(b, mode, cand ? v.x_cand : b->x, v, cand, true);
@@ -380,7 +428,7 @@ static int enqueue_solve(liw_ctx* c, const liw_batch* b, int mode, int K, void* 
 
 int liw_batch_solve(liw_ctx* c, const liw_batch* b, int mode, int max_iters, void* ws, void* stream, int use_graph) {
     NEEDDEV(c);
-    if (int r = check_batch(c, b)) return r;
+    if (int r = check_batch(c, b, min_frames(mode))) return r;
     if (mode != LIW_MODE_INIT && mode != LIW_MODE_TRACK) return fail(c, LIW_EINVAL, "liw_batch_solve: mode must be INIT or TRACK");
     const int K = resolve_iters(c, mode, max_iters);
     c->last_iters = K;
@@ -412,7 +460,7 @@ int liw_batch_solve(liw_ctx* c, const liw_batch* b, int mode, int max_iters, voi
 
 int liw_batch_marg_linearize(liw_ctx* c, const liw_batch* b, void* ws, void* stream) {
     NEEDDEV(c);
-    if (int r = check_batch(c, b)) return r;
+    if (int r = check_batch(c, b, 2)) return r;
     WsView v = make_view(ws, b->B, b->n, b->history_records);
     hipStream_t s = (hipStream_t)stream;
     launch_group_offsets(b->B, b->n, b->laser_off, b->laser_frame, v.group_off, s);
@@ -425,7 +473,7 @@ int liw_batch_marg_linearize(liw_ctx* c, const liw_batch* b, void* ws, void* str
 }
 int liw_batch_marg_schur(liw_ctx* c, const liw_batch* b, void* ws, double* sqrt_H, double* Delta_H, double* Delta_g, void* stream) {
     NEEDDEV(c);
-    if (int r = check_batch(c, b)) return r;
+    if (int r = check_batch(c, b, 2)) return r;
     if (c->prm.fast_mode) return LIW_OK;
     WsView v = make_view(ws, b->B, b->n, b->history_records);
     MargArgs a{};
@@ -438,7 +486,7 @@ int liw_batch_marg_schur(liw_ctx* c, const liw_batch* b, void* ws, double* sqrt_
 }
 int liw_batch_export_dense(liw_ctx* c, const liw_batch* b, int mode, int buf, void* ws, double* H, double* g, double* cost, void* stream) {
     NEEDDEV(c);
-    if (int r = check_batch(c, b)) return r;
+    if (int r = check_batch(c, b, min_frames(mode))) return r;
     WsView v = make_view(ws, b->B, b->n, b->history_records);
     ExportArgs a{};
     a.B = b->B; a.n = b->n; a.mode = mode; a.fast_mode = c->prm.fast_mode; a.buf = buf;
@@ -451,7 +499,7 @@ int liw_batch_export_dense(liw_ctx* c, const liw_batch* b, int mode, int buf, vo
 /* standalone linearisation at b->x into buffer 0 (no LM state): liw_linearize / tests / bench kernel timing */
 int liw_batch_linearize(liw_ctx* c, const liw_batch* b, int mode, void* ws, void* stream) {
     NEEDDEV(c);
-    if (int r = check_batch(c, b)) return r;
+    if (int r = check_batch(c, b, min_frames(mode))) return r;
     WsView v = make_view(ws, b->B, b->n, b->history_records);
     hipStream_t s = (hipStream_t)stream;
     launch_group_offsets(b->B, b->n, b->laser_off, b->laser_frame, v.group_off, s);
@@ -523,6 +571,11 @@ int liw_get_timing(liw_ctx* c, double* lin_ms, int* lin_n, double* step_ms, int*
 int liw_set_window(liw_ctx* c, const liw_window* w) {
     NEEDDEV(c);
     if (!w || w->n < 1 || w->n > 64 || w->L < 0) return fail(c, LIW_EINVAL, "liw_set_window: need 1 <= n <= 64, L >= 0");
+    if (!w->states || !w->match_pose || !w->has_match) return fail(c, LIW_EINVAL, "liw_set_window: states / match_pose / has_match are NULL");
+    if (w->L > 0 && (!w->laser_frame || !w->laser_pts)) return fail(c, LIW_EINVAL, "liw_set_window: L > 0 but laser_frame / laser_pts are NULL");
+    if (w->n > 1 && (!w->imu_X || !w->imu_J || !w->imu_sqrtP || !w->imu_Dt || !w->wheel_T || !w->wheel_sqrtP))
+        return fail(c, LIW_EINVAL, "liw_set_window: n > 1 but an IMU / wheel array is NULL");
+    c->solved_records = 0;
     HIPCHK(c, hipSetDevice(c->prm.device));
     const int n = w->n, L = w->L, nm = n > 1 ? n - 1 : 1;
     // laser blocks must be sorted by owning frame
@@ -588,6 +641,15 @@ int liw_set_window(liw_ctx* c, const liw_window* w) {
     b.eval_small = 1; b.history_records = c->hist_records;
     return LIW_OK;
 }
+/* Forget the uploaded window: afterwards every window-level call fails with LIW_ESTATE until the next liw_set_window.  For callers
+ * (the lvio_2d::solver shim) whose flat arrays die with the calling scope, so that the ctx never holds dangling host pointers. */
+int liw_clear_window(liw_ctx* c) {
+    if (!c) return LIW_EINVAL;
+    c->have_window = false;
+    c->hw = liw_window{};
+    c->solved_records = 0;
+    return LIW_OK;
+}
 #define NEEDWIN(c)                                                                          \
     do {                                                                                    \
         NEEDDEV(c);                                                                         \
@@ -609,11 +671,13 @@ static int download_states(liw_ctx* c) {
 int liw_solve(liw_ctx* c, int mode, int max_iters, liw_summary* summary) {
     NEEDWIN(c);
     if (mode != LIW_MODE_INIT && mode != LIW_MODE_TRACK) return fail(c, LIW_EINVAL, "liw_solve: mode must be LIW_MODE_INIT or LIW_MODE_TRACK");
+    if (c->n < min_frames(mode)) return fail(c, LIW_EINVAL, "liw_solve: TRACK topology needs n >= 2");
     // init topology ties every laser block to (frame 0, owning frame): a block owned by frame 0 would name the same
     // parameter block twice, which ceres::Problem::AddResidualBlock rejects (solver.cpp:93-106)
     if (mode == LIW_MODE_INIT && c->L > 0 && c->hw.laser_frame[0] == 0 && c->hw.has_match[0])
         return fail(c, LIW_EINVAL, "init topology: frame 0 must not own laser blocks (duplicate parameter blocks)");
     int K = resolve_iters(c, mode, max_iters);
+    c->solved_records = 0;
     if (K + 1 > c->hist_records) {   // grow the history region
         c->hist_records = K + 1;
         c->sb.history_records = c->hist_records;
@@ -630,7 +694,7 @@ int liw_solve(liw_ctx* c, int mode, int max_iters, liw_summary* summary) {
         hipStream_t s = c->stream;
         WsView v = make_view(c->ws.p, 1, c->n, b->history_records);
         launch_group_offsets(1, c->n, b->laser_off, b->laser_frame, v.group_off, s);
-        launch_lm_begin(1, c->n, v.lm, s);
+        launch_lm_begin(1, c->n, v.lm, K, s);
         StepArgs st = step_args(c, b, mode, K, v);
         auto lin = [&](int cand) {
             LinArgs A = lin_args(b, mode, cand ? v.x_cand : b->x, v, cand, true);
@@ -657,16 +721,18 @@ int liw_solve(liw_ctx* c, int mode, int max_iters, liw_summary* summary) {
     HIPCHK(c, hipMemcpyAsync(sp, (char*)c->ws.p + f.info, sizeof(liw_summary), hipMemcpyDeviceToHost, c->stream));
     if (int r = download_states(c)) return r;
     if (summary) *summary = *sp;
+    c->solved_records = std::max(0, std::min(sp->iterations + 1, c->hist_records));
     return LIW_OK;
 }
 int liw_get_history(liw_ctx* c, double* x, int max_records) {
     NEEDWIN(c);
+    // only a solve completed on the CURRENT window has a history: the record count is host state (cleared by
+    // liw_set_window and at the start of every liw_solve), never read from a possibly uninitialised workspace
+    if (c->solved_records <= 0) return fail(c, LIW_ESTATE, "liw_get_history: no completed liw_solve on the current window");
+    if (!x || max_records <= 0) return fail(c, LIW_EINVAL, "liw_get_history: null buffer");
     FullLayout f = full_layout(1, c->n, c->hist_records);
-    liw_summary s{};
-    HIPCHK(c, hipMemcpy(&s, (char*)c->ws.p + f.info, sizeof(s), hipMemcpyDeviceToHost));
-    int rec = s.iterations + 1;
+    int rec = c->solved_records;
     if (rec > max_records) rec = max_records;
-    if (rec > c->hist_records) rec = c->hist_records;
     HIPCHK(c, hipMemcpy(x, (char*)c->ws.p + f.history, sizeof(double) * (size_t)rec * c->n * 15, hipMemcpyDeviceToHost));
     return rec;
 }
@@ -714,6 +780,7 @@ int liw_eval_factors(liw_ctx* c, int mode, double* laser_res, double* laser_jac,
 int liw_marginalize(liw_ctx* c, double* sqrt_H36, double* Delta_H225, double* Delta_g15) {
     NEEDWIN(c);
     if (c->prm.fast_mode) return LIW_OK;   // solver.cpp:259-260
+    if (c->n < 2) return fail(c, LIW_EINVAL, "liw_marginalize: needs n >= 2");
     if (c->scratch.ensure(sizeof(double) * (36 + 225 + 15))) return fail(c, LIW_ENOMEM, "hipMalloc");
     double* d = c->scratch.as<double>();
     if (int r = liw_batch_marg_linearize(c, &c->sb, c->ws.p, c->stream)) return r;

@@ -37,6 +37,7 @@ struct LmState {
     double radius, decrease_factor, x_cost, x_norm, minimum_cost;
     double cand_step_norm, model_cost_change;
     int reuse_diagonal, iteration, done, termination, successful, cur, invalid_steps, have_candidate;
+    int max_iters, pad_;        // iteration cap of this solve (set by k_lm_begin: step / finish never depend on host state)
     double initial_cost;
     double scale[15 * 64];      // Jacobi scaling, up to n = 64 frames
     double diagonal[15 * 64];
@@ -80,6 +81,42 @@ struct LinArgs {
     double* dbg_laser_res; double* dbg_laser_jac; double* dbg_imu_res; double* dbg_imu_jac;
     double* dbg_wheel_res; double* dbg_wheel_jac; double* dbg_ground_res; double* dbg_ground_jac;
 };
+
+// Slot map of a laser group record (LP slots): which pair total (bits 0..5) of the group's NP unique pair products a slot holds,
+// bit 6 = negated, -1 = structural zero.  Unique columns of a block's two Jacobian rows: BOTH poses free
+// [a_x a_y a_th0..2 b_th0..2 r] (9 -> 45 pairs; b_x = -a_x, b_y = -a_y), one free pose [b_x b_y b_th0..2 r] (6 -> 21 pairs).
+// Record: Haa (0..35) Hbb (36..71) Hab (72..107) ga (108..113) gb (114..119) sum r^2 (120).  The laser kernel builds the same
+// table in LDS (k_lin_laser_body.inc); the factor-sharded exchange packs / unpacks records with it.
+template <bool BOTH>
+__host__ __device__ inline int laser_slot_code(int s) {
+    constexpr int NC = BOTH ? 9 : 6, RC = NC - 1;
+    auto pairidx = [](int c1, int c2) { if (c1 > c2) { const int t = c1; c1 = c2; c2 = t; } return c1 * NC - c1 * (c1 - 1) / 2 + (c2 - c1); };
+    auto col_a = [](int idx) { return idx < 2 ? idx : (idx == 2 ? -1 : idx - 1); };
+    auto col_b = [](int idx) { return BOTH ? (idx < 2 ? idx : (idx == 2 ? -1 : idx + 2)) : (idx == 2 ? -1 : (idx < 2 ? idx : idx - 1)); };
+    auto neg_b = [](int idx) { return BOTH && idx < 2; };
+    int src = -1;
+    bool neg = false;
+    if (s < 36) {
+        const int ca = col_a(s / 6), cb = col_a(s % 6);
+        if (BOTH && ca >= 0 && cb >= 0) src = pairidx(ca, cb);
+    } else if (s < 72) {
+        const int ia = (s - 36) / 6, ib = (s - 36) % 6, ca = col_b(ia), cb = col_b(ib);
+        if (ca >= 0 && cb >= 0) { src = pairidx(ca, cb); neg = neg_b(ia) != neg_b(ib); }
+    } else if (s < 108) {
+        const int ia = (s - 72) / 6, ib = (s - 72) % 6, ca = col_a(ia), cb = col_b(ib);
+        if (BOTH && ca >= 0 && cb >= 0) { src = pairidx(ca, cb); neg = neg_b(ib); }
+    } else if (s < 114) {
+        const int ca = col_a(s - 108);
+        if (BOTH && ca >= 0) src = pairidx(ca, RC);
+    } else if (s < 120) {
+        const int cb = col_b(s - 114);
+        if (cb >= 0) { src = pairidx(cb, RC); neg = neg_b(s - 114); }
+    } else if (s == 120) {
+        src = pairidx(RC, RC);
+    }
+    return src < 0 ? -1 : (src | (neg ? 64 : 0));
+}
+struct LaserPackTable { short slot[45]; unsigned char neg[45]; };   // representative record slot (and sign) of every pair total
 
 // side streams + events used to run the independent role kernels of one linearisation concurrently
 struct LinFork {

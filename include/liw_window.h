@@ -37,7 +37,8 @@ extern "C" {
  *                    constant laser_match (p1,q1); p,q of frames 0..n-2 constant (bs too in fast_mode);
  *                    prior block on frame n-2 when one is stored and !fast_mode
  *   LIW_MODE_MARG  = solver::marginalization (solver.cpp:257-442): every frame's laser rows w.r.t. its own
- *                    pose only, prior rows on frame n-2, g = -J^T R                                     */
+ *                    pose only, prior rows on frame n-2, g = -J^T R
+ * TRACK and MARG need n >= 2 (their prior block is tied to frame n-2); n = 1 is LIW_EINVAL there.      */
 enum { LIW_MODE_INIT = 0, LIW_MODE_TRACK = 1, LIW_MODE_MARG = 2 };
 
 /* The subset of param::manager the path reads (reference src/utilies/params.h; values config/office.yaml). */
@@ -96,12 +97,16 @@ int liw_get_extrinsics(const liw_ctx* ctx, double* T_imu_to_wheel16, double* T_i
  * liw_solve / liw_marginalize scatter results back into `states` and `match_pose` in place, as the
  * reference mutates frame_info / laser_match in place. */
 int liw_set_window(liw_ctx* ctx, const liw_window* w);
+/* Forget the uploaded window (the ctx keeps no host pointers afterwards); window-level calls then return LIW_ESTATE
+ * until the next liw_set_window.  The stored prior (solver.h:31-37) is kept. */
+int liw_clear_window(liw_ctx* ctx);
 /* replaces: solver::init_solve (mode INIT, incl. the laser_match fix-up solver.cpp:176-190) and
  * solver::solve (mode TRACK, incl. the p2,q2 write-back solver.cpp:804-814).  max_iters <= 0 -> Ceres
  * default 50 (10 in fast_mode for TRACK, solver.cpp:800-801). */
 int liw_solve(liw_ctx* ctx, int mode, int max_iters, liw_summary* summary);
 /* Per-iteration free-state history of the last liw_solve: x[(iters+1)][n][15] (all states, constant ones
- * included); returns the number of records written (tests / parity gate, BASELINE.md "equality gate"). */
+ * included); returns the number of records written (tests / parity gate, BASELINE.md "equality gate"), or
+ * LIW_ESTATE when no liw_solve has completed since the last liw_set_window. */
 int liw_get_history(liw_ctx* ctx, double* x, int max_records);
 /* Normal equations at the current states, dense over the full ordering [p q v ba bw] x n:
  * INIT/TRACK: tangent-space H = J^T J, g = J^T r (constant blocks -> zero rows/cols), cost = 1/2|r|^2
@@ -172,6 +177,21 @@ int liw_batch_lm_begin(liw_ctx* ctx, const liw_batch* b, int mode, int max_iters
 int liw_batch_lm_linearize(liw_ctx* ctx, const liw_batch* b, int mode, int candidate, void* ws, void* stream);
 int liw_batch_lm_step(liw_ctx* ctx, const liw_batch* b, int mode, void* ws, void* stream);
 int liw_batch_lm_finish(liw_ctx* ctx, const liw_batch* b, int mode, void* ws, void* stream);
+/* Factor-sharded (multi-GPU) exchange of the laser partial sums, SURVEY.md 8(e).  A laser group record (LIW_LASER_PARTIAL slots)
+ * is a signed expansion of 45 unique pair totals (INIT: both poses free) or 21 (TRACK / MARG), so ranks exchange
+ * liw_batch_exchange_doubles() = B*n*{45|21} + 1 doubles instead of B*n*128; the trailing double is the number of windows that
+ * are still iterating (identical on every rank after a sum, used for the early exit of the sharded loop).
+ *   liw_batch_lm_linearize_async : like liw_batch_lm_linearize, but the laser role alone is ordered on `stream`; the IMU / wheel /
+ *                                  ground roles keep running on the ctx's side streams until liw_batch_lm_join(stream)
+ *   liw_batch_exchange_pack      : records of buffer `candidate` -> buf (device)
+ *   [ host: all-reduce(buf) over RCCL, or all-gather into `copies` consecutive images (one-shot exchange) ]
+ *   liw_batch_exchange_unpack    : sum of the `copies` images in rank order -> records of buffer `candidate`
+ *   liw_batch_lm_join            : `stream` waits for the side roles; then liw_batch_lm_step */
+int liw_batch_lm_linearize_async(liw_ctx* ctx, const liw_batch* b, int mode, int candidate, void* ws, void* stream);
+int liw_batch_lm_join(liw_ctx* ctx, void* stream);
+int liw_batch_exchange_doubles(int B, int n, int mode);
+int liw_batch_exchange_pack(liw_ctx* ctx, const liw_batch* b, int mode, int candidate, void* ws, double* buf, void* stream);
+int liw_batch_exchange_unpack(liw_ctx* ctx, const liw_batch* b, int mode, int candidate, void* ws, const double* buf, int copies, void* stream);
 int liw_batch_solve(liw_ctx* ctx, const liw_batch* b, int mode, int max_iters, void* ws, void* stream, int use_graph);
 /* marginalisation of every window of the batch (linearise in MARG topology + chain Schur + eigen sqrt);
  * sqrt_H [B][36], Delta_H [B][225], Delta_g [B][15] optional device outputs */

@@ -69,6 +69,8 @@ struct frame_info {
     }
 };
 
+struct feature_manger {};   // camera feature tracks (reference src/trajectory/camera_type.h): out of scope, kept for the signatures
+
 class solver {
 public:
     int last_status = 0;
@@ -80,6 +82,11 @@ public:
     solver& operator=(const solver&) = delete;
     const char* last_error() const { return liw_last_error(ctx_); }
 
+    // reference signatures (src/factor/solver.h:71-79): the feature_manger is the camera track store, unused with
+    // enable_camera: false (every shipped config); the one-argument forms are what the camera-less driver calls
+    void init_solve(std::deque<frame_info::ptr>& frame_infos, feature_manger&) { run(frame_infos, LIW_MODE_INIT); }
+    void solve(std::deque<frame_info::ptr>& frame_infos, feature_manger&) { run(frame_infos, LIW_MODE_TRACK); }
+    void marginalization(std::deque<frame_info::ptr>& frame_infos, feature_manger&) { marginalization(frame_infos); }
     void init_solve(std::deque<frame_info::ptr>& frame_infos) { run(frame_infos, LIW_MODE_INIT); }
     void solve(std::deque<frame_info::ptr>& frame_infos) { run(frame_infos, LIW_MODE_TRACK); }
     void marginalization(std::deque<frame_info::ptr>& frame_infos) {
@@ -90,6 +97,7 @@ public:
         last_status = liw_marginalize(ctx_, sqrt_H, nullptr, nullptr);
         if (last_status == 0 && !fast_mode_)
             for (int k = 0; k < 36; ++k) frame_infos.back()->sqrt_H[k] = sqrt_H[k];
+        liw_clear_window(ctx_);   // `f` dies here: the ctx must not keep its host pointers
     }
 
 private:
@@ -162,6 +170,7 @@ private:
         if (last_status) return;
         last_status = liw_solve(ctx_, mode, 0, &last_summary);   // Summary is informational; the reference drops it
         if (last_status == 0) f.scatter(fi);
+        liw_clear_window(ctx_);   // `f` dies here: the ctx must not keep its host pointers
     }
     liw_ctx* ctx_;
     bool fast_mode_;

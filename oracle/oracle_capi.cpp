@@ -448,6 +448,28 @@ double oracle_time_solves(void* hv, oracle_window_c* w, int reps, int max_iters,
     return std::chrono::duration<double>(t1 - t0).count();
 }
 
+// the same loop with `warmup` untimed solves first and one steady_clock bracket PER solve (bench.py: median / p95 of the CPU leg)
+int oracle_time_solves_each(void* hv, oracle_window_c* w, int warmup, int reps, int max_iters, int dense_product, double* secs) {
+    oracle_ctx* h = (oracle_ctx*)hv;
+    std::vector<double> st(w->states, w->states + w->n * 15), mp(w->match_pose, w->match_pose + w->n * 12);
+    h->slv->options.max_num_iterations = max_iters;
+    h->slv->dense_product = dense_product != 0;
+    int iters = 0;
+    for (int r = -warmup; r < reps; ++r) {
+        std::memcpy(w->states, st.data(), st.size() * sizeof(double));
+        std::memcpy(w->match_pose, mp.data(), mp.size() * sizeof(double));
+        h->slv->has_linearized_block = false;
+        auto t0 = std::chrono::steady_clock::now();
+        build_frames(h, w);
+        h->slv->init_solve(h->frames);
+        h->slv->marginalization(h->frames);
+        scatter_back(h);
+        auto t1 = std::chrono::steady_clock::now();
+        if (r >= 0) { secs[r] = std::chrono::duration<double>(t1 - t0).count(); iters += h->slv->last_summary.num_iterations; }
+    }
+    return iters;
+}
+
 }  // extern "C"
 
 // ---------------------------------------------------------------------------------------------------

@@ -242,6 +242,12 @@ class Oracle:
         sec = self.L.oracle_time_solves(self.h, C.byref(w.c), C.c_int(reps), C.c_int(max_iters), C.c_int(int(dense_product)), C.byref(it))
         return sec, it.value
 
+    def time_solves_each(self, w, warmup, reps, max_iters=50, dense_product=True):
+        """-> per-solve seconds [reps] (after `warmup` untimed solves), total LM iterations of the timed solves"""
+        secs = np.zeros(max(reps, 1))
+        it = self.L.oracle_time_solves_each(self.h, C.byref(w.c), C.c_int(warmup), C.c_int(reps), C.c_int(max_iters), C.c_int(int(dense_product)), _p(secs))
+        return secs[:reps], int(it)
+
 
 # ---------------------------------------------------------------------------------------------------
 # laser front-end restatement (laser_frontend.h / laser_capi.cpp)

@@ -1,0 +1,58 @@
+"""Tolerance helpers shared by the parity tests.
+
+Normal equations are compared ENTRY-RELATIVE to the natural scale of each entry, not to the global maximum of the matrix
+(|H|max ~ 1e11 here, so a global-max bar of 1e-9 would be an absolute slack of ~100 — larger than whole velocity / bias blocks):
+
+    |H_ij - Ho_ij| <= tol * sqrt(Ho_ii * Ho_jj)            (Cauchy-Schwarz scale of entry (i, j) of a Gram matrix J^T J;
+                                                            invariant under column scaling of J, i.e. the error of the
+                                                            Jacobi-scaled matrix the LM actually factorises)
+    |g_i - go_i|    <= tol * sqrt(Ho_ii) * sqrt(2 * cost)   (|J_i^T r| <= |J_i| |r|)
+
+Rows / columns whose reference diagonal is exactly zero (constant parameter blocks) must be exactly zero.
+BASELINE.md 3 asks for 1e-10 on H, g: `TOL_HG` is that bar.
+"""
+import numpy as np
+
+TOL_HG = 1e-10
+
+
+def rel_inf(a, b):
+    """|a - b|_inf / max(|b|_inf, 1e-12) — the state-vector measure of north_star / BASELINE.md 3"""
+    a, b = np.asarray(a), np.asarray(b)
+    return float(np.abs(a - b).max() / max(np.abs(b).max(), 1e-12))
+
+
+def normal_eq_errors(H, g, Ho, go, cost):
+    """-> (max scaled error of H, max scaled error of g); structural zeros checked exactly"""
+    H, g, Ho, go = (np.asarray(v, dtype=np.float64) for v in (H, g, Ho, go))
+    d = np.sqrt(np.clip(np.diag(Ho), 0.0, None))
+    zero = d == 0.0
+    if zero.any():
+        assert np.all(H[zero, :] == 0.0) and np.all(H[:, zero] == 0.0) and np.all(g[zero] == 0.0), "constant blocks must be exactly zero"
+    ds = np.where(zero, 1.0, d)
+    eH = float((np.abs(H - Ho) / np.outer(ds, ds)).max())
+    eg = float((np.abs(g - go) / (ds * max(np.sqrt(2.0 * abs(cost)), 1e-300))).max())
+    return eH, eg
+
+
+def assert_normal_eq_close(H, g, Ho, go, cost, tol=TOL_HG, what=""):
+    eH, eg = normal_eq_errors(H, g, Ho, go, cost)
+    assert eH <= tol and eg <= tol, "%s: scaled errors H %.3e g %.3e exceed %.1e" % (what, eH, eg, tol)
+    return eH, eg
+
+
+def block_rel_errors(A, Ao, bs=3):
+    """max over bs x bs blocks of |A - Ao|_block,max / |Ao|_block,max (blocks that are exactly zero in both are skipped) — the
+    per-block measure VERDICT r1 asked for next to the entry-scaled one"""
+    A, Ao = np.asarray(A), np.asarray(Ao)
+    n0, n1 = A.shape[0] // bs, A.shape[1] // bs
+    worst = 0.0
+    for i in range(n0):
+        for j in range(n1):
+            b, bo = A[i * bs:(i + 1) * bs, j * bs:(j + 1) * bs], Ao[i * bs:(i + 1) * bs, j * bs:(j + 1) * bs]
+            s = np.abs(bo).max()
+            if s == 0.0:
+                assert np.abs(b).max() == 0.0
+                continue
+            worst = max(worst, float(np.abs(b - bo).max() / s))
+    return worst

@@ -1,0 +1,129 @@
+"""Error behaviour and hand-driven sequences of the C ABI: the iteration cap lives on the device, TRACK / MARG reject
+1-frame windows, liw_get_history needs a completed solve, liw_clear_window drops the host pointers, and the 2-frame
+TRACK -> MARG -> TRACK chain the reference's trajectory actually runs (src/trajectory/trajectory.cpp:525-560)."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+from parity_util import rel_inf
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def env(liw, synth, pyoracle):
+    prm = synth.office_params()
+    return prm, pyoracle.Oracle(prm)
+
+
+def test_hand_driven_lm_loop_keeps_its_cap_on_the_device(liw, synth, env):
+    """liw_batch_lm_begin(max_iters) -> linearize -> [step; linearize] x K -> step -> finish, WITHOUT liw_batch_set_max_iters and
+    after the ctx served a solve with a different cap: must equal liw_batch_solve with the same cap, bit for bit."""
+    import torch
+    prm, orc = env
+    ws = [synth.make_window(orc, prm, seed=300 + k, n=6, L=50 + 9 * k) for k in range(3)]
+    mode, K = liw.LIW_MODE_INIT, 7
+    ref = liw.BatchSolver(prm, ws)
+    ref.solve(mode, K)
+    bs = liw.BatchSolver(prm, ws)
+    bs.solve(mode, 2)                                   # leaves a stale host-side cap (2) in the ctx
+    bs.set_states(np.stack([w["states"] for w in ws]))
+    bs.t["match_pose"].copy_(torch.from_numpy(np.concatenate([np.asarray(w["match_pose"]).reshape(-1) for w in ws])).to(bs.dev))
+    bs._chk(bs.L.liw_batch_lm_begin(bs.h, C.byref(bs.b), C.c_int(mode), C.c_int(K), bs._wsp(), bs._stream()))
+    bs.lm_linearize(mode, 0)
+    for _ in range(K):
+        bs.lm_step(mode)
+        bs.lm_linearize(mode, 1)
+    bs.lm_step(mode)
+    bs.lm_finish(mode)
+    torch.cuda.synchronize()
+    assert np.array_equal(bs.states(), ref.states())
+    assert [s["iterations"] for s in bs.summaries()] == [s["iterations"] for s in ref.summaries()]
+    assert max(s["iterations"] for s in ref.summaries()) == K       # the cap (not the stale 2) ended the solve
+
+
+def test_track_and_marg_reject_one_frame_windows(liw, synth, env):
+    prm, orc = env
+    d = synth.make_window(orc, prm, seed=5, n=1, L=0)
+    slv = liw.Solver(prm)
+    slv.set_window(liw.Window(d))
+    slv.init_solve(3)                                   # INIT on one frame is legal (ground factors only)
+    for call in (slv.solve, slv.marginalization, lambda: slv.linearize(liw.LIW_MODE_TRACK), lambda: slv.linearize(liw.LIW_MODE_MARG)):
+        with pytest.raises(liw.LiwError) as e:
+            call()
+        assert e.value.code == -22
+    bs = liw.BatchSolver(prm, [d])
+    with pytest.raises(liw.LiwError):
+        bs.solve(liw.LIW_MODE_TRACK, 3)
+    with pytest.raises(liw.LiwError):
+        bs.marginalize()
+
+
+def test_history_needs_a_completed_solve_and_clear_window(liw, synth, env):
+    prm, orc = env
+    d = synth.make_window(orc, prm, seed=6, n=4, L=30)
+    slv = liw.Solver(prm)
+    slv.set_window(liw.Window(d))
+    with pytest.raises(liw.LiwError) as e:
+        slv.history()
+    assert e.value.code == -1                           # LIW_ESTATE: nothing solved on this window yet
+    s = slv.init_solve(5)
+    assert slv.history().shape[0] == s["iterations"] + 1
+    slv.set_window(liw.Window(d))                       # a new upload invalidates the old history
+    with pytest.raises(liw.LiwError):
+        slv.history()
+    assert slv.L.liw_clear_window(slv.h) == 0
+    with pytest.raises(liw.LiwError) as e:
+        slv.init_solve(5)
+    assert e.value.code == -1
+    # NULL arrays are rejected instead of dereferenced
+    w = liw.Window(d)
+    w.c.imu_J = None
+    with pytest.raises(liw.LiwError) as e:
+        slv.set_window(w)
+    assert e.value.code == -22
+
+
+def test_two_frame_tracking_chain_with_carried_prior(liw, synth, pyoracle, env):
+    """What lvio_2d::trajectory does in steady state: 2-frame windows (k-1, k): solve -> marginalization -> next window with the
+    prior just written, three times in a row, product and oracle each carrying their own prior."""
+    prm, orc = env
+    d = synth.make_window(orc, prm, seed=515, n=5, L=240, laser_on_frame0=False)
+
+    def sub(lo):
+        o = dict(d)
+        o["n"] = 2
+        for k in ("states", "match_pose"):
+            o[k] = np.asarray(d[k]).reshape(5, -1)[lo:lo + 2].copy()
+        o["has_match"] = np.asarray(d["has_match"])[lo:lo + 2].copy()
+        for k in ("imu_X", "imu_J", "imu_sqrtP", "imu_Dt", "wheel_T", "wheel_sqrtP", "wheel_Dt"):
+            o[k] = np.asarray(d[k])[lo:lo + 1].copy()
+        m = (np.asarray(d["laser_frame"]) >= lo) & (np.asarray(d["laser_frame"]) < lo + 2)
+        o["laser_frame"] = (np.asarray(d["laser_frame"])[m] - lo).astype(np.int32)
+        o["laser_pts"] = np.asarray(d["laser_pts"])[m].copy()
+        return o
+    slv = liw.Solver(prm)
+    slv.set_prior(None)
+    orc.set_prior(None)
+    orc.set_max_iterations(50)
+    prev_g = prev_o = None
+    for lo in range(4):
+        wg, wo = liw.Window(sub(lo)), pyoracle.Window(sub(lo))
+        if prev_g is not None:                          # the older frame of this window is the newer one of the last
+            wg["states"].reshape(-1)[0:15] = prev_g
+            wo["states"].reshape(-1)[0:15] = prev_o
+        slv.set_window(wg)
+        sg = slv.solve()
+        orc.solve(wo)
+        so = orc.summary()
+        assert sg["iterations"] == so["iterations"] and sg["termination"] == so["termination"], (lo, sg, so)
+        assert rel_inf(wg["states"], wo["states"]) <= 1e-6, lo
+        mg = slv.marginalization()
+        orc.marginalization(wo)
+        mo = orc.marg_pieces()
+        assert rel_inf(mg["Delta_H"], mo["Delta_H"]) <= 1e-6 and rel_inf(mg["Delta_g"], mo["Delta_g"]) <= 1e-6, lo
+        Xg, Jg, _ = slv.get_prior()
+        Xo, Jo, _ = orc.get_prior()
+        assert rel_inf(Xg, Xo) <= 1e-6 and rel_inf(Jg.T @ Jg, Jo.T @ Jo) <= 1e-6
+        prev_g, prev_o = wg["states"].reshape(2, 15)[1].copy(), wo["states"].reshape(2, 15)[1].copy()

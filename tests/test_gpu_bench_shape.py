@@ -1,0 +1,179 @@
+"""Parity at the shapes bench.py measures: the benchmarked configuration itself goes through the oracle.
+
+  * B > 2 048 windows of C2 (n = 30, L = 2 000) — the k_lm_step<THROUGHPUT> instantiation, G = 8 laser groups per wave, forked role
+    streams — per-iteration states, iteration counts and terminations of sampled windows against the oracle;
+  * C2- and C5-size batched marginalisation (Delta_H, Delta_g, prior J^T J) against the oracle at the same linearisation point;
+  * n = 50 / L = 5 000 LM history;
+  * a C4-size (n = 30, L = 20 000) 10-iteration factor-sharded solve: two rank objects on this one GPU driven in lock-step
+    through the REAL sharded loop (pack, exchange, unpack, join, early exit) with both exchange variants, against the un-sharded
+    solve and the oracle.
+Reference: src/factor/solver.cpp:4-40 (marginalization_matrix), :50-169 (do_init_solve)."""
+import threading
+
+import numpy as np
+import pytest
+
+from parity_util import rel_inf
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def env(liw, synth, pyoracle):
+    prm = synth.office_params()
+    return prm, pyoracle.Oracle(prm)
+
+
+def test_bench_configuration_per_iteration_parity(liw, synth, pyoracle, env):
+    """bench.py's own launch shape: 2 304 C2 windows (8 distinct seeds + jittered copies)."""
+    import importlib
+    import sys
+    import os
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    bench = importlib.import_module("bench")
+    prm, orc = env
+    B, n, L, K, nd = 2304, 30, 2000, 50, 8
+    windows = bench.make_batch(liw, synth, prm, B, n, L, seed0=20240, n_base=nd)
+    bs = liw.BatchSolver(prm, windows, history_records=K + 1)
+    bs.solve(liw.LIW_MODE_INIT, K)
+    hist, summ, xg = bs.history(), bs.summaries(), bs.states()
+    orc.set_max_iterations(K)
+    sample = list(range(nd)) + [nd + 3, B - 1]        # the generated windows + two jittered copies (their own oracle runs)
+    worst = 0.0
+    for b in sample:
+        w = pyoracle.Window(windows[b])
+        orc.set_prior(None)
+        orc.init_solve(w)
+        so, its = orc.summary(), orc.iterations()
+        assert summ[b]["iterations"] == so["iterations"] and summ[b]["termination"] == so["termination"], (b, summ[b], so)
+        for it in range(so["iterations"] + 1):
+            e = rel_inf(hist[it, b], its[it]["x"].reshape(n, 15))
+            worst = max(worst, e)
+            assert e <= 1e-6, (b, it, e)
+        assert rel_inf(xg[b], w["states"].reshape(n, 15)) <= 1e-6
+        assert abs(summ[b]["final_cost"] - so["final_cost"]) <= 1e-9 * so["final_cost"]
+    # distinct seeds really take distinct LM paths
+    assert len({(s["iterations"], s["termination"], round(s["final_cost"], 6)) for s in summ[:nd]}) > 1
+    print("bench-shape per-iteration state error (max over %d windows): %.2e" % (len(sample), worst))
+
+
+@pytest.mark.parametrize("n,L,seed", [(30, 2000, 20240), (50, 5000, 77)])
+def test_batch_marginalization_at_bench_sizes(liw, synth, pyoracle, env, n, L, seed):
+    """C2- / C5-size marginalisation (Hmm = 435^2 / 735^2 in the reference's dense form) after a short init solve, both sides
+    at the same linearisation point; with and without a prior carried in from a previous marginalisation."""
+    prm, orc = env
+    ws = [synth.make_window(orc, prm, seed=seed + k, n=n, L=L) for k in range(2)]
+    bs = liw.BatchSolver(prm, ws)
+    bs.solve(liw.LIW_MODE_INIT, 6)
+    xg = bs.states()
+    mpg = bs.t["match_pose"].cpu().numpy().reshape(2, n, 12)
+    for with_prior in (False, True):
+        sH, dH, dg = bs.marginalize()             # second pass: the prior written by the first one is in the window
+        dH, dg = dH.cpu().numpy().reshape(-1, 15, 15), dg.cpu().numpy()
+        pJ = bs.t["prior_J"].cpu().numpy().reshape(-1, 15, 15)
+        for k in range(2):
+            w = pyoracle.Window(ws[k])
+            w["states"][:] = xg[k].reshape(w["states"].shape)
+            w["match_pose"][:] = mpg[k].reshape(w["match_pose"].shape)
+            orc.set_prior(None)
+            if with_prior:
+                orc.marginalization(w)            # first pass on the oracle side
+            orc.marginalization(w)
+            m = orc.marg_pieces()
+            eH, eg = rel_inf(dH[k], m["Delta_H"]), rel_inf(dg[k], m["Delta_g"])
+            assert eH <= 1e-7 and eg <= 1e-7, (n, with_prior, k, eH, eg)
+            Xo, Jo, Ro = orc.get_prior()
+            assert rel_inf(pJ[k].T @ pJ[k], Jo.T @ Jo) <= 1e-7      # eigenvector signs are free: compare J^T J
+            print("marg n=%d prior=%s window %d: Delta_H %.2e Delta_g %.2e" % (n, with_prior, k, eH, eg))
+
+
+def test_c5_window_lm_history(liw, synth, pyoracle, env):
+    prm, orc = env
+    n, L, K = 50, 5000, 25
+    d = synth.make_window(orc, prm, seed=505, n=n, L=L)
+    bs = liw.BatchSolver(prm, [d], history_records=K + 1)
+    bs.solve(liw.LIW_MODE_INIT, K)
+    hist, s = bs.history(), bs.summaries()[0]
+    w = pyoracle.Window(d)
+    orc.set_prior(None)
+    orc.set_max_iterations(K)
+    orc.init_solve(w)
+    so, its = orc.summary(), orc.iterations()
+    assert s["iterations"] == so["iterations"] and s["termination"] == so["termination"]
+    for it in range(so["iterations"] + 1):
+        assert rel_inf(hist[it, 0], its[it]["x"].reshape(n, 15)) <= 1e-6, it
+    orc.set_max_iterations(50)
+
+
+@pytest.mark.parametrize("exchange", ["allreduce", "oneshot"])
+def test_c4_factor_sharded_solve_lockstep(liw, synth, pyoracle, env, exchange):
+    """C4 (n = 30, L = 20 000), 10 LM iterations, laser blocks split over two rank objects on this GPU.  The ranks run the real
+    sharded loop of BatchSolver.solve in two threads; LockstepComm stands in for RCCL only."""
+    import torch
+    prm, orc = env
+    n, L, K = 30, 20000, 10
+    ws = [synth.make_window(orc, prm, seed=4242 + k, n=n, L=L) for k in range(2)]
+    ref = liw.BatchSolver(prm, ws)
+    ref.solve(liw.LIW_MODE_INIT, K)
+    comms = liw.batch.LockstepComm.make(2)
+    ranks = [liw.BatchSolver(prm, ws, rank=r, world=2, exchange=exchange, comm=comms[r]) for r in range(2)]
+    assert sum(rk.Ltot for rk in ranks) == ref.Ltot
+    assert ranks[0].exchange_bytes(liw.LIW_MODE_INIT) == 8 * (2 * n * 45 + 1)        # compact record: 45 of 128 slots
+    errs = []
+
+    def drive(rk):
+        try:
+            rk.solve(liw.LIW_MODE_INIT, K)
+        except Exception as e:   # noqa: BLE001
+            errs.append(e)
+            comms[0].sh["bar"].abort()
+    th = [threading.Thread(target=drive, args=(rk,)) for rk in ranks]
+    for t in th:
+        t.start()
+    for t in th:
+        t.join(timeout=300)
+    assert not errs, errs
+    torch.cuda.synchronize()
+    a, b, r = ranks[0].states(), ranks[1].states(), ref.states()
+    assert np.array_equal(a, b)                                   # ranks stay bit-identical
+    assert rel_inf(a, r) <= 1e-9                                  # sharded sum == un-sharded sum up to summation order
+    assert [s["iterations"] for s in ranks[0].summaries()] == [s["iterations"] for s in ref.summaries()]
+    orc.set_max_iterations(K)
+    for k in range(2):
+        w = pyoracle.Window(ws[k])
+        orc.set_prior(None)
+        orc.init_solve(w)
+        assert ranks[0].summaries()[k]["iterations"] == orc.summary()["iterations"]
+        assert rel_inf(a[k], w["states"].reshape(n, 15)) <= 1e-6
+    orc.set_max_iterations(50)
+
+
+def test_exchange_variants_bit_identical_and_early_exit(liw, synth, pyoracle, env):
+    """Both exchange variants give bit-identical states (rank-order sums of two images commute), the compact record round-trips
+    the 128-slot record exactly (one rank, forced exchange == plain solve, bit for bit), and the sharded loop stops early when
+    every window has terminated (same result as the full-length loop)."""
+    import torch
+    prm, orc = env
+    ws = [synth.make_window(orc, prm, seed=90 + k, n=8, L=150 + 7 * k) for k in range(3)]
+    plain = liw.BatchSolver(prm, ws)
+    plain.solve(liw.LIW_MODE_INIT, 50)
+    forced = liw.BatchSolver(prm, ws, force_exchange=True)
+    forced.solve(liw.LIW_MODE_INIT, 50)
+    torch.cuda.synchronize()
+    assert np.array_equal(plain.states(), forced.states())
+    assert [s["iterations"] for s in plain.summaries()] == [s["iterations"] for s in forced.summaries()]
+    out = {}
+    for xch in ("allreduce", "oneshot"):
+        comms = liw.batch.LockstepComm.make(2)
+        ranks = [liw.BatchSolver(prm, ws, rank=r, world=2, exchange=xch, comm=comms[r]) for r in range(2)]
+        th = [threading.Thread(target=lambda rk=rk: rk.solve(liw.LIW_MODE_INIT, 50)) for rk in ranks]
+        for t in th:
+            t.start()
+        for t in th:
+            t.join(timeout=300)
+        torch.cuda.synchronize()
+        assert np.array_equal(ranks[0].states(), ranks[1].states())
+        out[xch] = (ranks[0].states(), [s["iterations"] for s in ranks[0].summaries()])
+    assert np.array_equal(out["allreduce"][0], out["oneshot"][0])
+    assert out["allreduce"][1] == [s["iterations"] for s in plain.summaries()]
+    assert rel_inf(out["allreduce"][0], plain.states()) <= 1e-9

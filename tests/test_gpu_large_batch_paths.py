@@ -4,6 +4,8 @@ single-window path (one group per wave, single-launch k_lin_all) and against the
 import numpy as np
 import pytest
 
+from parity_util import assert_normal_eq_close
+
 pytestmark = pytest.mark.gpu
 
 
@@ -40,7 +42,7 @@ def test_multi_group_laser_waves_match_single_window_path(liw, synth, pyoracle, 
             wo = pyoracle.Window(base[k])
             orc.set_prior(None)
             Ho, go, co = orc.linearize(wo, 0)
-            assert rel(H1[0], Ho) <= 1e-9 and rel(g1[0], go) <= 1e-9, k
+            assert_normal_eq_close(H1[0], g1[0], Ho, go, co, what="window %d" % k)
 
 
 def test_large_batch_solve_matches_oracle_on_sampled_windows(liw, synth, pyoracle):
