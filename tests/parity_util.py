@@ -9,11 +9,12 @@ Normal equations are compared ENTRY-RELATIVE to the natural scale of each entry,
     |g_i - go_i|    <= tol * sqrt(Ho_ii) * sqrt(2 * cost)   (|J_i^T r| <= |J_i| |r|)
 
 Rows / columns whose reference diagonal is exactly zero (constant parameter blocks) must be exactly zero.
-BASELINE.md 3 asks for 1e-10 on H, g: `TOL_HG` is that bar.
+BASELINE.md 3 asks for 1e-10 on H, g; measured on MI355X (round 2): <= 7e-15 entry-scaled, <= 2.4e-14 per 3x3 block at n = 3 / 10 / 30.
+`TOL_HG` is set two orders above the measurement and two below BASELINE's bar.
 """
 import numpy as np
 
-TOL_HG = 1e-10
+TOL_HG = 1e-12
 
 
 def rel_inf(a, b):

@@ -81,9 +81,9 @@ def test_batch_marginalization_at_bench_sizes(liw, synth, pyoracle, env, n, L, s
             orc.marginalization(w)
             m = orc.marg_pieces()
             eH, eg = rel_inf(dH[k], m["Delta_H"]), rel_inf(dg[k], m["Delta_g"])
-            assert eH <= 1e-7 and eg <= 1e-7, (n, with_prior, k, eH, eg)
+            assert eH <= 1e-10 and eg <= 1e-9, (n, with_prior, k, eH, eg)      # measured: 6e-16 / 1e-11
             Xo, Jo, Ro = orc.get_prior()
-            assert rel_inf(pJ[k].T @ pJ[k], Jo.T @ Jo) <= 1e-7      # eigenvector signs are free: compare J^T J
+            assert rel_inf(pJ[k].T @ pJ[k], Jo.T @ Jo) <= 1e-9      # eigenvector signs are free: compare J^T J
             print("marg n=%d prior=%s window %d: Delta_H %.2e Delta_g %.2e" % (n, with_prior, k, eH, eg))
 
 

@@ -2,7 +2,8 @@
 
 Tolerances (fp64 everywhere; BASELINE.md "equality gate"):
   per-factor residuals / Jacobians   |d| <= 1e-10 * max(1, |ref|_inf)      (round-off only: same math, different op order)
-  H, g                               <= 1e-10 relative to the scale of each entry, sqrt(H_ii H_jj) (tests/parity_util.py)
+  H, g                               <= 1e-12 relative to the scale of each entry, sqrt(H_ii H_jj), and per 15x15 block; <= 1e-11 per 3x3 block
+                                     (tests/parity_util.py; BASELINE.md asks 1e-10, measured 7e-15 / 2.4e-14)
   states after every LM iteration    <= 1e-6 relative  (north_star)
 """
 import numpy as np
@@ -59,9 +60,9 @@ def test_normal_equations_init(liw, synth, pyoracle, setup, n, L, seed):
     Ho, go, co = orc.linearize(pyoracle.Window(d), 0)
     assert abs(c - co) <= 1e-12 * co
     eH, eg = assert_normal_eq_close(H, g, Ho, go, co, what="init n=%d" % n)
-    b15 = block_rel_errors(H, Ho, 15)
-    print("H,g scaled errors n=%d: H %.2e g %.2e; worst 15x15 block-relative %.2e, 3x3 %.2e" % (n, eH, eg, b15, block_rel_errors(H, Ho, 3)))
-    assert b15 <= 1e-10
+    b15, b3 = block_rel_errors(H, Ho, 15), block_rel_errors(H, Ho, 3)
+    print("H,g scaled errors n=%d: H %.2e g %.2e; worst 15x15 block-relative %.2e, 3x3 %.2e" % (n, eH, eg, b15, b3))
+    assert b15 <= 1e-12 and b3 <= 1e-11          # measured: 5e-15 / 2.4e-14
     assert np.abs(H - H.T).max() <= 1e-12 * np.abs(H).max()
 
 
