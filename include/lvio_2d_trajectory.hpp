@@ -44,6 +44,10 @@ struct trajectory_params {   // the trajectory part of param::manager (config/of
     double p_motion_threshold = 0.1, q_motion_threshold = 0.05;
     double key_frame_p_motion_threshold = 0.05, key_frame_q_motion_threshold = 0.05;
     double min_delta_t = 0.001;
+    // frames kept in the window after a tracking solve.  1 = the reference (pop_frame_for_tracking keeps the newest laser frame only,
+    // trajectory.cpp:590-617: every tracking solve sees 2 frames); N keeps N, i.e. solver.solve / marginalization run on N + 1 frames —
+    // the explicit keep-N policy of SURVEY 8 f3 (BASELINE configs C3 / C5: 30 / 50-key-frame windows)
+    int keep_window_size = 1;
     bool output_tum = false;
     std::string output_dir;
 };
@@ -180,6 +184,9 @@ public:
     const char* solver_error() const { return opt_solver.last_error(); }
     liw_record* get_recorder() { return recorder; }
     void set_keyframe_sink(keyframe_sink s) { sink_ = std::move(s); }
+    // keyframe_manager::update_other_frame (trajectory.cpp:505-511): after every pop, the frames since the last key frame + the window
+    using other_frame_sink = std::function<void(const std::deque<frame_info::ptr>&)>;
+    void set_other_frame_sink(other_frame_sink s) { other_sink_ = std::move(s); }
     int tracked_frames = 0, initializations = 0;
 
 private:
@@ -259,10 +266,16 @@ private:
     }
     void pop_frame(int k) {   // (:488-524) key frames leave through the sink instead of keyframe_manager
         if (k <= 0) return;
+        std::deque<frame_info::ptr> tmp_frame_infos;
         for (int i = 0; i < k; i++) {
             frame_info::ptr f = frame_infos.front();
             frame_infos.pop_front();
-            if (f->is_key_frame && sink_) sink_(f);
+            if (f->is_key_frame) { if (sink_) sink_(f); tmp_frame_infos.clear(); }
+            else tmp_frame_infos.push_back(f);
+        }
+        if (other_sink_) {
+            for (const auto& f : frame_infos) tmp_frame_infos.push_back(f);
+            other_sink_(tmp_frame_infos);
         }
         if (last_laser_index > -1) last_laser_index -= k;
         if (current_index > -1) current_index -= k;
@@ -280,11 +293,12 @@ private:
         ++tracked_frames;
         if (o_fstream) liw_tum_append(o_fstream, frame_infos.back()->time, current_p, current_q);
     }
-    void pop_frame_for_tracking() {   // (:590-617) keep the last laser frame only
+    void pop_frame_for_tracking() {   // (:590-617) keep the last laser frame only (keep_window_size = 1) or the last N frames
         const int n = (int)frame_infos.size();
         int k = n - 1;
         for (int i = n - 1; i > -1; i--)
             if (frame_infos[i]->type == frame_info::laser) { k = i; break; }
+        k -= tprm_.keep_window_size - 1;         // keep-N policy (1 = reference)
         pop_frame(k);
         while (laser_manger_.num_keyframes() > 1) laser_manger_.pop_scan();
     }
@@ -307,6 +321,7 @@ private:
     liw_tum_writer* o_fstream = nullptr;
     liw_record* recorder = nullptr;
     keyframe_sink sink_;
+    other_frame_sink other_sink_;
 };
 
 // Offline form of lvio_2d::dispatch (dispatch.h:192-257): messages are queued per sensor and handed over oldest-first once

@@ -476,7 +476,8 @@ int oracle_time_solves_each(void* hv, oracle_window_c* w, int warmup, int reps, 
 // trajectory restatement (trajectory.h): offline replay of a flat sensor log
 #include "trajectory.h"
 extern "C" {
-struct oracle_traj_params_c { int slide_window_size; double p_motion_threshold, q_motion_threshold, key_frame_p_motion_threshold, key_frame_q_motion_threshold, min_delta_t; };
+struct oracle_traj_params_c { int slide_window_size; double p_motion_threshold, q_motion_threshold, key_frame_p_motion_threshold, key_frame_q_motion_threshold, min_delta_t;
+                              int keep_window_size; };
 struct oracle_laser_params_c2 {
     double w_laser_each_scan, h_laser_each_scan, laser_resolution, line_continuous_threshold, line_min_len, line_max_dis, line_max_tolerance_angle;
     double ref_motion_filter_p, ref_motion_filter_q;
@@ -484,7 +485,7 @@ struct oracle_laser_params_c2 {
     double T_imu_to_laser[16];
     int normalize_extrinsics;
 };
-struct oracle_traj_ctx { params prm; laser_params lprm; trajectory* t; };
+struct oracle_traj_ctx { params prm; laser_params lprm; trajectory* t; keyframe_manager* km = nullptr; };
 void* oracle_traj_create(const oracle_params_c* c, const oracle_laser_params_c2* l, const oracle_traj_params_c* tp) {
     oracle_traj_ctx* h = new oracle_traj_ctx();
     fill_params(c, h->prm);
@@ -497,10 +498,44 @@ void* oracle_traj_create(const oracle_params_c* c, const oracle_laser_params_c2*
     trajectory_params t;
     t.slide_window_size = tp->slide_window_size; t.p_motion_threshold = tp->p_motion_threshold; t.q_motion_threshold = tp->q_motion_threshold;
     t.key_frame_p_motion_threshold = tp->key_frame_p_motion_threshold; t.key_frame_q_motion_threshold = tp->key_frame_q_motion_threshold; t.min_delta_t = tp->min_delta_t;
+    t.keep_window_size = tp->keep_window_size > 0 ? tp->keep_window_size : 1;
     h->t = new trajectory(&h->prm, &h->lprm, t);
     return h;
 }
-void oracle_traj_destroy(void* hv) { oracle_traj_ctx* h = (oracle_traj_ctx*)hv; delete h->t; delete h; }
+void oracle_traj_destroy(void* hv) { oracle_traj_ctx* h = (oracle_traj_ctx*)hv; delete h->t; delete h->km; delete h; }
+// back-end (keyframe_manager.h) behind the trajectory: pose-graph parameters + the loop-edge schedule standing in for loop detection
+struct oracle_pg_params_c2 { double loop_sigma_p[3], loop_sigma_q[3]; double loop_edge_k; int use_ground_p_factor, use_ground_q_factor; };
+void oracle_traj_enable_backend(void* hv, const oracle_pg_params_c2* pc, double solve_period, int max_iterations, int n_loops, const int* trigger_older,
+                                const double* tf12) {
+    oracle_traj_ctx* h = (oracle_traj_ctx*)hv;
+    pg_params P;
+    for (int k = 0; k < 3; ++k) { P.loop_sigma_p[k] = pc->loop_sigma_p[k]; P.loop_sigma_q[k] = pc->loop_sigma_q[k]; }
+    P.loop_edge_k = pc->loop_edge_k; P.use_ground_p_factor = pc->use_ground_p_factor != 0; P.use_ground_q_factor = pc->use_ground_q_factor != 0;
+    delete h->km;
+    h->km = new keyframe_manager(&h->prm, P, solve_period, max_iterations);
+    for (int e = 0; e < n_loops; ++e) {
+        backend_loop l; l.trigger = trigger_older[2 * e]; l.older = trigger_older[2 * e + 1];
+        for (int a = 0; a < 3; ++a) { for (int b = 0; b < 3; ++b) l.tf12.R(a, b) = tf12[12 * e + a * 3 + b]; l.tf12.t(a) = tf12[12 * e + 9 + a]; }
+        h->km->schedule.push_back(l);
+    }
+    h->t->backend = h->km;
+}
+// out4: key frames, loop edges, solves, LM iterations of the last solve; modify12 = modify_delta_tf; poses [cap][6]; current6 = newest
+// front-end pose in the corrected frame.  Returns the number of key frames.
+int oracle_traj_backend(void* hv, int* out4, double* modify12, double* poses, int cap, double* times, double* current6) {
+    oracle_traj_ctx* h = (oracle_traj_ctx*)hv;
+    keyframe_manager* km = h->km;
+    if (!km) return 0;
+    const int N = (int)km->keyframe_queue.size();
+    if (out4) { out4[0] = N; out4[1] = (int)km->loop_idx.size(); out4[2] = km->solves; out4[3] = km->last_summary.num_iterations; }
+    if (modify12) for (int a = 0; a < 3; ++a) { for (int b = 0; b < 3; ++b) modify12[a * 3 + b] = km->modify_delta_tf.R(a, b); modify12[9 + a] = km->modify_delta_tf.t(a); }
+    for (int i = 0; i < N && i < cap; ++i) {
+        if (poses) for (int k = 0; k < 3; ++k) { poses[i * 6 + k] = km->keyframe_queue[i].p(k); poses[i * 6 + 3 + k] = km->keyframe_queue[i].q(k); }
+        if (times) times[i] = km->keyframe_queue[i].time;
+    }
+    if (current6) for (int k = 0; k < 3; ++k) { current6[k] = h->t->backend_p(k); current6[3 + k] = h->t->backend_q(k); }
+    return N;
+}
 void oracle_traj_add_imu(void* hv, double t, const double* acc, const double* gyro) {
     imu_sample s; s.time_stamp = t; s.acc = Vec3<double>(acc[0], acc[1], acc[2]); s.gyro = Vec3<double>(gyro[0], gyro[1], gyro[2]);
     ((oracle_traj_ctx*)hv)->t->add_sensor_data(s);

@@ -433,14 +433,15 @@ class OracleRecord:
 # trajectory restatement (trajectory.h)
 class TrajParamsC(C.Structure):
     _fields_ = [("slide_window_size", C.c_int), ("p_motion_threshold", C.c_double), ("q_motion_threshold", C.c_double),
-                ("key_frame_p_motion_threshold", C.c_double), ("key_frame_q_motion_threshold", C.c_double), ("min_delta_t", C.c_double)]
+                ("key_frame_p_motion_threshold", C.c_double), ("key_frame_q_motion_threshold", C.c_double), ("min_delta_t", C.c_double),
+                ("keep_window_size", C.c_int)]
 
 
 class TrajectoryOracle:
     """lvio_2d::trajectory restatement; prm / lp dicts as for Oracle / LaserOracle."""
 
     def __init__(self, prm, lp, slide_window_size=10, p_motion_threshold=0.1, q_motion_threshold=0.05, key_frame_p_motion_threshold=0.05,
-                 key_frame_q_motion_threshold=0.05, min_delta_t=0.001):
+                 key_frame_q_motion_threshold=0.05, min_delta_t=0.001, keep_window_size=1):
         L = lib()
         L.oracle_traj_create.restype = C.c_void_p
         ps = params_struct(prm)
@@ -453,7 +454,8 @@ class TrajectoryOracle:
         s.T_imu_to_laser[:] = [float(v) for v in np.asarray(lp["T_imu_to_laser"], dtype=np.float64).reshape(16)]
         s.normalize_extrinsics = int(bool(lp.get("normalize_extrinsics", True)))
         del ls
-        tp = TrajParamsC(int(slide_window_size), p_motion_threshold, q_motion_threshold, key_frame_p_motion_threshold, key_frame_q_motion_threshold, min_delta_t)
+        tp = TrajParamsC(int(slide_window_size), p_motion_threshold, q_motion_threshold, key_frame_p_motion_threshold, key_frame_q_motion_threshold, min_delta_t,
+                         int(keep_window_size))
         self.h = C.c_void_p(L.oracle_traj_create(C.byref(ps), C.byref(s), C.byref(tp)))
 
     def add_imu(self, t, acc, gyro):
@@ -486,6 +488,25 @@ class TrajectoryOracle:
 
     def last_iterations(self):
         return lib().oracle_traj_last_iterations(self.h)
+
+    def enable_backend(self, pg, loops, solve_period=10.0, max_iterations=0):
+        """pg: dict as posegraph.office_pg_params(); loops: list of (trigger key-frame index, older index, tf12[12])"""
+        s = PgParamsC()
+        s.loop_sigma_p[:] = [float(v) for v in pg["loop_sigma_p"]]
+        s.loop_sigma_q[:] = [float(v) for v in pg["loop_sigma_q"]]
+        s.loop_edge_k = float(pg["loop_edge_k"])
+        s.use_ground_p_factor = int(bool(pg["use_ground_p_factor"]))
+        s.use_ground_q_factor = int(bool(pg["use_ground_q_factor"]))
+        idx = np.ascontiguousarray([[l[0], l[1]] for l in loops] or [[0, 0]], dtype=np.int32)
+        tf = np.ascontiguousarray([l[2] for l in loops] or [np.zeros(12)], dtype=np.float64)
+        lib().oracle_traj_enable_backend(self.h, C.byref(s), C.c_double(solve_period), C.c_int(max_iterations), C.c_int(len(loops)),
+                                         idx.ctypes.data_as(C.POINTER(C.c_int)), _p(tf))
+
+    def backend(self, cap=4096):
+        out4, mod, poses, times, cur = (C.c_int * 4)(), np.zeros(12), np.zeros((cap, 6)), np.zeros(cap), np.zeros(6)
+        n = lib().oracle_traj_backend(self.h, out4, _p(mod), _p(poses), C.c_int(cap), _p(times), _p(cur))
+        return dict(keyframes=out4[0], loops=out4[1], solves=out4[2], iterations=out4[3], modify_delta_tf=mod, poses=poses[:n].copy(), times=times[:n].copy(),
+                    current=cur)
 
     def __del__(self):
         try:

@@ -10,6 +10,7 @@
 #include <string>
 
 #include "io_formats.h"
+#include "keyframe_manager.h"
 #include "laser_frontend.h"
 #include "solver.h"
 
@@ -20,6 +21,10 @@ struct trajectory_params {
     double p_motion_threshold = 0.1, q_motion_threshold = 0.05;
     double key_frame_p_motion_threshold = 0.05, key_frame_q_motion_threshold = 0.05;
     double min_delta_t = 0.001;
+    // frames kept in the window after a tracking solve.  1 = the reference (pop_frame_for_tracking keeps the newest laser frame only,
+    // trajectory.cpp:590-617, so every tracking solve sees 2 frames); N keeps N, i.e. TRACK-topology solves on N + 1 frames — the
+    // explicit keep-N policy SURVEY 8 f3 asks for (BASELINE configs C3 / C5: 30 / 50-key-frame windows)
+    int keep_window_size = 1;
 };
 struct laser_msg { double time_stamp; std::vector<Vec3<double>> points; std::vector<double> times; };
 
@@ -144,6 +149,8 @@ public:
     std::string tum;
     record rec;
     int tracked_frames = 0, initializations = 0, keyframes_out = 0;
+    keyframe_manager* backend = nullptr;      // optional back-end (BASELINE C5); not owned
+    Vec3<double> backend_p, backend_q;        // newest front-end pose in the corrected map frame (update_other_frame)
 
 private:
     static bool is_static(const Iso3<double>& delta_tf, double p_thr, double q_thr) {
@@ -219,11 +226,19 @@ private:
         last_keyframe_tf = lie::make_tf(current_p, current_q);
         return true;
     }
-    void pop_frame(int k) {
+    void pop_frame(int k) {   // trajectory.cpp:488-524: popped key frames go to the back-end, which then sees the newest pose
         if (k <= 0) return;
         for (int i = 0; i < k; i++) {
-            if (frame_infos.front().is_key_frame) ++keyframes_out;
+            if (frame_infos.front().is_key_frame) {
+                ++keyframes_out;
+                const frame_info& f = *frame_infos.front().f;
+                if (backend) backend->add_keyframe(frame_infos.front().time, Vec3<double>(f.p[0], f.p[1], f.p[2]), Vec3<double>(f.q[0], f.q[1], f.q[2]), f.type == frame_info::laser);
+            }
             frame_infos.pop_front();
+        }
+        if (backend && !frame_infos.empty()) {
+            const frame_info& b = *frame_infos.back().f;
+            backend->update_other_frame(Vec3<double>(b.p[0], b.p[1], b.p[2]), Vec3<double>(b.q[0], b.q[1], b.q[2]), backend_p, backend_q);
         }
         if (last_laser_index > -1) last_laser_index -= k;
         if (current_index > -1) current_index -= k;
@@ -243,6 +258,7 @@ private:
         int k = n - 1;
         for (int i = n - 1; i > -1; i--)
             if (frame_infos[i].f->type == frame_info::laser) { k = i; break; }
+        k -= tprm.keep_window_size - 1;          // keep-N policy (1 = reference)
         pop_frame(k);
         while (laser_manger_.key_frame.size() > 1) laser_manger_.pop_scan();
     }

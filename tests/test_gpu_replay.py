@@ -22,8 +22,11 @@ def build_replay(liw):
     return exe
 
 
-def oracle_replay(pyoracle, prm, lp, msgs):
-    orc = pyoracle.TrajectoryOracle(prm, lp)
+def oracle_replay(pyoracle, prm, lp, msgs, keep=1, backend=None):
+    """backend: None or (pg params, loop schedule, solve period)"""
+    orc = pyoracle.TrajectoryOracle(prm, lp, keep_window_size=keep)
+    if backend is not None:
+        orc.enable_backend(backend[0], backend[1], solve_period=backend[2])
     for m in msgs:
         if m["type"] == 0:
             orc.add_imu(m["time"], m["acc"], m["gyro"])
@@ -90,3 +93,98 @@ def test_replay_look_ahead_is_order_preserving(liw, synth, tmp_path):
         assert r.returncode == 0, r.stderr.decode()
         outs.append(open(str(d) + "/fornt_end.txt").read())
     assert outs[0] == outs[1] and outs[0].count("\n") > 10
+
+
+def _check_front_end(out, orc, replay, min_tracked):
+    raw = open(out + "result.bin", "rb").read()
+    status, frames, tracked, inits, keyframes, sstat = struct.unpack("<6i", raw[:24])
+    state = np.frombuffer(raw[32:32 + 120], dtype=np.float64)
+    c = orc.counters()
+    assert (status, frames, tracked, inits, keyframes) == (c["status"], c["frames"], c["tracked"], c["initializations"], c["keyframes"])
+    assert status == 1 and inits == 1 and tracked >= min_tracked and sstat == 0
+    _, so = orc.current()
+    assert np.abs(state - so).max() <= 1e-6 * max(1.0, np.abs(so).max())
+    got = replay.read_tum(out + "fornt_end.txt")
+    ref = np.array([ln.split() for ln in orc.tum().splitlines()[1:]], dtype=np.float64)
+    assert got.shape == ref.shape == (tracked, 8) and np.array_equal(got[:, 0], ref[:, 0])
+    err = np.abs(got[:, 1:] - ref[:, 1:]).max() / max(1.0, np.abs(ref[:, 1:]).max())
+    assert err <= 1e-6, err
+    return frames, tracked, got
+
+
+@pytest.mark.parametrize("keep,duration,seed", [(29, 6.0, 1), (49, 8.0, 2)])
+def test_keep_n_window_replay_matches_oracle(liw, synth, pyoracle, tmp_path, keep, duration, seed):
+    """BASELINE configs C3 / C5 in shape: the explicit keep-N window policy of SURVEY 8 f3 — the window keeps `keep`
+    frames after every tracking solve, so lvio_2d::solver::solve / marginalization run on 30- / 50-frame windows (TRACK topology:
+    solver.cpp:631-820) for every laser frame once the window has filled — product on the MI355X against the oracle twin running
+    the same policy, every pose of the trajectory within 1e-6."""
+    import importlib
+    replay = importlib.import_module("2dliw-slam_amd.replay")
+    prm = synth.office_params()
+    lp = liw.laser.office_laser_params(prm)
+    msgs, truth = replay.make_log(prm, duration=duration, seed=seed)
+    replay.write_log(str(tmp_path / "log.bin"), msgs)
+    out = str(tmp_path) + "/"
+    r = subprocess.run([build_replay(liw), str(tmp_path / "log.bin"), out, "--keep", str(keep)], capture_output=True)
+    assert r.returncode == 0, r.stderr.decode()
+    orc = oracle_replay(pyoracle, prm, lp, msgs, keep=keep)
+    frames, tracked, got = _check_front_end(out, orc, replay, min_tracked=keep + 5)
+    assert frames == keep                                   # the window really holds `keep` frames (keep + 1 at solve time)
+    T = truth.T_w_o(got[-1, 0])
+    assert np.linalg.norm(got[-1, 1:3] - T[:2, 3]) < 0.15
+
+
+def test_c5_shape_replay_with_pose_graph_backend(liw, synth, pyoracle, tmp_path):
+    """BASELINE C5 end to end in shape: 50-frame tracking windows, key frames leaving the window go to the back-end
+    (include/lvio_2d_keyframe_manager.hpp: sequential edges, loop edges from a schedule standing in for loop detection,
+    liw_posegraph_solve on the MI355X, modify_delta_tf, update_other_frame) — against the oracle twin (oracle/keyframe_manager.h).
+    Reference: keyframe_manager.cpp:407 (add_keyframe), :419-482, :722-838."""
+    import importlib
+    replay = importlib.import_module("2dliw-slam_amd.replay")
+    pgm = importlib.import_module("2dliw-slam_amd.posegraph")
+    prm = synth.office_params()
+    lp = liw.laser.office_laser_params(prm)
+    pg = pgm.office_pg_params()
+    msgs, truth = replay.make_log(prm, duration=11.0, seed=3)
+    replay.write_log(str(tmp_path / "log.bin"), msgs)
+    keep = 49
+    # pass 1 (oracle, empty schedule): which key frames reach the back-end, and when
+    first = oracle_replay(pyoracle, prm, lp, msgs, keep=keep, backend=(pg, [], 0.3))
+    times = first.backend()["times"]
+    assert len(times) >= 12, len(times)
+    rng = np.random.default_rng(5)
+
+    def rel_tf(i, j):       # tf12 of a loop edge (index1 = i newer, index2 = j older): T_i^-1 T_j from the simulated truth + a small error
+        Ti, Tj = truth.T_w_i(times[i]), truth.T_w_i(times[j])
+        E = np.eye(4)
+        E[:3, :3] = synth.exp_so3(rng.normal(0.0, 4e-3, 3))
+        E[:3, 3] = rng.normal(0.0, 0.02, 3)
+        T = synth.inv_se3(Ti) @ Tj @ E
+        return np.concatenate([T[:3, :3].reshape(9), T[:3, 3]])
+    n_kf = len(times)
+    loops = [(n_kf // 2, 1, rel_tf(n_kf // 2, 1)), (n_kf - 2, 3, rel_tf(n_kf - 2, 3))]
+    with open(str(tmp_path / "loops.bin"), "wb") as f:
+        f.write(struct.pack("<i", len(loops)))
+        for trig, older, tf in loops:
+            f.write(struct.pack("<ii", trig, older))
+            f.write(np.asarray(tf, dtype=np.float64).tobytes())
+    out = str(tmp_path) + "/"
+    r = subprocess.run([build_replay(liw), str(tmp_path / "log.bin"), out, "--keep", str(keep), "--loops", str(tmp_path / "loops.bin"),
+                        "--solve-period", "0.3"], capture_output=True)
+    assert r.returncode == 0, r.stderr.decode()
+    orc = oracle_replay(pyoracle, prm, lp, msgs, keep=keep, backend=(pg, loops, 0.3))
+    _check_front_end(out, orc, replay, min_tracked=keep + 5)
+    bo = orc.backend()
+    raw = open(out + "backend.bin", "rb").read()
+    nk, nl, ns, its = struct.unpack("<4i", raw[:16])
+    arr = np.frombuffer(raw[16:], dtype=np.float64)
+    modify, cur, poses = arr[:12], arr[12:18], arr[18:].reshape(-1, 6)
+    assert (nk, nl, ns) == (bo["keyframes"], bo["loops"], bo["solves"]) and nl == 2 and ns >= 2 and nk == n_kf
+    assert its == bo["iterations"]
+    scale = max(1.0, np.abs(bo["poses"]).max())
+    assert np.abs(poses - bo["poses"]).max() <= 1e-6 * scale
+    assert np.abs(modify - bo["modify_delta_tf"]).max() <= 1e-6 and np.abs(cur - bo["current"]).max() <= 1e-6 * scale
+    assert np.abs(modify - np.concatenate([np.eye(3).reshape(9), np.zeros(3)])).max() > 1e-4      # the loop closures moved the map frame
+    # back_end.txt: one TUM line per key frame, byte-compatible header
+    be = replay.read_tum(out + "back_end.txt")
+    assert be.shape == (nk, 8) and np.allclose(be[:, 0], bo["times"], atol=1e-9)

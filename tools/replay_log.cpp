@@ -1,14 +1,23 @@
 // replay_log — offline replay of a flat sensor log (format: 2dliw-slam_amd/replay.py) through lvio_2d::trajectory
 // (include/lvio_2d_trajectory.hpp): the reference's front-end driver with the MI355X estimator underneath, without ROS.
-//   usage: replay_log <log.bin> <output_dir/> [look_ahead]
-// writes <output_dir>fornt_end.txt (TUM trajectory, the reference's file name), <output_dir>traj.md (record tables) and
-// <output_dir>result.bin: int32 status, frames, tracked, initializations, keyframes, solver_status; float64 time, state[15].
+//   usage: replay_log <log.bin> <output_dir/> [look_ahead] [--keep N] [--loops <file>] [--solve-period S] [--pg-iters K]
+//     --keep N         frames kept in the window after a tracking solve (trajectory_params::keep_window_size; 1 = reference)
+//     --loops <file>   enables the back-end (include/lvio_2d_keyframe_manager.hpp -> liw_posegraph_solve) with a loop-edge schedule
+//                      standing in for loop detection: int32 count, then per edge int32 trigger key frame, int32 older key frame,
+//                      float64 tf12[12]
+// writes <output_dir>fornt_end.txt (TUM trajectory, the reference's file name), <output_dir>traj.md (record tables),
+// <output_dir>result.bin: int32 status, frames, tracked, initializations, keyframes, solver_status; float64 time, state[15], and with
+// --loops <output_dir>back_end.txt (TUM of the key frames, keyframe_manager.cpp:370-397) + <output_dir>backend.bin: int32 key frames,
+// loop edges, solves, LM iterations of the last solve; float64 modify_delta_tf[12], current pose in the corrected frame [6], poses [N][6].
 // Parameters are the values of reference config/office.yaml.  Exit code 19 (LIW_ENODEV) when no MI355X is usable.
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
+#include <memory>
 #include <string>
 #include <vector>
 
+#include "lvio_2d_keyframe_manager.hpp"
 #include "lvio_2d_trajectory.hpp"
 
 static const double OFFICE_T_IMU_TO_WHEEL[16] = {0.0040697, -0.9998940, -0.0139789, -0.061, 0.0099712, 0.0140189, -0.9998520, 0.919,
@@ -34,12 +43,49 @@ int main(int argc, char** argv) {
     lvio_2d::trajectory_params tp;
     tp.output_tum = true;
     tp.output_dir = argv[2];
+    int look_ahead = 40;
+    const char* loops_path = nullptr;
+    lvio_2d::keyframe_manager_params kp;
+    for (int k = 0; k < 3; ++k) { kp.pg.loop_sigma_p[k] = 0.1; kp.pg.loop_sigma_q[k] = 0.01; }   // config/office.yaml:106-115
+    kp.pg.loop_edge_k = 10.0; kp.pg.use_ground_p_factor = 1; kp.pg.use_ground_q_factor = 1;
+    kp.output_tum = true; kp.output_dir = argv[2];
+    for (int a = 3; a < argc; ++a) {
+        const std::string s = argv[a];
+        if (s == "--keep" && a + 1 < argc) tp.keep_window_size = atoi(argv[++a]);
+        else if (s == "--loops" && a + 1 < argc) loops_path = argv[++a];
+        else if (s == "--solve-period" && a + 1 < argc) kp.solve_period = atof(argv[++a]);
+        else if (s == "--pg-iters" && a + 1 < argc) kp.max_iterations = atoi(argv[++a]);
+        else if (a == 3 && s[0] != '-') look_ahead = atoi(argv[a]);
+        else { fprintf(stderr, "unknown argument %s\n", argv[a]); return 2; }
+    }
+    struct loop_rec { int trigger, older; double tf12[12]; };
+    std::vector<loop_rec> schedule;
+    if (loops_path) {
+        FILE* lf = fopen(loops_path, "rb");
+        int cnt = 0;
+        if (!lf || fread(&cnt, sizeof(int), 1, lf) != 1) { fprintf(stderr, "cannot read %s\n", loops_path); return 2; }
+        schedule.resize((size_t)cnt);
+        for (auto& l : schedule)
+            if (fread(&l.trigger, sizeof(int), 1, lf) != 1 || fread(&l.older, sizeof(int), 1, lf) != 1 || fread(l.tf12, sizeof(double), 12, lf) != 12) { fprintf(stderr, "short loop file\n"); return 2; }
+        fclose(lf);
+    }
     int keyframes = 0;
     int rc = 0;
     {
+        std::unique_ptr<lvio_2d::keyframe_manager> km;
+        double backend_pose[6] = {0, 0, 0, 0, 0, 0};
         lvio_2d::trajectory traj(prm, lp, tp);
-        traj.set_keyframe_sink([&](const lvio_2d::frame_info::ptr&) { ++keyframes; });
-        lvio_2d::dispatch_queue dq(&traj, argc > 3 ? atoi(argv[3]) : 40);
+        if (loops_path) {
+            km.reset(new lvio_2d::keyframe_manager(prm, kp));
+            km->set_loop_detector([&](int index, const std::deque<lvio_2d::frame_info::ptr>&, lvio_2d::edge* e) {
+                for (const auto& l : schedule)
+                    if (l.trigger == index) { e->index1 = index; e->index2 = l.older; std::memcpy(e->tf12, l.tf12, sizeof l.tf12); return true; }
+                return false;
+            });
+            traj.set_other_frame_sink([&](const std::deque<lvio_2d::frame_info::ptr>& fi) { km->update_other_frame(fi, backend_pose, backend_pose + 3); });
+        }
+        traj.set_keyframe_sink([&](const lvio_2d::frame_info::ptr& f) { ++keyframes; if (km) km->add_keyframe(f); });
+        lvio_2d::dispatch_queue dq(&traj, look_ahead);
         int type;
         while (fread(&type, sizeof(int), 1, f) == 1) {
             if (type == 0) {
@@ -71,6 +117,7 @@ int main(int argc, char** argv) {
                 dq.add(m);
             } else { fprintf(stderr, "unknown record type %d\n", type); return 2; }
             if (traj.solver_status()) { rc = -traj.solver_status(); fprintf(stderr, "solver: %s\n", traj.solver_error()); break; }
+            if (km && km->last_status) { rc = -km->last_status; fprintf(stderr, "back-end: %s\n", km->last_error()); break; }
         }
         if (!rc) dq.flush();
         if (!rc && traj.solver_status()) { rc = -traj.solver_status(); fprintf(stderr, "solver: %s\n", traj.solver_error()); }
@@ -82,6 +129,18 @@ int main(int argc, char** argv) {
             fwrite(&tm, sizeof(double), 1, o);
             fwrite(traj.p(), sizeof(double), 3, o); fwrite(traj.q(), sizeof(double), 3, o); fwrite(traj.v(), sizeof(double), 3, o); fwrite(traj.bs(), sizeof(double), 6, o);
             fclose(o);
+        }
+        if (km) {
+            FILE* b = fopen((std::string(argv[2]) + "backend.bin").c_str(), "wb");
+            if (b) {
+                const int cnt[4] = {(int)km->keyframe_queue.size(), (int)km->loop_edges.size(), km->solves, km->last_summary.iterations};
+                fwrite(cnt, sizeof(int), 4, b);
+                fwrite(km->modify_delta_tf, sizeof(double), 12, b);
+                fwrite(backend_pose, sizeof(double), 6, b);
+                for (const auto& f : km->keyframe_queue) { fwrite(f->p, sizeof(double), 3, b); fwrite(f->q, sizeof(double), 3, b); }
+                fclose(b);
+            }
+            fprintf(stderr, "back-end: %d key frames, %d loop edges, %d solve(s)\n", (int)km->keyframe_queue.size(), (int)km->loop_edges.size(), km->solves);
         }
         fprintf(stderr, "replay: dispatched %ld dropped %ld, %d initialisation(s), %d tracked frames, %d key frames\n", dq.dispatched, dq.dropped,
                 traj.initializations, traj.tracked_frames, keyframes);
