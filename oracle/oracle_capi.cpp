@@ -503,6 +503,34 @@ void* oracle_traj_create(const oracle_params_c* c, const oracle_laser_params_c2*
     return h;
 }
 void oracle_traj_destroy(void* hv) { oracle_traj_ctx* h = (oracle_traj_ctx*)hv; delete h->t; delete h->km; delete h; }
+// teacher-forcing capture of every tracking solve (trajectory.h capture_rec)
+void oracle_traj_set_capture(void* hv, int on) { ((oracle_traj_ctx*)hv)->t->capture = on != 0; }
+int oracle_traj_capture_count(void* hv) { return (int)((oracle_traj_ctx*)hv)->t->captures.size(); }
+// dims5: n, L, has_prior, iterations, termination
+int oracle_traj_capture_dims(void* hv, int k, int* dims5) {
+    trajectory* t = ((oracle_traj_ctx*)hv)->t;
+    if (k < 0 || k >= (int)t->captures.size()) return -1;
+    const auto& c = t->captures[k];
+    dims5[0] = c.n; dims5[1] = c.L; dims5[2] = c.has_prior; dims5[3] = c.iterations; dims5[4] = c.termination;
+    return 0;
+}
+// field ids: 0 states 1 laser_pts 2 match_pose 3 imu_X 4 imu_J 5 imu_sqrtP 6 imu_Dt 7 wheel_T 8 wheel_sqrtP 9 wheel_Dt 10 prior_X 11 prior_J
+// 12 prior_R 13 states_after 14 match_after 15 Delta_H 16 Delta_g 17 post_X 18 post_J 19 post_R; 20 laser_frame (as doubles) 21 has_match (as doubles)
+int oracle_traj_capture_field(void* hv, int k, int field, double* out, int cap) {
+    trajectory* t = ((oracle_traj_ctx*)hv)->t;
+    if (k < 0 || k >= (int)t->captures.size()) return -1;
+    const auto& c = t->captures[k];
+    const std::vector<double>* v[20] = {&c.states, &c.laser_pts, &c.match_pose, &c.imu_X, &c.imu_J, &c.imu_P, &c.imu_Dt, &c.wheel_T, &c.wheel_P, &c.wheel_Dt, &c.prior_X,
+                                        &c.prior_J, &c.prior_R, &c.states_after, &c.match_after, &c.Delta_H, &c.Delta_g, &c.post_X, &c.post_J, &c.post_R};
+    std::vector<double> tmp;
+    const std::vector<double>* src = nullptr;
+    if (field >= 0 && field < 20) src = v[field];
+    else if (field == 20) { tmp.assign(c.laser_frame.begin(), c.laser_frame.end()); src = &tmp; }
+    else if (field == 21) { tmp.assign(c.has_match.begin(), c.has_match.end()); src = &tmp; }
+    else return -1;
+    if (out) for (size_t i = 0; i < src->size() && (int)i < cap; ++i) out[i] = (*src)[i];
+    return (int)src->size();
+}
 // back-end (keyframe_manager.h) behind the trajectory: pose-graph parameters + the loop-edge schedule standing in for loop detection
 struct oracle_pg_params_c2 { double loop_sigma_p[3], loop_sigma_q[3]; double loop_edge_k; int use_ground_p_factor, use_ground_q_factor; };
 void oracle_traj_enable_backend(void* hv, const oracle_pg_params_c2* pc, double solve_period, int max_iterations, int n_loops, const int* trigger_older,
@@ -519,6 +547,26 @@ void oracle_traj_enable_backend(void* hv, const oracle_pg_params_c2* pc, double 
         h->km->schedule.push_back(l);
     }
     h->t->backend = h->km;
+}
+// the back-end alone on a given list of key frames (teacher forcing: the product's keyframe_manager is fed the same list)
+int oracle_backend_run(void* hv, const oracle_pg_params_c2* pc, double solve_period, int max_iterations, int N, const double* times, const double* poses6,
+                       int n_loops, const int* trigger_older, const double* tf12, int* out4, double* modify12, double* poses_out) {
+    oracle_ctx* h = (oracle_ctx*)hv;
+    pg_params P;
+    for (int k = 0; k < 3; ++k) { P.loop_sigma_p[k] = pc->loop_sigma_p[k]; P.loop_sigma_q[k] = pc->loop_sigma_q[k]; }
+    P.loop_edge_k = pc->loop_edge_k; P.use_ground_p_factor = pc->use_ground_p_factor != 0; P.use_ground_q_factor = pc->use_ground_q_factor != 0;
+    keyframe_manager km(&h->prm, P, solve_period, max_iterations);
+    for (int e = 0; e < n_loops; ++e) {
+        backend_loop l; l.trigger = trigger_older[2 * e]; l.older = trigger_older[2 * e + 1];
+        for (int a = 0; a < 3; ++a) { for (int b = 0; b < 3; ++b) l.tf12.R(a, b) = tf12[12 * e + a * 3 + b]; l.tf12.t(a) = tf12[12 * e + 9 + a]; }
+        km.schedule.push_back(l);
+    }
+    for (int i = 0; i < N; ++i)
+        km.add_keyframe(times[i], Vec3<double>(poses6[6 * i], poses6[6 * i + 1], poses6[6 * i + 2]), Vec3<double>(poses6[6 * i + 3], poses6[6 * i + 4], poses6[6 * i + 5]), true);
+    out4[0] = N; out4[1] = (int)km.loop_idx.size(); out4[2] = km.solves; out4[3] = km.last_summary.num_iterations;
+    for (int a = 0; a < 3; ++a) { for (int b = 0; b < 3; ++b) modify12[a * 3 + b] = km.modify_delta_tf.R(a, b); modify12[9 + a] = km.modify_delta_tf.t(a); }
+    for (int i = 0; i < N; ++i) for (int k = 0; k < 3; ++k) { poses_out[i * 6 + k] = km.keyframe_queue[i].p(k); poses_out[i * 6 + 3 + k] = km.keyframe_queue[i].q(k); }
+    return 0;
 }
 // out4: key frames, loop edges, solves, LM iterations of the last solve; modify12 = modify_delta_tf; poses [cap][6]; current6 = newest
 // front-end pose in the corrected frame.  Returns the number of key frames.

@@ -489,6 +489,30 @@ class TrajectoryOracle:
     def last_iterations(self):
         return lib().oracle_traj_last_iterations(self.h)
 
+    def set_capture(self, on=True):
+        lib().oracle_traj_set_capture(self.h, C.c_int(int(on)))
+
+    def captures(self):
+        """-> list of dicts: the flat window + prior every tracking solve started from, and what it produced"""
+        L = lib()
+        names = ("states", "laser_pts", "match_pose", "imu_X", "imu_J", "imu_sqrtP", "imu_Dt", "wheel_T", "wheel_sqrtP", "wheel_Dt", "prior_X", "prior_J",
+                 "prior_R", "states_after", "match_after", "Delta_H", "Delta_g", "post_X", "post_J", "post_R", "laser_frame", "has_match")
+        out = []
+        for k in range(L.oracle_traj_capture_count(self.h)):
+            d5 = (C.c_int * 5)()
+            L.oracle_traj_capture_dims(self.h, C.c_int(k), d5)
+            rec = dict(n=d5[0], L=d5[1], has_prior=d5[2], iterations=d5[3], termination=d5[4])
+            for fid, nm in enumerate(names):
+                sz = L.oracle_traj_capture_field(self.h, C.c_int(k), C.c_int(fid), None, C.c_int(0))
+                a = np.zeros(max(sz, 1))
+                L.oracle_traj_capture_field(self.h, C.c_int(k), C.c_int(fid), _p(a), C.c_int(sz))
+                rec[nm] = a[:sz].copy()
+            rec["laser_frame"] = rec["laser_frame"].astype(np.int32)
+            rec["has_match"] = rec["has_match"].astype(np.uint8)
+            rec["laser_pts"] = rec["laser_pts"].reshape(-1, 12)
+            out.append(rec)
+        return out
+
     def enable_backend(self, pg, loops, solve_period=10.0, max_iterations=0):
         """pg: dict as posegraph.office_pg_params(); loops: list of (trigger key-frame index, older index, tf12[12])"""
         s = PgParamsC()
@@ -540,6 +564,25 @@ def posegraph_solve(orc, pg, poses, seq_idx, seq_tf12, loop_idx=None, loop_tf12=
     lib().oracle_posegraph_solve(orc.h, C.byref(s), C.c_int(x.shape[0]), _p(x), C.c_int(si.shape[0]), si.ctypes.data_as(ipt), _p(st), C.c_int(nl),
                                  li.ctypes.data_as(ipt), _p(lt), C.c_int(max_iters), out3, cost2)
     return x, dict(iterations=out3[0], successful=out3[1], termination=out3[2], initial_cost=cost2[0], final_cost=cost2[1])
+
+
+def backend_run(orc, pg, times, poses, loops, solve_period=10.0, max_iterations=0):
+    """oracle/keyframe_manager.h alone on a list of key frames (time, [p q]); loops: (trigger, older, tf12[12]).
+    -> dict(keyframes, loops, solves, iterations, modify_delta_tf, poses)"""
+    s = PgParamsC()
+    s.loop_sigma_p[:] = [float(v) for v in pg["loop_sigma_p"]]
+    s.loop_sigma_q[:] = [float(v) for v in pg["loop_sigma_q"]]
+    s.loop_edge_k = float(pg["loop_edge_k"])
+    s.use_ground_p_factor = int(bool(pg["use_ground_p_factor"]))
+    s.use_ground_q_factor = int(bool(pg["use_ground_q_factor"]))
+    t = np.ascontiguousarray(times, dtype=np.float64)
+    x = np.ascontiguousarray(poses, dtype=np.float64).reshape(-1, 6)
+    idx = np.ascontiguousarray([[l[0], l[1]] for l in loops] or [[0, 0]], dtype=np.int32)
+    tf = np.ascontiguousarray([l[2] for l in loops] or [np.zeros(12)], dtype=np.float64)
+    out4, mod, po = (C.c_int * 4)(), np.zeros(12), np.zeros_like(x)
+    lib().oracle_backend_run(orc.h, C.byref(s), C.c_double(solve_period), C.c_int(max_iterations), C.c_int(x.shape[0]), _p(t), _p(x), C.c_int(len(loops)),
+                             idx.ctypes.data_as(C.POINTER(C.c_int)), _p(tf), out4, _p(mod), _p(po))
+    return dict(keyframes=out4[0], loops=out4[1], solves=out4[2], iterations=out4[3], modify_delta_tf=mod, poses=po)
 
 
 def posegraph_linearize(orc, pg, poses, seq_idx, seq_tf12, loop_idx=None, loop_tf12=None):

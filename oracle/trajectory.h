@@ -149,6 +149,17 @@ public:
     std::string tum;
     record rec;
     int tracked_frames = 0, initializations = 0, keyframes_out = 0;
+    // teacher-forcing capture (tests): the exact input of every tracking solve (flat window + prior) and its outputs, so that the
+    // product can be run on the oracle's own windows one solve at a time (a free-running replay is chaotic beyond ~10 frames)
+    struct capture_rec {
+        int n = 0, L = 0, has_prior = 0, iterations = 0, termination = 0;
+        std::vector<double> states, laser_pts, match_pose, imu_X, imu_J, imu_P, imu_Dt, wheel_T, wheel_P, wheel_Dt;
+        std::vector<int> laser_frame;
+        std::vector<unsigned char> has_match;
+        std::vector<double> prior_X, prior_J, prior_R, states_after, match_after, Delta_H, Delta_g, post_X, post_J, post_R;
+    };
+    bool capture = false;
+    std::vector<capture_rec> captures;
     keyframe_manager* backend = nullptr;      // optional back-end (BASELINE C5); not owned
     Vec3<double> backend_p, backend_q;        // newest front-end pose in the corrected map frame (update_other_frame)
 
@@ -180,6 +191,45 @@ private:
         solver::frames fi;
         for (const auto& fr : frame_infos) fi.push_back(fr.f);
         return fi;
+    }
+    static void capture_states(const solver::frames& fi, std::vector<double>& st, std::vector<double>& mp) {
+        st.clear(); mp.clear();
+        for (const auto& f : fi) {
+            st.insert(st.end(), f->p, f->p + 3); st.insert(st.end(), f->q, f->q + 3); st.insert(st.end(), f->v, f->v + 3); st.insert(st.end(), f->bs, f->bs + 6);
+            double m[12] = {0};
+            if (f->laser_match_ptr) for (int k = 0; k < 3; ++k) { m[k] = f->laser_match_ptr->p1[k]; m[3 + k] = f->laser_match_ptr->q1[k]; m[6 + k] = f->laser_match_ptr->p2[k]; m[9 + k] = f->laser_match_ptr->q2[k]; }
+            mp.insert(mp.end(), m, m + 12);
+        }
+    }
+    void capture_window(const solver::frames& fi, capture_rec& c) const {
+        c.n = (int)fi.size();
+        capture_states(fi, c.states, c.match_pose);
+        for (int i = 0; i < c.n; ++i) {
+            const frame_info& f = *fi[i];
+            const bool m = f.type == frame_info::laser && f.laser_match_ptr;
+            c.has_match.push_back(m ? 1 : 0);
+            if (m)
+                for (size_t j = 0; j < f.laser_match_ptr->lines1.size(); ++j) {
+                    c.laser_frame.push_back(i);
+                    const line& a = f.laser_match_ptr->lines1[j]; const line& b = f.laser_match_ptr->lines2[j];
+                    for (int k = 0; k < 3; ++k) c.laser_pts.push_back(a.p1(k));
+                    for (int k = 0; k < 3; ++k) c.laser_pts.push_back(a.p2(k));
+                    for (int k = 0; k < 3; ++k) c.laser_pts.push_back(b.p1(k));
+                    for (int k = 0; k < 3; ++k) c.laser_pts.push_back(b.p2(k));
+                }
+            if (i > 0) {
+                const imu_preint_result& r = *f.imu_observation_reslut;
+                c.imu_X.insert(c.imu_X.end(), r.X, r.X + 15); c.imu_J.insert(c.imu_J.end(), &r.J[0][0], &r.J[0][0] + 225);
+                c.imu_P.insert(c.imu_P.end(), &r.sqrt_inverse_P[0][0], &r.sqrt_inverse_P[0][0] + 225); c.imu_Dt.push_back(r.Dt);
+                const wheel_odom_preint_result& w = *f.wheel_observation_reslut;
+                for (int a = 0; a < 3; ++a) for (int b = 0; b < 3; ++b) c.wheel_T.push_back(w.delta_Tij.R(a, b));
+                for (int a = 0; a < 3; ++a) c.wheel_T.push_back(w.delta_Tij.t(a));
+                c.wheel_P.insert(c.wheel_P.end(), &w.sqrt_inverse_P[0][0], &w.sqrt_inverse_P[0][0] + 9); c.wheel_Dt.push_back(w.Dt);
+            }
+        }
+        c.L = (int)c.laser_frame.size();
+        c.has_prior = opt_solver.has_linearized_block ? 1 : 0;
+        if (c.has_prior) { c.prior_X = opt_solver.linearized_X; c.prior_J = opt_solver.linearized_jacobians.d; c.prior_R = opt_solver.linearized_residuals; }
     }
     void take_back_state() {
         const frame_info& b = *frame_infos.back().f;
@@ -246,9 +296,20 @@ private:
     void do_tracking() {
         if (status != TRACKING) return;
         solver::frames fi = solver_frames();
+        if (capture) { captures.emplace_back(); capture_window(fi, captures.back()); }
         opt_solver.solve(fi);
         take_back_state();
+        if (capture) {
+            capture_rec& c = captures.back();
+            capture_states(fi, c.states_after, c.match_after);
+            c.iterations = opt_solver.last_summary.num_iterations; c.termination = opt_solver.last_summary.termination;
+        }
         opt_solver.marginalization(fi);
+        if (capture && !prm->fast_mode) {
+            capture_rec& c = captures.back();
+            c.Delta_H = opt_solver.Delta_H.d; c.Delta_g = opt_solver.Delta_g;
+            c.post_X = opt_solver.linearized_X; c.post_J = opt_solver.linearized_jacobians.d; c.post_R = opt_solver.linearized_residuals;
+        }
         pop_frame_for_tracking();
         ++tracked_frames;
         tum += tum_line(prm->T_imu_to_wheel, frame_infos.back().time, current_p, current_q);

