@@ -96,362 +96,487 @@ __global__ __launch_bounds__(64, 2) void k_lin_laser(LinArgs A, DevParams P, int
 
 // ------------------------------------------------------------------------------------------- imu
 typedef double d4 __attribute__((ext_vector_type(4)));
-constexpr int IMU_XS = 31, IMU_X = 15 * IMU_XS;   // LDS tile of one block: [J_raw | r_raw], 15 rows x 31 columns
-constexpr int IMU_PER_WAVE = 6;   // 10 lanes per block: 9 derivative directions (theta_i, theta_j, bw_i) + the value lane
+typedef LJN<3> J3;
+// IMU role.  Only the rotation vectors theta_i, theta_j and the gyro bias bw_i enter the residual (imu_factor.h:41-83) non-linearly:
+// 9 derivative directions on THREE lanes per block (3 directions each), 21 blocks per wave, blocks indexed over the whole batch.
+// The rotation chain of the gamma rows is  E = exp(-gamma(bw_i)) * exp(-theta_i) * exp(theta_j), and each lane differentiates exactly
+// one of the three factors (lane 0: theta_i, lane 1: theta_j, lane 2: bw_i through gamma): the three VALUES are plain doubles, one
+// factor per lane carries its 3 derivative directions (exp_so3 on LJN<3>), dE_e = L * dM_e * R with lane-selected double matrices —
+// so every sqrt / sin / cos / division of the chain is evaluated once per three directions, and the three derivative chains of a lane
+// are independent instructions that hide each other's fp64 latency.  The remaining 21 Jacobian columns are closed forms of R_i^T, Dt
+// and the pre-integration Jacobian; they are never materialised: the MFMA operand of the whitening  Y = sqrt_info [J_raw | r_raw]
+// (imu_factor.h:85-86) is composed per lane from the compact block record below, and  G = Y^T Y  follows on the matrix cores
+// (8 + 12 v_mfma_f64_16x16x4_f64 per block, the accumulator layout of Y being the operand layout of Y^T Y).
+constexpr int IMU_PER_WAVE = 21;
+// compact block record in LDS (doubles): Xc[15][10] = the 9 derivative columns (theta_i 0-2, theta_j 3-5, bw_i 6-8) + r_raw (9);
+// Rt[9] = R_i^T; RtDt[9]; Jb[18] = alpha_J_ba (9), beta_J_ba (9)
+constexpr int IR_XS = 10, IR_RT = 150, IR_RTDT = 159, IR_JB = 168, IMU_REC = 188;
 
-// IMU role.  Only the rotation vectors and the gyro bias enter the residual non-linearly, so the dual-number pass
-// carries 9 directions per block (6 blocks per wave); the remaining 21 Jacobian columns are closed forms of R_i^T,
-// Dt and the pre-integration Jacobian blocks.  The whitening  Y = sqrt_info [J_raw | r_raw]  (imu_factor.h:85-86,
-// dense 15x15) and the normal-equation block  G = Y^T Y  run on the matrix cores: 8 + 12 v_mfma_f64_16x16x4_f64 per
-// block, the accumulator layout of Y being directly the operand layout of Y^T Y.
-__device__ void imu_group(const LinArgs& A, const DevParams& P, int b, int item, int sel, double* lds) {
-    const int lane = threadIdx.x & 63, grp = lane / 10, d = lane % 10;
-    const int n = A.n, k0 = IMU_PER_WAVE * item;
-    const int k = k0 + grp;
-    const bool on = grp < IMU_PER_WAVE && k < n - 1;
-    // [15][31] per block: [J_raw wrt x_i (15) | r_raw | J_raw wrt x_j (15)] — the residual sits in column 15 so that the three
-    // 16x16 tiles of G = Y^T Y are exactly the blocks ii (+ gradient_i, cost), ij (+ gradient_j) and jj
-    constexpr int XR = 15, XJ = 16;
-    double* Xg = lds + (grp < IMU_PER_WAVE ? grp : 0) * IMU_X;
-    // whitening-matrix operands of every block of this wave, fetched up front (one memory round trip, hidden behind
-    // the dual-number pass):  sop[g][c] = A[i = lane & 15][k = (lane >> 4) + 4c] = sqrt_info_g[i][k]
-    double sop[IMU_PER_WAVE][4];
-    {
-        const int ml = lane & 15, mk = lane >> 4;
-#pragma unroll
-        for (int g = 0; g < IMU_PER_WAVE; ++g) {
-            const bool gon = k0 + g < n - 1;
-            const double* S = A.imu_sqrtP + ((size_t)b * (n - 1) + (gon ? k0 + g : 0)) * 225;
-#pragma unroll
-            for (int c = 0; c < 4; ++c) {
-                const int kk = mk + 4 * c;
-                const bool in = gon && ml < 15 && kk < 15;
-                const double v = S[in ? ml * 15 + kk : 0];
-                sop[g][c] = in ? v : 0.0;
-            }
+// column `col` (0..30: x_i 15 | r_raw | x_j 15) of row kk of [J_raw | r_raw] as (record offset | negate flag) or a constant:
+// returns offset >= 0 (bit 30 = negated) or -1 with *cst set
+__device__ __forceinline__ int imu_entry_code(int kk, int col, double* cst) {
+    *cst = 0.0;
+    if (kk >= 15 || col > 30) return -1;
+    const int rg = kk / 3, rr = kk % 3;
+    if (col == 15) return kk * IR_XS + 9;
+    const bool second = col > 15;
+    const int c = second ? col - 16 : col, grp = c / 3, cc = c % 3;
+    if (!second) {
+        switch (grp) {
+        case 0: return rg == 0 ? IR_RT + rr * 3 + cc : -1;                                            // d r_alpha / d p_i = R_i^T
+        case 1: return kk * IR_XS + cc;                                                              // theta_i
+        case 2: return rg == 0 ? IR_RTDT + rr * 3 + cc : (rg == 1 ? IR_RT + rr * 3 + cc : -1);       // v_i
+        case 3: if (rg == 0) return IR_JB + rr * 3 + cc; if (rg == 1) return IR_JB + 9 + rr * 3 + cc;
+                if (rg == 3 && rr == cc) *cst = -1.0; return -1;                                     // ba_i
+        default: return kk * IR_XS + 6 + cc;                                                         // bw_i
         }
     }
+    switch (grp) {
+    case 0: return rg == 0 ? ((IR_RT + rr * 3 + cc) | (1 << 30)) : -1;                                // p_j: -R_i^T
+    case 1: return kk * IR_XS + 3 + cc;                                                              // theta_j
+    case 2: return rg == 1 ? ((IR_RT + rr * 3 + cc) | (1 << 30)) : -1;                                // v_j: -R_i^T
+    case 3: if (rg == 3 && rr == cc) *cst = 1.0; return -1;                                          // ba_j
+    default: if (rg == 4 && rr == cc) *cst = 1.0; return -1;                                         // bw_j
+    }
+}
+
+__device__ __forceinline__ V3<double> mulc(const double* m, int ld, const V3<double>& v) {   // 3x3 block of a row-major matrix times v
+    return V3<double>(m[0] * v.x + m[1] * v.y + m[2] * v.z, m[ld] * v.x + m[ld + 1] * v.y + m[ld + 2] * v.z,
+                      m[2 * ld] * v.x + m[2 * ld + 1] * v.y + m[2 * ld + 2] * v.z);
+}
+
+__device__ void imu_blocks(const LinArgs& A, const DevParams& P, int wave, double* lds) {
+    const int lane = threadIdx.x & 63, blk = lane / 3, g = lane % 3;
+    const int n = A.n, nb = n - 1, ipw = A.small_per_wave;   // blocks per wave: IMU_PER_WAVE for throughput, fewer for latency
+    const long total = (long)A.B * nb, gb0 = (long)wave * ipw;
+    if (gb0 >= total) return;
+    const long gb = gb0 + blk;
+    bool on = blk < ipw && gb < total;
+    const int b = on ? (int)(gb / nb) : 0, k = on ? (int)(gb % nb) : 0;
+    if (on && A.lm && A.lm[b].done) on = false;
+    double* rec = lds + (blk < IMU_PER_WAVE ? blk : 0) * IMU_REC;
+    const int sel_lane = (on && A.lm) ? (A.candidate ? 1 - A.lm[b].cur : A.lm[b].cur) : 0;   // partial buffer of this lane's block
     LSTAMP(300);
-    for (int e = lane; e < IMU_PER_WAVE * IMU_X; e += 64) lds[e] = 0.0;
-    __syncthreads();
-    LSTAMP(301);
-    const size_t fk = (size_t)b * (n - 1) + (on ? k : 0);
     if (on) {
+        const size_t fk = (size_t)b * nb + k;
         const double* si_ = A.x + ((size_t)b * n + k) * 15;
         const double* sj_ = si_ + 15;
         const double* Jp = A.imu_J + fk * 225;
-        const double Dt = A.imu_Dt[fk];
-        // imu_factor::operator() (imu_factor.h:41-83) evaluated stage by stage; every stage writes its rows of
-        // [J_raw | r_raw] to LDS at once so its temporaries die (keeps the kernel at 2 waves per SIMD)
         const double* X0 = A.imu_X + fk * 15;
-        const int col = d < 3 ? 3 + d : (d < 6 ? XJ + 3 + (d - 3) : (d < 9 ? 12 + (d - 6) : XR));
-        auto put3 = [&](int row0, const V3<LJ>& v) {
-            Xg[(row0 + 0) * IMU_XS + col] = d < 9 ? v.x.d : v.x.v;
-            Xg[(row0 + 1) * IMU_XS + col] = d < 9 ? v.y.d : v.y.v;
-            Xg[(row0 + 2) * IMU_XS + col] = d < 9 ? v.z.d : v.z.v;
-        };
-        auto blk = [&](int ro, int co) {
-            M3<LJ> m;
+        const double Dt = A.imu_Dt[fk];
+        const V3<double> thi = cast_v3<double>(si_ + 3), thj = cast_v3<double>(sj_ + 3);
+        const V3<double> dba = cast_v3<double>(si_ + 9) - cast_v3<double>(X0 + 9), dbw = cast_v3<double>(si_ + 12) - cast_v3<double>(X0 + 12);
+        const V3<double> gam = cast_v3<double>(X0 + 6) + mulc(Jp + 6 * 15 + 12, 15, dbw);
+        // this lane's differentiated rotation: lane 0 exp(-theta_i), lane 1 exp(theta_j), lane 2 exp(-gamma); seeds = d(arg)/d(direction)
+        V3<J3> arg;
+        {
+            const double av[3] = {g == 0 ? -thi.x : (g == 1 ? thj.x : -gam.x), g == 0 ? -thi.y : (g == 1 ? thj.y : -gam.y),
+                                  g == 0 ? -thi.z : (g == 1 ? thj.z : -gam.z)};
+            J3* ac[3] = {&arg.x, &arg.y, &arg.z};
 #pragma unroll
-            for (int r = 0; r < 3; ++r)
+            for (int c = 0; c < 3; ++c) {
+                ac[c]->v = av[c];
 #pragma unroll
-                for (int c = 0; c < 3; ++c) m(r, c) = LJ(Jp[(ro + r) * 15 + co + c]);
-            return m;
-        };
-        const V3<LJ> thetai(LJ(si_[3], d == 0 ? 1.0 : 0.0), LJ(si_[4], d == 1 ? 1.0 : 0.0), LJ(si_[5], d == 2 ? 1.0 : 0.0));
-        const V3<LJ> thetaj(LJ(sj_[3], d == 3 ? 1.0 : 0.0), LJ(sj_[4], d == 4 ? 1.0 : 0.0), LJ(sj_[5], d == 5 ? 1.0 : 0.0));
-        const V3<LJ> bwi(LJ(si_[12], d == 6 ? 1.0 : 0.0), LJ(si_[13], d == 7 ? 1.0 : 0.0), LJ(si_[14], d == 8 ? 1.0 : 0.0));
-        const V3<LJ> dbw = bwi - cast_v3<LJ>(X0 + 12);
-        const V3<LJ> dba = cast_v3<LJ>(si_ + 9) - cast_v3<LJ>(X0 + 9);
-        const LJ g_norm(P.g), DtJ(Dt);
-        const V3<LJ> gdir(LJ(0.0), LJ(0.0), LJ(1.0));
-        const M3<LJ> Rt = exp_so3(-thetai);                                        // bk_R_w
-        {   // alpha, beta rows
-            const V3<LJ> pi = cast_v3<LJ>(si_), vi = cast_v3<LJ>(si_ + 6), pj = cast_v3<LJ>(sj_), vj = cast_v3<LJ>(sj_ + 6);
-            const V3<LJ> alpha = cast_v3<LJ>(X0) + mul(blk(0, 9), dba) + mul(blk(0, 12), dbw);
-            put3(0, alpha - mul(Rt, pj - pi + ((gdir * LJ(0.5)) * g_norm) * DtJ * DtJ - vi * DtJ));
-            const V3<LJ> beta = cast_v3<LJ>(X0 + 3) + mul(blk(3, 9), dba) + mul(blk(3, 12), dbw);
-            put3(3, beta - mul(Rt, vj + (gdir * g_norm) * DtJ - vi));
-            put3(9, cast_v3<LJ>(sj_ + 9) - cast_v3<LJ>(si_ + 9));                  // res_ba
-            put3(12, cast_v3<LJ>(sj_ + 12) - bwi);                                  // res_bw
+                for (int e = 0; e < 3; ++e) ac[c]->d[e] = g == 0 ? (c == e ? -1.0 : 0.0) : (g == 1 ? (c == e ? 1.0 : 0.0) : -Jp[(6 + c) * 15 + 12 + e]);
+            }
+        }
+        const M3<J3> Md = exp_so3(arg);
+        const M3<double> Rt = exp_so3(-thi);                                      // bk_R_w
+        __builtin_amdgcn_sched_barrier(0);
+        // ---- alpha, beta, ba, bw rows
+        {
+            const V3<double> pi = cast_v3<double>(si_), vi = cast_v3<double>(si_ + 6), pj = cast_v3<double>(sj_), vj = cast_v3<double>(sj_ + 6);
+            const double gD = P.g * Dt;
+            const V3<double> va(pj.x - pi.x - vi.x * Dt, pj.y - pi.y - vi.y * Dt, pj.z - pi.z + 0.5 * gD * Dt - vi.z * Dt);
+            const V3<double> vb(vj.x - vi.x, vj.y - vi.y, vj.z + gD - vi.z);
+            const V3<double> ra = cast_v3<double>(X0) + mulc(Jp + 9, 15, dba) + mulc(Jp + 12, 15, dbw) - mul(Rt, va);
+            const V3<double> rb = cast_v3<double>(X0 + 3) + mulc(Jp + 3 * 15 + 9, 15, dba) + mulc(Jp + 3 * 15 + 12, 15, dbw) - mul(Rt, vb);
+#pragma unroll
+            for (int e = 0; e < 3; ++e) {
+                // lane 0: -(dR_i^T / d theta_i_e) v ; lane 2: the bias Jacobian column ; lane 1: nothing
+                M3<double> dM;
+#pragma unroll
+                for (int q = 0; q < 9; ++q) dM.m[q] = Md.m[q].d[e];
+                const V3<double> da = mul(dM, va), db = mul(dM, vb);
+                const double ca[3] = {g == 0 ? -da.x : (g == 2 ? Jp[0 * 15 + 12 + e] : 0.0), g == 0 ? -da.y : (g == 2 ? Jp[1 * 15 + 12 + e] : 0.0),
+                                      g == 0 ? -da.z : (g == 2 ? Jp[2 * 15 + 12 + e] : 0.0)};
+                const double cb[3] = {g == 0 ? -db.x : (g == 2 ? Jp[3 * 15 + 12 + e] : 0.0), g == 0 ? -db.y : (g == 2 ? Jp[4 * 15 + 12 + e] : 0.0),
+                                      g == 0 ? -db.z : (g == 2 ? Jp[5 * 15 + 12 + e] : 0.0)};
+#pragma unroll
+                for (int r = 0; r < 3; ++r) {
+                    rec[r * IR_XS + 3 * g + e] = ca[r];
+                    rec[(3 + r) * IR_XS + 3 * g + e] = cb[r];
+                    rec[(9 + r) * IR_XS + 3 * g + e] = 0.0;                                   // res_ba has no non-linear direction
+                    rec[(12 + r) * IR_XS + 3 * g + e] = (g == 2 && r == e) ? -1.0 : 0.0;      // d res_bw / d bw_i
+                }
+            }
+            if (g == 0) {
+                const double r3[3][3] = {{ra.x, ra.y, ra.z}, {rb.x, rb.y, rb.z}, {0.0, 0.0, 0.0}};
+#pragma unroll
+                for (int r = 0; r < 3; ++r) {
+                    rec[r * IR_XS + 9] = r3[0][r];
+                    rec[(3 + r) * IR_XS + 9] = r3[1][r];
+                    rec[(9 + r) * IR_XS + 9] = sj_[9 + r] - si_[9 + r];                       // res_ba
+                    rec[(12 + r) * IR_XS + 9] = sj_[12 + r] - si_[12 + r];                    // res_bw
+                }
+#pragma unroll
+                for (int q = 0; q < 9; ++q) {
+                    rec[IR_RT + q] = Rt.m[q];
+                    rec[IR_RTDT + q] = Rt.m[q] * Dt;
+                    rec[IR_JB + q] = Jp[(q / 3) * 15 + 9 + q % 3];                             // alpha_J_ba
+                    rec[IR_JB + 9 + q] = Jp[(3 + q / 3) * 15 + 9 + q % 3];                     // beta_J_ba
+                }
+            }
         }
         LSTAMP(302);
-        // closed-form columns (value parts are uniform over the block's lanes; each lane writes one column group)
-        if (d == 0) {
+        __builtin_amdgcn_sched_barrier(0);
+        // ---- gamma rows: log( exp(-gamma^) R_i^T R_j )
+        {
+            const M3<double> Rj = exp_so3(thj), Eg = exp_so3(-gam);
+            const M3<double> RtRj = mul(Rt, Rj), EgRt = mul(Eg, Rt);
+            M3<double> Lm, Rm;   // dE_e = Lm * dM_e * Rm
 #pragma unroll
-            for (int r = 0; r < 3; ++r)
+            for (int q = 0; q < 9; ++q) {
+                const double id = (q % 4 == 0) ? 1.0 : 0.0;
+                Lm.m[q] = g == 2 ? id : (g == 1 ? EgRt.m[q] : Eg.m[q]);
+                Rm.m[q] = g == 0 ? Rj.m[q] : (g == 1 ? id : RtRj.m[q]);
+            }
+            const M3<double> Ev = mul(Eg, RtRj);
+            M3<J3> E;
 #pragma unroll
-                for (int c = 0; c < 3; ++c) Xg[r * IMU_XS + c] = Rt(r, c).v;                      // d r_alpha / d p_i
-        } else if (d == 1) {
+            for (int q = 0; q < 9; ++q) E.m[q].v = Ev.m[q];
 #pragma unroll
-            for (int r = 0; r < 3; ++r)
+            for (int e = 0; e < 3; ++e) {
+                M3<double> dM;
 #pragma unroll
-                for (int c = 0; c < 3; ++c) { Xg[r * IMU_XS + 6 + c] = Rt(r, c).v * Dt; Xg[(3 + r) * IMU_XS + 6 + c] = Rt(r, c).v; }   // d/d v_i
-        } else if (d == 2) {
+                for (int q = 0; q < 9; ++q) dM.m[q] = Md.m[q].d[e];
+                const M3<double> dE = mul(mul(Lm, dM), Rm);
 #pragma unroll
-            for (int r = 0; r < 3; ++r)
+                for (int q = 0; q < 9; ++q) E.m[q].d[e] = dE.m[q];
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            const V3<J3> rg = log_SO3(E);
+            const J3* rr[3] = {&rg.x, &rg.y, &rg.z};
 #pragma unroll
-                for (int c = 0; c < 3; ++c) {
-                    Xg[r * IMU_XS + 9 + c] = Jp[r * 15 + 9 + c];               // alpha_J_ba
-                    Xg[(3 + r) * IMU_XS + 9 + c] = Jp[(3 + r) * 15 + 9 + c];   // beta_J_ba
-                    Xg[(9 + r) * IMU_XS + 9 + c] = r == c ? -1.0 : 0.0;        // d r_ba / d ba_i
-                }
-        } else if (d == 3) {
+            for (int r = 0; r < 3; ++r) {
 #pragma unroll
-            for (int r = 0; r < 3; ++r)
-#pragma unroll
-                for (int c = 0; c < 3; ++c) Xg[r * IMU_XS + XJ + c] = -Rt(r, c).v;                // d r_alpha / d p_j
-        } else if (d == 4) {
-#pragma unroll
-            for (int r = 0; r < 3; ++r)
-#pragma unroll
-                for (int c = 0; c < 3; ++c) Xg[(3 + r) * IMU_XS + XJ + 6 + c] = -Rt(r, c).v;      // d r_beta / d v_j
-        } else if (d == 5) {
-#pragma unroll
-            for (int r = 0; r < 3; ++r) { Xg[(9 + r) * IMU_XS + XJ + 9 + r] = 1.0; Xg[(12 + r) * IMU_XS + XJ + 12 + r] = 1.0; }   // d r_ba/d ba_j, d r_bw/d bw_j
+                for (int e = 0; e < 3; ++e) rec[(6 + r) * IR_XS + 3 * g + e] = rr[r]->d[e];
+                if (g == 0) rec[(6 + r) * IR_XS + 9] = rr[r]->v;
+            }
         }
         LSTAMP(303);
-        __builtin_amdgcn_sched_barrier(0);
-        {   // gamma rows: log( exp(-gamma^) R_i^T R_j )
-            const M3<LJ> RiRj = mul(Rt, exp_so3(thetaj));
-            __builtin_amdgcn_sched_barrier(0);
-            const V3<LJ> gamma = cast_v3<LJ>(X0 + 6) + mul(blk(6, 12), dbw);
-            const M3<LJ> E = mul(exp_so3(-gamma), RiRj);
-            __builtin_amdgcn_sched_barrier(0);
-            put3(6, log_SO3(E));
-        }
     }
     __syncthreads();
     LSTAMP(304);
-    // ---- matrix-core part, one block at a time (the whole wave cooperates)
+    // ---- matrix-core part, one block at a time (the whole wave cooperates).  Operand entry codes of this lane: x0 = column ml of
+    // [J_raw wrt x_i | r_raw], x1 = column ml of [J_raw wrt x_j] for the four k-chunks (row kk = mk + 4c)
     const int ml = lane & 15, mk = lane >> 4;
+    int code0[4], code1[4];
+    double cst0[4], cst1[4];
 #pragma unroll
-    for (int g = 0; g < IMU_PER_WAVE; ++g) {
-        const int kg = k0 + g;
-        if (kg >= n - 1) break;
-        const size_t fg = (size_t)b * (n - 1) + kg;
-        const double* X = lds + g * IMU_X;
-        d4 y0 = {0.0, 0.0, 0.0, 0.0}, y1 = {0.0, 0.0, 0.0, 0.0};
+    for (int c = 0; c < 4; ++c) {
+        code0[c] = imu_entry_code(mk + 4 * c, ml, &cst0[c]);
+        code1[c] = imu_entry_code(mk + 4 * c, ml < 15 ? 16 + ml : 31, &cst1[c]);
+    }
+    const int nblk = (int)min((long)ipw, total - gb0);
+    const unsigned long long onmask = __ballot(on);           // lane 3 q = block q is live (in range, window still iterating)
+    // sqrt_info operands (A[i = ml][k = mk + 4c]) are fetched for a whole group of blocks at once, the next group's fetch in flight
+    // while this group runs on the matrix cores: three memory round trips per wave instead of one per block
+    constexpr int GRP = 7;
+    auto load_sop = [&](int gq, double* o) {
+        const long gg = gb0 + gq;
+        const double* S = A.imu_sqrtP + (size_t)((gq < nblk && gg < total) ? gg : gb0) * 225;
 #pragma unroll
         for (int c = 0; c < 4; ++c) {
             const int kk = mk + 4 * c;
-            const double a = sop[g][c];                                        // A[i = ml][k = kk] = sqrt_info
-            // row 15 and column 31 of the 16x32 operand are zero padding: not stored (15 x 31 doubles per block keep 7 waves per CU in LDS)
-            const double x0v = kk < 15 ? X[kk * IMU_XS + ml] : 0.0;
-            const double x1v = (kk < 15 && ml < 15) ? X[kk * IMU_XS + 16 + ml] : 0.0;
-            y0 = __builtin_amdgcn_mfma_f64_16x16x4f64(a, x0v, y0, 0, 0, 0);
-            y1 = __builtin_amdgcn_mfma_f64_16x16x4f64(a, x1v, y1, 0, 0, 0);
+            const bool in = ml < 15 && kk < 15;
+            const double v = S[in ? ml * 15 + kk : 0];
+            o[c] = in ? v : 0.0;
         }
-        // y_t[r] = Y[mk + 4r][ml + 16t]  ==  operand chunk r of Y^T Y
-        d4 g00 = {0.0, 0.0, 0.0, 0.0}, g01 = g00, g11 = g00;
+    };
+    double sop[GRP][4], sopn[GRP][4];
 #pragma unroll
-        for (int c = 0; c < 4; ++c) {
-            g00 = __builtin_amdgcn_mfma_f64_16x16x4f64(y0[c], y0[c], g00, 0, 0, 0);
-            g01 = __builtin_amdgcn_mfma_f64_16x16x4f64(y0[c], y1[c], g01, 0, 0, 0);
-            g11 = __builtin_amdgcn_mfma_f64_16x16x4f64(y1[c], y1[c], g11, 0, 0, 0);
-        }
-        LSTAMP(310 + 2 * g);
-        double* out = A.PI[sel] + fg * PIS;
-        // tile (0,0) = [ii | gradient_i ; . | cost], tile (0,1) = [ij ; gradient_j], tile (1,1) = jj: one masked store per tile row group
+    for (int q = 0; q < GRP; ++q) load_sop(q, sop[q]);
+    for (int g0 = 0; g0 < nblk; g0 += GRP) {
+        __builtin_amdgcn_sched_barrier(0);
+        if (g0 + GRP < nblk) {
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            const int row = mk + 4 * r;
-            if (row < 15 && ml < 15) {
-                out[PI_II + row * 15 + ml] = g00[r];
-                out[PI_IJ + row * 15 + ml] = g01[r];
-                out[PI_JJ + row * 15 + ml] = g11[r];
+            for (int q = 0; q < GRP; ++q) load_sop(g0 + GRP + q, sopn[q]);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int q = 0; q < GRP; ++q) {
+            const int gq = g0 + q;
+            if (gq >= nblk || !((onmask >> (3 * gq)) & 1ull)) continue;
+            const long gg = gb0 + gq;
+            const double* R_ = lds + gq * IMU_REC;
+            d4 y0 = {0.0, 0.0, 0.0, 0.0}, y1 = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                const double l0 = R_[code0[c] >= 0 ? (code0[c] & 0xffff) : 0], l1 = R_[code1[c] >= 0 ? (code1[c] & 0xffff) : 0];
+                const double x0v = code0[c] >= 0 ? l0 : cst0[c];
+                const double x1v = code1[c] >= 0 ? ((code1[c] >> 30) ? -l1 : l1) : cst1[c];
+                y0 = __builtin_amdgcn_mfma_f64_16x16x4f64(sop[q][c], x0v, y0, 0, 0, 0);
+                y1 = __builtin_amdgcn_mfma_f64_16x16x4f64(sop[q][c], x1v, y1, 0, 0, 0);
             }
-            if (row < 15 && ml == 15) out[PI_G + row] = g00[r];
-            if (r == 3) {
-                if (row == 15 && ml < 15) out[PI_G + 15 + ml] = g01[r];
-                if (row == 15 && ml == 15) out[PI_C] = g00[r];
+            // y_t[r] = Y[mk + 4r][ml + 16t]  ==  operand chunk r of Y^T Y
+            d4 g00 = {0.0, 0.0, 0.0, 0.0}, g01 = g00, g11 = g00;
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                g00 = __builtin_amdgcn_mfma_f64_16x16x4f64(y0[c], y0[c], g00, 0, 0, 0);
+                g01 = __builtin_amdgcn_mfma_f64_16x16x4f64(y0[c], y1[c], g01, 0, 0, 0);
+                g11 = __builtin_amdgcn_mfma_f64_16x16x4f64(y1[c], y1[c], g11, 0, 0, 0);
             }
-            if (A.dbg_imu_res && ml == 15 && row < 15) A.dbg_imu_res[fg * 15 + row] = y0[r];
-            if (A.dbg_imu_jac && row < 15 && ml < 15) {
-                A.dbg_imu_jac[(fg * 15 + row) * 30 + ml] = y0[r];
-                A.dbg_imu_jac[(fg * 15 + row) * 30 + 15 + ml] = y1[r];
+            const size_t fg = (size_t)gg;
+            const int sel = __shfl(sel_lane, 3 * gq, 64);
+            double* out = A.PI[sel] + fg * PIS;
+            // tile (0,0) = [ii | gradient_i ; . | cost], tile (0,1) = [ij ; gradient_j], tile (1,1) = jj: one masked store per tile row group
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int row = mk + 4 * r;
+                if (row < 15 && ml < 15) {
+                    out[PI_II + row * 15 + ml] = g00[r];
+                    out[PI_IJ + row * 15 + ml] = g01[r];
+                    out[PI_JJ + row * 15 + ml] = g11[r];
+                }
+                if (row < 15 && ml == 15) out[PI_G + row] = g00[r];
+                if (r == 3) {
+                    if (row == 15 && ml < 15) out[PI_G + 15 + ml] = g01[r];
+                    if (row == 15 && ml == 15) out[PI_C] = g00[r];
+                }
+                if (A.dbg_imu_res && ml == 15 && row < 15) A.dbg_imu_res[fg * 15 + row] = y0[r];
+                if (A.dbg_imu_jac && row < 15 && ml < 15) {
+                    A.dbg_imu_jac[(fg * 15 + row) * 30 + ml] = y0[r];
+                    A.dbg_imu_jac[(fg * 15 + row) * 30 + 15 + ml] = y1[r];
+                }
             }
         }
-        LSTAMP(311 + 2 * g);
+#pragma unroll
+        for (int q = 0; q < GRP; ++q)
+#pragma unroll
+            for (int c = 0; c < 4; ++c) sop[q][c] = sopn[q][c];
     }
+    LSTAMP(311);
 }
 
 // ------------------------------------------------------------------------------------------- wheel
-// wheel_odom_factor::operator(), src/factor/wheel_factor.h:12-73
-template <class T>
-__device__ __forceinline__ void wheel_res(const DevParams& P, const double* T12, const double* sq9, const T* pi_, const T* qi_, const T* pj_, const T* qj_, T* res,
-                                          const T* dp, M3<T>* R_w_wheel_i) {
-    V3<T> pi(pi_[0], pi_[1], pi_[2]), thetai(qi_[0], qi_[1], qi_[2]), pj(pj_[0], pj_[1], pj_[2]), thetaj(qj_[0], qj_[1], qj_[2]);
-    Iso<T> T_i_w = cast_iso<T>(P.Riw, P.tiw);
-    Iso<T> tf_i = mul(make_tf(pi, thetai), T_i_w);
-    Iso<T> tf_j = mul(make_tf(pj, thetaj), T_i_w);
-    Iso<T> w_tf_ij = mul(inverse(tf_i), tf_j);
-    // dp: perturbation of the relative translation (the positions enter only through R_wi^T (p_j - p_i), see wheel_hex)
-    V3<T> p = w_tf_ij.t + V3<T>(dp[0], dp[1], dp[2]), q = log_SO3(w_tf_ij.R);
-    *R_w_wheel_i = tf_i.R;
-    // log_SE3 of the constant odometry increment: no parameter enters, so it is evaluated on plain doubles
-    const V3<double> oqd = log_SO3(cast_m3<double>(T12));
-    const V3<T> op = cast_v3<T>(T12 + 9);
-    const V3<T> oq = V3<T>(T(oqd.x), T(oqd.y), T(oqd.z));
-    T o_len = dsqrt(op.x * op.x + op.y * op.y);
-    T len = dsqrt(p.x * p.x + p.y * p.y);
-    V3<T> o_dir(op.x, op.y, T(0.0)), dir(p.x, p.y, T(0.0));
-    T angle(0.0);
-    if (norm(o_dir) > T(0.0001) && norm(dir) > T(0.0001)) {
-        o_dir = normalized(o_dir);
-        dir = normalized(dir);
-        T sinn = norm(cross(o_dir, dir));
-        angle = dasin(sinn);
-    } else {
-        angle = norm(dir);
-    }
-    if (len < T(0.0001) || o_len < T(0.0001)) res[0] = T(sq9[0]) * len;
-    else res[0] = T(sq9[0]) * (o_len - len);
-    res[1] = T(sq9[4]) * angle;
-    if (norm(q) < T(0.001) || norm(oq) < T(0.001)) res[2] = T(sq9[8]) * norm(q);
-    else res[2] = T(sq9[8]) * (norm(oq) - norm(q));
-}
-
-// Six blocks per wave, ten lanes each: 6 dual directions for theta_i, theta_j, 3 for the RELATIVE translation, the value.
+// 21 blocks per wave, three lanes each: lane 0 the 3 directions of theta_i, lane 1 theta_j, lane 2 the RELATIVE translation.
 // The positions enter the residual only through p = R_wi^T (p_j - p_i) + c(theta), R_wi = R_i R_imu_to_wheel, so
 // d res / d p_j = (d res / d p) R_wi^T and d res / d p_i = -(d res / d p_j): three directions instead of six.
-constexpr int WHEEL_PER_WAVE = 6;
-__device__ void wheel_hex(const LinArgs& A, const DevParams& P, int b, int item, int sel, double* lds) {
-    const int lane = threadIdx.x & 63, sub = lane / 10, dir = lane % 10;
-    const int n = A.n, k = WHEEL_PER_WAVE * item + sub;
-    const bool on = sub < WHEEL_PER_WAVE && k < n - 1;
-    double* Y = lds + (sub < WHEEL_PER_WAVE ? sub : 0) * 64;   // [3][13] then Dp [3][3] at 40, R_wi [3][3] at 49
-    const size_t fk = (size_t)b * (n - 1) + (on ? k : 0);
+// As in the IMU role every lane differentiates ONE rotation (lane 0 R_i, lane 1 R_j; lane 2 none) and the relative pose
+//   R_rel = R_iw^T R_i^T R_j R_iw,   t_rel = R_iw^T R_i^T (R_j t_iw + p_j - p_i) - R_iw^T t_iw      (wheel_factor.h:29-34)
+// gets its derivative parts as  L * dM_e * R  with lane-selected double matrices; only log_SO3 and the scalar tail of the residual
+// run on LJN<3>.
+constexpr int WHEEL_PER_WAVE = 21;
+__device__ void wheel_blocks(const LinArgs& A, const DevParams& P, int wave, double* lds) {
+    const int lane = threadIdx.x & 63, blk = lane / 3, g = lane % 3;
+    const int n = A.n, nb = n - 1;
+    const long total = (long)A.B * nb, gb = (long)wave * A.small_per_wave + blk;
+    bool on = blk < A.small_per_wave && gb < total;
+    const int b = on ? (int)(gb / nb) : 0, k = on ? (int)(gb % nb) : 0;
+    if (on && A.lm && A.lm[b].done) on = false;
+    double* Y = lds + (blk < WHEEL_PER_WAVE ? blk : 0) * 64;   // [3][13] then Dp [3][3] at 40, R_wi [3][3] at 49
+    const size_t fk = (size_t)(on ? gb : 0);
     if (on) {
         const double* si_ = A.x + ((size_t)b * n + k) * 15;
         const double* sj_ = si_ + 15;
-        LJ pi[3], qi[3], pj[3], qj[3], dp[3], res[3];
-        M3<LJ> Rwi;
+        const double* T12 = A.wheel_T + fk * 12;
+        const double* sq9 = A.wheel_sqrtP + fk * 9;
+        const V3<double> thi = cast_v3<double>(si_ + 3), thj = cast_v3<double>(sj_ + 3);
+        V3<J3> arg;   // the rotation this lane differentiates (lane 2: R_i with zero seeds)
+        {
+            J3* ac[3] = {&arg.x, &arg.y, &arg.z};
+            const double av[3] = {g == 1 ? thj.x : thi.x, g == 1 ? thj.y : thi.y, g == 1 ? thj.z : thi.z};
+#pragma unroll
+            for (int c = 0; c < 3; ++c) { *ac[c] = J3(av[c]); if (g < 2) ac[c]->d[c] = 1.0; }
+        }
+        const M3<J3> Md = exp_so3(arg);
+        const M3<double> Ri = exp_so3(thi), Rj = exp_so3(thj), Riw = cast_m3<double>(P.Riw);
+        const V3<double> tiw(P.tiw[0], P.tiw[1], P.tiw[2]);
+        const M3<double> Rwi = mul(Ri, Riw);                      // tf_i.R
+        const M3<double> Am = transpose(Rwi);                     // R_iw^T R_i^T
+        const M3<double> RjRiw = mul(Rj, Riw);
+        const V3<double> Rjt = mul(Rj, tiw);
+        const V3<double> w(Rjt.x + sj_[0] - si_[0], Rjt.y + sj_[1] - si_[1], Rjt.z + sj_[2] - si_[2]);
+        const M3<double> Rrel = mul(Am, RjRiw);
+        const V3<double> trel = mul(Am, w) - mulT(Riw, tiw);
+        M3<J3> E;
+        V3<J3> p;
+#pragma unroll
+        for (int q = 0; q < 9; ++q) E.m[q] = J3(Rrel.m[q]);
+        p.x = J3(trel.x); p.y = J3(trel.y); p.z = J3(trel.z);
+        {
+            const M3<double> RiwT = transpose(Riw);
+            M3<double> Lm, Rm;
+#pragma unroll
+            for (int q = 0; q < 9; ++q) { Lm.m[q] = g == 0 ? RiwT.m[q] : Am.m[q]; Rm.m[q] = g == 0 ? RjRiw.m[q] : Riw.m[q]; }
+            const V3<double> wv(g == 0 ? w.x : tiw.x, g == 0 ? w.y : tiw.y, g == 0 ? w.z : tiw.z);
+#pragma unroll
+            for (int e = 0; e < 3; ++e) {
+                M3<double> X;   // lane 0: (dR_i / d theta_i_e)^T, lane 1: dR_j / d theta_j_e
+#pragma unroll
+                for (int r = 0; r < 3; ++r)
+#pragma unroll
+                    for (int c = 0; c < 3; ++c) X(r, c) = g == 0 ? Md(c, r).d[e] : Md(r, c).d[e];
+                const M3<double> LX = mul(Lm, X);
+                const M3<double> dR = mul(LX, Rm);
+                const V3<double> dt = mul(LX, wv);
+#pragma unroll
+                for (int q = 0; q < 9; ++q) E.m[q].d[e] = g < 2 ? dR.m[q] : 0.0;
+                p.x.d[e] = g < 2 ? dt.x : (e == 0 ? 1.0 : 0.0);
+                p.y.d[e] = g < 2 ? dt.y : (e == 1 ? 1.0 : 0.0);
+                p.z.d[e] = g < 2 ? dt.z : (e == 2 ? 1.0 : 0.0);
+            }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        // wheel_odom_factor::operator() from (p, q) on (wheel_factor.h:36-70)
+        const V3<J3> q = log_SO3(E);
+        const V3<double> oq = log_SO3(cast_m3<double>(T12));      // log_SE3 of the constant odometry increment: plain doubles
+        const double opx = T12[9], opy = T12[10];
+        const double o_len = sqrt(opx * opx + opy * opy);
+        const J3 len = dsqrt(p.x * p.x + p.y * p.y);
+        J3 res[3];
+        J3 angle(0.0);
+        if (o_len > 0.0001 && len.v > 0.0001) {
+            const double odx = opx / o_len, ody = opy / o_len;     // normalized(o_dir)
+            const J3 dx = p.x / len, dy = p.y / len;
+            // |cross(o_dir, dir)| with both in the plane: |o_x d_y - o_y d_x| through norm() = sqrt(z^2), as the reference computes it
+            const J3 cz = dy * odx - dx * ody;
+            angle = dasin(dsqrt(cz * cz));
+        } else {
+            angle = len;
+        }
+        if (len.v < 0.0001 || o_len < 0.0001) res[0] = len * sq9[0];
+        else res[0] = (J3(o_len) - len) * sq9[0];
+        res[1] = angle * sq9[4];
+        const J3 nq = norm(q);
+        const double noq = sqrt(oq.x * oq.x + oq.y * oq.y + oq.z * oq.z);
+        if (nq.v < 0.001 || noq < 0.001) res[2] = nq * sq9[8];
+        else res[2] = (J3(noq) - nq) * sq9[8];
 #pragma unroll
         for (int e = 0; e < 3; ++e) {
-            pi[e] = LJ(si_[e]);
-            qi[e] = LJ(si_[3 + e], dir == e ? 1.0 : 0.0);
-            pj[e] = LJ(sj_[e]);
-            qj[e] = LJ(sj_[3 + e], dir == 3 + e ? 1.0 : 0.0);
-            dp[e] = LJ(0.0, dir == 6 + e ? 1.0 : 0.0);
+            // lane 0 -> columns theta_i (3..5), lane 1 -> theta_j (9..11), lane 2 -> Dp
+            const int col = g == 0 ? 3 + e : (g == 1 ? 9 + e : 0);
+#pragma unroll
+            for (int r = 0; r < 3; ++r) {
+                if (g < 2) Y[r * 13 + col] = res[r].d[e];
+                else Y[40 + r * 3 + e] = res[r].d[e];
+            }
         }
-        wheel_res<LJ>(P, A.wheel_T + fk * 12, A.wheel_sqrtP + fk * 9, pi, qi, pj, qj, res, dp, &Rwi);
-        if (dir < 3) { for (int r = 0; r < 3; ++r) Y[r * 13 + 3 + dir] = res[r].d; }
-        else if (dir < 6) { for (int r = 0; r < 3; ++r) Y[r * 13 + 6 + dir] = res[r].d; }
-        else if (dir < 9) { for (int r = 0; r < 3; ++r) Y[40 + r * 3 + (dir - 6)] = res[r].d; }
-        else {
+        if (g == 0) {
+#pragma unroll
             for (int r = 0; r < 3; ++r) Y[r * 13 + 12] = res[r].v;
-            for (int r = 0; r < 3; ++r) for (int c = 0; c < 3; ++c) Y[49 + r * 3 + c] = Rwi(r, c).v;
+#pragma unroll
+            for (int qq = 0; qq < 9; ++qq) Y[49 + qq] = Rwi.m[qq];
         }
     }
     __syncthreads();
-    if (on && dir < 9) {   // position columns: Y[r][p_j c] = sum_k Dp[r][k] R_wi[c][k],  Y[r][p_i c] = -Y[r][p_j c]
-        const int r = dir / 3, c = dir % 3;
-        const double v = Y[40 + r * 3] * Y[49 + c * 3] + Y[40 + r * 3 + 1] * Y[49 + c * 3 + 1] + Y[40 + r * 3 + 2] * Y[49 + c * 3 + 2];
-        Y[r * 13 + 6 + c] = v;
-        Y[r * 13 + c] = -v;
+    if (on) {   // position columns: Y[r][p_j c] = sum_k Dp[r][k] R_wi[c][k],  Y[r][p_i c] = -Y[r][p_j c]   (row r = g of this lane)
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            const double v = Y[40 + g * 3] * Y[49 + c * 3] + Y[40 + g * 3 + 1] * Y[49 + c * 3 + 1] + Y[40 + g * 3 + 2] * Y[49 + c * 3 + 2];
+            Y[g * 13 + 6 + c] = v;
+            Y[g * 13 + c] = -v;
+        }
     }
     __syncthreads();
-    if (on && dir == 9 && A.dbg_wheel_res)
+    if (on && g == 0 && A.dbg_wheel_res)
         for (int r = 0; r < 3; ++r) A.dbg_wheel_res[fk * 3 + r] = Y[r * 13 + 12];
     if (on && A.dbg_wheel_jac)
-        for (int e = dir; e < 36; e += 10) A.dbg_wheel_jac[fk * 36 + e] = Y[(e / 12) * 13 + e % 12];
+        for (int e = g; e < 36; e += 3) A.dbg_wheel_jac[fk * 36 + e] = Y[(e / 12) * 13 + e % 12];
     if (on) {
+        const int sel = A.lm ? (A.candidate ? 1 - A.lm[b].cur : A.lm[b].cur) : 0;
         double* out = A.PW[sel] + fk * PWS;
-        for (int e = dir; e < 91; e += 10) {
+        for (int e = g; e < 91; e += 3) {
             int c1 = 0, rem = e;
             while (rem >= 13 - c1) { rem -= 13 - c1; ++c1; }
             const int c2 = c1 + rem;
-            const double s = Y[c1] * Y[c2] + Y[13 + c1] * Y[13 + c2] + Y[26 + c1] * Y[26 + c2];
-            out[c1 * 13 + c2] = s;
-            out[c2 * 13 + c1] = s;
+            const double s_ = Y[c1] * Y[c2] + Y[13 + c1] * Y[13 + c2] + Y[26 + c1] * Y[26 + c2];
+            out[c1 * 13 + c2] = s_;
+            out[c2 * 13 + c1] = s_;
         }
     }
 }
 
 // ------------------------------------------------------------------------------------------- ground
-// ground_factor_p / ground_factor_q, src/factor/ground_factor.h:27-48, :59-82
-template <class T>
-__device__ __forceinline__ void ground_res(const DevParams& P, const T* p_, const T* q_, T* res) {
-    Iso<T> tf_w_o = mul(make_tf(V3<T>(p_[0], p_[1], p_[2]), V3<T>(q_[0], q_[1], q_[2])), cast_iso<T>(P.Riw, P.tiw));
-    res[0] = T(P.ground_p_info) * tf_w_o.t.z;
-    V3<T> ABC(T(0.0), T(0.0), T(1.0));
-    V3<T> z_axis(tf_w_o.R(0, 2), tf_w_o.R(1, 2), tf_w_o.R(2, 2));
-    T sinn = norm(cross(z_axis, ABC));
-    res[1] = T(P.ground_q_info) * dasin(sinn);
-}
-
-__device__ void ground_oct(const LinArgs& A, const DevParams& P, int b, int item, int sel, double* lds) {
-    const int lane = threadIdx.x & 63, sub = lane >> 3, dir = lane & 7;
-    const int n = A.n, i = 8 * item + sub;
-    const bool on = i < n;
+// ground_factor_p / ground_factor_q, src/factor/ground_factor.h:27-48, :59-82: height of the wheel-frame origin and tilt of its z axis,
+// tf_w_o = make_tf(p, theta) * T_imu_to_wheel
+// 32 frames per wave, two lanes each: lane 0 the 3 directions of p, lane 1 of theta
+constexpr int GROUND_PER_WAVE = 32;
+__device__ void ground_frames(const LinArgs& A, const DevParams& P, int wave, double* lds) {
+    const int lane = threadIdx.x & 63, sub = lane >> 1, g = lane & 1;
+    const int n = A.n;
+    const long total = (long)A.B * n, gf = (long)wave * GROUND_PER_WAVE + sub;
+    bool on = gf < total;
+    const int b = on ? (int)(gf / n) : 0;
+    if (on && A.lm && A.lm[b].done) on = false;
     double* Y = lds + sub * 16;   // [2][7]
-    const size_t fi = (size_t)b * n + (on ? i : 0);
-    double y[2] = {0.0, 0.0};
+    const size_t fi = (size_t)(on ? gf : 0);
     if (on) {
         const double* s_ = A.x + fi * 15;
-        LJ p[3], q[3], res[2];
-#pragma unroll
-        for (int e = 0; e < 3; ++e) {
-            p[e] = LJ(s_[e], dir == e ? 1.0 : 0.0);
-            q[e] = LJ(s_[3 + e], dir == 3 + e ? 1.0 : 0.0);
+        J3 res[2];
+        {
+            V3<J3> q;
+            q.x = seed<3>(s_[3], 0, g == 1); q.y = seed<3>(s_[4], 1, g == 1); q.z = seed<3>(s_[5], 2, g == 1);
+            const M3<J3> R = exp_so3(q);
+            const J3 pz = seed<3>(s_[2], 2, g == 0);
+            res[0] = (R(2, 0) * P.tiw[0] + R(2, 1) * P.tiw[1] + R(2, 2) * P.tiw[2] + pz) * P.ground_p_info;
+            // z axis of the wheel frame in the world; |z x e3| = sqrt(z_x^2 + z_y^2)
+            const J3 zx = R(0, 0) * P.Riw[2] + R(0, 1) * P.Riw[5] + R(0, 2) * P.Riw[8];
+            const J3 zy = R(1, 0) * P.Riw[2] + R(1, 1) * P.Riw[5] + R(1, 2) * P.Riw[8];
+            res[1] = dasin(dsqrt(zy * zy + zx * zx)) * P.ground_q_info;
         }
-        ground_res<LJ>(P, p, q, res);
 #pragma unroll
-        for (int r = 0; r < 2; ++r) y[r] = dir < 6 ? res[r].d : (dir == 6 ? res[r].v : 0.0);
+        for (int e = 0; e < 3; ++e) { Y[3 * g + e] = res[0].d[e]; Y[7 + 3 * g + e] = res[1].d[e]; }
+        if (g == 0) { Y[6] = res[0].v; Y[13] = res[1].v; }
+        if (g == 0 && A.dbg_ground_res) { A.dbg_ground_res[fi * 2] = res[0].v; A.dbg_ground_res[fi * 2 + 1] = res[1].v; }
+        if (A.dbg_ground_jac)
+            for (int e = 0; e < 3; ++e) { A.dbg_ground_jac[(fi * 2) * 6 + 3 * g + e] = res[0].d[e]; A.dbg_ground_jac[(fi * 2 + 1) * 6 + 3 * g + e] = res[1].d[e]; }
     }
-    if (dir < 7) { Y[dir] = y[0]; Y[7 + dir] = y[1]; }
-    if (on && dir == 6 && A.dbg_ground_res) { A.dbg_ground_res[fi * 2] = y[0]; A.dbg_ground_res[fi * 2 + 1] = y[1]; }
-    if (on && dir < 6 && A.dbg_ground_jac) { A.dbg_ground_jac[(fi * 2) * 6 + dir] = y[0]; A.dbg_ground_jac[(fi * 2 + 1) * 6 + dir] = y[1]; }
     __syncthreads();
     if (on) {
+        const int sel = A.lm ? (A.candidate ? 1 - A.lm[b].cur : A.lm[b].cur) : 0;
         double* out = A.PG[sel] + fi * PGS;
         const double mult = (double)n;   // the block set is added once per outer frame index (solver.cpp:142-159)
-        for (int e = dir; e < 28; e += 8) {
+        for (int e = g; e < 28; e += 2) {
             int c1 = 0, rem = e;
             while (rem >= 7 - c1) { rem -= 7 - c1; ++c1; }
             const int c2 = c1 + rem;
-            const double s = mult * (Y[c1] * Y[c2] + Y[7 + c1] * Y[7 + c2]);
-            out[c1 * 7 + c2] = s;
-            out[c2 * 7 + c1] = s;
+            const double s_ = mult * (Y[c1] * Y[c2] + Y[7 + c1] * Y[7 + c2]);
+            out[c1 * 7 + c2] = s_;
+            out[c2 * 7 + c1] = s_;
         }
     }
 }
 
 // ------------------------------------------------------------------------------------------- dispatch
-__device__ void imu_role(const LinArgs& A, const DevParams& P, int vblock, double* lds) {
-    const int n = A.n, items = (n - 1 + IMU_PER_WAVE - 1) / IMU_PER_WAVE;
-    const int b = vblock / items, item = vblock % items;
-    if (b >= A.B) return;
-    if (A.lm && A.lm[b].done) return;
-    const int sel = A.lm ? (A.candidate ? 1 - A.lm[b].cur : A.lm[b].cur) : 0;
-    imu_group(A, P, b, item, sel, lds);
-}
+// The IMU / wheel / ground roles index their blocks over the whole batch (21 / 21 / 32 per wave), so no wave is partly empty
+// because of window boundaries; `done` windows are skipped lane by lane.
+__host__ __device__ inline int imu_wave_count(int B, int n, int per_wave) { return n > 1 ? (int)(((long)B * (n - 1) + per_wave - 1) / per_wave) : 0; }
+__host__ __device__ inline int wheel_wave_count(int B, int n, int per_wave) { return imu_wave_count(B, n, per_wave); }
+__host__ __device__ inline int ground_wave_count(int B, int n) { return (int)(((long)B * n + GROUND_PER_WAVE - 1) / GROUND_PER_WAVE); }
 __device__ void small_role(const LinArgs& A, const DevParams& P, int vblock, double* lds) {
-    const int n = A.n, n_wheel = (n - 1 + WHEEL_PER_WAVE - 1) / WHEEL_PER_WAVE, items = n_wheel + (n + 7) / 8;
-    const int b = vblock / items, item = vblock % items;
-    if (b >= A.B) return;
-    if (A.lm && A.lm[b].done) return;
-    const int sel = A.lm ? (A.candidate ? 1 - A.lm[b].cur : A.lm[b].cur) : 0;
-    if (item < n_wheel) wheel_hex(A, P, b, item, sel, lds);
-    else ground_oct(A, P, b, item - n_wheel, sel, lds);
+    const int nw = wheel_wave_count(A.B, A.n, A.small_per_wave);
+    if (vblock < nw) wheel_blocks(A, P, vblock, lds);
+    else ground_frames(A, P, vblock - nw, lds);
 }
+constexpr int SMALL_LDS = WHEEL_PER_WAVE * 64;   // >= GROUND_PER_WAVE * 16
 __global__ __launch_bounds__(64, 2) void k_lin_imu(LinArgs A, DevParams P) {
-    __shared__ double lds[IMU_PER_WAVE * IMU_X];
-    imu_role(A, P, (int)blockIdx.x, lds);
+    __shared__ double lds[IMU_PER_WAVE * IMU_REC];
+    imu_blocks(A, P, (int)blockIdx.x, lds);
 }
-__global__ __launch_bounds__(64) void k_lin_small(LinArgs A, DevParams P) {
-    __shared__ double lds[WHEEL_PER_WAVE * 64];
+__global__ __launch_bounds__(64, 2) void k_lin_small(LinArgs A, DevParams P) {
+    __shared__ double lds[SMALL_LDS];
     small_role(A, P, (int)blockIdx.x, lds);
 }
 // Small batches (a single tracking window): every role in ONE launch, the role of a wave follows from its block index —
 // one kernel and no fork / join events per linearisation, which is what a latency-bound 2-frame window pays for.
 template <bool BOTH>
 __global__ __launch_bounds__(64, 2) void k_lin_all(LinArgs A, DevParams P, int G, int n_laser, int n_imu) {
-    __shared__ double lds[IMU_PER_WAVE * IMU_X];   // IMU / small roles; the laser role brings its own static LDS
+    __shared__ double lds[IMU_PER_WAVE * IMU_REC];   // IMU / small roles; the laser role brings its own static LDS
     const int v = (int)blockIdx.x;
     if (v < n_laser) laser_wave_local<BOTH>(A, P, G, v);
-    else if (v < n_laser + n_imu) imu_role(A, P, v - n_laser, lds);
+    else if (v < n_laser + n_imu) imu_blocks(A, P, v - n_laser, lds);
     else small_role(A, P, v - n_laser - n_imu, lds);
 }
 
@@ -473,14 +598,23 @@ __global__ void k_group_offsets(int B, int n, const int* laser_off, const int* l
 // overlaps the fp64 VALU work of the laser kernel on the same CUs.  Small batches: one launch for everything (k_lin_all).
 // defer_join: the laser role stays on `s`, the IMU / small roles on the side streams, and the join is left to launch_linearize_join —
 // a factor-sharded driver puts its exchange of the laser partial sums on `s` in between, so that it overlaps the small roles.
-void launch_linearize(const LinArgs& A, const DevParams& P, hipStream_t s, const LinFork* fk, bool defer_join) {
+void launch_linearize(const LinArgs& A_, const DevParams& P, hipStream_t s, const LinFork* fk, bool defer_join) {
+    LinArgs A = A_;
     const int n = A.n, B = A.B;
+    // IMU / wheel blocks per wave: 21 (all 63 lanes) once the batch fills the chip; small batches spread their blocks over more,
+    // shorter waves (the matrix-core stage of a wave is serial over its blocks)
+    {
+        const long blocks = (long)B * (n > 1 ? n - 1 : 0);
+        int pw = IMU_PER_WAVE;
+        while (pw > 3 && (blocks + pw - 1) / pw < 512) pw = (pw + 1) / 2;   // 21 -> 11 -> 6 -> 3
+        A.small_per_wave = pw;
+    }
     // groups per wave: one for small batches (latency), up to LASER_GMAX for large ones (no ragged last pass per group)
     int G = 1;
     if (A.mode != LIW_MODE_TRACK) while (G < LASER_GMAX && (long)B * ((n + 2 * G - 1) / (2 * G)) >= 4096) G *= 2;
     const int laser_waves = B * ((n + G - 1) / G);
-    const int imu_waves = (A.eval_small && n > 1) ? B * ((n - 1 + IMU_PER_WAVE - 1) / IMU_PER_WAVE) : 0;
-    const int small_waves = A.eval_small ? B * ((n - 1 + WHEEL_PER_WAVE - 1) / WHEEL_PER_WAVE + (n + 7) / 8) : 0;
+    const int imu_waves = A.eval_small ? imu_wave_count(B, n, A.small_per_wave) : 0;
+    const int small_waves = A.eval_small ? wheel_wave_count(B, n, A.small_per_wave) + ground_wave_count(B, n) : 0;
     if (A.eval_small && laser_waves + imu_waves + small_waves <= 256) {
         const unsigned tot = (unsigned)(laser_waves + imu_waves + small_waves);
         if (A.mode == LIW_MODE_INIT) hipLaunchKernelGGL(k_lin_all<true>, dim3(tot), dim3(64), 0, s, A, P, G, laser_waves, imu_waves);

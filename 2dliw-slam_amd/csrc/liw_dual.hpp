@@ -51,6 +51,53 @@ __host__ __device__ inline double dfloor(double x) { return floor(x); }
 __host__ __device__ inline double val(double x) { return x; }
 __host__ __device__ inline double val(const LJ& x) { return x.v; }
 
+// N derivative directions per lane.  The IMU / wheel / ground roles carry three (the 9 non-linear directions of an IMU or wheel block
+// on 3 lanes, the 6 of a ground block on 2): the value part — every sqrt / sin / cos / atan2 / division of the chain — is then
+// evaluated once per 3 directions instead of once per direction, a wave holds 21 blocks instead of 6, and the three derivative
+// chains of a lane are independent instructions that hide each other's fp64 latency.
+template <int N> struct LJN {
+    double v, d[N];
+    __host__ __device__ LJN() : v(0.0) { for (int k = 0; k < N; ++k) d[k] = 0.0; }
+    __host__ __device__ LJN(double c) : v(c) { for (int k = 0; k < N; ++k) d[k] = 0.0; }  // NOLINT(implicit)
+};
+template <int N> __host__ __device__ inline LJN<N> operator+(const LJN<N>& a, const LJN<N>& b) { LJN<N> r; r.v = a.v + b.v; for (int k = 0; k < N; ++k) r.d[k] = a.d[k] + b.d[k]; return r; }
+template <int N> __host__ __device__ inline LJN<N> operator-(const LJN<N>& a, const LJN<N>& b) { LJN<N> r; r.v = a.v - b.v; for (int k = 0; k < N; ++k) r.d[k] = a.d[k] - b.d[k]; return r; }
+template <int N> __host__ __device__ inline LJN<N> operator-(const LJN<N>& a) { LJN<N> r; r.v = -a.v; for (int k = 0; k < N; ++k) r.d[k] = -a.d[k]; return r; }
+template <int N> __host__ __device__ inline LJN<N> operator*(const LJN<N>& a, const LJN<N>& b) {
+    LJN<N> r; r.v = a.v * b.v;
+    for (int k = 0; k < N; ++k) r.d[k] = a.v * b.d[k] + a.d[k] * b.v;
+    return r;
+}
+template <int N> __host__ __device__ inline LJN<N> operator/(const LJN<N>& f, const LJN<N>& g) {
+    const double gi = 1.0 / g.v;
+    LJN<N> r; r.v = f.v * gi;
+    for (int k = 0; k < N; ++k) r.d[k] = (f.d[k] - r.v * g.d[k]) * gi;
+    return r;
+}
+template <int N> __host__ __device__ inline LJN<N> operator*(const LJN<N>& a, double c) { LJN<N> r; r.v = a.v * c; for (int k = 0; k < N; ++k) r.d[k] = a.d[k] * c; return r; }
+template <int N> __host__ __device__ inline LJN<N> operator*(double c, const LJN<N>& a) { return a * c; }
+template <int N> __host__ __device__ inline bool operator>(const LJN<N>& a, const LJN<N>& b) { return a.v > b.v; }
+template <int N> __host__ __device__ inline bool operator<(const LJN<N>& a, const LJN<N>& b) { return a.v < b.v; }
+template <int N> __host__ __device__ inline LJN<N> chain(double value, double slope, const LJN<N>& f) {   // g(f): value g(f.v), slope g'(f.v)
+    LJN<N> r; r.v = value;
+    for (int k = 0; k < N; ++k) r.d[k] = slope * f.d[k];
+    return r;
+}
+template <int N> __host__ __device__ inline LJN<N> dsqrt(const LJN<N>& f) { const double t = sqrt(f.v); return chain(t, 1.0 / (2.0 * t), f); }
+template <int N> __host__ __device__ inline LJN<N> dsin(const LJN<N>& f) { return chain(sin(f.v), cos(f.v), f); }
+template <int N> __host__ __device__ inline LJN<N> dcos(const LJN<N>& f) { return chain(cos(f.v), -sin(f.v), f); }
+template <int N> __host__ __device__ inline LJN<N> dasin(const LJN<N>& f) { return chain(asin(f.v), 1.0 / sqrt(1.0 - f.v * f.v), f); }
+template <int N> __host__ __device__ inline LJN<N> datan2(const LJN<N>& g, const LJN<N>& f) {
+    const double t = 1.0 / (f.v * f.v + g.v * g.v);
+    LJN<N> r; r.v = atan2(g.v, f.v);
+    for (int k = 0; k < N; ++k) r.d[k] = t * (-g.v * f.d[k] + f.v * g.d[k]);
+    return r;
+}
+template <int N> __host__ __device__ inline LJN<N> dfloor(const LJN<N>& f) { return LJN<N>(floor(f.v)); }
+template <int N> __host__ __device__ inline double val(const LJN<N>& x) { return x.v; }
+// seed: value x, derivative 1 in slot k when `on` (the lane that owns this group of directions), else a constant
+template <int N> __host__ __device__ inline LJN<N> seed(double x, int k, bool on) { LJN<N> r(x); if (on) r.d[k] = 1.0; return r; }
+
 template <class T> struct V3 {
     T x, y, z;
     __host__ __device__ V3() : x(0.0), y(0.0), z(0.0) {}

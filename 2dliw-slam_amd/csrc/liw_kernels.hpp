@@ -77,6 +77,7 @@ struct LinArgs {
     double* PI[2]; double* PW[2]; double* PG[2];
     const LmState* lm;          // null (buffer 0, no skipping), or per-window state: done windows skip
     int candidate;              // 1: write the small-factor partials of window b into buffer 1 - lm[b].cur
+    int small_per_wave;         // IMU / wheel blocks per wave (set by launch_linearize)
     // optional per-factor outputs (liw_eval_factors)
     double* dbg_laser_res; double* dbg_laser_jac; double* dbg_imu_res; double* dbg_imu_jac;
     double* dbg_wheel_res; double* dbg_wheel_jac; double* dbg_ground_res; double* dbg_ground_jac;
