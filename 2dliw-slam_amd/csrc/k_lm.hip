@@ -135,12 +135,17 @@ struct AsmRegs {
     double t1, t2, t3, t4, t8, t9, t10;     // 6x6 pose-block terms (laser, wheel, ground)
     double g1, g2, g3, g4, g5, g6;          // gradient terms
     double xq, sc_i, sc_m, dg_i;            // state entries, Jacobi scales, LM diagonal
+    double e1[2], e2;                       // upward sweep, frame 1 only: H[frame 0 pose, frame 1] of the IMU / wheel block (0,1)
 };
 
 // All loads of a frame are issued up front, branch-free (clamped addresses; masking happens in asm_commit), so the
 // wave pays ONE memory round trip per frame instead of one per conditional term.
-__device__ __forceinline__ AsmRegs asm_issue(const AsmCtx& c, int i, const double* scl, const double* dgl, int lane = threadIdx.x & 63) {
+// dir: which chain neighbour the O tile couples frame i to.  -1 (default): frame i-1 (frames are eliminated n-1 .. 1, then 0);
+// +1: frame i+1 (upward sweep of the two-wave kernel k_lm_step_tw, where frame 0 is split into its pose — the hub every laser
+// frame's arrow points to — and the rest, see there).
+__device__ __forceinline__ AsmRegs asm_issue(const AsmCtx& c, int i, const double* scl, const double* dgl, int lane = threadIdx.x & 63, int dir = -1) {
     const int n = c.n;
+    const bool up = dir > 0;
     const double* PLb = c.PL + (size_t)c.b * n * LP;
     const double* PIb = c.PI + (size_t)c.b * (n - 1) * PIS;
     const double* PWb = c.PW + (size_t)c.b * (n - 1) * PWS;
@@ -158,7 +163,7 @@ __device__ __forceinline__ AsmRegs asm_issue(const AsmCtx& c, int i, const doubl
         const int rs = valid ? r : 0, cs = valid ? cc : 0;
         R.v5[q] = PIm[PI_JJ + rs * 15 + cs];
         R.v6[q] = PIp[PI_II + rs * 15 + cs];
-        R.v7[q] = PIm[PI_IJ + rs * 15 + cs];
+        R.v7[q] = up ? PIp[PI_IJ + cs * 15 + rs] : PIm[PI_IJ + rs * 15 + cs];   // (row r = neighbour's entry, column cc = frame i's)
     }
     {   // the 6x6 pose block terms: one element per lane (lanes 0..35)
         const bool pl = lane < 36;
@@ -167,7 +172,8 @@ __device__ __forceinline__ AsmRegs asm_issue(const AsmCtx& c, int i, const doubl
         R.t2 = PWm[(6 + r) * 13 + 6 + cc];
         R.t3 = PWp[r * 13 + cc];
         R.t4 = PGb[(size_t)i * PGS + r * 7 + cc];
-        R.t8 = PWm[r * 13 + 6 + cc];
+        R.t8 = up ? PWp[cc * 13 + 6 + r] : PWm[r * 13 + 6 + cc];
+        R.e2 = up ? PWm[r * 13 + 6 + cc] : 0.0;
         R.t9 = PLb[(size_t)(n > 1 ? 1 : 0) * LP + 72 + r * 6 + cc];
         R.t10 = PLb[(size_t)i * LP + 72 + r * 6 + cc];
     }
@@ -180,15 +186,21 @@ __device__ __forceinline__ AsmRegs asm_issue(const AsmCtx& c, int i, const doubl
         R.g5 = PIm[PI_G + 15 + r];
         R.g6 = PIp[PI_G + r];
     }
-    {   // states (rotation vectors of frames i, i-1, 0 for the so3 Plus Jacobian test) and the LM scales
+    const int nbf = up ? (hasp ? i + 1 : i) : (hasm ? i - 1 : i);   // the sweep neighbour (or i itself at the end of the chain)
+    {   // states (rotation vectors of frames i, its neighbour, 0 for the so3 Plus Jacobian test) and the LM scales
         int idx = i * 15 + (lane < 15 ? lane : 0);
-        if (lane >= 16 && lane < 19) idx = (hasm ? i - 1 : i) * 15 + 3 + (lane - 16);
+        if (lane >= 16 && lane < 19) idx = nbf * 15 + 3 + (lane - 16);
         if (lane >= 20 && lane < 23) idx = 3 + (lane - 20);
         R.xq = c.x[idx];
         const int v = lane < 15 ? lane : 0;
         R.sc_i = scl ? scl[i * 15 + v] : 1.0;
-        R.sc_m = scl ? scl[(hasm ? i - 1 : i) * 15 + v] : 1.0;
+        R.sc_m = scl ? scl[nbf * 15 + v] : 1.0;
         R.dg_i = dgl ? dgl[i * 15 + v] : 0.0;
+    }
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {   // rows 0..5 (pose of frame i-1) of the IMU block (i-1, i): element e = r * 15 + c < 90
+        const int e = lane + 64 * q;
+        R.e1[q] = up ? PIm[PI_IJ + (e < 90 ? e : 0)] : 0.0;
     }
     return R;
 }
@@ -196,10 +208,13 @@ __device__ __forceinline__ AsmRegs asm_issue(const AsmCtx& c, int i, const doubl
 // Combine the loaded values into frame i's blocks (ambient -> tangent, constants masked), UNSCALED.
 template <int LAYOUT>
 __device__ void asm_commit(const AsmCtx& c, int i, const AsmRegs& R, const Tiles<LAYOUT>& T_, double* tmp, FrameExtra* ex = nullptr,
-                           int lane = threadIdx.x & 63) {
+                           int lane = threadIdx.x & 63, int dir = -1) {
     const int n = c.n;
     const double* PLb = c.PL + (size_t)c.b * n * LP;
     const bool hasm = i >= 1, hasp = i <= n - 2;
+    const bool up = dir > 0, hasnb = up ? hasp : hasm;
+    const int nbf = up ? (hasp ? i + 1 : i) : (hasm ? i - 1 : i);
+    const bool arrow1 = up && i == 1;   // upward sweep: frame 1 is tied to the hub (frame 0's pose) by the IMU / wheel block (0,1) too
     const bool prior_here = c.prior_on && i == n - 2;
     if (prior_here) {   // stage r_prior
         if (lane < 15) tmp[lane] = prior_r(c, lane);
@@ -211,16 +226,25 @@ __device__ void asm_commit(const AsmCtx& c, int i, const AsmRegs& R, const Tiles
         const int e = lane + 64 * q, r = e >> 4, cc = e & 15;
         const bool valid = r < 15 && cc < 15;
         dI[q] = ((valid && hasm) ? R.v5[q] : 0.0) + ((valid && hasp) ? R.v6[q] : 0.0);
-        oI[q] = (valid && hasm) ? R.v7[q] : 0.0;
+        oI[q] = (valid && hasnb) ? R.v7[q] : 0.0;
     }
     double dP = 0.0, oP = 0.0, rP = 0.0;
     {
         const bool pl = lane < 36;
         const int r = pl ? lane / 6 : 0, cc = pl ? lane % 6 : 0;
         dP = R.t1 + (hasm ? R.t2 : 0.0) + (hasp ? R.t3 : 0.0) + R.t4;
-        if (i == 0) for (int j = 0; j < n; ++j) dP += PLb[(size_t)j * LP + r * 6 + cc];
-        oP = hasm ? R.t8 + (i == 1 ? R.t9 : 0.0) : 0.0;
-        rP = i >= 2 ? R.t10 : 0.0;
+        if (i == 0) {   // every laser frame's Haa lands on frame 0's pose: 4 independent partial sums keep the n loads in flight together
+            double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
+            int j = 0;
+            for (; j + 4 <= n; j += 4) {
+                s0 += PLb[(size_t)j * LP + r * 6 + cc]; s1 += PLb[(size_t)(j + 1) * LP + r * 6 + cc];
+                s2 += PLb[(size_t)(j + 2) * LP + r * 6 + cc]; s3 += PLb[(size_t)(j + 3) * LP + r * 6 + cc];
+            }
+            for (; j < n; ++j) s0 += PLb[(size_t)j * LP + r * 6 + cc];
+            dP += (s0 + s1) + (s2 + s3);
+        }
+        oP = hasnb ? R.t8 + ((!up && i == 1) ? R.t9 : 0.0) : 0.0;
+        rP = (i >= 2 || arrow1) ? R.t10 + (arrow1 ? R.e2 : 0.0) : 0.0;
         if (!pl) { dP = 0.0; oP = 0.0; rP = 0.0; }
     }
     double gg = 0.0;
@@ -228,7 +252,16 @@ __device__ void asm_commit(const AsmCtx& c, int i, const AsmRegs& R, const Tiles
         const int r = lane < 15 ? lane : 0;
         if (r < 6) {
             gg = R.g1 + (hasm ? R.g2 : 0.0) + (hasp ? R.g3 : 0.0) + R.g4;
-            if (i == 0) for (int j = 0; j < n; ++j) gg += PLb[(size_t)j * LP + 108 + r];
+            if (i == 0) {
+                double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
+                int j = 0;
+                for (; j + 4 <= n; j += 4) {
+                    s0 += PLb[(size_t)j * LP + 108 + r]; s1 += PLb[(size_t)(j + 1) * LP + 108 + r];
+                    s2 += PLb[(size_t)(j + 2) * LP + 108 + r]; s3 += PLb[(size_t)(j + 3) * LP + 108 + r];
+                }
+                for (; j < n; ++j) s0 += PLb[(size_t)j * LP + 108 + r];
+                gg += (s0 + s1) + (s2 + s3);
+            }
         }
         gg += (hasm ? R.g5 : 0.0) + (hasp ? R.g6 : 0.0);
     }
@@ -255,6 +288,14 @@ __device__ void asm_commit(const AsmCtx& c, int i, const AsmRegs& R, const Tiles
         T_.d(r, cc) += dP; T_.o(r, cc) += oP; T_.rr(r, cc) = rP;
     }
     lds_sync();
+    if (arrow1) {   // + rows 0..5 of the IMU block (0,1): frame 0's pose against all 15 entries of frame 1
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+            const int e = lane + 64 * q;
+            if (e < 90) T_.rr(e / 15, e % 15) += R.e1[q];
+        }
+        lds_sync();
+    }
     if (c.mode == LIW_MODE_MARG) return;
     // ---- so3 local parameterisation (identity unless |q| > pi) on the q rows/cols (3..5)
     double Pi[9], Pm[9], P0[9];
@@ -263,12 +304,12 @@ __device__ void asm_commit(const AsmCtx& c, int i, const AsmRegs& R, const Tiles
     const double qc0 = rdlane(xq, 20), qc1 = rdlane(xq, 21), qc2 = rdlane(xq, 22);
     const double pi2 = kPi * kPi;
     bool li = qa0 * qa0 + qa1 * qa1 + qa2 * qa2 > pi2;
-    bool lm = i >= 1 && qb0 * qb0 + qb1 * qb1 + qb2 * qb2 > pi2;
-    bool l0 = i >= 2 && qc0 * qc0 + qc1 * qc1 + qc2 * qc2 > pi2;
+    bool lm = hasnb && qb0 * qb0 + qb1 * qb1 + qb2 * qb2 > pi2;
+    bool l0 = (i >= 2 || arrow1) && qc0 * qc0 + qc1 * qc1 + qc2 * qc2 > pi2;
     if (li || lm || l0) {   // rare path (|q| > pi), one lane
         li = so3_plus_jac(c.x + (size_t)i * 15 + 3, Pi);
-        lm = i >= 1 && so3_plus_jac(c.x + (size_t)(i - 1) * 15 + 3, Pm);
-        l0 = i >= 2 && so3_plus_jac(c.x + 3, P0);
+        lm = hasnb && so3_plus_jac(c.x + (size_t)nbf * 15 + 3, Pm);
+        l0 = (i >= 2 || arrow1) && so3_plus_jac(c.x + 3, P0);
         if (lane == 0) {
             // kind: 0 = D, 1 = O, 2 = R (rows 0..5 only)
             auto at = [&](int kind, int r, int cc) -> double& { return kind == 0 ? T_.d(r, cc) : (kind == 1 ? T_.o(r, cc) : T_.rr(r, cc)); };
@@ -304,7 +345,8 @@ __device__ void asm_commit(const AsmCtx& c, int i, const AsmRegs& R, const Tiles
             if (r < 15 && cc < 15) {
                 const bool cr = var_is_const(c.mode, c.fast, n, i, r), ccn = var_is_const(c.mode, c.fast, n, i, cc);
                 if (cr || ccn) T_.d(r, cc) = 0.0;
-                if ((i >= 1 && var_is_const(c.mode, c.fast, n, i - 1, r)) || ccn) T_.o(r, cc) = 0.0;
+                if ((hasnb && var_is_const(c.mode, c.fast, n, nbf, r)) || ccn) T_.o(r, cc) = 0.0;
+                if (arrow1 && r < 6 && (var_is_const(c.mode, c.fast, n, 0, r) || ccn)) T_.rr(r, cc) = 0.0;
             }
         }
         if (lane < 15 && var_is_const(c.mode, c.fast, n, i, lane)) T_.gg(lane) = 0.0;
@@ -405,13 +447,15 @@ __device__ __forceinline__ bool fused_chol_solve(double (&a)[15]) {
 }
 
 // diag(H) of frame i in tangent space (lane v < 15 returns H_vv), for the Jacobi scaling fixed at iteration 0
+// WAVE_ONLY: called by one wave of a multi-wave work-group (k_lm_step_tw): no work-group barrier
+template <bool WAVE_ONLY = false>
 __device__ double frame_diag(const AsmCtx& c, int i, LdsStep& T) {
     const int lane = threadIdx.x & 63, n = c.n;
     double Pq[9];
     if (so3_plus_jac(c.x + (size_t)i * 15 + 3, Pq)) {   // rare: |q| > pi -> full tangent assembly
         assemble_frame<1>(c, i, Tiles<1>{T.M, nullptr, nullptr, nullptr}, T.tmp);
         const double d = lane < 15 ? T.M[lane * MS + lane] : 0.0;
-        __syncthreads();
+        if (WAVE_ONLY) lds_sync(); else __syncthreads();
         return d;
     }
     if (lane >= 15) return 0.0;
@@ -803,6 +847,433 @@ __global__ __launch_bounds__(64, THROUGHPUT ? 3 : 2) void k_lm_step(StepArgs a) 
     }
 }
 
+// ---------------------------------------------------------------------------------------------------
+// Two-wave ("twisted") LM step for small batches — the latency of ONE window (the reference's own call pattern: one
+// ceres::Solve at a time, solver.cpp:168, :802).  The serial chain of k_lm_step is n dependent 15x15 eliminations; here the chain
+// is cut in the middle frame m and eliminated from both ends at once by the two waves of a work-group:
+//   wave 0:  frames n-1, n-2, .., m+1            (neighbour i-1, exactly the steps of k_lm_step)
+//   wave 1:  frame 0's non-pose entries ("0c"), then frames 1, 2, .., m-1   (neighbour i+1)
+//   wave 0:  frame m (both neighbours gone), then the hub = frame 0's pose, which every laser frame's arrow points to
+// Frame 0 is split because its velocity / bias entries couple to frame 1 through the IMU block: eliminated first (as a pseudo frame
+// whose pose entries are inert unit pivots) they leave a chain 1 .. n-1 whose only common neighbour is the 6-entry hub, so both
+// sweeps carry the same 6-wide arrow as before and the upward sweep creates no wider fill.  Back substitution runs hub -> m -> both
+// halves outwards, again one half per wave.  Same arithmetic as k_lm_step up to the order of the Schur updates (round-off).
+struct LdsTw {
+    LdsStep T[2];
+    double Haa[36], ga[8];        // frame 0: pose block / pose gradient of the assembled frame (wave 1, step 0c -> wave 0, hub)
+    double sc0[16], dg0[16];      // frame 0: Jacobi scale, LM diagonal
+    double ya[8];                 // solution of the hub
+    double red[2][4];             // per wave: step norm^2, y'g, y'D^2y, gradient max-norm
+    double ctld[4];               // prologue -> both waves: radius
+    int ctl[8];                   // proceed, reuse, cur, solved[2]
+};
+
+__global__ __launch_bounds__(128, 1) void k_lm_step_tw(StepArgs a) {
+    __shared__ LdsTw S;
+    const int b = blockIdx.x, lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    if (b >= a.B) return;
+    LmState& st = a.w.lm[b];
+    if (st.done) return;
+    const int n = a.n;
+    double* xw = a.x + (size_t)b * n * 15;
+    double* xc = a.w.x_cand + (size_t)b * n * 15;
+    LdsStep& T = S.T[w];
+#ifdef LIW_CLK
+    const int it_dbg = st.iteration;
+#define TSTAMP(id) do { if (b == 0 && lane == 0 && it_dbg == 3) g_clk[4000 + 1000 * w + (id)] = clock64(); } while (0)
+#else
+#define TSTAMP(id) do { } while (0)
+#endif
+    TSTAMP(0);
+
+    AsmCtx c;
+    c.n = n; c.mode = a.mode; c.fast = a.fast_mode; c.b = b;
+    c.pJ = a.prior_J + (size_t)b * 225; c.pX = a.prior_X + (size_t)b * 15;
+    c.prior_on = a.mode == LIW_MODE_TRACK && a.has_prior[b] && !a.fast_mode;
+
+    double radius = 0.0, dec = 0.0, x_cost = 0.0, x_norm = 0.0;
+    int reuse = 0, iteration = 0, cur = 0;
+    bool last_successful = true, fresh = false;
+
+    // ---- prologue on wave 0 (the candidate test / accept / reject logic of k_lm_step, statement for statement)
+    if (w == 0) {
+        radius = st.radius; dec = st.decrease_factor; x_cost = st.x_cost; x_norm = st.x_norm;
+        reuse = st.reuse_diagonal; iteration = st.iteration; cur = st.cur;
+        int proceed = 1;
+        if (iteration == 0 && !st.have_candidate) {
+            c.buf = cur; c.PL = a.w.PL[0]; c.PI = a.w.PI[cur]; c.PW = a.w.PW[cur]; c.PG = a.w.PG[cur]; c.x = xw;
+            x_cost = window_cost(c);
+            double sq = 0.0;
+            for (int e = lane; e < n * 15; e += 64) if (!var_is_const(a.mode, a.fast_mode, n, e / 15, e % 15)) sq += xw[e] * xw[e];
+            x_norm = sqrt(wave_sum(sq));
+            if (lane == 0) { st.initial_cost = x_cost; st.minimum_cost = x_cost; }
+            fresh = true;
+            if (a.w.history && a.w.history_records > 0)
+                for (int e = lane; e < n * 15; e += 64) a.w.history[((size_t)b) * n * 15 + e] = xw[e];
+        } else if (st.have_candidate) {
+            const int cb = 1 - cur;
+            c.buf = cb; c.PL = a.w.PL[1]; c.PI = a.w.PI[cb]; c.PW = a.w.PW[cb]; c.PG = a.w.PG[cb]; c.x = xc;
+            double cand_cost = window_cost(c);
+            if (!isfinite(cand_cost)) cand_cost = 1.7976931348623157e308;
+            int term = 0;
+            if (st.cand_step_norm <= kParamTol * (x_norm + kParamTol)) term = 3;
+            else if (fabs(x_cost - cand_cost) <= kFuncTol * x_cost) term = 2;
+            if (term) {
+                if (a.w.history && iteration < a.w.history_records)
+                    for (int e = lane; e < n * 15; e += 64) a.w.history[((size_t)iteration * a.B + b) * n * 15 + e] = xw[e];
+                if (lane == 0) { st.done = 1; st.termination = term; }
+                proceed = 0;
+            } else {
+                const double rho = (x_cost - cand_cost) / st.model_cost_change;
+                if (rho > kMinRelDec) {
+                    for (int e = lane; e < n * 15; e += 64) xw[e] = xc[e];
+                    {
+                        const double* src = a.w.PL[1] + (size_t)b * n * LP;
+                        double* dst = a.w.PL[0] + (size_t)b * n * LP;
+                        for (int e = lane; e < n * LP; e += 64) dst[e] = src[e];
+                    }
+                    cur = cb;
+                    x_cost = cand_cost;
+                    double sq = 0.0;
+                    for (int e = lane; e < n * 15; e += 64) if (!var_is_const(a.mode, a.fast_mode, n, e / 15, e % 15)) sq += xc[e] * xc[e];
+                    x_norm = sqrt(wave_sum(sq));
+                    radius = radius / fmax(1.0 / 3.0, 1.0 - pow(2.0 * rho - 1.0, 3.0));
+                    radius = fmin(kMaxRadius, radius);
+                    dec = 2.0; reuse = 0;
+                    if (lane == 0) { st.successful += 1; if (x_cost < st.minimum_cost) st.minimum_cost = x_cost; }
+                    last_successful = true;
+                } else {
+                    radius = radius / dec; dec *= 2.0; reuse = 1;
+                    last_successful = false;
+                }
+                if (a.w.history && iteration < a.w.history_records)
+                    for (int e = lane; e < n * 15; e += 64) a.w.history[((size_t)iteration * a.B + b) * n * 15 + e] = xw[e];
+            }
+        } else {
+            last_successful = false;   // previous step was invalid
+            if (a.w.history && iteration < a.w.history_records)
+                for (int e = lane; e < n * 15; e += 64) a.w.history[((size_t)iteration * a.B + b) * n * 15 + e] = xw[e];
+        }
+        if (proceed && iteration >= st.max_iters && !(iteration == 0 && fresh)) {
+            if (lane == 0) {
+                st.done = 1; st.termination = 4; st.radius = radius; st.decrease_factor = dec; st.x_cost = x_cost; st.x_norm = x_norm;
+                st.reuse_diagonal = reuse; st.cur = cur; st.have_candidate = 0;
+            }
+            proceed = 0;
+        }
+        if (proceed && fresh) {   // Jacobi scaling 1/(1+sqrt(H_jj)), computed once per solve
+            c.buf = cur; c.PL = a.w.PL[0]; c.PI = a.w.PI[cur]; c.PW = a.w.PW[cur]; c.PG = a.w.PG[cur]; c.x = xw;
+            for (int i = 0; i < n; ++i) {
+                const double hjj = frame_diag<true>(c, i, T);
+                if (lane < 15) st.scale[i * 15 + lane] = var_is_const(a.mode, a.fast_mode, n, i, lane) ? 1.0 : 1.0 / (1.0 + sqrt(hjj));
+            }
+        }
+        if (lane == 0) { S.ctl[0] = proceed; S.ctl[1] = reuse; S.ctl[2] = cur; S.ctld[0] = radius; }
+    }
+    __syncthreads();   // (drains wave 0's global writes: accepted states, laser partial copy, scales)
+    if (!S.ctl[0]) return;
+    TSTAMP(1);
+    reuse = S.ctl[1]; cur = S.ctl[2]; radius = S.ctld[0];
+    c.buf = cur; c.PL = a.w.PL[0]; c.PI = a.w.PI[cur]; c.PW = a.w.PW[cur]; c.PG = a.w.PG[cur]; c.x = xw;
+    const double* scl = st.scale;
+    double* dgl = st.diagonal;
+    double* sws = a.w.solve_ws + (size_t)b * n * SOLVE_WS;
+
+    for (int e = lane; e < 720; e += 64) { T.M[e] = 0.0; if (e < 15 * MS) T.C[e] = 0.0; }
+    if (lane < 16) T.Z[lane] = 0.0;
+    if (lane < 36) T.D0acc[lane] = 0.0;
+    if (lane < 8) T.g0acc[lane] = 0.0;
+    const double sc0reg = scl[lane < 15 ? lane : 0];           // scale of frame 0 (rows of the arrow block)
+    lds_sync();
+    bool solved = true;
+    double gmax = 0.0;
+    const Tiles<1> TM{T.M, nullptr, nullptr, nullptr};
+    const int m = (n + 1) / 2, nA = n - 1 - m;                 // wave 0: nA frames, then m and the hub; wave 1: 0c and 1 .. m-1
+    const int nsteps = w == 0 ? nA + 2 : m;
+    // step s of this wave: frame i, neighbour direction dir (0: none), kind 0 frame / 1 = 0c / 2 hub / 3 middle
+    auto sched = [&](int s_, int& i_, int& dir_, int& kind_) {
+        if (w == 0) {
+            if (s_ < nA) { i_ = n - 1 - s_; dir_ = -1; kind_ = 0; }
+            else if (s_ == nA) { i_ = m; dir_ = 0; kind_ = 3; }
+            else { i_ = 0; dir_ = 0; kind_ = 2; }
+        } else {
+            i_ = s_; dir_ = 1; kind_ = s_ == 0 ? 1 : 0;
+        }
+    };
+    AsmRegs areg;
+    {
+        int i0, d0, k0;
+        sched(0, i0, d0, k0);
+        areg = asm_issue(c, i0, scl, dgl, lane, d0 > 0 ? 1 : -1);
+    }
+    for (int s_ = 0; s_ < nsteps; ++s_) {
+        int i, dir, kind;
+        sched(s_, i, dir, kind);
+        TSTAMP(10 + s_ * 8);
+        if (w == 0 && s_ == nA) __syncthreads();               // wave 1's sweep (its carried terms in S.T[1]) is complete
+        TSTAMP(10 + s_ * 8 + 1);
+        int ln = lane;
+        asm volatile("" : "+v"(ln));
+        FrameExtra ex;
+        if (kind != 2) {
+            asm_commit<1>(c, i, areg, TM, T.tmp, &ex, ln, dir > 0 ? 1 : -1);
+        } else {   // hub: frame 0's pose block and gradient as saved by wave 1, nothing else
+            for (int e = ln; e < 15 * MS; e += 64) T.M[e] = 0.0;
+            lds_sync();
+            if (ln < 36) T.M[(ln / 6) * MS + ln % 6] = S.Haa[ln];
+            if (ln < 6) T.M[ln * MS + 40] = S.ga[ln];
+            lds_sync();
+            ex.sc_i = S.sc0[ln < 15 ? ln : 15]; ex.sc_m = 1.0; ex.dg_i = S.dg0[ln < 15 ? ln : 15]; ex.x_i = xw[ln < 15 ? ln : 0];
+        }
+        TSTAMP(10 + s_ * 8 + 2);
+        // LM diagonal of this frame (LevenbergMarquardtStrategy::ComputeStep), |x - Plus(x,-g)|
+        const bool cstl = ln < 15 && var_is_const(a.mode, a.fast_mode, n, i, ln);
+        double dgv = ex.dg_i;
+        if (kind != 2) {
+            const double gl = ln < 15 ? T.M[ln * MS + 40] : 0.0;          // tangent gradient entry of this lane
+            if (ln < 15) {
+                if (!reuse) { dgv = fmin(fmax(T.M[ln * MS + ln] * ex.sc_i * ex.sc_i, kMinDiag), kMaxDiag); dgl[i * 15 + ln] = dgv; }
+                sws[(size_t)i * SOLVE_WS + REC_GS + ln] = gl * ex.sc_i;          // original scaled gradient (model decrease)
+            }
+            const double qv[3] = {rdlane(ex.x_i, 3), rdlane(ex.x_i, 4), rdlane(ex.x_i, 5)};
+            const double ng[3] = {-rdlane(gl, 3), -rdlane(gl, 4), -rdlane(gl, 5)};
+            double qn[3];
+            so3_plus(qv, ng, qn);
+            double mg = fabs(gl);
+            if (ln >= 3 && ln < 6) mg = fabs(ex.x_i - (ln == 3 ? qn[0] : (ln == 4 ? qn[1] : qn[2])));
+            if (ln < 15 && !cstl) gmax = fmax(gmax, mg);
+        }
+        if (kind == 1) {
+            // frame 0 -> pseudo frame "0c": keep the pose block / gradient for the hub, turn H[pose, rest] into the arrow (R^T rows
+            // = the hub's entries), make the pose entries inert (zero rows / columns, unit pivots through the constant mask below)
+            if (ln < 36) S.Haa[ln] = T.M[(ln / 6) * MS + ln % 6];
+            if (ln < 6) S.ga[ln] = T.M[ln * MS + 40];
+            if (ln < 15) { S.sc0[ln] = ex.sc_i; S.dg0[ln] = dgv; }
+            if (ln == 15) { S.sc0[15] = 1.0; S.dg0[15] = 0.0; }
+            double rv[2];
+#pragma unroll
+            for (int q = 0; q < 2; ++q) {   // R^T(cc, r) = D_0(r, cc), r < 6 <= cc
+                const int e = ln + 64 * q, r = e / 15, cc = e % 15;
+                rv[q] = (e < 90 && cc >= 6) ? T.M[r * MS + cc] : 0.0;
+            }
+            lds_sync();
+#pragma unroll
+            for (int q = 0; q < 2; ++q) {
+                const int e = ln + 64 * q, r = e / 15, cc = e % 15;
+                if (e < 90) T.M[cc * MS + 32 + r] = rv[q];
+            }
+            for (int e = ln; e < 6 * MS; e += 64) {             // rows 0..5 of every tile (D, O^T, R^T, g)
+                const int cc = e % MS;
+                if (cc < 15 || (cc >= 16 && cc < 31) || cc == 40) T.M[e] = 0.0;
+            }
+            for (int e = ln; e < 15 * 6; e += 64) T.M[(e / 6) * MS + e % 6] = 0.0;   // columns 0..5 of D
+            lds_sync();
+        }
+        TSTAMP(10 + s_ * 8 + 3);
+        const bool dummy = (kind == 1 && ln < 6) || (kind == 2 && ln >= 6 && ln < 15);
+        const bool cst2 = cstl || dummy;
+        const bool hasnb = kind == 1 || (kind == 0 && (dir > 0 ? i <= n - 2 : i >= 1));
+        const bool hasarrow = kind == 1 || ((kind == 0 || kind == 3) && (i >= 2 || (dir > 0 && i == 1)));
+        const double s_m = __shfl(ex.sc_m, (ln - 16) & 63, 64), s_0 = __shfl(sc0reg, (ln - 32) & 63, 64);
+        double slane = 0.0;
+        if (ln < 15) slane = ex.sc_i;
+        else if (ln >= 16 && ln < 31) slane = hasnb ? s_m : 0.0;
+        else if (ln >= 32 && ln < 38) slane = hasarrow ? s_0 : 0.0;
+        else if (ln == 40) slane = 1.0;
+        double col[15];
+        const int lc = ln < MS ? ln : MS - 1;
+        // carried Schur terms: own sweep (not for the hub), plus wave 1's for frame m which closes both sweeps; as multipliers, so
+        // that the 45 LDS reads of this block stay one straight-line batch
+        if (kind == 3) {   // frame m closes both sweeps: the Schur terms of wave 1 as well
+            const double* C2 = S.T[1].C;
+#pragma unroll
+            for (int r = 0; r < 15; ++r) col[r] = T.M[r * MS + lc] * (rdlane(ex.sc_i, r) * slane) + (T.C[r * MS + lc] + C2[r * MS + lc]);
+        } else {
+            const double kc = kind == 2 ? 0.0 : 1.0;   // the hub takes its carried terms from D0acc / g0acc below
+#pragma unroll
+            for (int r = 0; r < 15; ++r) col[r] = T.M[r * MS + lc] * (rdlane(ex.sc_i, r) * slane) + T.C[r * MS + lc] * kc;
+        }
+        if (kind == 2) {
+            if (ln < 6) {
+#pragma unroll
+                for (int r = 0; r < 6; ++r) col[r] += S.T[0].D0acc[r * 6 + ln] + S.T[1].D0acc[r * 6 + ln];
+            }
+            if (ln == 40) {
+#pragma unroll
+                for (int r = 0; r < 6; ++r) col[r] += S.T[0].g0acc[r] + S.T[1].g0acc[r];
+            }
+        }
+        if (ln < 15) {
+            const double dmp = cst2 ? 0.0 : dgv / radius;
+#pragma unroll
+            for (int r = 0; r < 15; ++r) if (r == ln) col[r] = cst2 ? 1.0 : col[r] + dmp;
+        }
+        TSTAMP(10 + s_ * 8 + 4);
+        // software pipeline: the next frame's loads are in flight while this one is factorised
+        __builtin_amdgcn_sched_barrier(0);
+        if (s_ + 1 < nsteps) {
+            int i2, d2, k2;
+            sched(s_ + 1, i2, d2, k2);
+            if (k2 != 2) areg = asm_issue(c, i2, scl, dgl, ln, d2 > 0 ? 1 : -1);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        if (ln >= 41 && ln < 56) {
+#pragma unroll
+            for (int r = 0; r < 15; ++r) col[r] = (r == ln - 41) ? 1.0 : 0.0;
+        }
+        if (!fused_chol_solve(col)) solved = false;   // no early exit: both waves must keep meeting at the barriers (NaNs stay local)
+        TSTAMP(10 + s_ * 8 + 5);
+        {
+            const int toff = (ln >= 16 && ln < 31) ? LW + (ln - 16) : ((ln >= 32 && ln < 38) ? LWA + (ln - 32) : (ln == 40 ? LW + 15 : ((ln >= 41 && ln < 56) ? LLI + (ln - 41) : -1)));
+            if (toff >= 0) {
+#pragma unroll
+                for (int r = 0; r < 15; ++r) T.M[toff + r * 16] = col[r];
+            }
+        }
+        lds_sync();
+        {   // back-substitution operators [Yo | Yr | yz] = D^-1 [O^T | R^T | g] of this frame (the hub keeps its solution in LDS)
+            const d4 y1 = xty15<16, 16>(T.M + LLI, T.M + LW, T.Z), y2 = xty15<16, 16>(T.M + LLI, T.M + LWA, T.Z);
+            double* f = sws + (size_t)i * SOLVE_WS;
+            const int colx = ln & 15;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int row = (ln >> 4) + 4 * r;
+                if (row < 15) {
+                    if (kind != 2) {
+                        f[row * REC_LD + (colx < 15 ? colx : 21)] = y1[r];
+                        if (colx < 6) f[row * REC_LD + 15 + colx] = y2[r];
+                    } else if (colx == 15 && row < 6) {
+                        S.ya[row] = y1[r];
+                    }
+                }
+            }
+        }
+        TSTAMP(10 + s_ * 8 + 6);
+        if (kind != 2) {   // Schur products on the matrix cores
+            const d4 p1 = xty15<16, 16>(T.M + LW, T.M + LW, T.Z);      // [Wo|z]^T [Wo|z]
+            const d4 p2 = xty15<16, 16>(T.M + LWA, T.M + LW, T.Z);     // Wr^T [Wo|z]   (rows < 6)
+            const d4 p3 = xty15<16, 16>(T.M + LWA, T.M + LWA, T.Z);    // Wr^T Wr       (rows, cols < 6)
+            lds_sync();
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int row = (ln >> 4) + 4 * r, colx = ln & 15;
+                if (kind != 3) {   // carried into the neighbour, in its lane layout
+                    if (row < 15) T.C[row * MS + (colx < 15 ? colx : 40)] = -p1[r];
+                    if (row < 6 && colx < 15) T.C[colx * MS + 32 + row] = -p2[r];
+                }
+                if (row < 6 && colx == 15) T.g0acc[row] -= p2[r];
+                if (row < 6 && colx < 6) T.D0acc[row * 6 + colx] -= p3[r];
+            }
+            lds_sync();
+        }
+    }
+    TSTAMP(2);
+    gmax = wave_max(gmax);
+    if (lane == 0) { S.red[w][3] = gmax; S.ctl[3 + w] = solved ? 1 : 0; }
+    if (w == 1) __syncthreads();                                 // pairs with wave 0's barrier before frame m
+    __syncthreads();                                             // records of both sweeps, hub solution, flags
+    // ---- FinalizeIterationAndCheck, part 2
+    {
+        const double gm = fmax(S.red[0][3], S.red[1][3]);
+        int term = 0;
+        if (iteration == 0 && fresh) { if (gm <= kGradTol) term = 1; }
+        else if (last_successful && gm <= kGradTol) term = 1;
+        // (iteration / fresh / last_successful live on wave 0; wave 1 follows its decision through LDS)
+        if (w == 0) {
+            if (!term && !(radius > kMinRadius)) term = 5;
+            if (lane == 0) S.ctl[5] = term;
+        }
+        __syncthreads();
+        term = S.ctl[5];
+        if (term) {
+            if (w == 0 && lane == 0) {
+                st.done = 1; st.termination = term; st.radius = radius; st.decrease_factor = dec; st.x_cost = x_cost; st.x_norm = x_norm;
+                st.reuse_diagonal = reuse; st.cur = cur; st.have_candidate = 0;
+            }
+            return;
+        }
+    }
+    TSTAMP(3);
+    ++iteration;
+    const bool all_solved = S.ctl[3] && S.ctl[4];
+    double sn2 = 0.0, ytg = 0.0, dsum = 0.0;
+    if (all_solved) {
+        // ---- back substitution: hub -> frame m -> wave 0: m+1 .. n-1, wave 1: m-1 .. 1, then frame 0's other entries.
+        // Lane r owns unknown r: row r of Yo / Yr of the frame's record.
+        const int r15 = lane < 15 ? lane : 0;
+        auto load_row = [&](int i_, double* row, double& gsv, double& xold, double& scv, double& dgv_) {
+            const double* f = sws + (size_t)i_ * SOLVE_WS;
+            const double2* f2 = reinterpret_cast<const double2*>(f + r15 * REC_LD);
+#pragma unroll
+            for (int k = 0; k < 11; ++k) { const double2 v = f2[k]; row[2 * k] = v.x; row[2 * k + 1] = v.y; }
+            gsv = f[REC_GS + r15]; xold = xw[(size_t)i_ * 15 + r15]; scv = scl[i_ * 15 + r15]; dgv_ = dgl[i_ * 15 + r15];
+        };
+        double yav[6];
+#pragma unroll
+        for (int k = 0; k < 6; ++k) yav[k] = S.ya[k];
+        auto emit = [&](int i_, double t, double gsv, double xold, double scv, double dgv_) {
+            const bool cst = lane < 15 && var_is_const(a.mode, a.fast_mode, n, i_, lane);
+            const double del = (lane < 15 && !cst) ? -t * scv : 0.0;
+            const double qv[3] = {rdlane(xold, 3), rdlane(xold, 4), rdlane(xold, 5)};
+            double dq[3] = {rdlane(del, 3), rdlane(del, 4), rdlane(del, 5)}, qn[3];
+            so3_plus(qv, dq, qn);
+            if (lane < 15) {
+                double xnew = xold + del;
+                if (lane >= 3 && lane < 6) xnew = var_is_const(a.mode, a.fast_mode, n, i_, 3) ? xold : qn[lane - 3];
+                xc[(size_t)i_ * 15 + lane] = xnew;
+                if (!cst) {
+                    sn2 += (xold - xnew) * (xold - xnew);
+                    ytg += t * gsv;
+                    dsum += dgv_ / radius * t * t;
+                }
+            }
+        };
+        // wave 0 walks m, m+1, .., n-1; wave 1 walks m (solution only: wave 0 emits that frame), m-1, .., 1, 0.  Frame k+1's record is in
+        // flight while frame k is solved.
+        struct BsRow { double row[22], gsv, xold, scv, dgv_; };
+        auto fetch = [&](int i_) { BsRow R_; load_row(i_, R_.row, R_.gsv, R_.xold, R_.scv, R_.dgv_); return R_; };
+        const int cnt = w == 0 ? n - m : m + 1;
+        BsRow curr = fetch(m);
+        double yprev = 0.0;
+        for (int k = 0; k < cnt; ++k) {
+            const int i = w == 0 ? m + k : m - k;
+            BsRow nxt = curr;
+            __builtin_amdgcn_sched_barrier(0);
+            if (k + 1 < cnt) nxt = fetch(w == 0 ? i + 1 : i - 1);
+            __builtin_amdgcn_sched_barrier(0);
+            double t = curr.row[21];
+#pragma unroll
+            for (int q = 0; q < 15; ++q) t -= curr.row[q] * rdlane(yprev, q);      // frame m: no chain neighbour left (Yo = 0)
+#pragma unroll
+            for (int q = 0; q < 6; ++q) t -= curr.row[15 + q] * yav[q];
+            if (w == 1 && i == 0 && lane < 6) t = S.ya[lane];                        // frame 0: pose entries from the hub, the rest from "0c"
+            yprev = t;
+            if (!(w == 1 && k == 0)) emit(i, t, curr.gsv, curr.xold, curr.scv, curr.dgv_);
+            curr = nxt;
+        }
+        sn2 = wave_sum(sn2); ytg = wave_sum(ytg); dsum = wave_sum(dsum);
+    }
+    TSTAMP(4);
+    if (lane == 0) { S.red[w][0] = sn2; S.red[w][1] = ytg; S.red[w][2] = dsum; }
+    __syncthreads();
+    if (w == 0 && lane == 0) {
+        const double step_norm = sqrt(S.red[0][0] + S.red[1][0]);
+        // model cost change -(s'g_s + s'A s/2) with s = -y and (A + D^2) y = g_s  ==  (y'g_s + y'D^2 y)/2
+        const double model_cost_change = 0.5 * ((S.red[0][1] + S.red[1][1]) + (S.red[0][2] + S.red[1][2]));
+        const bool valid = all_solved && model_cost_change > 0.0 && isfinite(model_cost_change);
+        st.iteration = iteration; st.cur = cur; st.x_cost = x_cost; st.x_norm = x_norm;
+        if (valid) {
+            st.radius = radius; st.decrease_factor = dec; st.reuse_diagonal = 1;
+            st.model_cost_change = model_cost_change; st.cand_step_norm = step_norm; st.have_candidate = 1; st.invalid_steps = 0;
+        } else {
+            st.invalid_steps += 1;
+            st.have_candidate = 0;
+            if (st.invalid_steps >= 5) { st.done = 1; st.termination = 6; st.iteration = iteration - 1; }
+            st.radius = radius / dec; st.decrease_factor = dec * 2.0; st.reuse_diagonal = 1;
+        }
+    }
+}
+
 __global__ void k_lm_begin(int B, int n, LmState* lm, int max_iters) {
     const int b = blockIdx.x * blockDim.x + threadIdx.x;
     if (b >= B) return;
@@ -1046,9 +1517,12 @@ void launch_lm_begin(int B, int n, LmState* lm, int max_iters, hipStream_t s) {
     hipLaunchKernelGGL(k_lm_begin, dim3((B + 63) / 64), dim3(64), 0, s, B, n, lm, max_iters);
 }
 void launch_lm_step(const StepArgs& a, hipStream_t s) {
-    static const char* env = getenv("LIW_STEP_VARIANT");   // 0 / 1: force the latency / throughput variant (profiling aid)
+    static const char* env = getenv("LIW_STEP_VARIANT");   // 0 / 1 / 2: force the one-wave latency / throughput / two-wave variant (profiling aid)
     const bool tp = env ? env[0] == '1' : a.B > 2048;
-    if (tp) hipLaunchKernelGGL(k_lm_step<true>, dim3(a.B), dim3(64), 0, s, a);
+    // two waves per window while that does not take CUs away from other windows, and the chain is long enough to be worth cutting
+    const bool tw = (env ? env[0] == '2' : a.B <= 256) && a.n >= 6;
+    if (tw) hipLaunchKernelGGL(k_lm_step_tw, dim3(a.B), dim3(128), 0, s, a);
+    else if (tp) hipLaunchKernelGGL(k_lm_step<true>, dim3(a.B), dim3(64), 0, s, a);
     else hipLaunchKernelGGL(k_lm_step<false>, dim3(a.B), dim3(64), 0, s, a);
 }
 void launch_lm_finish(const StepArgs& a, hipStream_t s) { hipLaunchKernelGGL(k_lm_finish, dim3((a.B + 63) / 64), dim3(64), 0, s, a); }
