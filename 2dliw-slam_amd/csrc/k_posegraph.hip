@@ -446,6 +446,214 @@ int liw_dense_spd_solve(liw_ctx* c, int n, const double* A, const double* b, dou
     return LIW_OK;
 }
 
+}  // extern "C"
+namespace liw {
+// ------------------------------------------------------------------------------------------- sparse path
+// The key frames form a chain (sequential edges k -> k+1, keyframe_manager.cpp:444-453) closed by a few loop edges.  Key frames
+// that carry a loop edge, the constant one, both chain ends and every PG_STRIDE-th frame are SEPARATORS; the frames between two
+// consecutive separators a < b are interior: tied to their chain neighbours only.  Per LM iteration
+//   k_pg_seg_elim     one wave per segment eliminates its interior frames a+1 .. b-1 in chain order (6x6 pivots, register-resident
+//                     Cholesky with v_readlane broadcasts; the coupling to the left border a is the only fill) and leaves the Schur
+//                     terms on (a,a), (b,a), (b,b), g_a, g_b plus one 6x13 back-substitution record per interior frame;
+//   k_pg_reduced(+loops)  assembles the dense system of the separators only (a few hundred unknowns instead of 6N);
+//   the blocked MFMA Cholesky below solves that; k_pg_seg_backsub recovers the interior frames, again one wave per segment.
+// Exact (the same linear system as the dense path, which stays as the checker: LIW_PG_DENSE=1 or a non-chain edge list).
+constexpr int PG_STRIDE = 48;
+
+__device__ __forceinline__ double rdl64(double v, int l);
+
+// one wave per key frame: 6x6 diagonal block + gradient (as k_pg_assemble) into Dd / gd; the off-diagonal block H[index1, index2]
+// of every edge whose index1 is this key frame into Os[index1] (sequential edge) or Lb[e - n_seq] (loop edge)
+__global__ __launch_bounds__(64) void k_pg_assemble_blocks(int N, int n_seq, const int* inc_off, const int* inc, const int* eidx, const double* Ye, const double* Yg,
+                                                           int const_pose, double* Dd, double* gd, double* Os, double* Lb) {
+    const int i = blockIdx.x, lane = threadIdx.x & 63;
+    if (i >= N) return;
+    const int r = lane / 6, c = lane % 6;
+    double acc = 0.0;
+    const bool is_const = i == const_pose;
+    if (!is_const) {
+        if (lane < 36) acc = Yg[(size_t)i * 14 + r] * Yg[(size_t)i * 14 + c] + Yg[(size_t)i * 14 + 7 + r] * Yg[(size_t)i * 14 + 7 + c];
+        else if (lane < 42) acc = Yg[(size_t)i * 14 + (lane - 36)] * Yg[(size_t)i * 14 + 6] + Yg[(size_t)i * 14 + 7 + (lane - 36)] * Yg[(size_t)i * 14 + 13];
+    }
+    for (int t = inc_off[i]; t < inc_off[i + 1]; ++t) {
+        const int e = inc[t] >> 1, side = inc[t] & 1;
+        const double* Y = Ye + (size_t)e * 78;
+        if (!is_const) {
+            double sm = 0.0;
+            if (lane < 36) {
+#pragma unroll
+                for (int k = 0; k < 6; ++k) sm += Y[k * 13 + 6 * side + r] * Y[k * 13 + 6 * side + c];
+            } else if (lane < 42) {
+#pragma unroll
+                for (int k = 0; k < 6; ++k) sm += Y[k * 13 + 6 * side + (lane - 36)] * Y[k * 13 + 12];
+            }
+            acc += sm;
+        }
+        if (side == 0 && lane < 36) {   // H[index1, index2](r, c) = sum_k J1[k][r] J2[k][c]; zero against the constant key frame
+            const int j = eidx[e * 2 + 1];
+            double o = 0.0;
+            if (!is_const && j != const_pose) {
+#pragma unroll
+                for (int k = 0; k < 6; ++k) o += Y[k * 13 + r] * Y[k * 13 + 6 + c];
+            }
+            if (e < n_seq) Os[(size_t)i * 36 + lane] = o;
+            else Lb[(size_t)(e - n_seq) * 36 + lane] = o;
+        }
+    }
+    if (is_const && lane < 36) acc = r == c ? 1.0 : 0.0;
+    if (lane < 36) Dd[(size_t)i * 36 + lane] = acc;
+    else if (lane < 42) gd[i * 6 + (lane - 36)] = acc;
+}
+
+// Schur terms of one segment (doubles): aa[36] (on H[a,a]), ba[36] (H[b,a], rows b), bb[36], ga[6], gb[6]
+constexpr int PG_SEG = 36 * 3 + 12;
+__global__ __launch_bounds__(64) void k_pg_seg_elim(int nseg, const int* segs, const double* Dd, const double* gd, const double* Os, const double* scale,
+                                                    const double* dgn, double radius, double* Sred, double* rec, int* status) {
+    const int sg = blockIdx.x, lane = threadIdx.x & 63;
+    if (sg >= nseg) return;
+    const int a = segs[2 * sg], b = segs[2 * sg + 1];
+    double* out = Sred + (size_t)sg * PG_SEG;
+    // lane roles: j < 6 column j of the pivot block, 6..11 columns of H[f, f+1], 12..17 columns of H[f, a], 18 the gradient
+    const int role = lane < 6 ? 0 : (lane < 12 ? 1 : (lane < 18 ? 2 : (lane == 18 ? 3 : 4)));
+    const int cj = lane < 18 ? lane % 6 : 0;
+    double cD[6] = {0, 0, 0, 0, 0, 0}, cB[6] = {0, 0, 0, 0, 0, 0}, cg[6] = {0, 0, 0, 0, 0, 0}, aAA[6] = {0, 0, 0, 0, 0, 0}, aGa[6] = {0, 0, 0, 0, 0, 0};
+    bool ok = true;
+    for (int f = a + 1; f < b; ++f) {
+        const double* sf = scale + (size_t)f * 6;
+        double col[6];
+#pragma unroll
+        for (int r = 0; r < 6; ++r) {
+            double v = 0.0;
+            if (role == 0) v = Dd[(size_t)f * 36 + r * 6 + cj] * sf[r] * sf[cj] + cD[r] + (r == cj ? dgn[(size_t)f * 6 + cj] / radius : 0.0);
+            else if (role == 1) v = Os[(size_t)f * 36 + r * 6 + cj] * sf[r] * scale[(size_t)(f + 1) * 6 + cj];
+            else if (role == 2) v = (f == a + 1 ? Os[(size_t)a * 36 + cj * 6 + r] * scale[(size_t)a * 6 + cj] * sf[r] : 0.0) + cB[r];
+            else if (role == 3) v = gd[(size_t)f * 6 + r] * sf[r] + cg[r];
+            col[r] = v;
+        }
+        // right-looking Cholesky of the 6x6 pivot fused with the forward substitution of the other columns
+#pragma unroll
+        for (int k = 0; k < 6; ++k) {
+            const double piv = rdl64(col[k], k);
+            if (!(piv > 0.0) || !isfinite(piv)) ok = false;
+            const double wk = col[k] * rsqrt(piv);
+            col[k] = wk;
+#pragma unroll
+            for (int r = k + 1; r < 6; ++r) col[r] -= rdl64(wk, r) * wk;
+        }
+        // record [Yo | Yb | yz] = L^-T [Wo | Wb | z]: y_f = yz - Yo y_{f+1} - Yb y_a
+        {
+            double xs[6];
+#pragma unroll
+            for (int k = 5; k >= 0; --k) {
+                double t = col[k];
+#pragma unroll
+                for (int r = k + 1; r < 6; ++r) t -= rdl64(col[k], r) * xs[r];      // L[r][k] lives in lane r, register k
+                xs[k] = t / rdl64(col[k], k);
+            }
+            if (lane >= 6 && lane < 19) {
+#pragma unroll
+                for (int k = 0; k < 6; ++k) rec[(size_t)f * 78 + k * 13 + (lane - 6)] = xs[k];
+            }
+        }
+        // Schur terms: P(p, own) = W_p . W_own for the columns p of [Wo | Wb]
+        double P[12];
+#pragma unroll
+        for (int p_ = 0; p_ < 12; ++p_) {
+            double d = 0.0;
+#pragma unroll
+            for (int k = 0; k < 6; ++k) d += rdl64(col[k], 6 + p_) * col[k];
+            P[p_] = d;
+        }
+#pragma unroll
+        for (int q = 0; q < 6; ++q) {
+            const double fromO = __shfl(P[q], (lane + 6) & 63, 64);   // lane j < 6 <- P(Wo_q, Wo_j) held by lane 6 + j
+            if (role == 0) cD[q] = -fromO;
+            if (role == 2) { cB[q] = -P[q]; aAA[q] -= P[6 + q]; }
+            if (role == 3) { cg[q] = -P[q]; aGa[q] -= P[6 + q]; }
+        }
+    }
+#pragma unroll
+    for (int r = 0; r < 6; ++r) {
+        if (role == 0) out[72 + r * 6 + cj] = cD[r];                                 // bb
+        if (role == 2) { out[36 + r * 6 + cj] = cB[r]; out[r * 6 + cj] = aAA[r]; }   // ba (rows b), aa
+        if (role == 3) { out[108 + r] = aGa[r]; out[114 + r] = cg[r]; }              // ga, gb
+    }
+    if (!ok && lane == 0) atomicOr(status, 1);
+}
+
+// dense system of the separators (lower triangle): one wave per separator t (frame sep[t])
+__global__ __launch_bounds__(64) void k_pg_reduced(int ns, int nr, int ld, const int* sep, const double* Dd, const double* gd, const double* Os, const double* scale,
+                                                   const double* dgn, double radius, int const_pose, const double* Sred, double* Hr, double* rhs) {
+    const int t = blockIdx.x, lane = threadIdx.x & 63;
+    if (t >= ns) {   // padding rows of the blocked factorisation: identity
+        for (int k = nr + lane; k < ld; k += 64) Hr[(size_t)k * ld + k] = 1.0;
+        return;
+    }
+    const int f = sep[t], r = lane / 6, c = lane % 6;
+    const double* sf = scale + (size_t)f * 6;
+    const bool is_const = f == const_pose;
+    const bool left = t > 0 && sep[t] - sep[t - 1] > 1, right = t + 1 < ns && sep[t + 1] - sep[t] > 1;   // segments with interior frames
+    if (lane < 36) {
+        double v = is_const ? (r == c ? 1.0 : 0.0) : Dd[(size_t)f * 36 + lane] * sf[r] * sf[c] + (r == c ? dgn[(size_t)f * 6 + c] / radius : 0.0);
+        if (!is_const) {
+            if (right) v += Sred[(size_t)t * PG_SEG + lane];
+            if (left) v += Sred[(size_t)(t - 1) * PG_SEG + 72 + lane];
+        }
+        if (r >= c) Hr[(size_t)(t * 6 + r) * ld + t * 6 + c] = v;
+        if (t > 0) {   // block (t, t-1): direct edge when the separators are chain neighbours, else the segment's fill
+            const int fa = sep[t - 1];
+            const double o = left ? Sred[(size_t)(t - 1) * PG_SEG + 36 + lane] : Os[(size_t)fa * 36 + c * 6 + r] * scale[(size_t)fa * 6 + c] * sf[r];
+            Hr[(size_t)(t * 6 + r) * ld + (t - 1) * 6 + c] = (is_const || fa == const_pose) ? 0.0 : o;
+        }
+    } else if (lane < 42) {
+        const int k = lane - 36;
+        double v = is_const ? 0.0 : gd[(size_t)f * 6 + k] * sf[k];
+        if (!is_const) {
+            if (right) v += Sred[(size_t)t * PG_SEG + 108 + k];
+            if (left) v += Sred[(size_t)(t - 1) * PG_SEG + 114 + k];
+        }
+        rhs[t * 6 + k] = v;
+    }
+}
+// loop edges, in edge order by ONE wave (several edges may share a block: fixed order keeps the sums reproducible)
+__global__ __launch_bounds__(64) void k_pg_reduced_loops(int nl, const int* lidx, const int* sepidx, const double* Lb, const double* scale, int const_pose, int ld, double* Hr) {
+    const int lane = threadIdx.x & 63, r = lane / 6, c = lane % 6;
+    if (lane >= 36) return;
+    for (int e = 0; e < nl; ++e) {
+        const int i1 = lidx[2 * e], i2 = lidx[2 * e + 1];
+        if (i1 == const_pose || i2 == const_pose) continue;
+        const int t1 = sepidx[i1], t2 = sepidx[i2];
+        const double v = Lb[(size_t)e * 36 + lane] * scale[(size_t)i1 * 6 + r] * scale[(size_t)i2 * 6 + c];   // H[i1, i2](r, c)
+        if (t1 > t2) Hr[(size_t)(t1 * 6 + r) * ld + t2 * 6 + c] += v;
+        else Hr[(size_t)(t2 * 6 + c) * ld + t1 * 6 + r] += v;
+    }
+}
+__global__ void k_pg_scatter_sep(int ns, const int* sep, const double* ysep, double* y) {
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t < ns * 6) y[(size_t)sep[t / 6] * 6 + t % 6] = ysep[t];
+}
+__global__ __launch_bounds__(64) void k_pg_seg_backsub(int nseg, const int* segs, const double* rec, double* y) {
+    const int sg = blockIdx.x, lane = threadIdx.x & 63;
+    if (sg >= nseg) return;
+    const int a = segs[2 * sg], b = segs[2 * sg + 1];
+    const int k = lane < 6 ? lane : 0;
+    double ya[6], yn[6];
+#pragma unroll
+    for (int q = 0; q < 6; ++q) { ya[q] = y[(size_t)a * 6 + q]; yn[q] = y[(size_t)b * 6 + q]; }
+    for (int f = b - 1; f > a; --f) {
+        const double* R = rec + (size_t)f * 78 + k * 13;
+        double t = R[12];
+#pragma unroll
+        for (int q = 0; q < 6; ++q) t -= R[q] * yn[q] + R[6 + q] * ya[q];
+#pragma unroll
+        for (int q = 0; q < 6; ++q) yn[q] = rdl64(t, q);
+        if (lane < 6) y[(size_t)f * 6 + lane] = t;
+    }
+}
+}  // namespace liw
+extern "C" {
+using namespace liw;
+
 struct PgCall {
     liw_ctx* c; const liw_pg_params* pg; int N; double* poses; int n_seq; const int* seq_idx; const double* seq_tf12; int n_loop; const int* loop_idx;
     const double* loop_tf12; int max_iters; liw_summary* summary; double* H_out; double* g_out; double* cost_out;
@@ -488,6 +696,19 @@ static int pg_run(const PgCall& q) {
         std::vector<int> fill(inc_off.begin(), inc_off.end() - 1);
         for (int e = 0; e < E; ++e) { inc[fill[eidx[2 * e]]++] = e * 2; inc[fill[eidx[2 * e + 1]]++] = e * 2 + 1; }
     }
+    // sparse path: the sequential edges must be the chain k -> k+1 (what keyframe_manager builds, :444-453)
+    bool sparse = !linearize_only && n_seq == N - 1 && N >= 4 && !std::getenv("LIW_PG_DENSE");
+    for (int e = 0; e < n_seq && sparse; ++e) if (eidx[2 * e] != e || eidx[2 * e + 1] != e + 1) sparse = false;
+    std::vector<int> sep, sepidx(N, -1), segs;
+    if (sparse) {
+        std::vector<char> is_sep(N, 0);
+        is_sep[0] = is_sep[N - 1] = is_sep[const_pose] = 1;
+        for (int e = n_seq; e < E; ++e) { is_sep[eidx[2 * e]] = 1; is_sep[eidx[2 * e + 1]] = 1; }
+        for (int i = 0; i < N; i += PG_STRIDE) is_sep[i] = 1;
+        for (int i = 0; i < N; ++i) if (is_sep[i]) { sepidx[i] = (int)sep.size(); sep.push_back(i); }
+        for (size_t t = 0; t + 1 < sep.size(); ++t) { segs.push_back(sep[t]); segs.push_back(sep[t + 1]); }
+    }
+    const int ns = (int)sep.size(), nseg = ns > 0 ? ns - 1 : 0, nr = 6 * ns, npr = (nr + 63) / 64 * 64;
     PgNoise noise{};
     for (int k = 0; k < 36; ++k) noise.J[k] = (k % 7 == 0) ? 1.0 : 0.0;   // edge_noise (edge_factor.h:15-25), J(1,2) as written there
     noise.J[0] = 1.0 / pg->loop_sigma_p[0]; noise.J[1 * 6 + 2] = 1.0 / pg->loop_sigma_p[1]; noise.J[2 * 6 + 2] = 1.0 / pg->loop_sigma_p[2];
@@ -503,13 +724,27 @@ static int pg_run(const PgCall& q) {
     const int cost_blocks = 64;
     if (dx.alloc(sizeof(double) * n) || dxc.alloc(sizeof(double) * n) || deidx.alloc(sizeof(int) * 2 * (size_t)E) || detf.alloc(sizeof(double) * 12 * (size_t)E) ||
         dew.alloc(sizeof(double) * E) || dinc_off.alloc(sizeof(int) * (N + 1)) || dinc.alloc(sizeof(int) * 2 * (size_t)E) || dYe.alloc(sizeof(double) * 78 * (size_t)E) ||
-        dYg.alloc(sizeof(double) * 14 * (size_t)N) || dH.alloc(sizeof(double) * (size_t)np * np) || dA.alloc(sizeof(double) * (size_t)np * np) ||
+        dYg.alloc(sizeof(double) * 14 * (size_t)N) || dH.alloc(sparse ? 8 : sizeof(double) * (size_t)np * np) || dA.alloc(sparse ? 8 : sizeof(double) * (size_t)np * np) ||
         dg.alloc(sizeof(double) * np) || dscale.alloc(sizeof(double) * np) || ddgn.alloc(sizeof(double) * np) || drhs.alloc(sizeof(double) * np) ||
-        dpart.alloc(sizeof(double) * cost_blocks) || dst.alloc(sizeof(int) * (1 + 2 * (size_t)(np / 64))))
+        dpart.alloc(sizeof(double) * cost_blocks) || dst.alloc(sizeof(int) * (2 + 2 * (size_t)(np / 64))))
+        return liw_ctx_fail(c, LIW_ENOMEM, "hipMalloc");
+    DBuf dDd, dgd, dOs, dLb, dsep, dsepidx, dsegs, dSred, drec, dHr, drhsr, dlidx;
+    if (sparse && (dDd.alloc(sizeof(double) * 36 * (size_t)N) || dgd.alloc(sizeof(double) * 6 * (size_t)N) || dOs.alloc(sizeof(double) * 36 * (size_t)N) ||
+                   dLb.alloc(sizeof(double) * 36 * (size_t)std::max(n_loop, 1)) || dsep.alloc(sizeof(int) * ns) || dsepidx.alloc(sizeof(int) * N) ||
+                   dsegs.alloc(sizeof(int) * 2 * (size_t)std::max(nseg, 1)) || dSred.alloc(sizeof(double) * PG_SEG * (size_t)std::max(nseg, 1)) ||
+                   drec.alloc(sizeof(double) * 78 * (size_t)N) || dHr.alloc(sizeof(double) * (size_t)npr * npr) || drhsr.alloc(sizeof(double) * npr) ||
+                   dlidx.alloc(sizeof(int) * 2 * (size_t)std::max(n_loop, 1))))
         return liw_ctx_fail(c, LIW_ENOMEM, "hipMalloc");
     auto up = [&](DBuf& d, const void* src, size_t bytes) { (void)hipMemcpyAsync(d.p, src, bytes, hipMemcpyHostToDevice, s); };
     up(deidx, eidx.data(), sizeof(int) * eidx.size()); up(detf, etf.data(), sizeof(double) * etf.size()); up(dew, ew.data(), sizeof(double) * E);
     up(dinc_off, inc_off.data(), sizeof(int) * (N + 1)); up(dinc, inc.data(), sizeof(int) * inc.size());
+    std::vector<double> Ddh;
+    if (sparse) {
+        up(dsep, sep.data(), sizeof(int) * ns); up(dsepidx, sepidx.data(), sizeof(int) * N); up(dsegs, segs.data(), sizeof(int) * segs.size());
+        if (n_loop) up(dlidx, eidx.data() + 2 * (size_t)n_seq, sizeof(int) * 2 * (size_t)n_loop);
+        (void)hipMemsetAsync(dOs.p, 0, sizeof(double) * 36 * (size_t)N, s);
+        Ddh.resize((size_t)N * 36);
+    }
 
     std::vector<double> x(poses, poses + n), cand(n), g(n), scale(n, 1.0), dgn(n, 0.0), gs(n), y(np), Hdiag(n), part(cost_blocks);
     const unsigned lin_blocks = (unsigned)((E + 3) / 4 + (N + 7) / 8);
@@ -518,7 +753,12 @@ static int pg_run(const PgCall& q) {
         hipLaunchKernelGGL(k_pg_linearize, dim3(lin_blocks), dim3(64), 0, s, N, E, dxx.as<double>(), deidx.as<int>(), detf.as<double>(), dew.as<double>(), noise, P,
                            dYe.as<double>(), dYg.as<double>(), with_jac ? 1 : 0);
         hipLaunchKernelGGL(k_pg_cost, dim3(cost_blocks), dim3(256), 0, s, N, E, dYe.as<double>(), dYg.as<double>(), const_pose, dpart.as<double>());
-        if (with_jac) {
+        if (with_jac && sparse) {
+            hipLaunchKernelGGL(k_pg_assemble_blocks, dim3(N), dim3(64), 0, s, N, n_seq, dinc_off.as<int>(), dinc.as<int>(), deidx.as<int>(), dYe.as<double>(),
+                               dYg.as<double>(), const_pose, dDd.as<double>(), dgd.as<double>(), dOs.as<double>(), dLb.as<double>());
+            (void)hipMemcpyAsync(g.data(), dgd.p, sizeof(double) * n, hipMemcpyDeviceToHost, s);
+            (void)hipMemcpyAsync(Ddh.data(), dDd.p, sizeof(double) * 36 * (size_t)N, hipMemcpyDeviceToHost, s);
+        } else if (with_jac) {
             (void)hipMemsetAsync(dH.p, 0, sizeof(double) * (size_t)np * np, s);
             hipLaunchKernelGGL(k_pg_assemble, dim3(N), dim3(64), 0, s, N, np, dinc_off.as<int>(), dinc.as<int>(), deidx.as<int>(), dYe.as<double>(), dYg.as<double>(),
                                const_pose, dH.as<double>(), dg.as<double>());
@@ -528,6 +768,8 @@ static int pg_run(const PgCall& q) {
         }
         (void)hipMemcpyAsync(part.data(), dpart.p, sizeof(double) * cost_blocks, hipMemcpyDeviceToHost, s);
         if (hipStreamSynchronize(s) != hipSuccess || hipGetLastError() != hipSuccess) return liw_ctx_fail(c, LIW_EHIP, "pose graph evaluate");
+        if (with_jac && sparse)
+            for (int i = 0; i < n; ++i) Hdiag[i] = Ddh[(size_t)(i / 6) * 36 + (i % 6) * 7];
         double t = 0.0;
         for (double v : part) t += v;
         *cost = 0.5 * t;
@@ -590,14 +832,31 @@ static int pg_run(const PgCall& q) {
         std::fill(y.begin(), y.end(), 0.0);
         std::memcpy(y.data(), gs.data(), sizeof(double) * n);
         up(drhs, y.data(), sizeof(double) * np);
-        hipLaunchKernelGGL(k_pg_scale_damp, dim3((np + 255) / 256, np), dim3(256), 0, s, n, np, np, dH.as<double>(), dscale.as<double>(), ddgn.as<double>(), radius,
-                           dA.as<double>());
-        if (int r = dense_cholesky_solve(c, dA.as<double>(), np, drhs.as<double>(), dst.as<int>(), s)) return r;
-        int st = 0;
+        int st = 0, st2 = 0;
+        if (sparse) {
+            int* seg_status = dst.as<int>() + 1 + 2 * (np / 64);
+            (void)hipMemsetAsync(seg_status, 0, sizeof(int), s);
+            (void)hipMemsetAsync(dHr.p, 0, sizeof(double) * (size_t)npr * npr, s);
+            (void)hipMemsetAsync(drhsr.p, 0, sizeof(double) * npr, s);
+            hipLaunchKernelGGL(k_pg_seg_elim, dim3(nseg), dim3(64), 0, s, nseg, dsegs.as<int>(), dDd.as<double>(), dgd.as<double>(), dOs.as<double>(), dscale.as<double>(),
+                               ddgn.as<double>(), radius, dSred.as<double>(), drec.as<double>(), seg_status);
+            hipLaunchKernelGGL(k_pg_reduced, dim3(ns + 1), dim3(64), 0, s, ns, nr, npr, dsep.as<int>(), dDd.as<double>(), dgd.as<double>(), dOs.as<double>(),
+                               dscale.as<double>(), ddgn.as<double>(), radius, const_pose, dSred.as<double>(), dHr.as<double>(), drhsr.as<double>());
+            if (n_loop) hipLaunchKernelGGL(k_pg_reduced_loops, dim3(1), dim3(64), 0, s, n_loop, dlidx.as<int>(), dsepidx.as<int>(), dLb.as<double>(), dscale.as<double>(),
+                                           const_pose, npr, dHr.as<double>());
+            if (int r = dense_cholesky_solve(c, dHr.as<double>(), npr, drhsr.as<double>(), dst.as<int>(), s)) return r;
+            hipLaunchKernelGGL(k_pg_scatter_sep, dim3((nr + 255) / 256), dim3(256), 0, s, ns, dsep.as<int>(), drhsr.as<double>(), drhs.as<double>());
+            hipLaunchKernelGGL(k_pg_seg_backsub, dim3(nseg), dim3(64), 0, s, nseg, dsegs.as<int>(), drec.as<double>(), drhs.as<double>());
+            (void)hipMemcpyAsync(&st2, seg_status, sizeof(int), hipMemcpyDeviceToHost, s);
+        } else {
+            hipLaunchKernelGGL(k_pg_scale_damp, dim3((np + 255) / 256, np), dim3(256), 0, s, n, np, np, dH.as<double>(), dscale.as<double>(), ddgn.as<double>(), radius,
+                               dA.as<double>());
+            if (int r = dense_cholesky_solve(c, dA.as<double>(), np, drhs.as<double>(), dst.as<int>(), s)) return r;
+        }
         (void)hipMemcpyAsync(y.data(), drhs.p, sizeof(double) * np, hipMemcpyDeviceToHost, s);
         (void)hipMemcpyAsync(&st, dst.p, sizeof(int), hipMemcpyDeviceToHost, s);
         if (hipStreamSynchronize(s) != hipSuccess) return liw_ctx_fail(c, LIW_EHIP, "pose graph solve");
-        bool solved = st == 0;
+        bool solved = st == 0 && st2 == 0;
         for (int i = 0; i < n && solved; ++i) if (!std::isfinite(y[i])) solved = false;
         // model cost change with (A + D^2) y = g_s, step = -y:  (y'g_s + y'D^2 y) / 2
         double model_cost_change = 0.0;

@@ -96,3 +96,26 @@ def test_posegraph_cost_vs_cpu_restatement(liw, synth, pyoracle):
     print("pose graph 200 key frames: GPU %.1f ms, CPU oracle %.1f ms" % (tg * 1e3, to * 1e3))
     assert sg["iterations"] == so["iterations"] and np.abs(xg - xo).max() <= 1e-6 * max(1.0, np.abs(xo).max())
     assert tg < to
+
+
+@pytest.mark.parametrize("N,n_loop,seed", [(60, 4, 1), (400, 12, 2), (1500, 40, 3)])
+def test_chain_segment_path_equals_dense_path(liw, synth, N, n_loop, seed):
+    """The sparse solve (interior chain segments eliminated one wave each, dense Cholesky on the separators only) solves the same
+    linear system as the dense factorisation of the full 6N x 6N matrix (LIW_PG_DENSE=1, the checker): same LM path."""
+    import os
+    prm = synth.office_params()
+    pg = dict(liw.posegraph.office_pg_params(), use_ground_q_factor=False)
+    G = liw.posegraph.make_pose_graph(prm, N=N, seed=seed, n_loop=n_loop, laps=2.2)
+    G["loop_idx"] = np.vstack([G["loop_idx"], G["loop_idx"][:1], [[N - 1, 0]]]).astype(G["loop_idx"].dtype)      # a duplicated pair, and a loop on the constant key frame
+    G["loop_tf12"] = np.vstack([G["loop_tf12"], G["loop_tf12"][:1], G["loop_tf12"][:1]])
+    pgs = liw.posegraph.PoseGraph(prm)
+    args = (G["poses"], G["seq_idx"], G["seq_tf12"], G["loop_idx"], G["loop_tf12"])
+    xs, ss = pgs.solve(pg, *args, max_iters=12)
+    os.environ["LIW_PG_DENSE"] = "1"
+    try:
+        xd, sd = pgs.solve(pg, *args, max_iters=12)
+    finally:
+        del os.environ["LIW_PG_DENSE"]
+    assert (ss["iterations"], ss["termination"], ss["successful"]) == (sd["iterations"], sd["termination"], sd["successful"])
+    assert np.abs(xs - xd).max() <= 1e-9 * max(1.0, np.abs(xd).max())
+    assert abs(ss["final_cost"] - sd["final_cost"]) <= 1e-9 * sd["final_cost"]
