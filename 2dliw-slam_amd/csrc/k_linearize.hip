@@ -484,16 +484,22 @@ __device__ void wheel_blocks(const LinArgs& A, const DevParams& P, int wave, dou
         for (int r = 0; r < 3; ++r) A.dbg_wheel_res[fk * 3 + r] = Y[r * 13 + 12];
     if (on && A.dbg_wheel_jac)
         for (int e = g; e < 36; e += 3) A.dbg_wheel_jac[fk * 36 + e] = Y[(e / 12) * 13 + e % 12];
-    if (on) {
-        const int sel = A.lm ? (A.candidate ? 1 - A.lm[b].cur : A.lm[b].cur) : 0;
-        double* out = A.PW[sel] + fk * PWS;
-        for (int e = g; e < 91; e += 3) {
-            int c1 = 0, rem = e;
-            while (rem >= 13 - c1) { rem -= 13 - c1; ++c1; }
-            const int c2 = c1 + rem;
-            const double s_ = Y[c1] * Y[c2] + Y[13 + c1] * Y[13 + c2] + Y[26 + c1] * Y[26 + c2];
-            out[c1 * 13 + c2] = s_;
-            out[c2 * 13 + c1] = s_;
+    // G = Y^T Y (13 x 13 per block), written with consecutive lanes on consecutive addresses: the blocks of a wave are consecutive
+    // records of the partial buffer, so the wave's output is one contiguous region (a lane-per-pair scatter doubled the HBM write
+    // traffic of this role)
+    int* meta = reinterpret_cast<int*>(lds + WHEEL_PER_WAVE * 64);   // per block: partial buffer (0 / 1) or -1 = skip
+    if (g == 0 && blk < WHEEL_PER_WAVE) meta[blk] = on ? (A.lm ? (A.candidate ? 1 - A.lm[b].cur : A.lm[b].cur) : 0) : -1;
+    __syncthreads();
+    {
+        const long gb0 = (long)wave * A.small_per_wave;
+        const int nblk = (int)min((long)A.small_per_wave, total - gb0);
+        for (int idx = lane; idx < nblk * PWS; idx += 64) {
+            const int q = idx / PWS, e = idx % PWS, sel = meta[q];
+            if (sel < 0) continue;
+            const double* Yq = lds + q * 64;
+            const int r = e / 13, c = e % 13;
+            const double v = e < 169 ? Yq[r] * Yq[c] + Yq[13 + r] * Yq[13 + c] + Yq[26 + r] * Yq[26 + c] : 0.0;
+            A.PW[sel][(size_t)(gb0 + q) * PWS + e] = v;
         }
     }
 }
@@ -533,18 +539,20 @@ __device__ void ground_frames(const LinArgs& A, const DevParams& P, int wave, do
         if (A.dbg_ground_jac)
             for (int e = 0; e < 3; ++e) { A.dbg_ground_jac[(fi * 2) * 6 + 3 * g + e] = res[0].d[e]; A.dbg_ground_jac[(fi * 2 + 1) * 6 + 3 * g + e] = res[1].d[e]; }
     }
+    int* meta = reinterpret_cast<int*>(lds + GROUND_PER_WAVE * 16);
+    if (g == 0) meta[sub] = on ? (A.lm ? (A.candidate ? 1 - A.lm[b].cur : A.lm[b].cur) : 0) : -1;
     __syncthreads();
-    if (on) {
-        const int sel = A.lm ? (A.candidate ? 1 - A.lm[b].cur : A.lm[b].cur) : 0;
-        double* out = A.PG[sel] + fi * PGS;
-        const double mult = (double)n;   // the block set is added once per outer frame index (solver.cpp:142-159)
-        for (int e = g; e < 28; e += 2) {
-            int c1 = 0, rem = e;
-            while (rem >= 7 - c1) { rem -= 7 - c1; ++c1; }
-            const int c2 = c1 + rem;
-            const double s_ = mult * (Y[c1] * Y[c2] + Y[7 + c1] * Y[7 + c2]);
-            out[c1 * 7 + c2] = s_;
-            out[c2 * 7 + c1] = s_;
+    {   // n * Y^T Y (7 x 7 per frame; the block set is added once per outer frame index, solver.cpp:142-159), coalesced as in the wheel role
+        const long gf0 = (long)wave * GROUND_PER_WAVE;
+        const int nfr = (int)min((long)GROUND_PER_WAVE, total - gf0);
+        const double mult = (double)n;
+        for (int idx = lane; idx < nfr * PGS; idx += 64) {
+            const int q = idx / PGS, e = idx % PGS, sel = meta[q];
+            if (sel < 0) continue;
+            const double* Yq = lds + q * 16;
+            const int r = e / 7, c = e % 7;
+            const double v = e < 49 ? mult * (Yq[r] * Yq[c] + Yq[7 + r] * Yq[7 + c]) : 0.0;
+            A.PG[sel][(size_t)(gf0 + q) * PGS + e] = v;
         }
     }
 }
@@ -560,7 +568,7 @@ __device__ void small_role(const LinArgs& A, const DevParams& P, int vblock, dou
     if (vblock < nw) wheel_blocks(A, P, vblock, lds);
     else ground_frames(A, P, vblock - nw, lds);
 }
-constexpr int SMALL_LDS = WHEEL_PER_WAVE * 64;   // >= GROUND_PER_WAVE * 16
+constexpr int SMALL_LDS = WHEEL_PER_WAVE * 64 + 16;   // + per-block meta words; >= GROUND_PER_WAVE * 16 + 16
 __global__ __launch_bounds__(64, 2) void k_lin_imu(LinArgs A, DevParams P) {
     __shared__ double lds[IMU_PER_WAVE * IMU_REC];
     imu_blocks(A, P, (int)blockIdx.x, lds);
@@ -573,7 +581,7 @@ __global__ __launch_bounds__(64, 2) void k_lin_small(LinArgs A, DevParams P) {
 // one kernel and no fork / join events per linearisation, which is what a latency-bound 2-frame window pays for.
 template <bool BOTH>
 __global__ __launch_bounds__(64, 2) void k_lin_all(LinArgs A, DevParams P, int G, int n_laser, int n_imu) {
-    __shared__ double lds[IMU_PER_WAVE * IMU_REC];   // IMU / small roles; the laser role brings its own static LDS
+    __shared__ double lds[IMU_PER_WAVE * IMU_REC];   // IMU / small roles (>= SMALL_LDS); the laser role brings its own static LDS
     const int v = (int)blockIdx.x;
     if (v < n_laser) laser_wave_local<BOTH>(A, P, G, v);
     else if (v < n_laser + n_imu) imu_blocks(A, P, v - n_laser, lds);
