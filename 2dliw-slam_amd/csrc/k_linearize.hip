@@ -148,17 +148,19 @@ __device__ __forceinline__ V3<double> mulc(const double* m, int ld, const V3<dou
 __device__ void imu_blocks(const LinArgs& A, const DevParams& P, int wave, double* lds) {
     const int lane = threadIdx.x & 63, blk = lane / 3, g = lane % 3;
     const int n = A.n, nb = n - 1, ipw = A.small_per_wave;   // blocks per wave: IMU_PER_WAVE for throughput, fewer for latency
-    const long total = (long)A.B * nb, gb0 = (long)wave * ipw;
+    // blocks are indexed over the windows that are still iterating (compacted list), so finished windows cost no lanes
+    const long total = (long)(A.active ? A.active[0] : A.B) * nb, gb0 = (long)wave * ipw;
     if (gb0 >= total) return;
     const long gb = gb0 + blk;
-    bool on = blk < ipw && gb < total;
-    const int b = on ? (int)(gb / nb) : 0, k = on ? (int)(gb % nb) : 0;
-    if (on && A.lm && A.lm[b].done) on = false;
+    const bool on = blk < ipw && gb < total;
+    const int wi = on ? (int)(gb / nb) : 0, k = on ? (int)(gb % nb) : 0;
+    const int b = A.active ? A.active[1 + wi] : wi;
     double* rec = lds + (blk < IMU_PER_WAVE ? blk : 0) * IMU_REC;
     const int sel_lane = (on && A.lm) ? (A.candidate ? 1 - A.lm[b].cur : A.lm[b].cur) : 0;   // partial buffer of this lane's block
+    const int fk_lane = on ? b * nb + k : 0;                                                   // its record in the input / partial arrays
     LSTAMP(300);
     if (on) {
-        const size_t fk = (size_t)b * nb + k;
+        const size_t fk = (size_t)b * nb + k;   // record of this block in the (uncompacted) input / partial arrays
         const double* si_ = A.x + ((size_t)b * n + k) * 15;
         const double* sj_ = si_ + 15;
         const double* Jp = A.imu_J + fk * 225;
@@ -284,8 +286,8 @@ __device__ void imu_blocks(const LinArgs& A, const DevParams& P, int wave, doubl
     // while this group runs on the matrix cores: three memory round trips per wave instead of one per block
     constexpr int GRP = 7;
     auto load_sop = [&](int gq, double* o) {
-        const long gg = gb0 + gq;
-        const double* S = A.imu_sqrtP + (size_t)((gq < nblk && gg < total) ? gg : gb0) * 225;
+        const int fq = __shfl(fk_lane, gq < nblk ? 3 * gq : 0, 64);
+        const double* S = A.imu_sqrtP + (size_t)fq * 225;
 #pragma unroll
         for (int c = 0; c < 4; ++c) {
             const int kk = mk + 4 * c;
@@ -308,7 +310,6 @@ __device__ void imu_blocks(const LinArgs& A, const DevParams& P, int wave, doubl
         for (int q = 0; q < GRP; ++q) {
             const int gq = g0 + q;
             if (gq >= nblk || !((onmask >> (3 * gq)) & 1ull)) continue;
-            const long gg = gb0 + gq;
             const double* R_ = lds + gq * IMU_REC;
             d4 y0 = {0.0, 0.0, 0.0, 0.0}, y1 = {0.0, 0.0, 0.0, 0.0};
 #pragma unroll
@@ -327,7 +328,7 @@ __device__ void imu_blocks(const LinArgs& A, const DevParams& P, int wave, doubl
                 g01 = __builtin_amdgcn_mfma_f64_16x16x4f64(y0[c], y1[c], g01, 0, 0, 0);
                 g11 = __builtin_amdgcn_mfma_f64_16x16x4f64(y1[c], y1[c], g11, 0, 0, 0);
             }
-            const size_t fg = (size_t)gg;
+            const size_t fg = (size_t)__shfl(fk_lane, 3 * gq, 64);
             const int sel = __shfl(sel_lane, 3 * gq, 64);
             double* out = A.PI[sel] + fg * PIS;
             // tile (0,0) = [ii | gradient_i ; . | cost], tile (0,1) = [ij ; gradient_j], tile (1,1) = jj: one masked store per tile row group
@@ -371,12 +372,12 @@ constexpr int WHEEL_PER_WAVE = 21;
 __device__ void wheel_blocks(const LinArgs& A, const DevParams& P, int wave, double* lds) {
     const int lane = threadIdx.x & 63, blk = lane / 3, g = lane % 3;
     const int n = A.n, nb = n - 1;
-    const long total = (long)A.B * nb, gb = (long)wave * A.small_per_wave + blk;
-    bool on = blk < A.small_per_wave && gb < total;
-    const int b = on ? (int)(gb / nb) : 0, k = on ? (int)(gb % nb) : 0;
-    if (on && A.lm && A.lm[b].done) on = false;
+    const long total = (long)(A.active ? A.active[0] : A.B) * nb, gb = (long)wave * A.small_per_wave + blk;   // over the windows still iterating
+    const bool on = blk < A.small_per_wave && gb < total;
+    const int wi = on ? (int)(gb / nb) : 0, k = on ? (int)(gb % nb) : 0;
+    const int b = A.active ? A.active[1 + wi] : wi;
     double* Y = lds + (blk < WHEEL_PER_WAVE ? blk : 0) * 64;   // [3][13] then Dp [3][3] at 40, R_wi [3][3] at 49
-    const size_t fk = (size_t)(on ? gb : 0);
+    const size_t fk = on ? (size_t)b * nb + k : 0;
     if (on) {
         const double* si_ = A.x + ((size_t)b * n + k) * 15;
         const double* sj_ = si_ + 15;
@@ -487,8 +488,11 @@ __device__ void wheel_blocks(const LinArgs& A, const DevParams& P, int wave, dou
     // G = Y^T Y (13 x 13 per block), written with consecutive lanes on consecutive addresses: the blocks of a wave are consecutive
     // records of the partial buffer, so the wave's output is one contiguous region (a lane-per-pair scatter doubled the HBM write
     // traffic of this role)
-    int* meta = reinterpret_cast<int*>(lds + WHEEL_PER_WAVE * 64);   // per block: partial buffer (0 / 1) or -1 = skip
-    if (g == 0 && blk < WHEEL_PER_WAVE) meta[blk] = on ? (A.lm ? (A.candidate ? 1 - A.lm[b].cur : A.lm[b].cur) : 0) : -1;
+    int* meta = reinterpret_cast<int*>(lds + WHEEL_PER_WAVE * 64);   // per block: partial buffer (0 / 1) or -1 = skip; then its record index
+    if (g == 0 && blk < WHEEL_PER_WAVE) {
+        meta[blk] = on ? (A.lm ? (A.candidate ? 1 - A.lm[b].cur : A.lm[b].cur) : 0) : -1;
+        meta[32 + blk] = (int)fk;
+    }
     __syncthreads();
     {
         const long gb0 = (long)wave * A.small_per_wave;
@@ -499,7 +503,7 @@ __device__ void wheel_blocks(const LinArgs& A, const DevParams& P, int wave, dou
             const double* Yq = lds + q * 64;
             const int r = e / 13, c = e % 13;
             const double v = e < 169 ? Yq[r] * Yq[c] + Yq[13 + r] * Yq[13 + c] + Yq[26 + r] * Yq[26 + c] : 0.0;
-            A.PW[sel][(size_t)(gb0 + q) * PWS + e] = v;
+            A.PW[sel][(size_t)meta[32 + q] * PWS + e] = v;
         }
     }
 }
@@ -512,12 +516,12 @@ constexpr int GROUND_PER_WAVE = 32;
 __device__ void ground_frames(const LinArgs& A, const DevParams& P, int wave, double* lds) {
     const int lane = threadIdx.x & 63, sub = lane >> 1, g = lane & 1;
     const int n = A.n;
-    const long total = (long)A.B * n, gf = (long)wave * GROUND_PER_WAVE + sub;
-    bool on = gf < total;
-    const int b = on ? (int)(gf / n) : 0;
-    if (on && A.lm && A.lm[b].done) on = false;
+    const long total = (long)(A.active ? A.active[0] : A.B) * n, gf = (long)wave * GROUND_PER_WAVE + sub;
+    const bool on = gf < total;
+    const int wi = on ? (int)(gf / n) : 0;
+    const int b = A.active ? A.active[1 + wi] : wi;
     double* Y = lds + sub * 16;   // [2][7]
-    const size_t fi = (size_t)(on ? gf : 0);
+    const size_t fi = on ? (size_t)b * n + (size_t)(gf % n) : 0;
     if (on) {
         const double* s_ = A.x + fi * 15;
         J3 res[2];
@@ -540,7 +544,7 @@ __device__ void ground_frames(const LinArgs& A, const DevParams& P, int wave, do
             for (int e = 0; e < 3; ++e) { A.dbg_ground_jac[(fi * 2) * 6 + 3 * g + e] = res[0].d[e]; A.dbg_ground_jac[(fi * 2 + 1) * 6 + 3 * g + e] = res[1].d[e]; }
     }
     int* meta = reinterpret_cast<int*>(lds + GROUND_PER_WAVE * 16);
-    if (g == 0) meta[sub] = on ? (A.lm ? (A.candidate ? 1 - A.lm[b].cur : A.lm[b].cur) : 0) : -1;
+    if (g == 0) { meta[sub] = on ? (A.lm ? (A.candidate ? 1 - A.lm[b].cur : A.lm[b].cur) : 0) : -1; meta[32 + sub] = (int)fi; }
     __syncthreads();
     {   // n * Y^T Y (7 x 7 per frame; the block set is added once per outer frame index, solver.cpp:142-159), coalesced as in the wheel role
         const long gf0 = (long)wave * GROUND_PER_WAVE;
@@ -552,7 +556,7 @@ __device__ void ground_frames(const LinArgs& A, const DevParams& P, int wave, do
             const double* Yq = lds + q * 16;
             const int r = e / 7, c = e % 7;
             const double v = e < 49 ? mult * (Yq[r] * Yq[c] + Yq[7 + r] * Yq[7 + c]) : 0.0;
-            A.PG[sel][(size_t)(gf0 + q) * PGS + e] = v;
+            A.PG[sel][(size_t)meta[32 + q] * PGS + e] = v;
         }
     }
 }
@@ -568,7 +572,7 @@ __device__ void small_role(const LinArgs& A, const DevParams& P, int vblock, dou
     if (vblock < nw) wheel_blocks(A, P, vblock, lds);
     else ground_frames(A, P, vblock - nw, lds);
 }
-constexpr int SMALL_LDS = WHEEL_PER_WAVE * 64 + 16;   // + per-block meta words; >= GROUND_PER_WAVE * 16 + 16
+constexpr int SMALL_LDS = WHEEL_PER_WAVE * 64 + 32;   // + 64 per-block meta words; >= GROUND_PER_WAVE * 16 + 32
 __global__ __launch_bounds__(64, 2) void k_lin_imu(LinArgs A, DevParams P) {
     __shared__ double lds[IMU_PER_WAVE * IMU_REC];
     imu_blocks(A, P, (int)blockIdx.x, lds);
@@ -586,6 +590,25 @@ __global__ __launch_bounds__(64, 2) void k_lin_all(LinArgs A, DevParams P, int G
     if (v < n_laser) laser_wave_local<BOTH>(A, P, G, v);
     else if (v < n_laser + n_imu) imu_blocks(A, P, v - n_laser, lds);
     else small_role(A, P, v - n_laser - n_imu, lds);
+}
+
+// ids of the windows that are still iterating, in window order (deterministic): active[0] = count, active[1 ..] = ids.  One work-group.
+__global__ __launch_bounds__(1024) void k_compact_active(int B, const LmState* lm, int* active) {
+    __shared__ int cnt[1024];
+    const int t = threadIdx.x, per = (B + 1023) / 1024, lo = t * per, hi = min(B, lo + per);
+    int c = 0;
+    for (int b = lo; b < hi; ++b) c += lm[b].done ? 0 : 1;
+    cnt[t] = c;
+    __syncthreads();
+    for (int o = 1; o < 1024; o <<= 1) {   // inclusive scan
+        const int v = t >= o ? cnt[t - o] : 0;
+        __syncthreads();
+        cnt[t] += v;
+        __syncthreads();
+    }
+    int pos = cnt[t] - c;
+    for (int b = lo; b < hi; ++b) if (!lm[b].done) active[1 + pos++] = b;
+    if (t == 1023) active[0] = cnt[1023];
 }
 
 // laser block range of every (window, frame): first block of window b owned by a frame >= i
@@ -623,6 +646,10 @@ void launch_linearize(const LinArgs& A_, const DevParams& P, hipStream_t s, cons
     const int laser_waves = B * ((n + G - 1) / G);
     const int imu_waves = A.eval_small ? imu_wave_count(B, n, A.small_per_wave) : 0;
     const int small_waves = A.eval_small ? wheel_wave_count(B, n, A.small_per_wave) + ground_wave_count(B, n) : 0;
+    // large batches only: a single window gains nothing from the list and would pay one more launch per LM iteration
+    static const bool no_compact = getenv("LIW_NO_COMPACT") != nullptr;   // profiling aid: index the small roles over all windows
+    if (A.lm && A.active && A.eval_small && B >= 512 && !no_compact) hipLaunchKernelGGL(k_compact_active, dim3(1), dim3(1024), 0, s, B, A.lm, A.active);
+    else A.active = nullptr;
     if (A.eval_small && laser_waves + imu_waves + small_waves <= 256) {
         const unsigned tot = (unsigned)(laser_waves + imu_waves + small_waves);
         if (A.mode == LIW_MODE_INIT) hipLaunchKernelGGL(k_lin_all<true>, dim3(tot), dim3(64), 0, s, A, P, G, laser_waves, imu_waves);

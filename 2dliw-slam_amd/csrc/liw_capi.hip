@@ -224,7 +224,7 @@ int liw_get_extrinsics(const liw_ctx* c, double* A, double* Bm) {
 // ------------------------------------------------------------------------------------------ workspace
 static size_t al256(size_t v) { return (v + 255) & ~(size_t)255; }
 struct FullLayout {
-    size_t PL[2], PI[2], PW[2], PG[2], x_cand, group_off, lm, solve_ws, info, history, ftf, bytes;
+    size_t PL[2], PI[2], PW[2], PG[2], x_cand, group_off, lm, solve_ws, info, history, ftf, active, bytes;
 };
 static FullLayout full_layout(int B, int n, int hist) {
     FullLayout f{};
@@ -237,6 +237,7 @@ static FullLayout full_layout(int B, int n, int hist) {
     f.x_cand = o; o = al256(o + sizeof(double) * (size_t)B * n * 15);
     f.group_off = o; o = al256(o + sizeof(int) * (size_t)B * (n + 1));
     f.ftf = o; o = al256(o + sizeof(double) * (size_t)B * n * 2 * FTF);
+    f.active = o; o = al256(o + sizeof(int) * ((size_t)B + 1));
     f.lm = o; o = al256(o + sizeof(LmState) * (size_t)B);
     f.solve_ws = o; o = al256(o + sizeof(double) * (size_t)B * n * SOLVE_WS);
     f.info = o; o = al256(o + sizeof(liw_summary) * (size_t)B);
@@ -261,6 +262,7 @@ static WsView make_view(void* ws, int B, int n, int hist) {
     v.history = hist > 0 ? (double*)(base + f.history) : nullptr;
     v.history_records = hist;
     v.ftf = (double*)(base + f.ftf);
+    v.active = (int*)(base + f.active);
     return v;
 }
 
@@ -295,6 +297,7 @@ static LinArgs lin_args(const liw_batch* b, int mode, const double* x, const WsV
     A.PL = v.PL[candidate ? 1 : 0];
     for (int k = 0; k < 2; ++k) { A.PI[k] = v.PI[k]; A.PW[k] = v.PW[k]; A.PG[k] = v.PG[k]; }
     A.lm = use_lm ? v.lm : nullptr;
+    A.active = use_lm ? v.active : nullptr;
     A.candidate = candidate;
     return A;
 }

@@ -57,6 +57,7 @@ struct WsView {
     double* history;      // [(records)][B][n][15] or null
     int history_records;
     double* ftf;          // [B][n][2][FTF] frame transform records
+    int* active;          // [1 + B] compacted list of the windows still iterating (IMU / wheel / ground roles index their blocks over it)
 };
 constexpr int REC_LD = 22;                 // rec[15][22]: back-substitution operators Yo (15), Yr (6), yz columns of a frame
 constexpr int REC_GS = 15 * REC_LD;       // + the scaled gradient (model decrease)
@@ -78,6 +79,7 @@ struct LinArgs {
     const LmState* lm;          // null (buffer 0, no skipping), or per-window state: done windows skip
     int candidate;              // 1: write the small-factor partials of window b into buffer 1 - lm[b].cur
     int small_per_wave;         // IMU / wheel blocks per wave (set by launch_linearize)
+    int* active;                // [1 + B]: number of windows still iterating, then their ids (built per linearisation when lm != null)
     // optional per-factor outputs (liw_eval_factors)
     double* dbg_laser_res; double* dbg_laser_jac; double* dbg_imu_res; double* dbg_imu_jac;
     double* dbg_wheel_res; double* dbg_wheel_jac; double* dbg_ground_res; double* dbg_ground_jac;
