@@ -336,9 +336,12 @@ __device__ void imu_blocks(const LinArgs& A, const DevParams& P, int wave, doubl
             for (int r = 0; r < 4; ++r) {
                 const int row = mk + 4 * r;
                 if (row < 15 && ml < 15) {
-                    out[PI_II + row * 15 + ml] = g00[r];
                     out[PI_IJ + row * 15 + ml] = g01[r];
-                    out[PI_JJ + row * 15 + ml] = g11[r];
+                    if (ml >= row) {   // symmetric blocks: upper triangle only
+                        const int tq = row * 15 - (row * (row - 1)) / 2 + (ml - row);
+                        out[PI_II + tq] = g00[r];
+                        out[PI_JJ + tq] = g11[r];
+                    }
                 }
                 if (row < 15 && ml == 15) out[PI_G + row] = g00[r];
                 if (r == 3) {

@@ -161,8 +161,9 @@ __device__ __forceinline__ AsmRegs asm_issue(const AsmCtx& c, int i, const doubl
         const int e = lane + 64 * q, r = e >> 4, cc = e & 15;
         const bool valid = r < 15 && cc < 15;
         const int rs = valid ? r : 0, cs = valid ? cc : 0;
-        R.v5[q] = PIm[PI_JJ + rs * 15 + cs];
-        R.v6[q] = PIp[PI_II + rs * 15 + cs];
+        const int tq = pi_tri(rs, cs);
+        R.v5[q] = PIm[PI_JJ + tq];
+        R.v6[q] = PIp[PI_II + tq];
         R.v7[q] = up ? PIp[PI_IJ + cs * 15 + rs] : PIm[PI_IJ + rs * 15 + cs];   // (row r = neighbour's entry, column cc = frame i's)
     }
     {   // the 6x6 pose block terms: one element per lane (lanes 0..35)
@@ -472,8 +473,8 @@ __device__ double frame_diag(const AsmCtx& c, int i, LdsStep& T) {
         if (i <= n - 2) d += PWb[(size_t)i * PWS + r * 14];
         d += PGb[(size_t)i * PGS + r * 8];
     }
-    if (i >= 1) d += PIb[(size_t)(i - 1) * PIS + PI_JJ + r * 16];
-    if (i <= n - 2) d += PIb[(size_t)i * PIS + PI_II + r * 16];
+    if (i >= 1) d += PIb[(size_t)(i - 1) * PIS + PI_JJ + pi_tri(r, r)];
+    if (i <= n - 2) d += PIb[(size_t)i * PIS + PI_II + pi_tri(r, r)];
     if (c.prior_on && i == n - 2) { double s = 0.0; for (int k = 0; k < 15; ++k) s += c.pJ[k * 15 + r] * c.pJ[k * 15 + r]; d += s; }
     return d;
 }

@@ -21,13 +21,18 @@ struct DevParams {
 
 // Partial-sum slots written by k_linearize, per buffer (doubles):
 //   PL[B][n][LP]   laser group (window, owning frame): Haa(36) Hbb(36) Hab(36) ga(6) gb(6) sum r^2 (1), pad -> 128
-//   PI[B][n-1][PIS] IMU block k (frames k,k+1): G = Y^T Y, Y = [J(15x30) | r]: blocks ii, ij, jj (15x15 each), g(30), sum r^2 -> 708
+//   PI[B][n-1][PIS] IMU block k (frames k,k+1): G = Y^T Y, Y = [J(15x30) | r]: blocks ii, jj (packed upper triangles), ij (15x15), g(30), sum r^2 -> 496
 //   PW[B][n-1][PWS] wheel block k: G 13x13 (Y = [J(3x12) | r]), pad -> 172
 //   PG[B][n][PGS]   ground of frame i: n * G 7x7 (Y = [J(2x6) | r]), pad -> 52
 constexpr int LP = LIW_LASER_PARTIAL;
-constexpr int PIS = 708;
-// compact IMU partial: G = Y^T Y restricted to what the assembly reads
-constexpr int PI_II = 0, PI_IJ = 225, PI_JJ = 450, PI_G = 675, PI_C = 705;   // ii(15x15) ij(15x15) jj(15x15) g(30) sum r^2
+constexpr int PIS = 496;
+// compact IMU partial: G = Y^T Y restricted to what the assembly reads; the symmetric blocks ii and jj as packed upper triangles
+// (k_lin_imu is HBM-bound on this record: 708 -> 496 doubles per block)
+constexpr int PI_II = 0, PI_IJ = 120, PI_JJ = 345, PI_G = 465, PI_C = 495;   // ii(120) ij(15x15) jj(120) g(30) sum r^2
+__host__ __device__ inline int pi_tri(int r, int c) {   // offset of entry (r, c) = (c, r) inside a packed upper triangle of order 15
+    const int lo = r < c ? r : c, hi = r < c ? c : r;
+    return lo * 15 - (lo * (lo - 1)) / 2 + (hi - lo);
+}
 constexpr int PWS = 172;
 constexpr int PGS = 52;
 constexpr int FTF = 32;   // frame transform record (k_frame_tf)
