@@ -859,17 +859,27 @@ __global__ __launch_bounds__(64, THROUGHPUT ? 3 : 2) void k_lm_step(StepArgs a) 
 // whose pose entries are inert unit pivots) they leave a chain 1 .. n-1 whose only common neighbour is the 6-entry hub, so both
 // sweeps carry the same 6-wide arrow as before and the upward sweep creates no wider fill.  Back substitution runs hub -> m -> both
 // halves outwards, again one half per wave.  Same arithmetic as k_lm_step up to the order of the Schur updates (round-off).
+struct LdsTwSide {               // one sweep: a producer wave assembles / scales frame s+1 while the eliminator works on frame s
+    double PM[720], Ptmp[16];    // producer: assembled frame (lane layout of k_lm_step)
+    double PT[2][15 * MS];       // prepared columns, double-buffered: S H S + D^2 of the frame in lane layout, constants / inert entries as unit pivots
+    LdsStep T;                   // eliminator: MFMA operand tiles (T.M), carried Schur terms (T.C), hub accumulators
+};
 struct LdsTw {
-    LdsStep T[2];
-    double Haa[36], ga[8];        // frame 0: pose block / pose gradient of the assembled frame (wave 1, step 0c -> wave 0, hub)
+    LdsTwSide side[2];
+    double Haa[36], ga[8];        // frame 0: pose block / pose gradient of the assembled frame (step 0c -> hub)
     double sc0[16], dg0[16];      // frame 0: Jacobi scale, LM diagonal
     double ya[8];                 // solution of the hub
-    double red[2][4];             // per wave: step norm^2, y'g, y'D^2y, gradient max-norm
-    double ctld[4];               // prologue -> both waves: radius
-    int ctl[8];                   // proceed, reuse, cur, solved[2]
+    double red[4][4];             // per wave: step norm^2, y'g, y'D^2y, gradient max-norm
+    double ctld[4];               // prologue -> all waves: radius
+    int ctl[8];                   // proceed, reuse, cur, solved[2], termination
 };
 
-__global__ __launch_bounds__(128, 1) void k_lm_step_tw(StepArgs a) {
+// 256 threads: waves 0 / 1 eliminate the downward / upward sweep (k_lm_step's chain cut in the middle, see above), waves 2 / 3 are their
+// producers.  Per step and sweep, the part of the work that does not depend on the carried Schur terms — assembling the frame from the
+// partial sums, so3 / constant masks, LM diagonal, gradient norm, Jacobi scaling, damping — runs one step ahead in the producer; the
+// eliminator only adds the carried terms, factorises, forms the back-substitution record and the Schur products.  One work-group
+// barrier per step hands the prepared columns over.
+__global__ __launch_bounds__(256, 1) void k_lm_step_tw(StepArgs a) {
     __shared__ LdsTw S;
     const int b = blockIdx.x, lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     if (b >= a.B) return;
@@ -878,14 +888,10 @@ __global__ __launch_bounds__(128, 1) void k_lm_step_tw(StepArgs a) {
     const int n = a.n;
     double* xw = a.x + (size_t)b * n * 15;
     double* xc = a.w.x_cand + (size_t)b * n * 15;
-    LdsStep& T = S.T[w];
-#ifdef LIW_CLK
-    const int it_dbg = st.iteration;
-#define TSTAMP(id) do { if (b == 0 && lane == 0 && it_dbg == 3) g_clk[4000 + 1000 * w + (id)] = clock64(); } while (0)
-#else
-#define TSTAMP(id) do { } while (0)
-#endif
-    TSTAMP(0);
+    const int sd = w & 1;                       // sweep: 0 downward (frames n-1 .. m+1, then m and the hub), 1 upward (0c, 1 .. m-1)
+    const bool producer = w >= 2;
+    LdsTwSide& SS = S.side[sd];
+    LdsStep& T = SS.T;
 
     AsmCtx c;
     c.n = n; c.mode = a.mode; c.fast = a.fast_mode; c.b = b;
@@ -973,27 +979,30 @@ __global__ __launch_bounds__(128, 1) void k_lm_step_tw(StepArgs a) {
     }
     __syncthreads();   // (drains wave 0's global writes: accepted states, laser partial copy, scales)
     if (!S.ctl[0]) return;
-    TSTAMP(1);
     reuse = S.ctl[1]; cur = S.ctl[2]; radius = S.ctld[0];
     c.buf = cur; c.PL = a.w.PL[0]; c.PI = a.w.PI[cur]; c.PW = a.w.PW[cur]; c.PG = a.w.PG[cur]; c.x = xw;
     const double* scl = st.scale;
     double* dgl = st.diagonal;
     double* sws = a.w.solve_ws + (size_t)b * n * SOLVE_WS;
 
-    for (int e = lane; e < 720; e += 64) { T.M[e] = 0.0; if (e < 15 * MS) T.C[e] = 0.0; }
-    if (lane < 16) T.Z[lane] = 0.0;
-    if (lane < 36) T.D0acc[lane] = 0.0;
-    if (lane < 8) T.g0acc[lane] = 0.0;
+    if (!producer) {
+        for (int e = lane; e < 720; e += 64) { T.M[e] = 0.0; if (e < 15 * MS) T.C[e] = 0.0; }
+        if (lane < 16) T.Z[lane] = 0.0;
+        if (lane < 36) T.D0acc[lane] = 0.0;
+        if (lane < 8) T.g0acc[lane] = 0.0;
+    } else {
+        for (int e = lane; e < 720; e += 64) SS.PM[e] = 0.0;
+    }
     const double sc0reg = scl[lane < 15 ? lane : 0];           // scale of frame 0 (rows of the arrow block)
     lds_sync();
     bool solved = true;
     double gmax = 0.0;
-    const Tiles<1> TM{T.M, nullptr, nullptr, nullptr};
-    const int m = (n + 1) / 2, nA = n - 1 - m;                 // wave 0: nA frames, then m and the hub; wave 1: 0c and 1 .. m-1
-    const int nsteps = w == 0 ? nA + 2 : m;
-    // step s of this wave: frame i, neighbour direction dir (0: none), kind 0 frame / 1 = 0c / 2 hub / 3 middle
+    // m <= nA: frame m (step nA of the downward sweep) must come after the last step (m - 1) of the upward sweep
+    const int m = (n - 1) / 2, nA = n - 1 - m;
+    const int nsteps = sd == 0 ? nA + 2 : m, NS = nA + 2;
+    // step s of a sweep: frame i, neighbour direction dir (0: none), kind 0 frame / 1 = 0c / 2 hub / 3 middle
     auto sched = [&](int s_, int& i_, int& dir_, int& kind_) {
-        if (w == 0) {
+        if (sd == 0) {
             if (s_ < nA) { i_ = n - 1 - s_; dir_ = -1; kind_ = 0; }
             else if (s_ == nA) { i_ = m; dir_ = 0; kind_ = 3; }
             else { i_ = 0; dir_ = 0; kind_ = 2; }
@@ -1001,39 +1010,46 @@ __global__ __launch_bounds__(128, 1) void k_lm_step_tw(StepArgs a) {
             i_ = s_; dir_ = 1; kind_ = s_ == 0 ? 1 : 0;
         }
     };
+    const Tiles<1> TP{SS.PM, nullptr, nullptr, nullptr};
     AsmRegs areg;
-    {
+    if (producer) {
         int i0, d0, k0;
         sched(0, i0, d0, k0);
         areg = asm_issue(c, i0, scl, dgl, lane, d0 > 0 ? 1 : -1);
     }
-    for (int s_ = 0; s_ < nsteps; ++s_) {
+    // ---- producer: columns of step s_ into PT[s_ & 1]
+    auto prepare = [&](int s_) {
         int i, dir, kind;
         sched(s_, i, dir, kind);
-        TSTAMP(10 + s_ * 8);
-        if (w == 0 && s_ == nA) __syncthreads();               // wave 1's sweep (its carried terms in S.T[1]) is complete
-        TSTAMP(10 + s_ * 8 + 1);
         int ln = lane;
         asm volatile("" : "+v"(ln));
         FrameExtra ex;
         if (kind != 2) {
-            asm_commit<1>(c, i, areg, TM, T.tmp, &ex, ln, dir > 0 ? 1 : -1);
-        } else {   // hub: frame 0's pose block and gradient as saved by wave 1, nothing else
-            for (int e = ln; e < 15 * MS; e += 64) T.M[e] = 0.0;
+            asm_commit<1>(c, i, areg, TP, SS.Ptmp, &ex, ln, dir > 0 ? 1 : -1);
+        } else {   // hub: frame 0's pose block and gradient as saved at step 0c, nothing else
+            for (int e = ln; e < 15 * MS; e += 64) SS.PM[e] = 0.0;
             lds_sync();
-            if (ln < 36) T.M[(ln / 6) * MS + ln % 6] = S.Haa[ln];
-            if (ln < 6) T.M[ln * MS + 40] = S.ga[ln];
+            if (ln < 36) SS.PM[(ln / 6) * MS + ln % 6] = S.Haa[ln];
+            if (ln < 6) SS.PM[ln * MS + 40] = S.ga[ln];
             lds_sync();
             ex.sc_i = S.sc0[ln < 15 ? ln : 15]; ex.sc_m = 1.0; ex.dg_i = S.dg0[ln < 15 ? ln : 15]; ex.x_i = xw[ln < 15 ? ln : 0];
         }
-        TSTAMP(10 + s_ * 8 + 2);
+        // software pipeline: the loads of the next step's frame are in flight during the rest of this one
+        __builtin_amdgcn_sched_barrier(0);
+        AsmRegs nreg = areg;
+        if (s_ + 1 < nsteps) {
+            int i2, d2, k2;
+            sched(s_ + 1, i2, d2, k2);
+            if (k2 != 2) nreg = asm_issue(c, i2, scl, dgl, ln, d2 > 0 ? 1 : -1);
+        }
+        __builtin_amdgcn_sched_barrier(0);
         // LM diagonal of this frame (LevenbergMarquardtStrategy::ComputeStep), |x - Plus(x,-g)|
         const bool cstl = ln < 15 && var_is_const(a.mode, a.fast_mode, n, i, ln);
         double dgv = ex.dg_i;
         if (kind != 2) {
-            const double gl = ln < 15 ? T.M[ln * MS + 40] : 0.0;          // tangent gradient entry of this lane
+            const double gl = ln < 15 ? SS.PM[ln * MS + 40] : 0.0;          // tangent gradient entry of this lane
             if (ln < 15) {
-                if (!reuse) { dgv = fmin(fmax(T.M[ln * MS + ln] * ex.sc_i * ex.sc_i, kMinDiag), kMaxDiag); dgl[i * 15 + ln] = dgv; }
+                if (!reuse) { dgv = fmin(fmax(SS.PM[ln * MS + ln] * ex.sc_i * ex.sc_i, kMinDiag), kMaxDiag); dgl[i * 15 + ln] = dgv; }
                 sws[(size_t)i * SOLVE_WS + REC_GS + ln] = gl * ex.sc_i;          // original scaled gradient (model decrease)
             }
             const double qv[3] = {rdlane(ex.x_i, 3), rdlane(ex.x_i, 4), rdlane(ex.x_i, 5)};
@@ -1047,30 +1063,29 @@ __global__ __launch_bounds__(128, 1) void k_lm_step_tw(StepArgs a) {
         if (kind == 1) {
             // frame 0 -> pseudo frame "0c": keep the pose block / gradient for the hub, turn H[pose, rest] into the arrow (R^T rows
             // = the hub's entries), make the pose entries inert (zero rows / columns, unit pivots through the constant mask below)
-            if (ln < 36) S.Haa[ln] = T.M[(ln / 6) * MS + ln % 6];
-            if (ln < 6) S.ga[ln] = T.M[ln * MS + 40];
+            if (ln < 36) S.Haa[ln] = SS.PM[(ln / 6) * MS + ln % 6];
+            if (ln < 6) S.ga[ln] = SS.PM[ln * MS + 40];
             if (ln < 15) { S.sc0[ln] = ex.sc_i; S.dg0[ln] = dgv; }
             if (ln == 15) { S.sc0[15] = 1.0; S.dg0[15] = 0.0; }
             double rv[2];
 #pragma unroll
             for (int q = 0; q < 2; ++q) {   // R^T(cc, r) = D_0(r, cc), r < 6 <= cc
                 const int e = ln + 64 * q, r = e / 15, cc = e % 15;
-                rv[q] = (e < 90 && cc >= 6) ? T.M[r * MS + cc] : 0.0;
+                rv[q] = (e < 90 && cc >= 6) ? SS.PM[r * MS + cc] : 0.0;
             }
             lds_sync();
 #pragma unroll
             for (int q = 0; q < 2; ++q) {
                 const int e = ln + 64 * q, r = e / 15, cc = e % 15;
-                if (e < 90) T.M[cc * MS + 32 + r] = rv[q];
+                if (e < 90) SS.PM[cc * MS + 32 + r] = rv[q];
             }
             for (int e = ln; e < 6 * MS; e += 64) {             // rows 0..5 of every tile (D, O^T, R^T, g)
                 const int cc = e % MS;
-                if (cc < 15 || (cc >= 16 && cc < 31) || cc == 40) T.M[e] = 0.0;
+                if (cc < 15 || (cc >= 16 && cc < 31) || cc == 40) SS.PM[e] = 0.0;
             }
-            for (int e = ln; e < 15 * 6; e += 64) T.M[(e / 6) * MS + e % 6] = 0.0;   // columns 0..5 of D
+            for (int e = ln; e < 15 * 6; e += 64) SS.PM[(e / 6) * MS + e % 6] = 0.0;   // columns 0..5 of D
             lds_sync();
         }
-        TSTAMP(10 + s_ * 8 + 3);
         const bool dummy = (kind == 1 && ln < 6) || (kind == 2 && ln >= 6 && ln < 15);
         const bool cst2 = cstl || dummy;
         const bool hasnb = kind == 1 || (kind == 0 && (dir > 0 ? i <= n - 2 : i >= 1));
@@ -1081,49 +1096,51 @@ __global__ __launch_bounds__(128, 1) void k_lm_step_tw(StepArgs a) {
         else if (ln >= 16 && ln < 31) slane = hasnb ? s_m : 0.0;
         else if (ln >= 32 && ln < 38) slane = hasarrow ? s_0 : 0.0;
         else if (ln == 40) slane = 1.0;
-        double col[15];
         const int lc = ln < MS ? ln : MS - 1;
-        // carried Schur terms: own sweep (not for the hub), plus wave 1's for frame m which closes both sweeps; as multipliers, so
-        // that the 45 LDS reads of this block stay one straight-line batch
-        if (kind == 3) {   // frame m closes both sweeps: the Schur terms of wave 1 as well
-            const double* C2 = S.T[1].C;
+        double* PT = SS.PT[s_ & 1];
+        const double dmp = cst2 ? 0.0 : dgv / radius;
 #pragma unroll
-            for (int r = 0; r < 15; ++r) col[r] = T.M[r * MS + lc] * (rdlane(ex.sc_i, r) * slane) + (T.C[r * MS + lc] + C2[r * MS + lc]);
-        } else {
-            const double kc = kind == 2 ? 0.0 : 1.0;   // the hub takes its carried terms from D0acc / g0acc below
-#pragma unroll
-            for (int r = 0; r < 15; ++r) col[r] = T.M[r * MS + lc] * (rdlane(ex.sc_i, r) * slane) + T.C[r * MS + lc] * kc;
+        for (int r = 0; r < 15; ++r) {
+            double v = SS.PM[r * MS + lc] * (rdlane(ex.sc_i, r) * slane);
+            if (ln < 15 && r == ln) v = cst2 ? 1.0 : v + dmp;
+            if (ln < MS) PT[r * MS + ln] = v;
         }
-        if (kind == 2) {
+        areg = nreg;
+    };
+    // ---- eliminator: step s_ from PT[s_ & 1]
+    auto eliminate = [&](int s_) {
+        int i, dir, kind;
+        sched(s_, i, dir, kind);
+        int ln = lane;
+        asm volatile("" : "+v"(ln));
+        const int lc = ln < MS ? ln : MS - 1;
+        const double* PT = SS.PT[s_ & 1];
+        double col[15];
+        if (kind == 3) {   // frame m closes both sweeps: the Schur terms of the upward sweep as well
+            const double* C2 = S.side[1].T.C;
+#pragma unroll
+            for (int r = 0; r < 15; ++r) col[r] = PT[r * MS + lc] + (T.C[r * MS + lc] + C2[r * MS + lc]);
+        } else if (kind == 2) {   // the hub takes its carried terms from the accumulators of both sweeps
+#pragma unroll
+            for (int r = 0; r < 15; ++r) col[r] = PT[r * MS + lc];
             if (ln < 6) {
 #pragma unroll
-                for (int r = 0; r < 6; ++r) col[r] += S.T[0].D0acc[r * 6 + ln] + S.T[1].D0acc[r * 6 + ln];
+                for (int r = 0; r < 6; ++r) col[r] += S.side[0].T.D0acc[r * 6 + ln] + S.side[1].T.D0acc[r * 6 + ln];
             }
             if (ln == 40) {
 #pragma unroll
-                for (int r = 0; r < 6; ++r) col[r] += S.T[0].g0acc[r] + S.T[1].g0acc[r];
+                for (int r = 0; r < 6; ++r) col[r] += S.side[0].T.g0acc[r] + S.side[1].T.g0acc[r];
             }
-        }
-        if (ln < 15) {
-            const double dmp = cst2 ? 0.0 : dgv / radius;
+        } else {
 #pragma unroll
-            for (int r = 0; r < 15; ++r) if (r == ln) col[r] = cst2 ? 1.0 : col[r] + dmp;
+            for (int r = 0; r < 15; ++r) col[r] = PT[r * MS + lc] + T.C[r * MS + lc];
         }
-        TSTAMP(10 + s_ * 8 + 4);
-        // software pipeline: the next frame's loads are in flight while this one is factorised
-        __builtin_amdgcn_sched_barrier(0);
-        if (s_ + 1 < nsteps) {
-            int i2, d2, k2;
-            sched(s_ + 1, i2, d2, k2);
-            if (k2 != 2) areg = asm_issue(c, i2, scl, dgl, ln, d2 > 0 ? 1 : -1);
-        }
-        __builtin_amdgcn_sched_barrier(0);
+        // lanes 41..55 carry the unit vectors: the fused pass leaves the columns of L^-1 in them
         if (ln >= 41 && ln < 56) {
 #pragma unroll
             for (int r = 0; r < 15; ++r) col[r] = (r == ln - 41) ? 1.0 : 0.0;
         }
-        if (!fused_chol_solve(col)) solved = false;   // no early exit: both waves must keep meeting at the barriers (NaNs stay local)
-        TSTAMP(10 + s_ * 8 + 5);
+        if (!fused_chol_solve(col)) solved = false;   // no early exit: every wave keeps meeting at the barriers (NaNs stay local)
         {
             const int toff = (ln >= 16 && ln < 31) ? LW + (ln - 16) : ((ln >= 32 && ln < 38) ? LWA + (ln - 32) : (ln == 40 ? LW + 15 : ((ln >= 41 && ln < 56) ? LLI + (ln - 41) : -1)));
             if (toff >= 0) {
@@ -1149,7 +1166,6 @@ __global__ __launch_bounds__(128, 1) void k_lm_step_tw(StepArgs a) {
                 }
             }
         }
-        TSTAMP(10 + s_ * 8 + 6);
         if (kind != 2) {   // Schur products on the matrix cores
             const d4 p1 = xty15<16, 16>(T.M + LW, T.M + LW, T.Z);      // [Wo|z]^T [Wo|z]
             const d4 p2 = xty15<16, 16>(T.M + LWA, T.M + LW, T.Z);     // Wr^T [Wo|z]   (rows < 6)
@@ -1167,25 +1183,29 @@ __global__ __launch_bounds__(128, 1) void k_lm_step_tw(StepArgs a) {
             }
             lds_sync();
         }
+    };
+    if (producer) prepare(0);
+    __syncthreads();
+    for (int s_ = 0; s_ < NS; ++s_) {
+        if (producer) { if (s_ + 1 < nsteps) prepare(s_ + 1); }
+        else if (s_ < nsteps) eliminate(s_);
+        __syncthreads();
     }
-    TSTAMP(2);
     gmax = wave_max(gmax);
-    if (lane == 0) { S.red[w][3] = gmax; S.ctl[3 + w] = solved ? 1 : 0; }
-    if (w == 1) __syncthreads();                                 // pairs with wave 0's barrier before frame m
+    if (lane == 0) { S.red[w][3] = gmax; if (!producer) S.ctl[3 + sd] = solved ? 1 : 0; }
     __syncthreads();                                             // records of both sweeps, hub solution, flags
-    // ---- FinalizeIterationAndCheck, part 2
+    // ---- FinalizeIterationAndCheck, part 2 (iteration / fresh / last_successful live on wave 0; the others follow through LDS)
     {
-        const double gm = fmax(S.red[0][3], S.red[1][3]);
-        int term = 0;
-        if (iteration == 0 && fresh) { if (gm <= kGradTol) term = 1; }
-        else if (last_successful && gm <= kGradTol) term = 1;
-        // (iteration / fresh / last_successful live on wave 0; wave 1 follows its decision through LDS)
         if (w == 0) {
+            const double gm = fmax(S.red[2][3], S.red[3][3]);
+            int term = 0;
+            if (iteration == 0 && fresh) { if (gm <= kGradTol) term = 1; }
+            else if (last_successful && gm <= kGradTol) term = 1;
             if (!term && !(radius > kMinRadius)) term = 5;
             if (lane == 0) S.ctl[5] = term;
         }
         __syncthreads();
-        term = S.ctl[5];
+        const int term = S.ctl[5];
         if (term) {
             if (w == 0 && lane == 0) {
                 st.done = 1; st.termination = term; st.radius = radius; st.decrease_factor = dec; st.x_cost = x_cost; st.x_norm = x_norm;
@@ -1194,11 +1214,10 @@ __global__ __launch_bounds__(128, 1) void k_lm_step_tw(StepArgs a) {
             return;
         }
     }
-    TSTAMP(3);
     ++iteration;
     const bool all_solved = S.ctl[3] && S.ctl[4];
     double sn2 = 0.0, ytg = 0.0, dsum = 0.0;
-    if (all_solved) {
+    if (all_solved && !producer) {
         // ---- back substitution: hub -> frame m -> wave 0: m+1 .. n-1, wave 1: m-1 .. 1, then frame 0's other entries.
         // Lane r owns unknown r: row r of Yo / Yr of the frame's record.
         const int r15 = lane < 15 ? lane : 0;
@@ -1254,7 +1273,6 @@ __global__ __launch_bounds__(128, 1) void k_lm_step_tw(StepArgs a) {
         }
         sn2 = wave_sum(sn2); ytg = wave_sum(ytg); dsum = wave_sum(dsum);
     }
-    TSTAMP(4);
     if (lane == 0) { S.red[w][0] = sn2; S.red[w][1] = ytg; S.red[w][2] = dsum; }
     __syncthreads();
     if (w == 0 && lane == 0) {
@@ -1522,7 +1540,7 @@ void launch_lm_step(const StepArgs& a, hipStream_t s) {
     const bool tp = env ? env[0] == '1' : a.B > 2048;
     // two waves per window while that does not take CUs away from other windows, and the chain is long enough to be worth cutting
     const bool tw = (env ? env[0] == '2' : a.B <= 256) && a.n >= 6;
-    if (tw) hipLaunchKernelGGL(k_lm_step_tw, dim3(a.B), dim3(128), 0, s, a);
+    if (tw) hipLaunchKernelGGL(k_lm_step_tw, dim3(a.B), dim3(256), 0, s, a);
     else if (tp) hipLaunchKernelGGL(k_lm_step<true>, dim3(a.B), dim3(64), 0, s, a);
     else hipLaunchKernelGGL(k_lm_step<false>, dim3(a.B), dim3(64), 0, s, a);
 }
