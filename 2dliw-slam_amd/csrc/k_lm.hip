@@ -432,10 +432,13 @@ constexpr int LW = 0, LLI = 240, LWA = 480;   // offsets of W / Li / Wa inside L
 // substitution of every other lane's column (right-hand sides): step k broadcasts the pivot, every lane forms
 // w_k = a[k]/L_kk (matrix lane j >= k: L[j][k]; rhs lane: (L^-1 b)[k]) and updates a[r] -= L[r][k] w_k with L[r][k]
 // read from lane r.  Afterwards matrix lane j holds row j of L in a[0..j]; rhs lanes hold L^-1 b.  No LDS, no barrier.
+// NP < 15: only the leading NP pivots are real, the rest are inert unit pivots with no coupling (the hub of k_lm_step_tw): skipping
+// them leaves exactly the same registers
+template <int NP = 15>
 __device__ __forceinline__ bool fused_chol_solve(double (&a)[15]) {
     bool ok = true;
 #pragma unroll
-    for (int k = 0; k < 15; ++k) {
+    for (int k = 0; k < NP; ++k) {
         const double piv = rdlane(a[k], k);
         if (!(piv > 0.0) || !isfinite(piv)) ok = false;
         const double inv = rsqrt(piv);
@@ -1140,7 +1143,7 @@ __global__ __launch_bounds__(256, 1) void k_lm_step_tw(StepArgs a) {
 #pragma unroll
             for (int r = 0; r < 15; ++r) col[r] = (r == ln - 41) ? 1.0 : 0.0;
         }
-        if (!fused_chol_solve(col)) solved = false;   // no early exit: every wave keeps meeting at the barriers (NaNs stay local)
+        if (!(kind == 2 ? fused_chol_solve<6>(col) : fused_chol_solve<15>(col))) solved = false;   // no early exit: every wave keeps meeting at the barriers
         {
             const int toff = (ln >= 16 && ln < 31) ? LW + (ln - 16) : ((ln >= 32 && ln < 38) ? LWA + (ln - 32) : (ln == 40 ? LW + 15 : ((ln >= 41 && ln < 56) ? LLI + (ln - 41) : -1)));
             if (toff >= 0) {
@@ -1303,24 +1306,24 @@ __global__ void k_lm_begin(int B, int n, LmState* lm, int max_iters) {
 }
 
 // write-backs the reference does after ceres::Solve (solver.cpp:176-190 init, :804-814 tracking) + summaries
-__global__ void k_lm_finish(StepArgs a) {
-    const int b = blockIdx.x * blockDim.x + threadIdx.x;
-    if (b >= a.B) return;
+__global__ void k_lm_finish(StepArgs a) {   // one thread per (window, frame, pose entry): a thread per window walked n frames serially (40 us at n = 30)
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
     const int n = a.n;
-    LmState& st = a.w.lm[b];
+    if (t >= a.B * n * 6) return;
+    const int k = t % 6, i = (t / 6) % n, b = t / (6 * n);
     const double* xw = a.x + (size_t)b * n * 15;
     double* mp = a.match_pose + (size_t)b * n * 12;
     if (a.mode == LIW_MODE_INIT) {
-        for (int i = 0; i < n; ++i)
-            if (a.has_match[b * n + i])
-                for (int k = 0; k < 6; ++k) { mp[i * 12 + k] = xw[k]; mp[i * 12 + 6 + k] = xw[(size_t)i * 15 + k]; }
+        if (a.has_match[b * n + i]) { mp[i * 12 + k] = xw[k]; mp[i * 12 + 6 + k] = xw[(size_t)i * 15 + k]; }
     } else if (a.mode == LIW_MODE_TRACK) {
-        const int i = n - 1;
-        if (a.has_match[b * n + i]) for (int k = 0; k < 6; ++k) mp[i * 12 + 6 + k] = xw[(size_t)i * 15 + k];
+        if (i == n - 1 && a.has_match[b * n + i]) mp[i * 12 + 6 + k] = xw[(size_t)i * 15 + k];
     }
-    liw_summary& o = a.w.info[b];
-    o.iterations = st.iteration; o.successful_steps = st.successful; o.termination = st.termination;
-    o.initial_cost = st.initial_cost; o.final_cost = st.x_cost;
+    if (i == 0 && k == 0) {
+        const LmState& st = a.w.lm[b];
+        liw_summary& o = a.w.info[b];
+        o.iterations = st.iteration; o.successful_steps = st.successful; o.termination = st.termination;
+        o.initial_cost = st.initial_cost; o.final_cost = st.x_cost;
+    }
 }
 
 // ---------------------------------------------------------------------------------------------------
@@ -1392,8 +1395,13 @@ __global__ __launch_bounds__(64, 2) void k_marg_schur(MargArgs a) {
     double* Dc = T.D; double* gc = T.g;          // cur
     double* Dn = T.Wa; double* gn = T.y0;        // nxt   (T.O receives H[i, i+1]; T.R is the unused arrow tile)
     assemble_frame<0>(c, 0, Tiles<0>{Dc, T.O, T.R, gc}, T.tmp);
+    AsmRegs areg = asm_issue(c, n > 1 ? 1 : 0, nullptr, nullptr);
     for (int i = 0; i + 1 < n; ++i) {
-        assemble_frame<0>(c, i + 1, Tiles<0>{Dn, T.O, T.R, gn}, T.tmp);
+        asm_commit<0>(c, i + 1, areg, Tiles<0>{Dn, T.O, T.R, gn}, T.tmp);
+        // software pipeline: frame i+2's partial sums are in flight while frame i is eliminated
+        __builtin_amdgcn_sched_barrier(0);
+        if (i + 2 < n) areg = asm_issue(c, i + 2, nullptr, nullptr);
+        __builtin_amdgcn_sched_barrier(0);
         double col[15];
 #pragma unroll
         for (int r = 0; r < 15; ++r) {
@@ -1544,7 +1552,7 @@ void launch_lm_step(const StepArgs& a, hipStream_t s) {
     else if (tp) hipLaunchKernelGGL(k_lm_step<true>, dim3(a.B), dim3(64), 0, s, a);
     else hipLaunchKernelGGL(k_lm_step<false>, dim3(a.B), dim3(64), 0, s, a);
 }
-void launch_lm_finish(const StepArgs& a, hipStream_t s) { hipLaunchKernelGGL(k_lm_finish, dim3((a.B + 63) / 64), dim3(64), 0, s, a); }
+void launch_lm_finish(const StepArgs& a, hipStream_t s) { hipLaunchKernelGGL(k_lm_finish, dim3((a.B * a.n * 6 + 255) / 256), dim3(256), 0, s, a); }
 void launch_export_dense(const ExportArgs& a, hipStream_t s) { hipLaunchKernelGGL(k_export_dense, dim3(a.B), dim3(64), 0, s, a); }
 void launch_marg_schur(const MargArgs& a, hipStream_t s) { hipLaunchKernelGGL(k_marg_schur, dim3(a.B), dim3(64), 0, s, a); }
 
