@@ -2,9 +2,9 @@
 //
 // One linearisation = three role kernels over every residual block of every window of a batch (or ONE kernel for small
 // batches), one wavefront (64-thread work-group) per work item; the roles write disjoint partial slots and run concurrently:
-//   k_frame_tf  : per (window, frame): rows 0,1 of make_tf(p,theta) * T_imu_to_laser and d/dtheta_k (dual numbers,
-//                 direction-per-lane) — every exp_so3 of the laser path is hoisted out of the blocks (k_lin_all: done by
-//                 the laser waves themselves).
+//   (frame transforms: rows 0,1 of make_tf(p,theta) * T_imu_to_laser and d/dtheta_k per (window, frame), dual numbers with a
+//                 direction per lane — every exp_so3 of the laser path is hoisted out of the blocks and computed once per wave for
+//                 the wave's frames; a separate k_frame_tf launch writing them to HBM was 3 % slower, round 2)
 //   k_lin_laser : G (window, owning frame) groups per wave; a LANE is one laser_factor block (reference
 //                 src/factor/laser_factor.h:45-89, two point-to-line rows), 64 blocks per pass, coalesced reads of the
 //                 component-major end-point arrays, closed-form Jacobian, register accumulation of the pair products
@@ -37,16 +37,6 @@ __device__ __forceinline__ void frame_tf_record(const DevParams& P, const double
         for (int r = 0; r < 2; ++r) { for (int c = 0; c < 3; ++c) o[8 + 6 * dir + r * 3 + c] = Twl.R(r, c).d; o[26 + 2 * dir + r] = tt[r].d; }
     }
 }
-// large batches: every record once, ahead of the laser kernel (k_lin_all computes its records in the laser waves instead)
-__global__ void k_frame_tf(int B, int n, const double* x, const double* match_pose, double* ftf, DevParams P, const LmState* lm) {
-    const int t = blockIdx.x * blockDim.x + threadIdx.x;
-    const int dir = t & 3, rec = t >> 2;
-    if (rec >= B * n * 2) return;
-    const int slot = rec & 1, fi = rec >> 1;
-    if (lm && lm[fi / n].done) return;
-    frame_tf_record(P, slot ? (match_pose + (size_t)fi * 12) : (x + (size_t)fi * 15), dir, ftf + (size_t)rec * FTF);
-}
-
 // Wave-wide sums of V per-lane values (V = 32 or 16) in V-1 pair exchanges + log2(64/V) plain steps: each step pairs
 // value j with value j + V/2 across the lane bit BIT, halving the values a lane still owns.  Afterwards every lane
 // holds the total of value  lane >> log2(64/V).
@@ -82,16 +72,12 @@ constexpr int LASER_GMAX = 8;   // (window, frame) groups one wave may own
 // registers over all passes; one butterfly per group reduces them across the wave.
 template <bool BOTH>
 __device__ void laser_wave_local(const LinArgs& A, const DevParams& P, int G, int vblock) {
-#define LASER_LOCAL_TF 1
 #include "k_lin_laser_body.inc"
-#undef LASER_LOCAL_TF
 }
 template <bool BOTH>
 __global__ __launch_bounds__(64, 2) void k_lin_laser(LinArgs A, DevParams P, int G) {
     const int vblock = (int)blockIdx.x;
-#define LASER_LOCAL_TF 0
 #include "k_lin_laser_body.inc"
-#undef LASER_LOCAL_TF
 }
 
 // ------------------------------------------------------------------------------------------- imu
@@ -666,7 +652,6 @@ void launch_linearize(const LinArgs& A_, const DevParams& P, hipStream_t s, cons
         hipStreamWaitEvent(fk->side[1], fk->ev_fork, 0);
     }
     hipStream_t s_imu = fork ? fk->side[0] : s, s_small = fork ? fk->side[1] : s;
-    hipLaunchKernelGGL(k_frame_tf, dim3((B * n * 2 * 4 + 255) / 256), dim3(256), 0, s, B, n, A.x, A.match_pose, A.ftf, P, A.lm);
     if (A.mode == LIW_MODE_INIT) hipLaunchKernelGGL(k_lin_laser<true>, dim3((unsigned)laser_waves), dim3(64), 0, s, A, P, G);
     else hipLaunchKernelGGL(k_lin_laser<false>, dim3((unsigned)laser_waves), dim3(64), 0, s, A, P, G);
     if (imu_waves) hipLaunchKernelGGL(k_lin_imu, dim3((unsigned)imu_waves), dim3(64), 0, s_imu, A, P);

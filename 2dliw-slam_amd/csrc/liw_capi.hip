@@ -224,7 +224,7 @@ int liw_get_extrinsics(const liw_ctx* c, double* A, double* Bm) {
 // ------------------------------------------------------------------------------------------ workspace
 static size_t al256(size_t v) { return (v + 255) & ~(size_t)255; }
 struct FullLayout {
-    size_t PL[2], PI[2], PW[2], PG[2], x_cand, group_off, lm, solve_ws, info, history, ftf, active, bytes;
+    size_t PL[2], PI[2], PW[2], PG[2], x_cand, group_off, lm, solve_ws, info, history, active, bytes;
 };
 static FullLayout full_layout(int B, int n, int hist) {
     FullLayout f{};
@@ -236,7 +236,6 @@ static FullLayout full_layout(int B, int n, int hist) {
     for (int k = 0; k < 2; ++k) { f.PG[k] = o; o = al256(o + sizeof(double) * (size_t)B * n * PGS); }
     f.x_cand = o; o = al256(o + sizeof(double) * (size_t)B * n * 15);
     f.group_off = o; o = al256(o + sizeof(int) * (size_t)B * (n + 1));
-    f.ftf = o; o = al256(o + sizeof(double) * (size_t)B * n * 2 * FTF);
     f.active = o; o = al256(o + sizeof(int) * ((size_t)B + 1));
     f.lm = o; o = al256(o + sizeof(LmState) * (size_t)B);
     f.solve_ws = o; o = al256(o + sizeof(double) * (size_t)B * n * SOLVE_WS);
@@ -261,7 +260,6 @@ static WsView make_view(void* ws, int B, int n, int hist) {
     v.info = (liw_summary*)(base + f.info);
     v.history = hist > 0 ? (double*)(base + f.history) : nullptr;
     v.history_records = hist;
-    v.ftf = (double*)(base + f.ftf);
     v.active = (int*)(base + f.active);
     return v;
 }
@@ -290,7 +288,7 @@ static int min_frames(int mode) { return mode == LIW_MODE_INIT ? 1 : 2; }
 static LinArgs lin_args(const liw_batch* b, int mode, const double* x, const WsView& v, int candidate, bool use_lm) {
     LinArgs A{};
     A.B = b->B; A.n = b->n; A.mode = mode; A.eval_small = b->eval_small;
-    A.x = x; A.group_off = v.group_off; A.ftf = v.ftf; A.laser_off = b->laser_off; A.laser_pts = b->laser_pts; A.Ltot = b->Ltot;
+    A.x = x; A.group_off = v.group_off; A.laser_off = b->laser_off; A.laser_pts = b->laser_pts; A.Ltot = b->Ltot;
     A.match_pose = b->match_pose; A.has_match = b->has_match;
     A.imu_X = b->imu_X; A.imu_J = b->imu_J; A.imu_sqrtP = b->imu_sqrtP; A.imu_Dt = b->imu_Dt;
     A.wheel_T = b->wheel_T; A.wheel_sqrtP = b->wheel_sqrtP;

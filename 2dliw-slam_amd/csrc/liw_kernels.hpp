@@ -61,7 +61,6 @@ struct WsView {
     liw_summary* info;    // [B]
     double* history;      // [(records)][B][n][15] or null
     int history_records;
-    double* ftf;          // [B][n][2][FTF] frame transform records
     int* active;          // [1 + B] compacted list of the windows still iterating (IMU / wheel / ground roles index their blocks over it)
 };
 constexpr int REC_LD = 22;                 // rec[15][22]: back-substitution operators Yo (15), Yr (6), yz columns of a frame
@@ -72,7 +71,6 @@ struct LinArgs {
     int B, n, mode, eval_small;
     const double* x;            // states to linearise at [B][n][15]
     const int* group_off;
-    double* ftf;
     const int* laser_off;
     const double* laser_pts; int Ltot;
     const double* match_pose;

@@ -271,7 +271,7 @@ def main():
             step_traffic = int(pmcj["k_lm_step_hbm_bytes_per_launch"] / pmcj["windows"] * B)
         except Exception:
             traffic = step_traffic = None
-    roofline = {"bound": "hbm", "kernel": "linearise = k_frame_tf + k_lin_laser + k_lin_imu + k_lin_small (Jacobian evaluation, one HIP-event bracket)",
+    roofline = {"bound": "hbm", "kernel": "linearise = k_lin_laser + k_lin_imu + k_lin_small (Jacobian evaluation, one HIP-event bracket)",
                 "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
                 # the same launch priced by the HBM bytes the PMC counters saw (the kernels fuse J^T J, so no Jacobian ever reaches
