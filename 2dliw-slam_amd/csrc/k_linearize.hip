@@ -581,12 +581,19 @@ __global__ __launch_bounds__(64, 2) void k_lin_all(LinArgs A, DevParams P, int G
     else small_role(A, P, v - n_laser - n_imu, lds);
 }
 
-// ids of the windows that are still iterating, in window order (deterministic): active[0] = count, active[1 ..] = ids.  One work-group.
+// ids of the windows that are still iterating, in window order (deterministic): active[0] = count, active[1 ..] = ids.  One work-group:
+// phase 1 pulls the `done` words (one cache line per window: LmState is 15 kB) with independent loads into LDS, phase 2 scans.
+constexpr int COMPACT_MAX = 16384;
 __global__ __launch_bounds__(1024) void k_compact_active(int B, const LmState* lm, int* active) {
+    __shared__ int flag[COMPACT_MAX];
     __shared__ int cnt[1024];
-    const int t = threadIdx.x, per = (B + 1023) / 1024, lo = t * per, hi = min(B, lo + per);
+    const int t = threadIdx.x;
+#pragma unroll 8
+    for (int b = t; b < B; b += 1024) flag[b] = lm[b].done ? 0 : 1;
+    __syncthreads();
+    const int per = (B + 1023) / 1024, lo = t * per, hi = min(B, lo + per);
     int c = 0;
-    for (int b = lo; b < hi; ++b) c += lm[b].done ? 0 : 1;
+    for (int b = lo; b < hi; ++b) c += flag[b];
     cnt[t] = c;
     __syncthreads();
     for (int o = 1; o < 1024; o <<= 1) {   // inclusive scan
@@ -596,7 +603,7 @@ __global__ __launch_bounds__(1024) void k_compact_active(int B, const LmState* l
         __syncthreads();
     }
     int pos = cnt[t] - c;
-    for (int b = lo; b < hi; ++b) if (!lm[b].done) active[1 + pos++] = b;
+    for (int b = lo; b < hi; ++b) if (flag[b]) active[1 + pos++] = b;
     if (t == 1023) active[0] = cnt[1023];
 }
 
@@ -637,8 +644,8 @@ void launch_linearize(const LinArgs& A_, const DevParams& P, hipStream_t s, cons
     const int small_waves = A.eval_small ? wheel_wave_count(B, n, A.small_per_wave) + ground_wave_count(B, n) : 0;
     // large batches only: a single window gains nothing from the list and would pay one more launch per LM iteration
     static const bool no_compact = getenv("LIW_NO_COMPACT") != nullptr;   // profiling aid: index the small roles over all windows
-    if (A.lm && A.active && A.eval_small && B >= 512 && !no_compact) hipLaunchKernelGGL(k_compact_active, dim3(1), dim3(1024), 0, s, B, A.lm, A.active);
-    else A.active = nullptr;
+    const bool compact = A.lm && A.active && A.eval_small && B >= 512 && B <= COMPACT_MAX && !no_compact;
+    if (!compact) A.active = nullptr;
     if (A.eval_small && laser_waves + imu_waves + small_waves <= 256) {
         const unsigned tot = (unsigned)(laser_waves + imu_waves + small_waves);
         if (A.mode == LIW_MODE_INIT) hipLaunchKernelGGL(k_lin_all<true>, dim3(tot), dim3(64), 0, s, A, P, G, laser_waves, imu_waves);
@@ -652,6 +659,10 @@ void launch_linearize(const LinArgs& A_, const DevParams& P, hipStream_t s, cons
         hipStreamWaitEvent(fk->side[1], fk->ev_fork, 0);
     }
     hipStream_t s_imu = fork ? fk->side[0] : s, s_small = fork ? fk->side[1] : s;
+    if (compact) {   // only the IMU / wheel / ground roles read the list: off the laser role's stream when the roles are forked
+        hipLaunchKernelGGL(k_compact_active, dim3(1), dim3(1024), 0, s_imu, B, A.lm, A.active);
+        if (fork) { hipEventRecord(fk->ev_compact, s_imu); hipStreamWaitEvent(s_small, fk->ev_compact, 0); }
+    }
     if (A.mode == LIW_MODE_INIT) hipLaunchKernelGGL(k_lin_laser<true>, dim3((unsigned)laser_waves), dim3(64), 0, s, A, P, G);
     else hipLaunchKernelGGL(k_lin_laser<false>, dim3((unsigned)laser_waves), dim3(64), 0, s, A, P, G);
     if (imu_waves) hipLaunchKernelGGL(k_lin_imu, dim3((unsigned)imu_waves), dim3(64), 0, s_imu, A, P);

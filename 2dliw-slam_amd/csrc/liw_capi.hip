@@ -177,7 +177,8 @@ liw_ctx* liw_create(const liw_params* prm) {
                     hipStreamCreateWithFlags(&c->fork.side[1], hipStreamNonBlocking) == hipSuccess &&
                     hipEventCreateWithFlags(&c->fork.ev_fork, hipEventDisableTiming) == hipSuccess &&
                     hipEventCreateWithFlags(&c->fork.ev_join[0], hipEventDisableTiming) == hipSuccess &&
-                    hipEventCreateWithFlags(&c->fork.ev_join[1], hipEventDisableTiming) == hipSuccess)
+                    hipEventCreateWithFlags(&c->fork.ev_join[1], hipEventDisableTiming) == hipSuccess &&
+                    hipEventCreateWithFlags(&c->fork.ev_compact, hipEventDisableTiming) == hipSuccess)
                     c->have_fork = true;
                 if (std::getenv("LIW_SERIAL_ROLES")) c->have_fork = false;   // profiling aid: role kernels back to back
             } else {
@@ -201,7 +202,7 @@ void liw_destroy(liw_ctx* c) {
         if (c->gexec) (void)hipGraphExecDestroy(c->gexec);
         if (c->have_fork) {
             (void)hipStreamDestroy(c->fork.side[0]); (void)hipStreamDestroy(c->fork.side[1]);
-            (void)hipEventDestroy(c->fork.ev_fork); (void)hipEventDestroy(c->fork.ev_join[0]); (void)hipEventDestroy(c->fork.ev_join[1]);
+            (void)hipEventDestroy(c->fork.ev_fork); (void)hipEventDestroy(c->fork.ev_join[0]); (void)hipEventDestroy(c->fork.ev_join[1]); (void)hipEventDestroy(c->fork.ev_compact);
         }
         if (c->stream) (void)hipStreamDestroy(c->stream);
     }

@@ -127,7 +127,7 @@ struct LaserPackTable { short slot[45]; unsigned char neg[45]; };   // represent
 // side streams + events used to run the independent role kernels of one linearisation concurrently
 struct LinFork {
     hipStream_t side[2];
-    hipEvent_t ev_fork, ev_join[2];
+    hipEvent_t ev_fork, ev_join[2], ev_compact;
 };
 
 // batched pre-integration (k_preint.hip)
