@@ -686,19 +686,22 @@ void launch_linearize_join(hipStream_t s, const LinFork* fk) {
 // A laser group record (LP = 128 slots) is a signed expansion of NP pair totals (45 with both poses free, 21 with one): the
 // exchange between ranks moves the NP totals only.  pack: record -> totals (representative slot and sign per total, table built on
 // the host with the same slot map the laser kernel uses); unpack: sum over `world` gathered copies in rank order -> record.
-__global__ void k_exchange_pack(int groups, int n, int np, LaserPackTable tb, const double* PL, const LmState* lm, double* buf) {
+__global__ void k_exchange_pack(int groups, int n, int np, LaserPackTable tb, const double* PL0, const double* PL1, int candidate, const LmState* lm, double* buf) {
     const int t = blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= groups * np) return;
     const int grp = t / np, p = t % np;
     const bool dead = lm && lm[grp / n].done;   // finished windows are not re-linearised: their stale sums must not accumulate
-    const double v = PL[(size_t)grp * LP + tb.slot[p]];
+    const int sel = lm ? (candidate ? 1 - lm[grp / n].cur : lm[grp / n].cur) : 0;
+    const double v = (sel ? PL1 : PL0)[(size_t)grp * LP + tb.slot[p]];
     buf[t] = dead ? 0.0 : (tb.neg[p] ? -v : v);
 }
 template <bool BOTH>
-__global__ void k_exchange_unpack(int groups, int np, int world, size_t stride, const double* buf, double* PL) {
+__global__ void k_exchange_unpack(int groups, int n, int np, int world, size_t stride, const double* buf, double* PL0, double* PL1, int candidate, const LmState* lm) {
     const int t = blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= groups * LP) return;
     const int grp = t / LP, s = t % LP;
+    const int sel = lm ? (candidate ? 1 - lm[grp / n].cur : lm[grp / n].cur) : 0;
+    double* PL = sel ? PL1 : PL0;
     const int code = laser_slot_code<BOTH>(s);
     double v = 0.0;
     if (code >= 0) {
@@ -718,7 +721,7 @@ __global__ void k_count_active(int B, const LmState* lm, double* out) {
     __syncthreads();
     if (threadIdx.x == 0) out[0] = (double)cnt;
 }
-void launch_exchange_pack(int B, int n, bool both, const double* PL, const LmState* lm, double* buf, hipStream_t s) {
+void launch_exchange_pack(int B, int n, bool both, const double* PL0, const double* PL1, int candidate, const LmState* lm, double* buf, hipStream_t s) {
     const int np = both ? 45 : 21, groups = B * n;
     LaserPackTable tb{};
     for (int p = 0; p < np; ++p) tb.slot[p] = -1;
@@ -726,13 +729,13 @@ void launch_exchange_pack(int B, int n, bool both, const double* PL, const LmSta
         const int code = both ? laser_slot_code<true>(sl) : laser_slot_code<false>(sl);
         if (code >= 0 && tb.slot[code & 63] < 0) { tb.slot[code & 63] = sl; tb.neg[code & 63] = (code & 64) ? 1 : 0; }
     }
-    hipLaunchKernelGGL(k_exchange_pack, dim3((groups * np + 255) / 256), dim3(256), 0, s, groups, n, np, tb, PL, lm, buf);
+    hipLaunchKernelGGL(k_exchange_pack, dim3((groups * np + 255) / 256), dim3(256), 0, s, groups, n, np, tb, PL0, PL1, candidate, lm, buf);
     if (lm) hipLaunchKernelGGL(k_count_active, dim3(1), dim3(256), 0, s, B, lm, buf + (size_t)groups * np);
 }
-void launch_exchange_unpack(int B, int n, bool both, int world, size_t stride, const double* buf, double* PL, hipStream_t s) {
+void launch_exchange_unpack(int B, int n, bool both, int world, size_t stride, const double* buf, double* PL0, double* PL1, int candidate, const LmState* lm, hipStream_t s) {
     const int np = both ? 45 : 21, groups = B * n;
-    if (both) hipLaunchKernelGGL(k_exchange_unpack<true>, dim3((groups * LP + 255) / 256), dim3(256), 0, s, groups, np, world, stride, buf, PL);
-    else hipLaunchKernelGGL(k_exchange_unpack<false>, dim3((groups * LP + 255) / 256), dim3(256), 0, s, groups, np, world, stride, buf, PL);
+    if (both) hipLaunchKernelGGL(k_exchange_unpack<true>, dim3((groups * LP + 255) / 256), dim3(256), 0, s, groups, n, np, world, stride, buf, PL0, PL1, candidate, lm);
+    else hipLaunchKernelGGL(k_exchange_unpack<false>, dim3((groups * LP + 255) / 256), dim3(256), 0, s, groups, n, np, world, stride, buf, PL0, PL1, candidate, lm);
 }
 #ifdef LIW_CLK
 extern "C" void liw_debug_clk_lin(long long* out, int nn) { hipMemcpyFromSymbol(out, HIP_SYMBOL(g_clk_lin), sizeof(long long) * nn); }

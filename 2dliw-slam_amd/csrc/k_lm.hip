@@ -509,7 +509,7 @@ __global__ __launch_bounds__(64, THROUGHPUT ? 3 : 2) void k_lm_step(StepArgs a) 
 
     if (iteration == 0 && !st.have_candidate) {
         // ---- iteration 0: cost at the initial point
-        c.buf = cur; c.PL = a.w.PL[0]; c.PI = a.w.PI[cur]; c.PW = a.w.PW[cur]; c.PG = a.w.PG[cur]; c.x = xw;
+        c.buf = cur; c.PL = a.w.PL[cur]; c.PI = a.w.PI[cur]; c.PW = a.w.PW[cur]; c.PG = a.w.PG[cur]; c.x = xw;
         x_cost = window_cost(c);
         double s = 0.0;
         for (int e = lane; e < n * 15; e += 64) if (!var_is_const(a.mode, a.fast_mode, n, e / 15, e % 15)) s += xw[e] * xw[e];
@@ -521,7 +521,7 @@ __global__ __launch_bounds__(64, THROUGHPUT ? 3 : 2) void k_lm_step(StepArgs a) 
     } else if (st.have_candidate) {
         // ---- candidate evaluated by the previous linearise launch
         const int cb = 1 - cur;
-        c.buf = cb; c.PL = a.w.PL[1]; c.PI = a.w.PI[cb]; c.PW = a.w.PW[cb]; c.PG = a.w.PG[cb]; c.x = xc;
+        c.buf = cb; c.PL = a.w.PL[cb]; c.PI = a.w.PI[cb]; c.PW = a.w.PW[cb]; c.PG = a.w.PG[cb]; c.x = xc;
         double cand_cost = window_cost(c);
         if (!isfinite(cand_cost)) cand_cost = 1.7976931348623157e308;
         int term = 0;
@@ -536,11 +536,6 @@ __global__ __launch_bounds__(64, THROUGHPUT ? 3 : 2) void k_lm_step(StepArgs a) 
         const double rho = (x_cost - cand_cost) / st.model_cost_change;
         if (rho > kMinRelDec) {
             for (int e = lane; e < n * 15; e += 64) xw[e] = xc[e];
-            {   // laser partial sums: candidate region -> current region (copy-on-accept)
-                const double* src = a.w.PL[1] + (size_t)b * n * LP;
-                double* dst = a.w.PL[0] + (size_t)b * n * LP;
-                for (int e = lane; e < n * LP; e += 64) dst[e] = src[e];
-            }
             cur = cb;
             x_cost = cand_cost;
             double s = 0.0;
@@ -576,7 +571,7 @@ __global__ __launch_bounds__(64, THROUGHPUT ? 3 : 2) void k_lm_step(StepArgs a) 
 
     // current linearisation
     __syncthreads();
-    c.buf = cur; c.PL = a.w.PL[0]; c.PI = a.w.PI[cur]; c.PW = a.w.PW[cur]; c.PG = a.w.PG[cur]; c.x = xw;
+    c.buf = cur; c.PL = a.w.PL[cur]; c.PI = a.w.PI[cur]; c.PW = a.w.PW[cur]; c.PG = a.w.PG[cur]; c.x = xw;
 
     if (fresh) {   // Jacobi scaling 1/(1+sqrt(H_jj)), computed once per solve
         for (int i = 0; i < n; ++i) {
@@ -911,7 +906,7 @@ __global__ __launch_bounds__(256, 1) void k_lm_step_tw(StepArgs a) {
         reuse = st.reuse_diagonal; iteration = st.iteration; cur = st.cur;
         int proceed = 1;
         if (iteration == 0 && !st.have_candidate) {
-            c.buf = cur; c.PL = a.w.PL[0]; c.PI = a.w.PI[cur]; c.PW = a.w.PW[cur]; c.PG = a.w.PG[cur]; c.x = xw;
+            c.buf = cur; c.PL = a.w.PL[cur]; c.PI = a.w.PI[cur]; c.PW = a.w.PW[cur]; c.PG = a.w.PG[cur]; c.x = xw;
             x_cost = window_cost(c);
             double sq = 0.0;
             for (int e = lane; e < n * 15; e += 64) if (!var_is_const(a.mode, a.fast_mode, n, e / 15, e % 15)) sq += xw[e] * xw[e];
@@ -922,7 +917,7 @@ __global__ __launch_bounds__(256, 1) void k_lm_step_tw(StepArgs a) {
                 for (int e = lane; e < n * 15; e += 64) a.w.history[((size_t)b) * n * 15 + e] = xw[e];
         } else if (st.have_candidate) {
             const int cb = 1 - cur;
-            c.buf = cb; c.PL = a.w.PL[1]; c.PI = a.w.PI[cb]; c.PW = a.w.PW[cb]; c.PG = a.w.PG[cb]; c.x = xc;
+            c.buf = cb; c.PL = a.w.PL[cb]; c.PI = a.w.PI[cb]; c.PW = a.w.PW[cb]; c.PG = a.w.PG[cb]; c.x = xc;
             double cand_cost = window_cost(c);
             if (!isfinite(cand_cost)) cand_cost = 1.7976931348623157e308;
             int term = 0;
@@ -937,11 +932,6 @@ __global__ __launch_bounds__(256, 1) void k_lm_step_tw(StepArgs a) {
                 const double rho = (x_cost - cand_cost) / st.model_cost_change;
                 if (rho > kMinRelDec) {
                     for (int e = lane; e < n * 15; e += 64) xw[e] = xc[e];
-                    {
-                        const double* src = a.w.PL[1] + (size_t)b * n * LP;
-                        double* dst = a.w.PL[0] + (size_t)b * n * LP;
-                        for (int e = lane; e < n * LP; e += 64) dst[e] = src[e];
-                    }
                     cur = cb;
                     x_cost = cand_cost;
                     double sq = 0.0;
@@ -972,7 +962,7 @@ __global__ __launch_bounds__(256, 1) void k_lm_step_tw(StepArgs a) {
             proceed = 0;
         }
         if (proceed && fresh) {   // Jacobi scaling 1/(1+sqrt(H_jj)), computed once per solve
-            c.buf = cur; c.PL = a.w.PL[0]; c.PI = a.w.PI[cur]; c.PW = a.w.PW[cur]; c.PG = a.w.PG[cur]; c.x = xw;
+            c.buf = cur; c.PL = a.w.PL[cur]; c.PI = a.w.PI[cur]; c.PW = a.w.PW[cur]; c.PG = a.w.PG[cur]; c.x = xw;
             for (int i = 0; i < n; ++i) {
                 const double hjj = frame_diag<true>(c, i, T);
                 if (lane < 15) st.scale[i * 15 + lane] = var_is_const(a.mode, a.fast_mode, n, i, lane) ? 1.0 : 1.0 / (1.0 + sqrt(hjj));
@@ -983,7 +973,7 @@ __global__ __launch_bounds__(256, 1) void k_lm_step_tw(StepArgs a) {
     __syncthreads();   // (drains wave 0's global writes: accepted states, laser partial copy, scales)
     if (!S.ctl[0]) return;
     reuse = S.ctl[1]; cur = S.ctl[2]; radius = S.ctld[0];
-    c.buf = cur; c.PL = a.w.PL[0]; c.PI = a.w.PI[cur]; c.PW = a.w.PW[cur]; c.PG = a.w.PG[cur]; c.x = xw;
+    c.buf = cur; c.PL = a.w.PL[cur]; c.PI = a.w.PI[cur]; c.PW = a.w.PW[cur]; c.PG = a.w.PG[cur]; c.x = xw;
     const double* scl = st.scale;
     double* dgl = st.diagonal;
     double* sws = a.w.solve_ws + (size_t)b * n * SOLVE_WS;

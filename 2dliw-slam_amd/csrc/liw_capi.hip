@@ -16,8 +16,8 @@ namespace liw {
 // kernel launchers (k_linearize.hip, k_lm.hip)
 void launch_linearize(const LinArgs& A, const DevParams& P, hipStream_t s, const LinFork* fk, bool defer_join = false);
 void launch_linearize_join(hipStream_t s, const LinFork* fk);
-void launch_exchange_pack(int B, int n, bool both, const double* PL, const LmState* lm, double* buf, hipStream_t s);
-void launch_exchange_unpack(int B, int n, bool both, int world, size_t stride, const double* buf, double* PL, hipStream_t s);
+void launch_exchange_pack(int B, int n, bool both, const double* PL0, const double* PL1, int candidate, const LmState* lm, double* buf, hipStream_t s);
+void launch_exchange_unpack(int B, int n, bool both, int world, size_t stride, const double* buf, double* PL0, double* PL1, int candidate, const LmState* lm, hipStream_t s);
 void launch_group_offsets(int B, int n, const int* laser_off, const int* laser_frame, int* group_off, hipStream_t s);
 struct StepArgs {
     int B, n, mode, max_iters, fast_mode;
@@ -293,8 +293,7 @@ static LinArgs lin_args(const liw_batch* b, int mode, const double* x, const WsV
     A.match_pose = b->match_pose; A.has_match = b->has_match;
     A.imu_X = b->imu_X; A.imu_J = b->imu_J; A.imu_sqrtP = b->imu_sqrtP; A.imu_Dt = b->imu_Dt;
     A.wheel_T = b->wheel_T; A.wheel_sqrtP = b->wheel_sqrtP;
-    A.PL = v.PL[candidate ? 1 : 0];
-    for (int k = 0; k < 2; ++k) { A.PI[k] = v.PI[k]; A.PW[k] = v.PW[k]; A.PG[k] = v.PG[k]; }
+    for (int k = 0; k < 2; ++k) { A.PL[k] = v.PL[k]; A.PI[k] = v.PI[k]; A.PW[k] = v.PW[k]; A.PG[k] = v.PG[k]; }
     A.lm = use_lm ? v.lm : nullptr;
     A.active = use_lm ? v.active : nullptr;
     A.candidate = candidate;
@@ -361,7 +360,7 @@ int liw_batch_exchange_pack(liw_ctx* c, const liw_batch* b, int mode, int candid
     if (int r = check_batch(c, b, min_frames(mode))) return r;
     if (!buf) return fail(c, LIW_EINVAL, "liw_batch_exchange_pack: null buffer");
     WsView v = make_view(ws, b->B, b->n, b->history_records);
-    launch_exchange_pack(b->B, b->n, mode == LIW_MODE_INIT, v.PL[candidate ? 1 : 0], mode == LIW_MODE_MARG ? nullptr : v.lm, buf, (hipStream_t)stream);
+    launch_exchange_pack(b->B, b->n, mode == LIW_MODE_INIT, v.PL[0], v.PL[1], candidate, mode == LIW_MODE_MARG ? nullptr : v.lm, buf, (hipStream_t)stream);
     HIPCHK(c, hipGetLastError());
     return LIW_OK;
 }
@@ -371,7 +370,7 @@ int liw_batch_exchange_unpack(liw_ctx* c, const liw_batch* b, int mode, int cand
     if (!buf || copies < 1) return fail(c, LIW_EINVAL, "liw_batch_exchange_unpack: null buffer / copies < 1");
     WsView v = make_view(ws, b->B, b->n, b->history_records);
     const size_t stride = (size_t)liw_batch_exchange_doubles(b->B, b->n, mode);
-    launch_exchange_unpack(b->B, b->n, mode == LIW_MODE_INIT, copies, stride, buf, v.PL[candidate ? 1 : 0], (hipStream_t)stream);
+    launch_exchange_unpack(b->B, b->n, mode == LIW_MODE_INIT, copies, stride, buf, v.PL[0], v.PL[1], candidate, mode == LIW_MODE_MARG ? nullptr : v.lm, (hipStream_t)stream);
     HIPCHK(c, hipGetLastError());
     return LIW_OK;
 }

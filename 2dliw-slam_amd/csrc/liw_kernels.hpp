@@ -50,9 +50,9 @@ struct LmState {
 
 struct WsView {
     // all device pointers into the caller's workspace
-    // laser partial sums: fixed "current" (0) and "candidate" (1) regions, copy-on-accept (these are the only
-    // partials a factor-sharded multi-GPU run all-reduces); IMU/wheel/ground partials: two buffers, the current
-    // one of window b is lm[b].cur and the candidate goes to the other.
+    // every role has two partial buffers: the current one of window b is lm[b].cur, its candidate linearisation goes to the other
+    // (an accepted step just flips lm[b].cur; round 1 copied the laser partials on accept).  A factor-sharded run exchanges the laser
+    // partials through liw_batch_exchange_pack / _unpack, which follow the same per-window selection.
     double* PL[2]; double* PI[2]; double* PW[2]; double* PG[2];
     double* x_cand;       // [B][n][15]
     int* group_off;       // [B][n+1] laser block range of each (window, frame)
@@ -77,8 +77,7 @@ struct LinArgs {
     const unsigned char* has_match;
     const double* imu_X; const double* imu_J; const double* imu_sqrtP; const double* imu_Dt;
     const double* wheel_T; const double* wheel_sqrtP;
-    double* PL;                 // laser partial region to write (current or candidate)
-    double* PI[2]; double* PW[2]; double* PG[2];
+    double* PL[2]; double* PI[2]; double* PW[2]; double* PG[2];   // partial buffers: window b writes buffer lm[b].cur (candidate: the other one)
     const LmState* lm;          // null (buffer 0, no skipping), or per-window state: done windows skip
     int candidate;              // 1: write the small-factor partials of window b into buffer 1 - lm[b].cur
     int small_per_wave;         // IMU / wheel blocks per wave (set by launch_linearize)

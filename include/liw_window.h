@@ -157,7 +157,8 @@ typedef struct liw_batch {
  * all-reduce the laser partial-sum region between liw_batch_lm_linearize and liw_batch_lm_step. */
 typedef struct liw_ws_layout {
     size_t bytes;                /* total */
-    size_t laser_partial_off[2]; /* byte offset of the laser partial sums: [0] current point, [1] candidate point */
+    size_t laser_partial_off[2]; /* byte offsets of the two laser partial-sum buffers (a window's current linearisation lives in the
+                                  * buffer its LM state selects, the candidate in the other: exchange them with liw_batch_exchange_*) */
     size_t laser_partial_bytes;  /* B*n*LIW_LASER_PARTIAL doubles */
     size_t info_off;             /* liw_summary[B] (device) */
     size_t history_off;          /* optional x history, 0 if not requested */

@@ -183,7 +183,7 @@ def test_full_size_normal_equations(liw, synth, pyoracle, env, n, L):
 def test_factor_sharded_solve_on_one_gpu(liw, synth, pyoracle, env):
     """The multi-GPU factor-parallel path driven in lock-step on ONE device: two rank objects hold
     disjoint laser shards of the same windows, the all-reduce of the laser partial sums is emulated by adding the
-    two partial regions, everything else (replicated small factors, identical LM steps) is the real code path.
+    two packed records, everything else (replicated small factors, identical LM steps) is the real code path.
     Must reproduce the unsharded solve."""
     import torch
     prm, orc = env
@@ -194,10 +194,18 @@ def test_factor_sharded_solve_on_one_gpu(liw, synth, pyoracle, env):
     assert sum(rk.Ltot for rk in ranks) == ref.Ltot
     mode = liw.LIW_MODE_INIT
 
-    def exchange(which):
-        tot = ranks[0].PL[which] + ranks[1].PL[which]
+    import ctypes as C
+
+    def exchange(cand):   # the two ranks' compact records added by hand, through the pack / unpack entry points of the C ABI
+        bufs = []
         for rk in ranks:
-            rk.PL[which].copy_(tot)
+            buf, _, _ = rk._xbuffers(mode)
+            rk._chk(rk.L.liw_batch_exchange_pack(rk.h, C.byref(rk.b), C.c_int(mode), C.c_int(cand), rk._wsp(), C.c_void_p(buf.data_ptr()), rk._stream()))
+            bufs.append(buf)
+        tot = bufs[0] + bufs[1]
+        for rk, buf in zip(ranks, bufs):
+            buf.copy_(tot)
+            rk._chk(rk.L.liw_batch_exchange_unpack(rk.h, C.byref(rk.b), C.c_int(mode), C.c_int(cand), rk._wsp(), C.c_void_p(buf.data_ptr()), C.c_int(1), rk._stream()))
 
     K = [rk.lm_begin(mode, 15) for rk in ranks][0]
     for rk in ranks:
