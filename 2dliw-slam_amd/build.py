@@ -11,6 +11,8 @@ HEADERS = ["liw_dual.hpp", "liw_kernels.hpp", "k_lin_laser_body.inc", os.path.jo
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wno-unused-result"]
 if os.environ.get("LIW_CLK"):   # phase-timing build for tools/clk_probe.py
     FLAGS.append("-DLIW_CLK")
+    if os.environ.get("LIW_CLK_IT"):
+        FLAGS.append("-DLIW_CLK_IT=" + os.environ["LIW_CLK_IT"])
 
 
 def _hipcc():

@@ -138,9 +138,10 @@ __device__ void imu_blocks(const LinArgs& A, const DevParams& P, int wave, doubl
     const long total = (long)(A.active ? A.active[0] : A.B) * nb, gb0 = (long)wave * ipw;
     if (gb0 >= total) return;
     const long gb = gb0 + blk;
-    const bool on = blk < ipw && gb < total;
+    bool on = blk < ipw && gb < total;
     const int wi = on ? (int)(gb / nb) : 0, k = on ? (int)(gb % nb) : 0;
     const int b = A.active ? A.active[1 + wi] : wi;
+    if (on && !A.active) on = window_live(A, b);
     double* rec = lds + (blk < IMU_PER_WAVE ? blk : 0) * IMU_REC;
     const int sel_lane = (on && A.lm) ? (A.candidate ? 1 - A.lm[b].cur : A.lm[b].cur) : 0;   // partial buffer of this lane's block
     const int fk_lane = on ? b * nb + k : 0;                                                   // its record in the input / partial arrays
@@ -362,9 +363,10 @@ __device__ void wheel_blocks(const LinArgs& A, const DevParams& P, int wave, dou
     const int lane = threadIdx.x & 63, blk = lane / 3, g = lane % 3;
     const int n = A.n, nb = n - 1;
     const long total = (long)(A.active ? A.active[0] : A.B) * nb, gb = (long)wave * A.small_per_wave + blk;   // over the windows still iterating
-    const bool on = blk < A.small_per_wave && gb < total;
+    bool on = blk < A.small_per_wave && gb < total;
     const int wi = on ? (int)(gb / nb) : 0, k = on ? (int)(gb % nb) : 0;
     const int b = A.active ? A.active[1 + wi] : wi;
+    if (on && !A.active) on = window_live(A, b);
     double* Y = lds + (blk < WHEEL_PER_WAVE ? blk : 0) * 64;   // [3][13] then Dp [3][3] at 40, R_wi [3][3] at 49
     const size_t fk = on ? (size_t)b * nb + k : 0;
     if (on) {
@@ -506,9 +508,10 @@ __device__ void ground_frames(const LinArgs& A, const DevParams& P, int wave, do
     const int lane = threadIdx.x & 63, sub = lane >> 1, g = lane & 1;
     const int n = A.n;
     const long total = (long)(A.active ? A.active[0] : A.B) * n, gf = (long)wave * GROUND_PER_WAVE + sub;
-    const bool on = gf < total;
+    bool on = gf < total;
     const int wi = on ? (int)(gf / n) : 0;
     const int b = A.active ? A.active[1 + wi] : wi;
+    if (on && !A.active) on = window_live(A, b);
     double* Y = lds + sub * 16;   // [2][7]
     const size_t fi = on ? (size_t)b * n + (size_t)(gf % n) : 0;
     if (on) {

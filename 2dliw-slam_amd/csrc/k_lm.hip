@@ -23,14 +23,28 @@ typedef double d4 __attribute__((ext_vector_type(4)));
 #ifdef LIW_CLK
 __device__ long long g_clk[8192];
 __device__ long long g_span[3 * 16384];   // per window: start, end (s_memtime), hardware id of the wave
-#define STAMP(id) do { if (b == 0 && lane == 0 && iteration_dbg == 3) g_clk[(id)] = clock64(); } while (0)
-#define SPAN(k) do { if (lane == 0 && iteration_dbg == 3 && b < 16384) { g_span[3 * b + (k)] = clock64(); \
+#ifndef LIW_CLK_IT
+#define LIW_CLK_IT 3
+#endif
+#define STAMP(id) do { if (b == 0 && lane == 0 && iteration_dbg == LIW_CLK_IT) g_clk[(id)] = clock64(); } while (0)
+#define STAMPE(id) do { if (b == 0 && lane == 0 && iteration == LIW_CLK_IT) g_clk[(id)] = clock64(); } while (0)   // before iteration_dbg exists
+#define STAMPM(id) do { if (b == 0 && lane == 0) g_clk[(id)] = clock64(); } while (0)                              // marginalisation kernel
+#define SPAN(k) do { if (lane == 0 && iteration_dbg == LIW_CLK_IT && b < 16384) { g_span[3 * b + (k)] = clock64(); \
                      if ((k) == 0) g_span[3 * b + 2] = __builtin_amdgcn_s_getreg((4 << 0) | (0 << 6) | (31 << 11)); } } while (0)
 #else
 #define STAMP(id) do { } while (0)
+#define STAMPE(id) do { } while (0)
+#define STAMPM(id) do { } while (0)
 #define SPAN(k) do { } while (0)
 #endif
 
+constexpr int LIW_RESULT_HDR = 8;   // doubles: 4 ints, then liw_summary (32 bytes), padded
+struct PackArgs {
+    int n;
+    const LmState* lm; const liw_summary* info; const double* x; const double* match_pose;
+    const double* marg; const int* marg_status;   // null without a speculative marginalisation
+    double* out;
+};
 struct StepArgs {
     int B, n, mode, max_iters, fast_mode;
     double* x;                   // [B][n][15] live states
@@ -506,6 +520,7 @@ __global__ __launch_bounds__(64, THROUGHPUT ? 3 : 2) void k_lm_step(StepArgs a) 
     int reuse = st.reuse_diagonal, iteration = st.iteration, cur = st.cur;
     bool last_successful = true;
     bool fresh = false;
+    STAMPE(4000);
 
     if (iteration == 0 && !st.have_candidate) {
         // ---- iteration 0: cost at the initial point
@@ -523,6 +538,7 @@ __global__ __launch_bounds__(64, THROUGHPUT ? 3 : 2) void k_lm_step(StepArgs a) 
         const int cb = 1 - cur;
         c.buf = cb; c.PL = a.w.PL[cb]; c.PI = a.w.PI[cb]; c.PW = a.w.PW[cb]; c.PG = a.w.PG[cb]; c.x = xc;
         double cand_cost = window_cost(c);
+        STAMPE(4001);
         if (!isfinite(cand_cost)) cand_cost = 1.7976931348623157e308;
         int term = 0;
         if (st.cand_step_norm <= kParamTol * (x_norm + kParamTol)) term = 3;
@@ -570,7 +586,9 @@ __global__ __launch_bounds__(64, THROUGHPUT ? 3 : 2) void k_lm_step(StepArgs a) 
     }
 
     // current linearisation
+    STAMPE(4002);
     __syncthreads();
+    STAMPE(4003);
     c.buf = cur; c.PL = a.w.PL[cur]; c.PI = a.w.PI[cur]; c.PW = a.w.PW[cur]; c.PG = a.w.PG[cur]; c.x = xw;
 
     if (fresh) {   // Jacobi scaling 1/(1+sqrt(H_jj)), computed once per solve
@@ -750,7 +768,9 @@ __global__ __launch_bounds__(64, THROUGHPUT ? 3 : 2) void k_lm_step(StepArgs a) 
 
     double model_cost_change = 0.0, step_norm = 0.0;
     bool valid = false;
+    STAMP(4004);
     __syncthreads();   // factor records (global) written above are read by other lanes below
+    STAMP(4005);
     if (solved) {
         // ---- back substitution, frame 0 first.  Lane r owns unknown r: row r of Yo / Yr.
         double ytg = 0.0, dsum = 0.0, sn2 = 0.0;
@@ -844,6 +864,7 @@ __global__ __launch_bounds__(64, THROUGHPUT ? 3 : 2) void k_lm_step(StepArgs a) 
             st.radius = radius / dec; st.decrease_factor = dec * 2.0; st.reuse_diagonal = 1;
         }
     }
+    STAMP(4006);
 }
 
 // ---------------------------------------------------------------------------------------------------
@@ -1295,6 +1316,40 @@ __global__ void k_lm_begin(int B, int n, LmState* lm, int max_iters) {
     s.successful = 0; s.cur = 0; s.invalid_steps = 0; s.have_candidate = 0; s.initial_cost = 0.0; s.max_iters = max_iters; s.pad_ = 0;
 }
 
+// single-window entry (liw_solve): laser group offsets (k_group_offsets) and the LM state reset in one launch
+__global__ void k_begin_all(int B, int n, const int* laser_off, const int* laser_frame, int* group_off, LmState* lm, int max_iters) {
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t < B * (n + 1)) {
+        const int b = t / (n + 1), i = t % (n + 1);
+        int lo = laser_off[b], hi = laser_off[b + 1];
+        while (lo < hi) {
+            const int mid = (lo + hi) >> 1;
+            if (laser_frame[mid] < i) lo = mid + 1; else hi = mid;
+        }
+        group_off[t] = lo;
+    }
+    if (t < B) {
+        LmState& s = lm[t];
+        s.radius = kInitRadius; s.decrease_factor = 2.0; s.x_cost = 0.0; s.x_norm = 0.0; s.minimum_cost = 0.0;
+        s.cand_step_norm = 0.0; s.model_cost_change = 0.0; s.reuse_diagonal = 0; s.iteration = 0; s.done = 0; s.termination = 0;
+        s.successful = 0; s.cur = 0; s.invalid_steps = 0; s.have_candidate = 0; s.initial_cost = 0.0; s.max_iters = max_iters; s.pad_ = 0;
+    }
+}
+// everything liw_solve reads back, gathered into ONE record (one device-to-host copy per chunk of iterations):
+// [done, marg status, -, - | liw_summary | states n*15 | match_pose n*12 | sqrt_H 36, Delta_H 225, Delta_g 15]
+__global__ void k_pack_result(PackArgs a) {
+    const int t = threadIdx.x, n = a.n;
+    int* hdr = reinterpret_cast<int*>(a.out);
+    if (t == 0) { hdr[0] = a.lm[0].done; hdr[1] = a.marg_status ? a.marg_status[0] : 3; hdr[2] = 0; hdr[3] = 0; }
+    if (t == 1) *reinterpret_cast<liw_summary*>(a.out + 2) = a.info[0];
+    double* o = a.out + LIW_RESULT_HDR;
+    for (int e = t; e < n * 15; e += blockDim.x) o[e] = a.x[e];
+    o += n * 15;
+    for (int e = t; e < n * 12; e += blockDim.x) o[e] = a.match_pose[e];
+    o += n * 12;
+    if (a.marg) for (int e = t; e < 276; e += blockDim.x) o[e] = a.marg[e];
+}
+
 // write-backs the reference does after ceres::Solve (solver.cpp:176-190 init, :804-814 tracking) + summaries
 __global__ void k_lm_finish(StepArgs a) {   // one thread per (window, frame, pose entry): a thread per window walked n frames serially (40 us at n = 30)
     const int t = blockIdx.x * blockDim.x + threadIdx.x;
@@ -1363,17 +1418,25 @@ struct MargArgs {
     const double* x; double* prior_X; double* prior_J; double* prior_R; int* has_prior;
     WsView w;
     double* sqrt_H; double* Delta_H; double* Delta_g; int* status;
+    // the new prior goes to out_* when set (a marginalisation enqueued speculatively behind liw_solve must not replace the live prior
+    // before the caller asks for it), else in place; gate: run window b only if its solve has terminated, status 2 otherwise
+    double* out_X; double* out_J; double* out_R; int* out_has;
+    const LmState* gate;
 };
 __global__ __launch_bounds__(64, 2) void k_marg_schur(MargArgs a) {
     __shared__ LdsTiles T;
     __shared__ double V[256], Am[256], rot[32];
     const int b = blockIdx.x, lane = threadIdx.x & 63, n = a.n;
+    if (a.gate && !a.gate[b].done) { if (a.status && lane == 0) a.status[b] = 2; return; }
+    double* oX = a.out_X ? a.out_X : a.prior_X; double* oJ = a.out_J ? a.out_J : a.prior_J; double* oR = a.out_R ? a.out_R : a.prior_R;
+    int* oHas = a.out_has ? a.out_has : a.has_prior;
     AsmCtx c;
     c.n = n; c.mode = LIW_MODE_MARG; c.fast = 0; c.b = b; c.buf = 0;
     c.PL = a.w.PL[0]; c.PI = a.w.PI[0]; c.PW = a.w.PW[0]; c.PG = a.w.PG[0];
     c.x = a.x + (size_t)b * n * 15;
     c.pJ = a.prior_J + (size_t)b * 225; c.pX = a.prior_X + (size_t)b * 15;
     c.prior_on = a.has_prior[b] != 0;
+    STAMPM(5000);
     for (int e = lane; e < 256; e += 64) { T.CD[e] = 0.0; T.W[e] = 0.0; }
     if (lane < 16) T.Cg[lane] = 0.0;
     lds_sync();
@@ -1442,6 +1505,7 @@ __global__ __launch_bounds__(64, 2) void k_marg_schur(MargArgs a) {
     // Delta_H = T.D (15x15), Delta_g = -T.g  (g = -J^T R in the reference)
     if (a.Delta_H) for (int e = lane; e < 225; e += 64) a.Delta_H[(size_t)b * 225 + e] = T.D[(e / 15) * 16 + e % 15];
     if (a.Delta_g && lane < 15) a.Delta_g[(size_t)b * 15 + lane] = -T.g[lane];
+    STAMPM(5001);
     // ---- symmetric eigen-decomposition by cyclic Jacobi (15x15), A -> Am, eigenvectors -> V (columns)
     for (int e = lane; e < 256; e += 64) {
         const int r = e >> 4, cc = e & 15;
@@ -1502,6 +1566,7 @@ __global__ __launch_bounds__(64, 2) void k_marg_schur(MargArgs a) {
             lds_sync();
         }
     }
+    STAMPM(5002);
     // sort ascending (rank by counting; ties by index), sign convention: largest |component| positive
     if (lane < 15) {
         const double w = Am[lane * 16 + lane];
@@ -1516,20 +1581,26 @@ __global__ __launch_bounds__(64, 2) void k_marg_schur(MargArgs a) {
         double dotg = 0.0;
         for (int k = 0; k < 15; ++k) dotg += sg * V[k * 16 + lane] * (-T.g[k]);   // V^T Delta_g
         // linearized_jacobians row `rank` = sqrt(S) v^T ; linearized_residuals[rank] = -(S^-1/2 v^T Delta_g)
-        for (int k = 0; k < 15; ++k) a.prior_J[(size_t)b * 225 + rank * 15 + k] = ssq * sg * V[k * 16 + lane];
-        a.prior_R[(size_t)b * 15 + rank] = -(sisq * dotg);
+        for (int k = 0; k < 15; ++k) oJ[(size_t)b * 225 + rank * 15 + k] = ssq * sg * V[k * 16 + lane];
+        oR[(size_t)b * 15 + rank] = -(sisq * dotg);
     }
     __syncthreads();
     __threadfence_block();
-    if (lane < 15) a.prior_X[(size_t)b * 15 + lane] = c.x[(size_t)(n - 1) * 15 + lane];
-    if (a.sqrt_H) for (int e = lane; e < 36; e += 64) a.sqrt_H[(size_t)b * 36 + e] = a.prior_J[(size_t)b * 225 + (e / 6) * 15 + e % 6];
-    if (lane == 0) a.has_prior[b] = 1;
+    if (lane < 15) oX[(size_t)b * 15 + lane] = c.x[(size_t)(n - 1) * 15 + lane];
+    if (a.sqrt_H) for (int e = lane; e < 36; e += 64) a.sqrt_H[(size_t)b * 36 + e] = oJ[(size_t)b * 225 + (e / 6) * 15 + e % 6];
+    if (lane == 0) oHas[b] = 1;
+    STAMPM(5003);
 }
 
 #ifdef LIW_CLK
 extern "C" void liw_debug_clk(long long* out, int nn) { hipMemcpyFromSymbol(out, HIP_SYMBOL(g_clk), sizeof(long long) * nn); }
 extern "C" void liw_debug_span(long long* out, int nn) { hipMemcpyFromSymbol(out, HIP_SYMBOL(g_span), sizeof(long long) * nn); }
 #endif
+void launch_begin_all(int B, int n, const int* laser_off, const int* laser_frame, int* group_off, LmState* lm, int max_iters, hipStream_t s) {
+    const int tot = B * (n + 1);
+    hipLaunchKernelGGL(k_begin_all, dim3((tot + 255) / 256), dim3(256), 0, s, B, n, laser_off, laser_frame, group_off, lm, max_iters);
+}
+void launch_pack_result(const PackArgs& a, hipStream_t s) { hipLaunchKernelGGL(k_pack_result, dim3(1), dim3(256), 0, s, a); }
 void launch_lm_begin(int B, int n, LmState* lm, int max_iters, hipStream_t s) {
     hipLaunchKernelGGL(k_lm_begin, dim3((B + 63) / 64), dim3(64), 0, s, B, n, lm, max_iters);
 }

@@ -36,7 +36,18 @@ struct MargArgs {
     const double* x; double* prior_X; double* prior_J; double* prior_R; int* has_prior;
     WsView w;
     double* sqrt_H; double* Delta_H; double* Delta_g; int* status;
+    double* out_X; double* out_J; double* out_R; int* out_has;
+    const LmState* gate;
 };
+constexpr int LIW_RESULT_HDR = 8;
+struct PackArgs {
+    int n;
+    const LmState* lm; const liw_summary* info; const double* x; const double* match_pose;
+    const double* marg; const int* marg_status;
+    double* out;
+};
+void launch_begin_all(int B, int n, const int* laser_off, const int* laser_frame, int* group_off, LmState* lm, int max_iters, hipStream_t s);
+void launch_pack_result(const PackArgs& a, hipStream_t s);
 void launch_lm_begin(int B, int n, LmState* lm, int max_iters, hipStream_t s);
 void launch_lm_step(const StepArgs& a, hipStream_t s);
 void launch_lm_finish(const StepArgs& a, hipStream_t s);
@@ -72,10 +83,21 @@ struct liw_ctx {
     bool have_window = false;
     int n = 0, L = 0;
     DevBuf arena;                 // every input array of the window, one allocation (one H2D copy per liw_set_window)
-    void* pinned = nullptr;       // page-locked staging image of the arena + read-back slots
-    size_t pinned_cap = 0;
-    size_t off_x = 0, off_mp = 0;
+    // page-locked memory: [image 0 | image 1 | read-back record].  An image is the byte image of the arena; image `img_cur` mirrors what
+    // the device holds (liw_solve folds the solved states back into it), the other one is where the next liw_set_window stages its
+    // window — identical to the mirror means the device already has this window: no upload, and a marginalisation result computed
+    // speculatively behind the solve stays valid (the lvio_2d::solver shim re-flattens the same frames for marginalization()).
+    void* pinned = nullptr;
+    size_t pinned_cap = 0, img_cap = 0, readback_cap = 0;
+    int img_cur = 0;
+    bool img_valid = false;
+    size_t part_off[12] = {0}, part_bytes[12] = {0};
+    hipEvent_t ev_upload = nullptr;   // completion of the last host-to-device copy (liw_set_window does not wait for it)
     DevBuf prior_X, prior_J, prior_R, has_prior, ws, scratch;
+    // speculative marginalisation (TRACK solves): next prior + packed result record
+    DevBuf priorn_X, priorn_J, priorn_R, has_priorn, result, marg_status;
+    bool spec_marg = true, spec_valid = false;
+    double spec_out[36 + 225 + 15];
     liw_batch sb{};
     liw_ws_layout lay{};
     int hist_records = 0;
@@ -181,6 +203,8 @@ liw_ctx* liw_create(const liw_params* prm) {
                     hipEventCreateWithFlags(&c->fork.ev_compact, hipEventDisableTiming) == hipSuccess)
                     c->have_fork = true;
                 if (std::getenv("LIW_SERIAL_ROLES")) c->have_fork = false;   // profiling aid: role kernels back to back
+                if (std::getenv("LIW_NO_SPEC_MARG")) c->spec_marg = false;   // profiling / test aid: marginalise only when asked
+                (void)hipEventCreateWithFlags(&c->ev_upload, hipEventDisableTiming);
             } else {
                 c->err = std::string("device is ") + props.gcnArchName + ", this library is built for gfx950 only";
             }
@@ -194,8 +218,10 @@ void liw_destroy(liw_ctx* c) {
     if (!c) return;
     if (c->have_device) {
         (void)hipSetDevice(c->prm.device);
-        DevBuf* bufs[] = {&c->arena, &c->prior_X, &c->prior_J, &c->prior_R, &c->has_prior, &c->ws, &c->scratch};
+        DevBuf* bufs[] = {&c->arena, &c->prior_X, &c->prior_J, &c->prior_R, &c->has_prior, &c->ws, &c->scratch,
+                          &c->priorn_X, &c->priorn_J, &c->priorn_R, &c->has_priorn, &c->result, &c->marg_status};
         if (c->pinned) (void)hipHostFree(c->pinned);
+        if (c->ev_upload) (void)hipEventDestroy(c->ev_upload);
         for (DevBuf* b : bufs) b->release();
         for (auto e : c->ev_lin) (void)hipEventDestroy(e);
         for (auto e : c->ev_step) (void)hipEventDestroy(e);
@@ -576,49 +602,69 @@ int liw_set_window(liw_ctx* c, const liw_window* w) {
     if (w->L > 0 && (!w->laser_frame || !w->laser_pts)) return fail(c, LIW_EINVAL, "liw_set_window: L > 0 but laser_frame / laser_pts are NULL");
     if (w->n > 1 && (!w->imu_X || !w->imu_J || !w->imu_sqrtP || !w->imu_Dt || !w->wheel_T || !w->wheel_sqrtP))
         return fail(c, LIW_EINVAL, "liw_set_window: n > 1 but an IMU / wheel array is NULL");
-    c->solved_records = 0;
     HIPCHK(c, hipSetDevice(c->prm.device));
-    const int n = w->n, L = w->L, nm = n > 1 ? n - 1 : 1;
+    const int n = w->n, L = w->L;
     // laser blocks must be sorted by owning frame
     for (int j = 1; j < L; ++j) if (w->laser_frame[j] < w->laser_frame[j - 1]) return fail(c, LIW_EINVAL, "laser_frame must be ascending");
     for (int j = 0; j < L; ++j) if (w->laser_frame[j] < 0 || w->laser_frame[j] >= n) return fail(c, LIW_EINVAL, "laser_frame out of range");
-    // one page-locked staging image + ONE host-to-device copy (a tracking window is a dozen arrays of a few hundred
-    // bytes: a dozen pageable copies cost more than the solve)
-    struct Part { const void* src; size_t bytes; size_t off; };
+    // one page-locked staging image + ONE asynchronous host-to-device copy (a tracking window is a dozen arrays of a few hundred
+    // bytes: a dozen pageable copies cost more than the solve); the copy is ordered before the solve on the ctx stream, nobody waits
+    struct Part { const void* src; size_t bytes; };
     int off2[2] = {0, L};
-    Part parts[12] = {
-        {w->states, sizeof(double) * n * 15, 0}, {off2, sizeof(off2), 0}, {w->laser_frame, sizeof(int) * (size_t)L, 0},
-        {nullptr, sizeof(double) * 12 * (size_t)L, 0},   // laser_pts: transposed to component-major below
-        {w->match_pose, sizeof(double) * n * 12, 0}, {w->has_match, (size_t)n, 0},
-        {w->imu_X, sizeof(double) * (n - 1) * 15, 0}, {w->imu_J, sizeof(double) * (n - 1) * 225, 0},
-        {w->imu_sqrtP, sizeof(double) * (n - 1) * 225, 0}, {w->imu_Dt, sizeof(double) * (n - 1), 0},
-        {w->wheel_T, sizeof(double) * (n - 1) * 12, 0}, {w->wheel_sqrtP, sizeof(double) * (n - 1) * 9, 0},
+    const Part parts[12] = {
+        {w->states, sizeof(double) * n * 15}, {off2, sizeof(off2)}, {w->laser_frame, sizeof(int) * (size_t)L},
+        {nullptr, sizeof(double) * 12 * (size_t)L},   // laser_pts: transposed to component-major below
+        {w->match_pose, sizeof(double) * n * 12}, {w->has_match, (size_t)n},
+        {w->imu_X, sizeof(double) * (n - 1) * 15}, {w->imu_J, sizeof(double) * (n - 1) * 225},
+        {w->imu_sqrtP, sizeof(double) * (n - 1) * 225}, {w->imu_Dt, sizeof(double) * (n - 1)},
+        {w->wheel_T, sizeof(double) * (n - 1) * 12}, {w->wheel_sqrtP, sizeof(double) * (n - 1) * 9},
     };
-    size_t tot = 0;
-    for (auto& pt : parts) { pt.off = tot; tot = al256(tot + (pt.bytes ? pt.bytes : 8)); }
-    const size_t readback = al256(sizeof(liw_summary)) + al256(sizeof(double) * n * 27) + 256;
-    if (c->arena.ensure(tot)) return fail(c, LIW_ENOMEM, "hipMalloc");
-    if (c->pinned_cap < tot + readback) {
+    size_t off[12], tot = 0;
+    for (int k = 0; k < 12; ++k) { off[k] = tot; tot = al256(tot + (parts[k].bytes ? parts[k].bytes : 8)); }
+    const size_t readback = al256(sizeof(double) * (LIW_RESULT_HDR + (size_t)n * 27 + 276));
+    if (c->img_cap < tot || c->readback_cap < readback) {
+        (void)hipStreamSynchronize(c->stream);   // an upload out of the old block may still be in flight
         if (c->pinned) (void)hipHostFree(c->pinned);
-        c->pinned = nullptr; c->pinned_cap = 0;
-        if (hipHostMalloc(&c->pinned, (tot + readback) * 2, hipHostMallocDefault) != hipSuccess) return fail(c, LIW_ENOMEM, "hipHostMalloc");
-        c->pinned_cap = (tot + readback) * 2;
+        c->pinned = nullptr; c->img_cap = c->readback_cap = c->pinned_cap = 0; c->img_valid = false;
+        const size_t ic = std::max(tot * 2, (size_t)65536), rc = std::max(readback * 2, (size_t)8192);
+        if (hipHostMalloc(&c->pinned, 2 * ic + rc, hipHostMallocDefault) != hipSuccess) return fail(c, LIW_ENOMEM, "hipHostMalloc");
+        c->img_cap = ic; c->readback_cap = rc; c->pinned_cap = 2 * ic + rc;
     }
-    char* stage = (char*)c->pinned;
+    const int stage_id = c->img_valid ? 1 - c->img_cur : 0;
+    char* stage = (char*)c->pinned + (size_t)stage_id * c->img_cap;
+    // `stage` was the source of the upload two calls ago; uploads are ordered on the ctx stream and the latest one carries ev_upload
+    if (c->ev_upload) (void)hipEventSynchronize(c->ev_upload);
     for (int k = 0; k < 12; ++k) {
         if (k == 3) {
-            double* soa = (double*)(stage + parts[k].off);
+            double* soa = (double*)(stage + off[k]);
             for (int j = 0; j < L; ++j) for (int q = 0; q < 12; ++q) soa[(size_t)q * L + j] = w->laser_pts[(size_t)j * 12 + q];
         } else if (parts[k].bytes) {
-            std::memcpy(stage + parts[k].off, parts[k].src, parts[k].bytes);
+            std::memcpy(stage + off[k], parts[k].src, parts[k].bytes);
         }
     }
+    // the same bytes as the device already holds (the lvio_2d::solver shim flattens the frames again for marginalization()):
+    // nothing to upload, and what liw_solve left behind — history, the speculative marginalisation — stays valid
+    bool same = c->img_valid && c->n == n && c->L == L;
+    if (same) {
+        const char* cur = (const char*)c->pinned + (size_t)c->img_cur * c->img_cap;
+        for (int k = 0; k < 12 && same; ++k)
+            if (parts[k].bytes && std::memcmp(stage + off[k], cur + off[k], parts[k].bytes) != 0) same = false;
+    }
+    if (same) { c->hw = *w; c->have_window = true; return LIW_OK; }
+    c->solved_records = 0;
+    c->spec_valid = false;
+    c->have_window = false;
+    if (c->arena.ensure(tot)) return fail(c, LIW_ENOMEM, "hipMalloc");
     HIPCHK(c, hipMemcpyAsync(c->arena.p, stage, tot, hipMemcpyHostToDevice, c->stream));
+    if (c->ev_upload) HIPCHK(c, hipEventRecord(c->ev_upload, c->stream));
+    c->img_cur = stage_id; c->img_valid = true;
+    for (int k = 0; k < 12; ++k) { c->part_off[k] = off[k]; c->part_bytes[k] = parts[k].bytes; }
     char* dev = (char*)c->arena.p;
-    (void)nm;
     bool fresh_prior = c->prior_X.p == nullptr;
     if (c->prior_X.ensure(sizeof(double) * 15) || c->prior_J.ensure(sizeof(double) * 225) || c->prior_R.ensure(sizeof(double) * 15) ||
-        c->has_prior.ensure(sizeof(int)))
+        c->has_prior.ensure(sizeof(int)) || c->priorn_X.ensure(sizeof(double) * 15) || c->priorn_J.ensure(sizeof(double) * 225) ||
+        c->priorn_R.ensure(sizeof(double) * 15) || c->has_priorn.ensure(sizeof(int)) || c->marg_status.ensure(sizeof(int)) ||
+        c->result.ensure(sizeof(double) * (LIW_RESULT_HDR + (size_t)n * 27 + 276)))
         return fail(c, LIW_ENOMEM, "hipMalloc");
     if (fresh_prior) {
         HIPCHK(c, hipMemsetAsync(c->prior_X.p, 0, sizeof(double) * 15, c->stream));
@@ -629,21 +675,20 @@ int liw_set_window(liw_ctx* c, const liw_window* w) {
     c->hist_records = 64;
     FullLayout f = full_layout(1, n, c->hist_records);
     if (c->ws.ensure(f.bytes)) return fail(c, LIW_ENOMEM, "hipMalloc workspace");
-    HIPCHK(c, hipStreamSynchronize(c->stream));
     c->hw = *w; c->have_window = true; c->n = n; c->L = L;
     liw_batch& b = c->sb;
     b.B = 1; b.n = n; b.Ltot = L;
-    b.x = (double*)(dev + parts[0].off); b.laser_off = (int*)(dev + parts[1].off); b.laser_frame = (int*)(dev + parts[2].off);
-    b.laser_pts = (double*)(dev + parts[3].off); b.match_pose = (double*)(dev + parts[4].off); b.has_match = (unsigned char*)(dev + parts[5].off);
-    b.imu_X = (double*)(dev + parts[6].off); b.imu_J = (double*)(dev + parts[7].off); b.imu_sqrtP = (double*)(dev + parts[8].off);
-    b.imu_Dt = (double*)(dev + parts[9].off); b.wheel_T = (double*)(dev + parts[10].off); b.wheel_sqrtP = (double*)(dev + parts[11].off);
-    c->off_x = tot; c->off_mp = tot;   // read-back slots live behind the staging image (see download_states)
+    b.x = (double*)(dev + off[0]); b.laser_off = (int*)(dev + off[1]); b.laser_frame = (int*)(dev + off[2]);
+    b.laser_pts = (double*)(dev + off[3]); b.match_pose = (double*)(dev + off[4]); b.has_match = (unsigned char*)(dev + off[5]);
+    b.imu_X = (double*)(dev + off[6]); b.imu_J = (double*)(dev + off[7]); b.imu_sqrtP = (double*)(dev + off[8]);
+    b.imu_Dt = (double*)(dev + off[9]); b.wheel_T = (double*)(dev + off[10]); b.wheel_sqrtP = (double*)(dev + off[11]);
     b.prior_X = c->prior_X.as<double>(); b.prior_J = c->prior_J.as<double>(); b.prior_R = c->prior_R.as<double>(); b.has_prior = c->has_prior.as<int>();
     b.eval_small = 1; b.history_records = c->hist_records;
     return LIW_OK;
 }
 /* Forget the uploaded window: afterwards every window-level call fails with LIW_ESTATE until the next liw_set_window.  For callers
- * (the lvio_2d::solver shim) whose flat arrays die with the calling scope, so that the ctx never holds dangling host pointers. */
+ * (the lvio_2d::solver shim) whose flat arrays die with the calling scope, so that the ctx never holds dangling host pointers.
+ * The device copy stays: a liw_set_window with the same bytes re-attaches to it (and to a speculative marginalisation result). */
 int liw_clear_window(liw_ctx* c) {
     if (!c) return LIW_EINVAL;
     c->have_window = false;
@@ -658,17 +703,6 @@ int liw_clear_window(liw_ctx* c) {
         HIPCHK(c, hipSetDevice((c)->prm.device));                                           \
     } while (0)
 
-static int download_states(liw_ctx* c) {
-    // page-locked read-back slots behind the staging image: [summary | states | match_pose]
-    char* rb = (char*)c->pinned + c->off_x + al256(sizeof(liw_summary));
-    HIPCHK(c, hipMemcpyAsync(rb, c->sb.x, sizeof(double) * c->n * 15, hipMemcpyDeviceToHost, c->stream));
-    HIPCHK(c, hipMemcpyAsync(rb + sizeof(double) * c->n * 15, c->sb.match_pose, sizeof(double) * c->n * 12, hipMemcpyDeviceToHost, c->stream));
-    HIPCHK(c, hipStreamSynchronize(c->stream));
-    std::memcpy(c->hw.states, rb, sizeof(double) * c->n * 15);
-    std::memcpy(c->hw.match_pose, rb + sizeof(double) * c->n * 15, sizeof(double) * c->n * 12);
-    return LIW_OK;
-}
-
 int liw_solve(liw_ctx* c, int mode, int max_iters, liw_summary* summary) {
     NEEDWIN(c);
     if (mode != LIW_MODE_INIT && mode != LIW_MODE_TRACK) return fail(c, LIW_EINVAL, "liw_solve: mode must be LIW_MODE_INIT or LIW_MODE_TRACK");
@@ -679,48 +713,84 @@ int liw_solve(liw_ctx* c, int mode, int max_iters, liw_summary* summary) {
         return fail(c, LIW_EINVAL, "init topology: frame 0 must not own laser blocks (duplicate parameter blocks)");
     int K = resolve_iters(c, mode, max_iters);
     c->solved_records = 0;
+    c->spec_valid = false;
     if (K + 1 > c->hist_records) {   // grow the history region
         c->hist_records = K + 1;
         c->sb.history_records = c->hist_records;
         FullLayout f = full_layout(1, c->n, c->hist_records);
         if (c->ws.ensure(f.bytes)) return fail(c, LIW_ENOMEM, "hipMalloc workspace");
     }
-    // Same launch sequence as liw_batch_solve (lin, K x [step, lin], step, finish), enqueued in growing chunks with a
-    // 4-byte read-back of the window's `done` flag in between: a tracking solve converges in a few iterations, and 50
-    // iterations' worth of no-op launches would cost milliseconds.  Launches skipped after `done` are exactly the ones
-    // whose kernels return immediately, so the result is identical.
+    // Same launch sequence as liw_batch_solve (lin, K x [step, lin], step, finish), enqueued in growing chunks.  Every chunk ends with
+    // the write-backs (k_lm_finish reads the LM state as it is; its result only counts once the window is done) and ONE packed
+    // read-back record, so a tracking solve that converges inside the first chunk costs one submission and one synchronisation.
+    // Launches enqueued behind the terminating step are exactly the ones whose kernels return immediately: same result.
+    // TRACK solves also enqueue the marginalisation the reference runs next (trajectory.cpp:548-559: solver.solve();
+    // solver.marginalization();) behind the solve, gated on the device by the window's `done` flag: its outputs wait in the read-back
+    // record and its prior in a second set of buffers until liw_marginalize asks for them (or a new window / prior drops them).
+    const bool spec = c->spec_marg && mode == LIW_MODE_TRACK && !c->prm.fast_mode && c->n >= 2;
+    const size_t rdoubles = LIW_RESULT_HDR + (size_t)c->n * 27 + 276;
+    char* rb = (char*)c->pinned + 2 * c->img_cap;
     {
         c->last_iters = K;
         const liw_batch* b = &c->sb;
         hipStream_t s = c->stream;
         WsView v = make_view(c->ws.p, 1, c->n, b->history_records);
-        launch_group_offsets(1, c->n, b->laser_off, b->laser_frame, v.group_off, s);
-        launch_lm_begin(1, c->n, v.lm, K, s);
+        launch_begin_all(1, c->n, b->laser_off, b->laser_frame, v.group_off, v.lm, K, s);
         StepArgs st = step_args(c, b, mode, K, v);
         auto lin = [&](int cand) {
             LinArgs A = lin_args(b, mode, cand ? v.x_cand : b->x, v, cand, true);
             launch_linearize(A, c->dp, s, c->have_fork ? &c->fork : nullptr);
         };
-        int* done_flag = (int*)((char*)c->pinned + c->off_x + al256(sizeof(liw_summary)) + al256(sizeof(double) * c->n * 27));
-        *done_flag = 0;
+        double* res = c->result.as<double>();
+        double* marg_out = res + LIW_RESULT_HDR + (size_t)c->n * 27;
+        PackArgs pk{};
+        pk.n = c->n; pk.lm = v.lm; pk.info = v.info; pk.x = b->x; pk.match_pose = b->match_pose;
+        pk.marg = nullptr; pk.marg_status = spec ? c->marg_status.as<int>() : nullptr; pk.out = res;
         lin(0);
         int k = 0, chunk = 4;
-        while (k < K && !*done_flag) {
+        bool done = false;
+        while (!done) {
             const int m = std::min(chunk, K - k);
             for (int i = 0; i < m; ++i) { launch_lm_step(st, s); lin(1); }
             k += m;
-            HIPCHK(c, hipMemcpyAsync(done_flag, &v.lm[0].done, sizeof(int), hipMemcpyDeviceToHost, s));
+            if (k >= K) launch_lm_step(st, s);   // takes the last candidate / meets the iteration cap
+            launch_lm_finish(st, s);
+            if (spec) {
+                LinArgs A = lin_args(b, LIW_MODE_MARG, b->x, v, 0, false);
+                A.gate = v.lm;
+                launch_linearize(A, c->dp, s, c->have_fork ? &c->fork : nullptr);
+                MargArgs a{};
+                a.B = 1; a.n = c->n; a.x = b->x;
+                a.prior_X = b->prior_X; a.prior_J = b->prior_J; a.prior_R = b->prior_R; a.has_prior = b->has_prior;
+                a.out_X = c->priorn_X.as<double>(); a.out_J = c->priorn_J.as<double>(); a.out_R = c->priorn_R.as<double>(); a.out_has = c->has_priorn.as<int>();
+                a.w = v; a.sqrt_H = marg_out; a.Delta_H = marg_out + 36; a.Delta_g = marg_out + 36 + 225; a.status = c->marg_status.as<int>();
+                a.gate = v.lm;
+                launch_marg_schur(a, s);
+            }
+            launch_pack_result(pk, s);
+            HIPCHK(c, hipGetLastError());
+            HIPCHK(c, hipMemcpyAsync(rb, res, sizeof(double) * rdoubles, hipMemcpyDeviceToHost, s));
             HIPCHK(c, hipStreamSynchronize(s));
+            done = ((const int*)rb)[0] != 0;
+            if (!done && k >= K) return fail(c, LIW_EHIP, "liw_solve: the window did not terminate within its iteration cap");
             chunk *= 2;
         }
-        if (!*done_flag) launch_lm_step(st, s);
-        launch_lm_finish(st, s);
-        HIPCHK(c, hipGetLastError());
     }
-    FullLayout f = full_layout(1, c->n, c->hist_records);
-    liw_summary* sp = (liw_summary*)((char*)c->pinned + c->off_x);
-    HIPCHK(c, hipMemcpyAsync(sp, (char*)c->ws.p + f.info, sizeof(liw_summary), hipMemcpyDeviceToHost, c->stream));
-    if (int r = download_states(c)) return r;
+    const int* hdr = (const int*)rb;
+    const liw_summary* sp = (const liw_summary*)(rb + 16);
+    const double* xs = (const double*)rb + LIW_RESULT_HDR;
+    const double* mp = xs + (size_t)c->n * 15;
+    std::memcpy(c->hw.states, xs, sizeof(double) * c->n * 15);
+    std::memcpy(c->hw.match_pose, mp, sizeof(double) * c->n * 12);
+    {   // the staging image keeps mirroring the device
+        char* img = (char*)c->pinned + (size_t)c->img_cur * c->img_cap;
+        std::memcpy(img + c->part_off[0], xs, sizeof(double) * c->n * 15);
+        std::memcpy(img + c->part_off[4], mp, sizeof(double) * c->n * 12);
+    }
+    if (spec && hdr[1] == 0) {
+        std::memcpy(c->spec_out, mp + (size_t)c->n * 12, sizeof(c->spec_out));
+        c->spec_valid = true;
+    }
     if (summary) *summary = *sp;
     c->solved_records = std::max(0, std::min(sp->iterations + 1, c->hist_records));
     return LIW_OK;
@@ -782,6 +852,16 @@ int liw_marginalize(liw_ctx* c, double* sqrt_H36, double* Delta_H225, double* De
     NEEDWIN(c);
     if (c->prm.fast_mode) return LIW_OK;   // solver.cpp:259-260
     if (c->n < 2) return fail(c, LIW_EINVAL, "liw_marginalize: needs n >= 2");
+    if (c->spec_valid) {   // computed behind the solve of this very window (liw_solve): hand it over and make its prior the live one
+        c->spec_valid = false;
+        if (sqrt_H36) std::memcpy(sqrt_H36, c->spec_out, sizeof(double) * 36);
+        if (Delta_H225) std::memcpy(Delta_H225, c->spec_out + 36, sizeof(double) * 225);
+        if (Delta_g15) std::memcpy(Delta_g15, c->spec_out + 36 + 225, sizeof(double) * 15);
+        std::swap(c->prior_X, c->priorn_X); std::swap(c->prior_J, c->priorn_J); std::swap(c->prior_R, c->priorn_R); std::swap(c->has_prior, c->has_priorn);
+        c->sb.prior_X = c->prior_X.as<double>(); c->sb.prior_J = c->prior_J.as<double>();
+        c->sb.prior_R = c->prior_R.as<double>(); c->sb.has_prior = c->has_prior.as<int>();
+        return LIW_OK;
+    }
     if (c->scratch.ensure(sizeof(double) * (36 + 225 + 15))) return fail(c, LIW_ENOMEM, "hipMalloc");
     double* d = c->scratch.as<double>();
     if (int r = liw_batch_marg_linearize(c, &c->sb, c->ws.p, c->stream)) return r;
@@ -806,6 +886,7 @@ int liw_get_prior(liw_ctx* c, double* X15, double* J225, double* R15) {
     return 1;
 }
 int liw_set_prior(liw_ctx* c, int has_prior, const double* X15, const double* J225, const double* R15) {
+    if (c) c->spec_valid = false;
     NEEDDEV(c);
     HIPCHK(c, hipSetDevice(c->prm.device));
     if (c->prior_X.ensure(sizeof(double) * 15) || c->prior_J.ensure(sizeof(double) * 225) || c->prior_R.ensure(sizeof(double) * 15) ||

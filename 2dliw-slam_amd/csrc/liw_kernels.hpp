@@ -79,6 +79,7 @@ struct LinArgs {
     const double* wheel_T; const double* wheel_sqrtP;
     double* PL[2]; double* PI[2]; double* PW[2]; double* PG[2];   // partial buffers: window b writes buffer lm[b].cur (candidate: the other one)
     const LmState* lm;          // null (buffer 0, no skipping), or per-window state: done windows skip
+    const LmState* gate;        // non-null: linearise window b only if gate[b].done (a marginalisation enqueued speculatively behind a solve)
     int candidate;              // 1: write the small-factor partials of window b into buffer 1 - lm[b].cur
     int small_per_wave;         // IMU / wheel blocks per wave (set by launch_linearize)
     int* active;                // [1 + B]: number of windows still iterating, then their ids (built per linearisation when lm != null)
@@ -122,6 +123,13 @@ __host__ __device__ inline int laser_slot_code(int s) {
     return src < 0 ? -1 : (src | (neg ? 64 : 0));
 }
 struct LaserPackTable { short slot[45]; unsigned char neg[45]; };   // representative record slot (and sign) of every pair total
+
+// is window b linearised by this launch?  (with a compacted `active` list the roles index live windows only and skip this test)
+__device__ __forceinline__ bool window_live(const LinArgs& A, int b) {
+    if (A.gate) return A.gate[b].done != 0;
+    if (A.lm) return A.lm[b].done == 0;
+    return true;
+}
 
 // side streams + events used to run the independent role kernels of one linearisation concurrently
 struct LinFork {

@@ -127,3 +127,97 @@ def test_two_frame_tracking_chain_with_carried_prior(liw, synth, pyoracle, env):
         Xo, Jo, _ = orc.get_prior()
         assert rel_inf(Xg, Xo) <= 1e-6 and rel_inf(Jg.T @ Jg, Jo.T @ Jo) <= 1e-6
         prev_g, prev_o = wg["states"].reshape(2, 15)[1].copy(), wo["states"].reshape(2, 15)[1].copy()
+
+
+def _two_frame_windows(synth, orc, prm, seed=515):
+    d = synth.make_window(orc, prm, seed=seed, n=3, L=150)
+
+    def sub(lo):
+        o = dict(d)
+        o["n"] = 2
+        for k in ("states", "match_pose"):
+            o[k] = np.asarray(d[k]).reshape(3, -1)[lo:lo + 2].copy()
+        o["has_match"] = np.asarray(d["has_match"])[lo:lo + 2].copy()
+        for k in ("imu_X", "imu_J", "imu_sqrtP", "imu_Dt", "wheel_T", "wheel_sqrtP", "wheel_Dt"):
+            o[k] = np.asarray(d[k])[lo:lo + 1].copy()
+        m = (np.asarray(d["laser_frame"]) >= lo) & (np.asarray(d["laser_frame"]) < lo + 2)
+        o["laser_frame"] = (np.asarray(d["laser_frame"])[m] - lo).astype(np.int32)
+        o["laser_pts"] = np.asarray(d["laser_pts"])[m].copy()
+        return o
+    return sub(0), sub(1)
+
+
+def test_marginalisation_enqueued_behind_the_solve_is_the_marginalisation(liw, synth, env, monkeypatch):
+    """liw_solve(TRACK) enqueues the marginalisation the reference runs next behind the solve (one submission, one read-back);
+    liw_marginalize then hands the stored result over.  Must equal, bit for bit, the same calls with that turned off
+    (LIW_NO_SPEC_MARG, read at liw_create), and a solve that is NOT followed by liw_marginalize must leave the prior alone."""
+    prm, orc = env
+    w01, w12 = _two_frame_windows(synth, orc, prm)
+    out = []
+    for off in (False, True):
+        if off:
+            monkeypatch.setenv("LIW_NO_SPEC_MARG", "1")
+        else:
+            monkeypatch.delenv("LIW_NO_SPEC_MARG", raising=False)
+        slv = liw.Solver(prm)
+        slv.set_prior(None)
+        rec = []
+        for d in (w01, w12):
+            w = liw.Window(d)
+            slv.set_window(w)
+            s = slv.solve()
+            before = slv.get_prior()
+            m = slv.marginalization()
+            X, J, R = slv.get_prior()
+            rec.append((s["iterations"], w["states"].copy(), w["match_pose"].copy(), m["sqrt_H"], m["Delta_H"], m["Delta_g"], X, J, R))
+            if d is w12:                                # the solve alone did not touch the live prior
+                assert before is not None and np.array_equal(before[1], rec[0][7])
+        # a second marginalisation of the same window runs the kernels again (nothing stored any more) on the NEW prior
+        m2 = slv.marginalization()
+        assert np.isfinite(m2["Delta_H"]).all()
+        out.append(rec)
+        slv.close()
+    for a, b in zip(out[0], out[1]):
+        assert a[0] == b[0]
+        for x, y in zip(a[1:], b[1:]):
+            assert np.array_equal(x, y)
+
+
+def test_same_window_again_reattaches_a_different_one_does_not(liw, synth, env):
+    """The lvio_2d::solver shim flattens the frames again for marginalization(): a liw_set_window with the bytes the device already
+    holds (the solved states folded in) keeps the history and the stored marginalisation; different bytes drop both."""
+    prm, orc = env
+    w01, w12 = _two_frame_windows(synth, orc, prm, seed=77)
+    ref = liw.Solver(prm)
+    ref.set_prior(None)
+    wr = liw.Window(w01)
+    ref.set_window(wr)
+    ref.solve()
+    mr = ref.marginalization()
+    slv = liw.Solver(prm)
+    slv.set_prior(None)
+    w = liw.Window(w01)
+    slv.set_window(w)
+    s = slv.solve()
+    again = {k: w[k].copy() for k in w.a}
+    again["n"] = 2
+    slv.L.liw_clear_window(slv.h)
+    slv.set_window(liw.Window(again))                   # same bytes as the device holds now
+    m = slv.marginalization()
+    for k in ("sqrt_H", "Delta_H", "Delta_g"):
+        assert np.array_equal(m[k], mr[k])
+    assert np.array_equal(slv.get_prior()[1], ref.get_prior()[1])
+    # different bytes: the stored result of a new solve is dropped, liw_marginalize computes on what was uploaded
+    slv.set_prior(None)
+    w2 = liw.Window(w01)
+    slv.set_window(w2)
+    slv.solve()
+    moved = {k: w2[k].copy() for k in w2.a}
+    moved["n"] = 2
+    moved["states"].reshape(-1)[15] += 1e-3             # newest frame 1 mm away from where the solve left it
+    slv.set_window(liw.Window(moved))
+    with pytest.raises(liw.LiwError):
+        slv.history()
+    m3 = slv.marginalization()
+    assert not np.array_equal(m3["Delta_g"], mr["Delta_g"])
+    assert s["iterations"] >= 1
