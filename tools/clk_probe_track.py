@@ -50,3 +50,4 @@ for i in (1, 0):
     print(" frame", i, "assemble", t[1] - t[0], "diag/gmax", t[2] - t[1], "colload", t[3] - t[2], "chol", t[4] - t[3], "ldsW", t[5] - t[4],
           "mfma+record+C", (clk[10 + (i - 1) * 8] if i else clk[1]) - t[5])
 print("k_marg_schur: chain %d | eigen %d | tail %d" % (d(5000, 5001), d(5001, 5002), d(5002, 5003)))
+print("eig15_ql: load+tridiag %d | store Q %d | QL %d  (rotations %d, sweeps %d, inner loops %d ticks)" % (d(5001, 5020), d(5020, 5021), d(5021, 5022), clk[5023], clk[5024], clk[5025]))
