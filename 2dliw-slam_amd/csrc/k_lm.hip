@@ -172,6 +172,21 @@ struct AsmRegs {
     double xq, sc_i, sc_m, dg_i;            // state entries, Jacobi scales, LM diagonal
     double e1[2], e2;                       // upward sweep, frame 1 only: H[frame 0 pose, frame 1] of the IMU / wheel block (0,1)
 };
+// frame n-2 with a prior: linearized_jacobians (this lane's elements of the 16x16 tile), x - linearized_X.  Kept out of AsmRegs: the
+// throughput instantiation of k_lm_step has no registers to spare and loads them inside asm_commit instead.
+struct PriorRegs { double pj[4], pdx; };
+__device__ __forceinline__ PriorRegs prior_issue(const AsmCtx& c, int lane) {
+    PriorRegs P;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const int e = lane + 64 * q, r = e >> 4, cc = e & 15;
+        P.pj[q] = (r < 15 && cc < 15) ? c.pJ[r * 15 + cc] : 0.0;
+    }
+    const int v = lane < 15 ? lane : 0;
+    P.pdx = c.x[(size_t)(c.n - 2) * 15 + v] - c.pX[v];
+    return P;
+}
+constexpr int ASM_TMP = 16 + 256 + 16;      // asm_commit scratch: r_prior (16) | prior J as a 16x16 tile | x - X (16)
 
 // All loads of a frame are issued up front, branch-free (clamped addresses; masking happens in asm_commit), so the
 // wave pays ONE memory round trip per frame instead of one per conditional term.
@@ -241,10 +256,11 @@ __device__ __forceinline__ AsmRegs asm_issue(const AsmCtx& c, int i, const doubl
     return R;
 }
 
+__device__ __forceinline__ d4 xty16(const double* X, const double* Y);
 // Combine the loaded values into frame i's blocks (ambient -> tangent, constants masked), UNSCALED.
 template <int LAYOUT>
 __device__ void asm_commit(const AsmCtx& c, int i, const AsmRegs& R, const Tiles<LAYOUT>& T_, double* tmp, FrameExtra* ex = nullptr,
-                           int lane = threadIdx.x & 63, int dir = -1) {
+                           int lane = threadIdx.x & 63, int dir = -1, const PriorRegs* pr = nullptr) {
     const int n = c.n;
     const double* PLb = c.PL + (size_t)c.b * n * LP;
     const bool hasm = i >= 1, hasp = i <= n - 2;
@@ -252,8 +268,22 @@ __device__ void asm_commit(const AsmCtx& c, int i, const AsmRegs& R, const Tiles
     const int nbf = up ? (hasp ? i + 1 : i) : (hasm ? i - 1 : i);
     const bool arrow1 = up && i == 1;   // upward sweep: frame 1 is tied to the hub (frame 0's pose) by the IMU / wheel block (0,1) too
     const bool prior_here = c.prior_on && i == n - 2;
-    if (prior_here) {   // stage r_prior
-        if (lane < 15) tmp[lane] = prior_r(c, lane);
+    d4 jtj = {0.0, 0.0, 0.0, 0.0};
+    double* Jt = tmp + 16;       // linearized_jacobians as a zero-padded 16x16 tile
+    double* dxp = tmp + 272;     // x - linearized_X
+    if (prior_here) {   // r_prior = J (x - X) into tmp[0..14]; J^T J on the matrix cores (element layout = the one of the loop below)
+        const PriorRegs P_ = pr ? *pr : prior_issue(c, lane);   // pr: issued by the caller one frame ahead, with the partial sums
+#pragma unroll
+        for (int q = 0; q < 4; ++q) Jt[lane + 64 * q] = P_.pj[q];
+        if (lane < 16) dxp[lane] = lane < 15 ? P_.pdx : 0.0;
+        lds_sync();
+        if (lane < 15) {
+            double sp = 0.0;
+#pragma unroll
+            for (int j = 0; j < 15; ++j) sp += Jt[lane * 16 + j] * dxp[j];
+            tmp[lane] = sp;
+        }
+        jtj = xty16(Jt, Jt);
         lds_sync();
     }
     double dI[4], oI[4];
@@ -309,13 +339,18 @@ __device__ void asm_commit(const AsmCtx& c, int i, const AsmRegs& R, const Tiles
         const int r = e >> 4, cc = e & 15;
         const bool valid = r < 15 && cc < 15;
         double d = dI[q];
-        if (prior_here && valid) { double sp = 0.0; for (int k = 0; k < 15; ++k) sp += c.pJ[k * 15 + r] * c.pJ[k * 15 + cc]; d += sp; }
+        if (prior_here && valid) d += jtj[q];
         if (LAYOUT == 0) { T_.D[e] = valid ? d : 0.0; T_.O[e] = valid ? oI[q] : 0.0; T_.R[e] = 0.0; }
         else if (valid) { T_.d(r, cc) = d; T_.o(r, cc) = oI[q]; if (r < 6) T_.rr(r, cc) = 0.0; }
     }
     if (lane < 16) {
         double g = lane < 15 ? gg : 0.0;
-        if (prior_here && lane < 15) { double sp = 0.0; for (int k = 0; k < 15; ++k) sp += c.pJ[k * 15 + lane] * tmp[k]; g += sp; }
+        if (prior_here && lane < 15) {
+            double sp = 0.0;
+#pragma unroll
+            for (int k = 0; k < 15; ++k) sp += Jt[k * 16 + lane] * tmp[k];
+            g += sp;
+        }
         if (LAYOUT == 0) T_.g[lane] = g; else if (lane < 15) T_.gg(lane) = g;
     }
     lds_sync();
@@ -450,7 +485,7 @@ __device__ __forceinline__ d4 xty15(const double* X, const double* Y, const doub
 
 struct LdsTiles {   // export / marginalisation kernels (tile layout)
     double D[256], O[256], R[256], W[256], Wa[256], CD[256], CR[256];
-    double g[16], Cg[16], y0[16], yprev[16], tmp[16], D0acc[36], g0acc[8], sci[16], scm[16], sc0[16], dgi[16];
+    double g[16], Cg[16], y0[16], yprev[16], tmp[ASM_TMP], D0acc[36], g0acc[8], sci[16], scm[16], sc0[16], dgi[16];
 };
 struct LdsStep {    // k_lm_step (lane layout): M = assembled frame, C = carried Schur terms
     // The MFMA operand tiles live in M's storage (M is dead once the lanes hold their columns): W = L^-1 [O^T | g] (15 rows,
@@ -458,7 +493,7 @@ struct LdsStep {    // k_lm_step (lane layout): M = assembled frame, C = carried
     // 15 immediate offsets (ONE masked store per row).  Their 16th row (k = 15) is the shared zero row Z; columns a product does
     // not use may hold stale words (each output depends on one column of either operand only).
     double M[720], C[15 * MS], Z[16];
-    double tmp[16], D0acc[36], g0acc[8];
+    double tmp[ASM_TMP], D0acc[36], g0acc[8];
 };
 constexpr int LW = 0, LLI = 240, LWA = 480;   // offsets of W / Li / Wa inside LdsStep::M
 
@@ -639,6 +674,7 @@ __global__ __launch_bounds__(64, THROUGHPUT ? 3 : 2) void k_lm_step(StepArgs a) 
     STAMP(0); SPAN(0);
     const Tiles<1> TM{T.M, nullptr, nullptr, nullptr};
     AsmRegs areg;
+    PriorRegs preg;
     if constexpr (LIW_PF1) areg = asm_issue(c, n - 1, scl, dgl);
     for (int i = n - 1; i >= 0; --i) {
         STAMP(10 + i * 8 + 0);
@@ -648,7 +684,7 @@ __global__ __launch_bounds__(64, THROUGHPUT ? 3 : 2) void k_lm_step(StepArgs a) 
         asm volatile("" : "+v"(ln));
         FrameExtra ex;
         if constexpr (!LIW_PF1) areg = asm_issue(c, i, scl, dgl, ln);
-        asm_commit<1>(c, i, areg, TM, T.tmp, &ex, ln);
+        asm_commit<1>(c, i, areg, TM, T.tmp, &ex, ln, -1, (LIW_PF1 && c.prior_on && i == n - 2) ? &preg : nullptr);
         STAMP(10 + i * 8 + 1);
         // LM diagonal of this frame (LevenbergMarquardtStrategy::ComputeStep), |x - Plus(x,-g)|
         const bool cstl = ln < 15 && var_is_const(a.mode, a.fast_mode, n, i, ln);
@@ -712,6 +748,7 @@ __global__ __launch_bounds__(64, THROUGHPUT ? 3 : 2) void k_lm_step(StepArgs a) 
         if constexpr (LIW_PF1) {
         __builtin_amdgcn_sched_barrier(0);
         if (i > 0) areg = asm_issue(c, i - 1, scl, dgl, ln);
+        if (c.prior_on && i - 1 == n - 2) preg = prior_issue(c, ln);
         __builtin_amdgcn_sched_barrier(0);
         }
         // lanes 41..55 carry the unit vectors: the fused pass leaves the columns of L^-1 in them
@@ -900,7 +937,7 @@ __global__ __launch_bounds__(64, THROUGHPUT ? 3 : 2) void k_lm_step(StepArgs a) 
 // sweeps carry the same 6-wide arrow as before and the upward sweep creates no wider fill.  Back substitution runs hub -> m -> both
 // halves outwards, again one half per wave.  Same arithmetic as k_lm_step up to the order of the Schur updates (round-off).
 struct LdsTwSide {               // one sweep: a producer wave assembles / scales frame s+1 while the eliminator works on frame s
-    double PM[720], Ptmp[16];    // producer: assembled frame (lane layout of k_lm_step)
+    double PM[720], Ptmp[ASM_TMP];    // producer: assembled frame (lane layout of k_lm_step)
     double PT[2][15 * MS];       // prepared columns, double-buffered: S H S + D^2 of the frame in lane layout, constants / inert entries as unit pivots
     LdsStep T;                   // eliminator: MFMA operand tiles (T.M), carried Schur terms (T.C), hub accumulators
 };
