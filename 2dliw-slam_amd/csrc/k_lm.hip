@@ -44,8 +44,8 @@ __device__ long long g_span[3 * 16384];   // per window: start, end (s_memtime),
 
 constexpr int LIW_RESULT_HDR = 8;   // doubles: 4 ints, then liw_summary (32 bytes), padded
 struct PackArgs {
-    int n;
-    const LmState* lm; const liw_summary* info; const double* x; const double* match_pose;
+    int n, mode;
+    const LmState* lm; liw_summary* info; const double* x; double* match_pose; const unsigned char* has_match;
     const double* marg; const int* marg_status;   // null without a speculative marginalisation
     double* out;
 };
@@ -1397,9 +1397,26 @@ __global__ void k_begin_all(int B, int n, const int* laser_off, const int* laser
 // [done, marg status, -, - | liw_summary | states n*15 | match_pose n*12 | sqrt_H 36, Delta_H 225, Delta_g 15]
 __global__ void k_pack_result(PackArgs a) {
     const int t = threadIdx.x, n = a.n;
+    // the write-backs of k_lm_finish for this one window first (one launch less per tracking frame), then the record
+    if (t < n * 6) {
+        const int k = t % 6, i = t / 6;
+        if (a.mode == LIW_MODE_INIT) {
+            if (a.has_match[i]) { a.match_pose[i * 12 + k] = a.x[k]; a.match_pose[i * 12 + 6 + k] = a.x[(size_t)i * 15 + k]; }
+        } else if (a.mode == LIW_MODE_TRACK) {
+            if (i == n - 1 && a.has_match[i]) a.match_pose[i * 12 + 6 + k] = a.x[(size_t)i * 15 + k];
+        }
+    }
+    __syncthreads();
     int* hdr = reinterpret_cast<int*>(a.out);
     if (t == 0) { hdr[0] = a.lm[0].done; hdr[1] = a.marg_status ? a.marg_status[0] : 3; hdr[2] = 0; hdr[3] = 0; }
-    if (t == 1) *reinterpret_cast<liw_summary*>(a.out + 2) = a.info[0];
+    if (t == 1) {
+        const LmState& st = a.lm[0];
+        liw_summary o;
+        o.iterations = st.iteration; o.successful_steps = st.successful; o.termination = st.termination;
+        o.initial_cost = st.initial_cost; o.final_cost = st.x_cost;
+        *reinterpret_cast<liw_summary*>(a.out + 2) = o;
+        a.info[0] = o;
+    }
     double* o = a.out + LIW_RESULT_HDR;
     for (int e = t; e < n * 15; e += blockDim.x) o[e] = a.x[e];
     o += n * 15;
@@ -1739,7 +1756,7 @@ void launch_begin_all(int B, int n, const int* laser_off, const int* laser_frame
     const int tot = B * (n + 1);
     hipLaunchKernelGGL(k_begin_all, dim3((tot + 255) / 256), dim3(256), 0, s, B, n, laser_off, laser_frame, group_off, lm, max_iters);
 }
-void launch_pack_result(const PackArgs& a, hipStream_t s) { hipLaunchKernelGGL(k_pack_result, dim3(1), dim3(256), 0, s, a); }
+void launch_pack_result(const PackArgs& a, hipStream_t s) { hipLaunchKernelGGL(k_pack_result, dim3(1), dim3(512), 0, s, a); }
 void launch_lm_begin(int B, int n, LmState* lm, int max_iters, hipStream_t s) {
     hipLaunchKernelGGL(k_lm_begin, dim3((B + 63) / 64), dim3(64), 0, s, B, n, lm, max_iters);
 }

@@ -41,8 +41,8 @@ struct MargArgs {
 };
 constexpr int LIW_RESULT_HDR = 8;
 struct PackArgs {
-    int n;
-    const LmState* lm; const liw_summary* info; const double* x; const double* match_pose;
+    int n, mode;
+    const LmState* lm; liw_summary* info; const double* x; double* match_pose; const unsigned char* has_match;
     const double* marg; const int* marg_status;
     double* out;
 };
@@ -721,8 +721,9 @@ int liw_solve(liw_ctx* c, int mode, int max_iters, liw_summary* summary) {
         if (c->ws.ensure(f.bytes)) return fail(c, LIW_ENOMEM, "hipMalloc workspace");
     }
     // Same launch sequence as liw_batch_solve (lin, K x [step, lin], step, finish), enqueued in growing chunks.  Every chunk ends with
-    // the write-backs (k_lm_finish reads the LM state as it is; its result only counts once the window is done) and ONE packed
-    // read-back record, so a tracking solve that converges inside the first chunk costs one submission and one synchronisation.
+    // k_pack_result: the write-backs of k_lm_finish (they read the LM state as it is; the result only counts once the window is done)
+    // and ONE packed read-back record, so a tracking solve that converges inside the first chunk costs one submission and one
+    // synchronisation.
     // Launches enqueued behind the terminating step are exactly the ones whose kernels return immediately: same result.
     // TRACK solves also enqueue the marginalisation the reference runs next (trajectory.cpp:548-559: solver.solve();
     // solver.marginalization();) behind the solve, gated on the device by the window's `done` flag: its outputs wait in the read-back
@@ -744,17 +745,16 @@ int liw_solve(liw_ctx* c, int mode, int max_iters, liw_summary* summary) {
         double* res = c->result.as<double>();
         double* marg_out = res + LIW_RESULT_HDR + (size_t)c->n * 27;
         PackArgs pk{};
-        pk.n = c->n; pk.lm = v.lm; pk.info = v.info; pk.x = b->x; pk.match_pose = b->match_pose;
+        pk.n = c->n; pk.mode = mode; pk.lm = v.lm; pk.info = v.info; pk.x = b->x; pk.match_pose = b->match_pose; pk.has_match = b->has_match;
         pk.marg = nullptr; pk.marg_status = spec ? c->marg_status.as<int>() : nullptr; pk.out = res;
-        lin(0);
+        // (linearise, step) pairs: pair 0 linearises at the initial point, pair j > 0 at the candidate of step j.  K + 1 pairs in all
+        // (the last step takes the last candidate / meets the iteration cap); a solve of `it` iterations is done after it + 1 pairs.
         int k = 0, chunk = 4;
         bool done = false;
         while (!done) {
-            const int m = std::min(chunk, K - k);
-            for (int i = 0; i < m; ++i) { launch_lm_step(st, s); lin(1); }
+            const int m = std::min(chunk, K + 1 - k);
+            for (int i = 0; i < m; ++i) { lin(k + i > 0 ? 1 : 0); launch_lm_step(st, s); }
             k += m;
-            if (k >= K) launch_lm_step(st, s);   // takes the last candidate / meets the iteration cap
-            launch_lm_finish(st, s);
             if (spec) {
                 LinArgs A = lin_args(b, LIW_MODE_MARG, b->x, v, 0, false);
                 A.gate = v.lm;
@@ -772,7 +772,7 @@ int liw_solve(liw_ctx* c, int mode, int max_iters, liw_summary* summary) {
             HIPCHK(c, hipMemcpyAsync(rb, res, sizeof(double) * rdoubles, hipMemcpyDeviceToHost, s));
             HIPCHK(c, hipStreamSynchronize(s));
             done = ((const int*)rb)[0] != 0;
-            if (!done && k >= K) return fail(c, LIW_EHIP, "liw_solve: the window did not terminate within its iteration cap");
+            if (!done && k >= K + 1) return fail(c, LIW_EHIP, "liw_solve: the window did not terminate within its iteration cap");
             chunk *= 2;
         }
     }
