@@ -255,7 +255,7 @@ __device__ void imu_blocks(const LinArgs& A, const DevParams& P, int wave, doubl
         }
         LSTAMP(303);
     }
-    __syncthreads();
+    lds_sync();
     LSTAMP(304);
     // ---- matrix-core part, one block at a time (the whole wave cooperates).  Operand entry codes of this lane: x0 = column ml of
     // [J_raw wrt x_i | r_raw], x1 = column ml of [J_raw wrt x_j] for the four k-chunks (row kk = mk + 4c)
@@ -462,7 +462,7 @@ __device__ void wheel_blocks(const LinArgs& A, const DevParams& P, int wave, dou
             for (int qq = 0; qq < 9; ++qq) Y[49 + qq] = Rwi.m[qq];
         }
     }
-    __syncthreads();
+    lds_sync();
     if (on) {   // position columns: Y[r][p_j c] = sum_k Dp[r][k] R_wi[c][k],  Y[r][p_i c] = -Y[r][p_j c]   (row r = g of this lane)
 #pragma unroll
         for (int c = 0; c < 3; ++c) {
@@ -471,7 +471,7 @@ __device__ void wheel_blocks(const LinArgs& A, const DevParams& P, int wave, dou
             Y[g * 13 + c] = -v;
         }
     }
-    __syncthreads();
+    lds_sync();
     if (on && g == 0 && A.dbg_wheel_res)
         for (int r = 0; r < 3; ++r) A.dbg_wheel_res[fk * 3 + r] = Y[r * 13 + 12];
     if (on && A.dbg_wheel_jac)
@@ -484,7 +484,7 @@ __device__ void wheel_blocks(const LinArgs& A, const DevParams& P, int wave, dou
         meta[blk] = on ? (A.lm ? (A.candidate ? 1 - A.lm[b].cur : A.lm[b].cur) : 0) : -1;
         meta[32 + blk] = (int)fk;
     }
-    __syncthreads();
+    lds_sync();
     {
         const long gb0 = (long)wave * A.small_per_wave;
         const int nblk = (int)min((long)A.small_per_wave, total - gb0);
@@ -537,7 +537,7 @@ __device__ void ground_frames(const LinArgs& A, const DevParams& P, int wave, do
     }
     int* meta = reinterpret_cast<int*>(lds + GROUND_PER_WAVE * 16);
     if (g == 0) { meta[sub] = on ? (A.lm ? (A.candidate ? 1 - A.lm[b].cur : A.lm[b].cur) : 0) : -1; meta[32 + sub] = (int)fi; }
-    __syncthreads();
+    lds_sync();
     {   // n * Y^T Y (7 x 7 per frame; the block set is added once per outer frame index, solver.cpp:142-159), coalesced as in the wheel role
         const long gf0 = (long)wave * GROUND_PER_WAVE;
         const int nfr = (int)min((long)GROUND_PER_WAVE, total - gf0);

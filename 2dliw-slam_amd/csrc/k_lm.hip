@@ -42,34 +42,10 @@ __device__ long long g_span[3 * 16384];   // per window: start, end (s_memtime),
 #define SPAN(k) do { } while (0)
 #endif
 
-constexpr int LIW_RESULT_HDR = 8;   // doubles: 4 ints, then liw_summary (32 bytes), padded
-struct PackArgs {
-    int n, mode;
-    const LmState* lm; liw_summary* info; const double* x; double* match_pose; const unsigned char* has_match;
-    const double* marg; const int* marg_status;   // null without a speculative marginalisation
-    double* out;
-};
-struct StepArgs {
-    int B, n, mode, max_iters, fast_mode;
-    double* x;                   // [B][n][15] live states
-    double* match_pose;
-    const unsigned char* has_match;
-    const double* prior_X; const double* prior_J; const int* has_prior;
-    WsView w;
-};
 
 constexpr double kMinDiag = 1e-6, kMaxDiag = 1e32, kMinRelDec = 1e-3, kFuncTol = 1e-6, kGradTol = 1e-10, kParamTol = 1e-8;
 constexpr double kMaxRadius = 1e16, kMinRadius = 1e-32, kInitRadius = 1e4;
 constexpr double kPi = 3.141592653589793238462643383279, kTwoPi = 6.283185307179586476925286766559;
-
-// Work-groups here are ONE wavefront.  DS instructions of a wave execute in order, so a wave's LDS write is visible to
-// its later LDS reads from any lane without s_barrier / vmcnt drains; only compiler reordering has to be fenced.
-// (Global-memory hand-offs between lanes still use __syncthreads(), which drains vmcnt.)
-__device__ __forceinline__ void lds_sync() {
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-}
 
 // Cross-lane reductions on DPP row operations (v_mov_b32_dpp on both halves of the double): a row of 16 lanes in 4 steps, the four
 // rows joined by row_bcast:15 / :31, result broadcast from lane 63 — 175 cycles measured (tools/ubench/dpp.hip) against 460 for six
@@ -106,6 +82,21 @@ __device__ __forceinline__ double rdlane(double v, int l) {   // v_readlane_b32 
     return __hiloint2double(hi, lo);
 }
 
+// reciprocal square root / reciprocal from the hardware estimate + two Newton steps (7 / 5 instructions; the library rsqrt() and
+// an IEEE division expand to 3-4 times that, on the dependent chain of single-wave code)
+__device__ __forceinline__ double fast_rsqrt(double x) {   // v_rsq_f64 + two Newton steps
+    double y = __builtin_amdgcn_rsq(x);
+    const double hx = 0.5 * x;
+    y = y * __builtin_fma(-hx, y * y, 1.5);
+    y = y * __builtin_fma(-hx, y * y, 1.5);
+    return y;
+}
+__device__ __forceinline__ double fast_rcp(double x) {     // v_rcp_f64 + two Newton steps
+    double y = __builtin_amdgcn_rcp(x);
+    y = __builtin_fma(__builtin_fma(-x, y, 1.0), y, y);
+    y = __builtin_fma(__builtin_fma(-x, y, 1.0), y, y);
+    return y;
+}
 // so3 Plus and its Jacobian at delta = 0 (factor_common.h:41-53 through AutoDiffLocalParameterization)
 __device__ __forceinline__ void so3_plus(const double* x, const double* d, double* out) {
     const double a0 = x[0] + d[0], a1 = x[1] + d[1], a2 = x[2] + d[2];
@@ -186,7 +177,7 @@ __device__ __forceinline__ PriorRegs prior_issue(const AsmCtx& c, int lane) {
     P.pdx = c.x[(size_t)(c.n - 2) * 15 + v] - c.pX[v];
     return P;
 }
-constexpr int ASM_TMP = 16 + 256 + 16;      // asm_commit scratch: r_prior (16) | prior J as a 16x16 tile | x - X (16)
+constexpr int ASM_TMP = 16;                 // asm_commit scratch: r_prior
 
 // All loads of a frame are issued up front, branch-free (clamped addresses; masking happens in asm_commit), so the
 // wave pays ONE memory round trip per frame instead of one per conditional term.
@@ -269,9 +260,13 @@ __device__ void asm_commit(const AsmCtx& c, int i, const AsmRegs& R, const Tiles
     const bool arrow1 = up && i == 1;   // upward sweep: frame 1 is tied to the hub (frame 0's pose) by the IMU / wheel block (0,1) too
     const bool prior_here = c.prior_on && i == n - 2;
     d4 jtj = {0.0, 0.0, 0.0, 0.0};
-    double* Jt = tmp + 16;       // linearized_jacobians as a zero-padded 16x16 tile
-    double* dxp = tmp + 272;     // x - linearized_X
-    if (prior_here) {   // r_prior = J (x - X) into tmp[0..14]; J^T J on the matrix cores (element layout = the one of the loop below)
+    double gprior = 0.0;
+    if (prior_here) {
+        // linearized_jacobians as a zero-padded 16x16 tile, x - linearized_X behind it: staged in the storage of the output tiles (dead
+        // until the stores below), so the prior costs the step kernels no LDS.  r_prior = J (x - X) into tmp[0..14]; J^T J on the matrix
+        // cores (element layout = the one of the loop below); gradient term J^T r_prior.
+        double* Jt = T_.D;
+        double* dxp = LAYOUT ? T_.D + 256 : T_.O;
         const PriorRegs P_ = pr ? *pr : prior_issue(c, lane);   // pr: issued by the caller one frame ahead, with the partial sums
 #pragma unroll
         for (int q = 0; q < 4; ++q) Jt[lane + 64 * q] = P_.pj[q];
@@ -284,6 +279,11 @@ __device__ void asm_commit(const AsmCtx& c, int i, const AsmRegs& R, const Tiles
             tmp[lane] = sp;
         }
         jtj = xty16(Jt, Jt);
+        lds_sync();
+        if (lane < 15) {
+#pragma unroll
+            for (int k = 0; k < 15; ++k) gprior += Jt[k * 16 + lane] * tmp[k];
+        }
         lds_sync();
     }
     double dI[4], oI[4];
@@ -345,12 +345,7 @@ __device__ void asm_commit(const AsmCtx& c, int i, const AsmRegs& R, const Tiles
     }
     if (lane < 16) {
         double g = lane < 15 ? gg : 0.0;
-        if (prior_here && lane < 15) {
-            double sp = 0.0;
-#pragma unroll
-            for (int k = 0; k < 15; ++k) sp += Jt[k * 16 + lane] * tmp[k];
-            g += sp;
-        }
+        if (prior_here && lane < 15) g += gprior;
         if (LAYOUT == 0) T_.g[lane] = g; else if (lane < 15) T_.gg(lane) = g;
     }
     lds_sync();
@@ -511,7 +506,7 @@ __device__ __forceinline__ bool fused_chol_solve(double (&a)[15]) {
     for (int k = 0; k < NP; ++k) {
         const double piv = rdlane(a[k], k);
         if (!(piv > 0.0) || !isfinite(piv)) ok = false;
-        const double inv = rsqrt(piv);
+        const double inv = fast_rsqrt(piv);
         const double wk = a[k] * inv;
         a[k] = wk;
 #pragma unroll
@@ -529,7 +524,7 @@ __device__ double frame_diag(const AsmCtx& c, int i, LdsStep& T) {
     if (so3_plus_jac(c.x + (size_t)i * 15 + 3, Pq)) {   // rare: |q| > pi -> full tangent assembly
         assemble_frame<1>(c, i, Tiles<1>{T.M, nullptr, nullptr, nullptr}, T.tmp);
         const double d = lane < 15 ? T.M[lane * MS + lane] : 0.0;
-        if (WAVE_ONLY) lds_sync(); else __syncthreads();
+        lds_sync();
         return d;
     }
     if (lane >= 15) return 0.0;
@@ -556,11 +551,9 @@ __device__ double frame_diag(const AsmCtx& c, int i, LdsStep& T) {
 // latency of one window).  THROUGHPUT = true: 3 waves per SIMD (<= 168 VGPRs, no look-ahead there): the other waves hide
 // the round trip instead (large batches).
 template <bool THROUGHPUT>
-__global__ __launch_bounds__(64, THROUGHPUT ? 3 : 2) void k_lm_step(StepArgs a) {
+__device__ __forceinline__ void lm_step_body(const StepArgs& a, const int b, LdsStep& T) {   // one wave = one window
     constexpr bool LIW_PF1 = !THROUGHPUT, LIW_PF2 = true;
-    __shared__ LdsStep T;
-    const int b = blockIdx.x, lane = threadIdx.x & 63;
-    if (b >= a.B) return;
+    const int lane = threadIdx.x & 63;
     LmState& st = a.w.lm[b];
     if (st.done) return;
     const int n = a.n;
@@ -613,7 +606,7 @@ __global__ __launch_bounds__(64, THROUGHPUT ? 3 : 2) void k_lm_step(StepArgs a) 
             double s = 0.0;
             for (int e = lane; e < n * 15; e += 64) if (!var_is_const(a.mode, a.fast_mode, n, e / 15, e % 15)) s += xc[e] * xc[e];
             x_norm = sqrt(wave_sum(s));
-            radius = radius / fmax(1.0 / 3.0, 1.0 - pow(2.0 * rho - 1.0, 3.0));
+            { const double t3 = 2.0 * rho - 1.0; radius = radius / fmax(1.0 / 3.0, 1.0 - t3 * t3 * t3); }   // (not pow(): 200 instructions of one wave)
             radius = fmin(kMaxRadius, radius);
             dec = 2.0; reuse = 0;
             if (lane == 0) { st.successful += 1; if (x_cost < st.minimum_cost) st.minimum_cost = x_cost; }
@@ -622,7 +615,7 @@ __global__ __launch_bounds__(64, THROUGHPUT ? 3 : 2) void k_lm_step(StepArgs a) 
             radius = radius / dec; dec *= 2.0; reuse = 1;
             last_successful = false;
         }
-        __syncthreads();
+        wave_mem_sync();
         if (a.w.history && iteration < a.w.history_records)
             for (int e = lane; e < n * 15; e += 64) a.w.history[((size_t)iteration * a.B + b) * n * 15 + e] = xw[e];
     } else {
@@ -643,7 +636,7 @@ __global__ __launch_bounds__(64, THROUGHPUT ? 3 : 2) void k_lm_step(StepArgs a) 
 
     // current linearisation
     STAMPE(4002);
-    __syncthreads();
+    wave_mem_sync();
     STAMPE(4003);
     c.buf = cur; c.PL = a.w.PL[cur]; c.PI = a.w.PI[cur]; c.PW = a.w.PW[cur]; c.PG = a.w.PG[cur]; c.x = xw;
 
@@ -652,7 +645,7 @@ __global__ __launch_bounds__(64, THROUGHPUT ? 3 : 2) void k_lm_step(StepArgs a) 
             const double hjj = frame_diag(c, i, T);
             if (lane < 15) st.scale[i * 15 + lane] = var_is_const(a.mode, a.fast_mode, n, i, lane) ? 1.0 : 1.0 / (1.0 + sqrt(hjj));
         }
-        __syncthreads();
+        wave_mem_sync();
     }
     const double* scl = st.scale;
     double* dgl = st.diagonal;
@@ -827,7 +820,7 @@ __global__ __launch_bounds__(64, THROUGHPUT ? 3 : 2) void k_lm_step(StepArgs a) 
     double model_cost_change = 0.0, step_norm = 0.0;
     bool valid = false;
     STAMP(4004);
-    __syncthreads();   // factor records (global) written above are read by other lanes below
+    wave_mem_sync();   // factor records (global) written above are read by other lanes below
     STAMP(4005);
     if (solved) {
         // ---- back substitution, frame 0 first.  Lane r owns unknown r: row r of Yo / Yr.
@@ -924,6 +917,12 @@ __global__ __launch_bounds__(64, THROUGHPUT ? 3 : 2) void k_lm_step(StepArgs a) 
     }
     STAMP(4006);
 }
+template <bool THROUGHPUT>
+__global__ __launch_bounds__(64, THROUGHPUT ? 3 : 2) void k_lm_step(StepArgs a) {
+    __shared__ LdsStep T;
+    if ((int)blockIdx.x >= a.B) return;
+    lm_step_body<THROUGHPUT>(a, (int)blockIdx.x, T);
+}
 
 // ---------------------------------------------------------------------------------------------------
 // Two-wave ("twisted") LM step for small batches — the latency of ONE window (the reference's own call pattern: one
@@ -1016,7 +1015,7 @@ __global__ __launch_bounds__(256, 1) void k_lm_step_tw(StepArgs a) {
                     double sq = 0.0;
                     for (int e = lane; e < n * 15; e += 64) if (!var_is_const(a.mode, a.fast_mode, n, e / 15, e % 15)) sq += xc[e] * xc[e];
                     x_norm = sqrt(wave_sum(sq));
-                    radius = radius / fmax(1.0 / 3.0, 1.0 - pow(2.0 * rho - 1.0, 3.0));
+                    { const double t3 = 2.0 * rho - 1.0; radius = radius / fmax(1.0 / 3.0, 1.0 - t3 * t3 * t3); }   // (not pow(): 200 instructions of one wave)
                     radius = fmin(kMaxRadius, radius);
                     dec = 2.0; reuse = 0;
                     if (lane == 0) { st.successful += 1; if (x_cost < st.minimum_cost) st.minimum_cost = x_cost; }
@@ -1395,7 +1394,7 @@ __global__ void k_begin_all(int B, int n, const int* laser_off, const int* laser
 }
 // everything liw_solve reads back, gathered into ONE record (one device-to-host copy per chunk of iterations):
 // [done, marg status, -, - | liw_summary | states n*15 | match_pose n*12 | sqrt_H 36, Delta_H 225, Delta_g 15]
-__global__ void k_pack_result(PackArgs a) {
+__device__ __forceinline__ void pack_result_body(const PackArgs& a) {   // the whole work-group
     const int t = threadIdx.x, n = a.n;
     // the write-backs of k_lm_finish for this one window first (one launch less per tracking frame), then the record
     if (t < n * 6) {
@@ -1424,6 +1423,7 @@ __global__ void k_pack_result(PackArgs a) {
     o += n * 12;
     if (a.marg) for (int e = t; e < 276; e += blockDim.x) o[e] = a.marg[e];
 }
+__global__ void k_pack_result(PackArgs a) { pack_result_body(a); }
 
 // write-backs the reference does after ceres::Solve (solver.cpp:176-190 init, :804-814 tracking) + summaries
 __global__ void k_lm_finish(StepArgs a) {   // one thread per (window, frame, pose entry): a thread per window walked n frames serially (40 us at n = 30)
@@ -1448,12 +1448,6 @@ __global__ void k_lm_finish(StepArgs a) {   // one thread per (window, frame, po
 
 // ---------------------------------------------------------------------------------------------------
 // dense export of the assembled normal equations (tests, liw_linearize): H [15n x 15n], g, cost
-struct ExportArgs {
-    int B, n, mode, fast_mode, buf;
-    const double* x; const double* prior_X; const double* prior_J; const int* has_prior;
-    WsView w;
-    double* H; double* g; double* cost;
-};
 __global__ __launch_bounds__(64) void k_export_dense(ExportArgs a) {
     __shared__ LdsTiles T;
     const int b = blockIdx.x, lane = threadIdx.x & 63, n = a.n, N = 15 * n;
@@ -1494,19 +1488,6 @@ __global__ __launch_bounds__(64) void k_export_dense(ExportArgs a) {
 // (51 us of the 65 us k_marg_schur took on a tracking window in round 1).
 // In: A (LDS, ld 16, symmetric).  Out: return value = eigenvalue `lane` (lane < 15, unsorted), Vc[c * 16 + r] = component r of
 // eigenvector c.
-__device__ __forceinline__ double fast_rsqrt(double x) {   // v_rsq_f64 + two Newton steps
-    double y = __builtin_amdgcn_rsq(x);
-    const double hx = 0.5 * x;
-    y = y * __builtin_fma(-hx, y * y, 1.5);
-    y = y * __builtin_fma(-hx, y * y, 1.5);
-    return y;
-}
-__device__ __forceinline__ double fast_rcp(double x) {     // v_rcp_f64 + two Newton steps
-    double y = __builtin_amdgcn_rcp(x);
-    y = __builtin_fma(__builtin_fma(-x, y, 1.0), y, y);
-    y = __builtin_fma(__builtin_fma(-x, y, 1.0), y, y);
-    return y;
-}
 __device__ __noinline__ double eig15_ql(const double* A, double* Vc, int lane) {
     const bool row = lane < 15;
     const int rl = row ? lane : 15;                      // lanes beyond the matrix work on the unused row 15 of the 16 x 16 tiles
@@ -1619,20 +1600,8 @@ __device__ __noinline__ double eig15_ql(const double* A, double* Vc, int lane) {
 // ---------------------------------------------------------------------------------------------------
 // marginalisation: chain Schur complement of frames 0..n-2 onto frame n-1 (marginalization_matrix,
 // solver.cpp:4-40, on the block tri-diagonal H), eigen square root (solver.cpp:390-402), prior update (:407-441)
-struct MargArgs {
-    int B, n;
-    const double* x; double* prior_X; double* prior_J; double* prior_R; int* has_prior;
-    WsView w;
-    double* sqrt_H; double* Delta_H; double* Delta_g; int* status;
-    // the new prior goes to out_* when set (a marginalisation enqueued speculatively behind liw_solve must not replace the live prior
-    // before the caller asks for it), else in place; gate: run window b only if its solve has terminated, status 2 otherwise
-    double* out_X; double* out_J; double* out_R; int* out_has;
-    const LmState* gate;
-};
-__global__ __launch_bounds__(64, 2) void k_marg_schur(MargArgs a) {
-    __shared__ LdsTiles T;
-    __shared__ double V[256], Am[256];
-    const int b = blockIdx.x, lane = threadIdx.x & 63, n = a.n;
+__device__ __forceinline__ void marg_schur_body(const MargArgs& a, const int b, LdsTiles& T, double* V, double* Am) {
+    const int lane = threadIdx.x & 63, n = a.n;
     if (a.gate && !a.gate[b].done) { if (a.status && lane == 0) a.status[b] = 2; return; }
     double* oX = a.out_X ? a.out_X : a.prior_X; double* oJ = a.out_J ? a.out_J : a.prior_J; double* oR = a.out_R ? a.out_R : a.prior_R;
     int* oHas = a.out_has ? a.out_has : a.has_prior;
@@ -1740,12 +1709,17 @@ __global__ __launch_bounds__(64, 2) void k_marg_schur(MargArgs a) {
         for (int k = 0; k < 15; ++k) oJ[(size_t)b * 225 + rank * 15 + k] = ssq * sg * Vl[k];
         oR[(size_t)b * 15 + rank] = -(sisq * dotg);
     }
-    __syncthreads();
+    wave_mem_sync();
     __threadfence_block();
     if (lane < 15) oX[(size_t)b * 15 + lane] = c.x[(size_t)(n - 1) * 15 + lane];
     if (a.sqrt_H) for (int e = lane; e < 36; e += 64) a.sqrt_H[(size_t)b * 36 + e] = oJ[(size_t)b * 225 + (e / 6) * 15 + e % 6];
     if (lane == 0) oHas[b] = 1;
     STAMPM(5003);
+}
+__global__ __launch_bounds__(64, 2) void k_marg_schur(MargArgs a) {
+    __shared__ LdsTiles T;
+    __shared__ double V[256], Am[256];
+    marg_schur_body(a, (int)blockIdx.x, T, V, Am);
 }
 
 #ifdef LIW_CLK

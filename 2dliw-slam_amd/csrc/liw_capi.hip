@@ -12,49 +12,6 @@
 
 #include "liw_kernels.hpp"
 
-namespace liw {
-// kernel launchers (k_linearize.hip, k_lm.hip)
-void launch_linearize(const LinArgs& A, const DevParams& P, hipStream_t s, const LinFork* fk, bool defer_join = false);
-void launch_linearize_join(hipStream_t s, const LinFork* fk);
-void launch_exchange_pack(int B, int n, bool both, const double* PL0, const double* PL1, int candidate, const LmState* lm, double* buf, hipStream_t s);
-void launch_exchange_unpack(int B, int n, bool both, int world, size_t stride, const double* buf, double* PL0, double* PL1, int candidate, const LmState* lm, hipStream_t s);
-void launch_group_offsets(int B, int n, const int* laser_off, const int* laser_frame, int* group_off, hipStream_t s);
-struct StepArgs {
-    int B, n, mode, max_iters, fast_mode;
-    double* x; double* match_pose; const unsigned char* has_match;
-    const double* prior_X; const double* prior_J; const int* has_prior;
-    WsView w;
-};
-struct ExportArgs {
-    int B, n, mode, fast_mode, buf;
-    const double* x; const double* prior_X; const double* prior_J; const int* has_prior;
-    WsView w;
-    double* H; double* g; double* cost;
-};
-struct MargArgs {
-    int B, n;
-    const double* x; double* prior_X; double* prior_J; double* prior_R; int* has_prior;
-    WsView w;
-    double* sqrt_H; double* Delta_H; double* Delta_g; int* status;
-    double* out_X; double* out_J; double* out_R; int* out_has;
-    const LmState* gate;
-};
-constexpr int LIW_RESULT_HDR = 8;
-struct PackArgs {
-    int n, mode;
-    const LmState* lm; liw_summary* info; const double* x; double* match_pose; const unsigned char* has_match;
-    const double* marg; const int* marg_status;
-    double* out;
-};
-void launch_begin_all(int B, int n, const int* laser_off, const int* laser_frame, int* group_off, LmState* lm, int max_iters, hipStream_t s);
-void launch_pack_result(const PackArgs& a, hipStream_t s);
-void launch_lm_begin(int B, int n, LmState* lm, int max_iters, hipStream_t s);
-void launch_lm_step(const StepArgs& a, hipStream_t s);
-void launch_lm_finish(const StepArgs& a, hipStream_t s);
-void launch_export_dense(const ExportArgs& a, hipStream_t s);
-void launch_marg_schur(const MargArgs& a, hipStream_t s);
-}  // namespace liw
-
 using namespace liw;
 
 struct DevBuf {
@@ -747,6 +704,14 @@ int liw_solve(liw_ctx* c, int mode, int max_iters, liw_summary* summary) {
         PackArgs pk{};
         pk.n = c->n; pk.mode = mode; pk.lm = v.lm; pk.info = v.info; pk.x = b->x; pk.match_pose = b->match_pose; pk.has_match = b->has_match;
         pk.marg = nullptr; pk.marg_status = spec ? c->marg_status.as<int>() : nullptr; pk.out = res;
+        MargArgs ma{};
+        if (spec) {
+            ma.B = 1; ma.n = c->n; ma.x = b->x;
+            ma.prior_X = b->prior_X; ma.prior_J = b->prior_J; ma.prior_R = b->prior_R; ma.has_prior = b->has_prior;
+            ma.out_X = c->priorn_X.as<double>(); ma.out_J = c->priorn_J.as<double>(); ma.out_R = c->priorn_R.as<double>(); ma.out_has = c->has_priorn.as<int>();
+            ma.w = v; ma.sqrt_H = marg_out; ma.Delta_H = marg_out + 36; ma.Delta_g = marg_out + 36 + 225; ma.status = c->marg_status.as<int>();
+            ma.gate = v.lm;
+        }
         // (linearise, step) pairs: pair 0 linearises at the initial point, pair j > 0 at the candidate of step j.  K + 1 pairs in all
         // (the last step takes the last candidate / meets the iteration cap); a solve of `it` iterations is done after it + 1 pairs.
         int k = 0, chunk = 4;
@@ -759,13 +724,7 @@ int liw_solve(liw_ctx* c, int mode, int max_iters, liw_summary* summary) {
                 LinArgs A = lin_args(b, LIW_MODE_MARG, b->x, v, 0, false);
                 A.gate = v.lm;
                 launch_linearize(A, c->dp, s, c->have_fork ? &c->fork : nullptr);
-                MargArgs a{};
-                a.B = 1; a.n = c->n; a.x = b->x;
-                a.prior_X = b->prior_X; a.prior_J = b->prior_J; a.prior_R = b->prior_R; a.has_prior = b->has_prior;
-                a.out_X = c->priorn_X.as<double>(); a.out_J = c->priorn_J.as<double>(); a.out_R = c->priorn_R.as<double>(); a.out_has = c->has_priorn.as<int>();
-                a.w = v; a.sqrt_H = marg_out; a.Delta_H = marg_out + 36; a.Delta_g = marg_out + 36 + 225; a.status = c->marg_status.as<int>();
-                a.gate = v.lm;
-                launch_marg_schur(a, s);
+                launch_marg_schur(ma, s);
             }
             launch_pack_result(pk, s);
             HIPCHK(c, hipGetLastError());

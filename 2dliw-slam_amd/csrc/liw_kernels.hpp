@@ -124,6 +124,21 @@ __host__ __device__ inline int laser_slot_code(int s) {
 }
 struct LaserPackTable { short slot[45]; unsigned char neg[45]; };   // representative record slot (and sign) of every pair total
 
+// Work-groups of the role / step kernels are ONE wavefront .  DS
+// instructions of a wave execute in order, so a wave's LDS write is visible to its later LDS reads from any lane without s_barrier /
+// vmcnt drains; only compiler reordering has to be fenced.
+__device__ __forceinline__ void lds_sync() {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+// the same for GLOBAL memory handed from one lane of a wave to another (drains the wave's outstanding stores / loads first)
+__device__ __forceinline__ void wave_mem_sync() {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+}
+
 // is window b linearised by this launch?  (with a compacted `active` list the roles index live windows only and skip this test)
 __device__ __forceinline__ bool window_live(const LinArgs& A, int b) {
     if (A.gate) return A.gate[b].done != 0;
@@ -136,6 +151,52 @@ struct LinFork {
     hipStream_t side[2];
     hipEvent_t ev_fork, ev_join[2], ev_compact;
 };
+
+
+// ---- arguments of the LM / marginalisation kernels (k_lm.hip), shared with the host side (liw_capi.hip)
+struct StepArgs {
+    int B, n, mode, max_iters, fast_mode;
+    double* x;                   // [B][n][15] live states
+    double* match_pose;
+    const unsigned char* has_match;
+    const double* prior_X; const double* prior_J; const int* has_prior;
+    WsView w;
+};
+struct ExportArgs {
+    int B, n, mode, fast_mode, buf;
+    const double* x; const double* prior_X; const double* prior_J; const int* has_prior;
+    WsView w;
+    double* H; double* g; double* cost;
+};
+struct MargArgs {
+    int B, n;
+    const double* x; double* prior_X; double* prior_J; double* prior_R; int* has_prior;
+    WsView w;
+    double* sqrt_H; double* Delta_H; double* Delta_g; int* status;
+    // the new prior goes to out_* when set (a marginalisation enqueued speculatively behind liw_solve must not replace the live prior
+    // before the caller asks for it), else in place; gate: run window b only if its solve has terminated, status 2 otherwise
+    double* out_X; double* out_J; double* out_R; int* out_has;
+    const LmState* gate;
+};
+constexpr int LIW_RESULT_HDR = 8;   // doubles: 4 ints, then liw_summary (32 bytes), padded
+struct PackArgs {
+    int n, mode;
+    const LmState* lm; liw_summary* info; const double* x; double* match_pose; const unsigned char* has_match;
+    const double* marg; const int* marg_status;   // null without a speculative marginalisation
+    double* out;
+};
+void launch_linearize(const LinArgs& A, const DevParams& P, hipStream_t s, const LinFork* fk, bool defer_join = false);
+void launch_linearize_join(hipStream_t s, const LinFork* fk);
+void launch_exchange_pack(int B, int n, bool both, const double* PL0, const double* PL1, int candidate, const LmState* lm, double* buf, hipStream_t s);
+void launch_exchange_unpack(int B, int n, bool both, int world, size_t stride, const double* buf, double* PL0, double* PL1, int candidate, const LmState* lm, hipStream_t s);
+void launch_group_offsets(int B, int n, const int* laser_off, const int* laser_frame, int* group_off, hipStream_t s);
+void launch_begin_all(int B, int n, const int* laser_off, const int* laser_frame, int* group_off, LmState* lm, int max_iters, hipStream_t s);
+void launch_pack_result(const PackArgs& a, hipStream_t s);
+void launch_lm_begin(int B, int n, LmState* lm, int max_iters, hipStream_t s);
+void launch_lm_step(const StepArgs& a, hipStream_t s);
+void launch_lm_finish(const StepArgs& a, hipStream_t s);
+void launch_export_dense(const ExportArgs& a, hipStream_t s);
+void launch_marg_schur(const MargArgs& a, hipStream_t s);
 
 // batched pre-integration (k_preint.hip)
 struct PreintNoise { double q_na[3], q_nw[3], q_nba[3], q_nbw[3], wheel_cov[3]; };

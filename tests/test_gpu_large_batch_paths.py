@@ -97,4 +97,7 @@ def test_throughput_step_kernel_variant_matches_latency_variant_and_oracle(liw, 
     gb, gs, sb, ss = big.states(), small.states(), big.summaries(), small.summaries()
     for k, b in picks:
         assert sb[b]["iterations"] == ss[k]["iterations"] and sb[b]["termination"] == ss[k]["termination"], (k, b)
-        assert rel(gb[b], gs[k]) <= 1e-9, (k, b)
+        # the two schedules leave the init solve 1e-14 apart; the marginalisation (cond(H_mm) ~ 1e5 .. 1e7 on these windows) and the
+        # tracking solve on its prior amplify that to ~1e-8 (measured 5e-10 .. 9e-9), the same factor by which either one moves
+        # when its own summation order changes
+        assert rel(gb[b], gs[k]) <= 1e-7, (k, b)
