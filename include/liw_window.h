@@ -95,14 +95,23 @@ int liw_get_extrinsics(const liw_ctx* ctx, double* T_imu_to_wheel16, double* T_i
 /* ---- single window, host buffers (the lvio_2d::solver drop-in) ----------------------------------- */
 /* Upload one window (batch of 1).  The liw_window arrays must stay valid until the next liw_set_window:
  * liw_solve / liw_marginalize scatter results back into `states` and `match_pose` in place, as the
- * reference mutates frame_info / laser_match in place. */
+ * reference mutates frame_info / laser_match in place.  The arrays are staged into one page-locked image and copied with ONE
+ * asynchronous host-to-device copy, ordered before the next solve on the ctx stream (the call does not wait for it).  A window whose
+ * bytes equal what the device already holds (the previous window with the solved states folded in — what lvio_2d::solver passes to
+ * marginalization() right after solve()) is recognised: nothing is uploaded and the results of the last liw_solve stay attached. */
 int liw_set_window(liw_ctx* ctx, const liw_window* w);
 /* Forget the uploaded window (the ctx keeps no host pointers afterwards); window-level calls then return LIW_ESTATE
- * until the next liw_set_window.  The stored prior (solver.h:31-37) is kept. */
+ * until the next liw_set_window.  The stored prior (solver.h:31-37) and the device copy of the window are kept. */
 int liw_clear_window(liw_ctx* ctx);
 /* replaces: solver::init_solve (mode INIT, incl. the laser_match fix-up solver.cpp:176-190) and
  * solver::solve (mode TRACK, incl. the p2,q2 write-back solver.cpp:804-814).  max_iters <= 0 -> Ceres
- * default 50 (10 in fast_mode for TRACK, solver.cpp:800-801). */
+ * default 50 (10 in fast_mode for TRACK, solver.cpp:800-801).
+ * One submission and one synchronisation per solve that converges within the first chunk of 4 LM iterations (tracking windows do):
+ * the launches of the chunk, the write-backs and ONE packed read-back record (summary, states, laser_match poses).  A TRACK solve
+ * also enqueues — behind the solve, gated on the device by the window's termination flag — the marginalisation the reference runs
+ * next (trajectory.cpp:548-559); its outputs ride in the same record and its prior goes to a second set of device buffers, so the
+ * live prior is untouched until liw_marginalize asks for the result (a new window, liw_set_prior or another solve drop it).
+ * Environment: LIW_NO_SPEC_MARG=1 (read at liw_create) turns that off. */
 int liw_solve(liw_ctx* ctx, int mode, int max_iters, liw_summary* summary);
 /* Per-iteration free-state history of the last liw_solve: x[(iters+1)][n][15] (all states, constant ones
  * included); returns the number of records written (tests / parity gate, BASELINE.md "equality gate"), or
@@ -119,7 +128,9 @@ int liw_eval_factors(liw_ctx* ctx, int mode, double* laser_res, double* laser_ja
                      double* wheel_res, double* wheel_jac, double* ground_res, double* ground_jac);
 /* replaces: solver::marginalization (solver.cpp:257-442): updates the ctx-owned prior
  * (linearized_X / linearized_jacobians / linearized_residuals) and returns frame_infos.back()->sqrt_H (6x6).
- * No-op returning 0 in fast_mode (solver.cpp:259-260).  Delta_H (15x15) / Delta_g (15) optional outputs. */
+ * No-op returning 0 in fast_mode (solver.cpp:259-260).  Delta_H (15x15) / Delta_g (15) optional outputs.
+ * Right after a TRACK liw_solve of the same window this hands over the result computed behind that solve (no launch, no
+ * synchronisation: the new prior buffers are swapped in); otherwise it linearises and eliminates now. */
 int liw_marginalize(liw_ctx* ctx, double* sqrt_H36, double* Delta_H225, double* Delta_g15);
 /* the solver's persistent private state (solver.h:31-37); returns 1/0 = has_linearized_block */
 int liw_get_prior(liw_ctx* ctx, double* X15, double* J225, double* R15);
