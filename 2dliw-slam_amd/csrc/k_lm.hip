@@ -82,21 +82,6 @@ __device__ __forceinline__ double rdlane(double v, int l) {   // v_readlane_b32 
     return __hiloint2double(hi, lo);
 }
 
-// reciprocal square root / reciprocal from the hardware estimate + two Newton steps (7 / 5 instructions; the library rsqrt() and
-// an IEEE division expand to 3-4 times that, on the dependent chain of single-wave code)
-__device__ __forceinline__ double fast_rsqrt(double x) {   // v_rsq_f64 + two Newton steps
-    double y = __builtin_amdgcn_rsq(x);
-    const double hx = 0.5 * x;
-    y = y * __builtin_fma(-hx, y * y, 1.5);
-    y = y * __builtin_fma(-hx, y * y, 1.5);
-    return y;
-}
-__device__ __forceinline__ double fast_rcp(double x) {     // v_rcp_f64 + two Newton steps
-    double y = __builtin_amdgcn_rcp(x);
-    y = __builtin_fma(__builtin_fma(-x, y, 1.0), y, y);
-    y = __builtin_fma(__builtin_fma(-x, y, 1.0), y, y);
-    return y;
-}
 // so3 Plus and its Jacobian at delta = 0 (factor_common.h:41-53 through AutoDiffLocalParameterization)
 __device__ __forceinline__ void so3_plus(const double* x, const double* d, double* out) {
     const double a0 = x[0] + d[0], a1 = x[1] + d[1], a2 = x[2] + d[2];

@@ -139,6 +139,22 @@ __device__ __forceinline__ void wave_mem_sync() {
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
 }
 
+// reciprocal square root / reciprocal from the hardware estimate + two Newton steps (7 / 5 instructions; the library rsqrt() and
+// an IEEE division expand to 3-4 times that, on the dependent chain of single-wave code)
+__device__ __forceinline__ double fast_rsqrt(double x) {   // v_rsq_f64 + two Newton steps
+    double y = __builtin_amdgcn_rsq(x);
+    const double hx = 0.5 * x;
+    y = y * __builtin_fma(-hx, y * y, 1.5);
+    y = y * __builtin_fma(-hx, y * y, 1.5);
+    return y;
+}
+__device__ __forceinline__ double fast_rcp(double x) {     // v_rcp_f64 + two Newton steps
+    double y = __builtin_amdgcn_rcp(x);
+    y = __builtin_fma(__builtin_fma(-x, y, 1.0), y, y);
+    y = __builtin_fma(__builtin_fma(-x, y, 1.0), y, y);
+    return y;
+}
+
 // is window b linearised by this launch?  (with a compacted `active` list the roles index live windows only and skip this test)
 __device__ __forceinline__ bool window_live(const LinArgs& A, int b) {
     if (A.gate) return A.gate[b].done != 0;
