@@ -45,7 +45,7 @@ def allgather_(out, t, group=None):
     return out
 
 
-EXCHANGES = ("allreduce", "oneshot")
+EXCHANGES = ("allreduce", "oneshot", "auto")
 
 
 class TorchComm:
@@ -59,6 +59,17 @@ class TorchComm:
 
     def all_gather_(self, out, t):
         return allgather_(out, t, self.group)
+
+    def all_reduce_max_(self, t):
+        import torch.distributed as dist
+        if dist.is_available() and dist.is_initialized() and dist.get_world_size(self.group) > 1:
+            if t.is_cuda and dist.get_backend(self.group) == "gloo":
+                h = t.cpu()
+                dist.all_reduce(h, op=dist.ReduceOp.MAX, group=self.group)
+                t.copy_(h)
+            else:
+                dist.all_reduce(t, op=dist.ReduceOp.MAX, group=self.group)
+        return t
 
 
 class LockstepComm:
@@ -96,6 +107,21 @@ class LockstepComm:
         self.sh["bar"].wait()
         return out
 
+    def all_reduce_max_(self, t):
+        self._deposit(t)
+        tot = self.sh["slots"][0].clone()
+        for r in range(1, self.sh["world"]):
+            tot = self.torch_max(tot, self.sh["slots"][r])
+        self.sh["bar"].wait()
+        t.copy_(tot)
+        self.sh["bar"].wait()
+        return t
+
+    @staticmethod
+    def torch_max(a, b):
+        import torch
+        return torch.maximum(a, b)
+
 
 class BatchSolver:
     """B independent windows (uniform n) resident on one GPU.
@@ -118,8 +144,10 @@ class BatchSolver:
         assert exchange in EXCHANGES, exchange
         # exchange: how the ranks of a factor-sharded run combine their laser partial sums:
         #   "allreduce": RCCL all-reduce(SUM) of the compact record; "oneshot": all-gather of every rank's compact record
-        #   (each GPU pushes its image to all peers once) + local sum in rank order.  force_exchange runs the pack / exchange /
-        #   unpack path even with one rank (tests).
+        #   (each GPU pushes its image to all peers once) + local sum in rank order; "auto": both are timed once on the record size
+        #   of this batch (pick_exchange, at the first sharded solve) and the faster one is used — SURVEY 8e's "pick per size", decided
+        #   by measurement on the machine at hand and agreed between the ranks.  force_exchange runs the pack / exchange / unpack
+        #   path even with one rank (tests).
         self.exchange, self.sharded = exchange, (world > 1 or force_exchange)
         self.comm = comm if comm is not None else TorchComm(group)
         self.exchange_ms, self.exchange_calls, self._xev, self._xbuf = 0.0, 0, [], {}
@@ -227,7 +255,41 @@ class BatchSolver:
         self.lm_step(mode)
         self.lm_finish(mode)
 
+    def pick_exchange(self, mode, reps=3):
+        """exchange="auto": time `reps` all-reduces and `reps` all-gather + rank-order sums of this batch's compact record (collective +
+        unpack, HIP events), take the maximum over the ranks of each (one small all-reduce: every rank sees the same two numbers)
+        and keep the faster transport.  Returns {"allreduce": ms, "oneshot": ms, "picked": name}."""
+        t = self.torch
+        nd = int(self.L.liw_batch_exchange_doubles(C.c_int(self.B), C.c_int(self.n), C.c_int(mode)))
+        buf = t.zeros(nd, dtype=t.float64, device=self.dev)
+        allb = t.zeros((max(self.world, 1), nd), dtype=t.float64, device=self.dev)
+        ms = {}
+        for name in ("allreduce", "oneshot"):
+            for rep in range(reps + 1):                    # first pass untimed (lazy channel set-up of the transport)
+                if rep == 1:
+                    e0, e1 = t.cuda.Event(enable_timing=True), t.cuda.Event(enable_timing=True)
+                    e0.record()
+                if name == "allreduce":
+                    self.comm.all_reduce_sum_(buf)
+                else:
+                    self.comm.all_gather_(allb, buf)
+                    buf.copy_(allb.sum(dim=0))             # stands in for the P-term sum of liw_batch_exchange_unpack
+            e1.record()
+            t.cuda.synchronize(self.dev)
+            ms[name] = e0.elapsed_time(e1) / reps
+            buf.zero_()
+        both = t.tensor([ms["allreduce"], ms["oneshot"]], dtype=t.float64, device=self.dev)
+        self.comm.all_reduce_max_(both)
+        ms = {"allreduce": float(both[0].item()), "oneshot": float(both[1].item())}
+        ms["picked"] = "oneshot" if ms["oneshot"] < ms["allreduce"] else "allreduce"
+        self.exchange = ms["picked"]
+        self._xbuf = {}
+        self.exchange_pick = ms
+        return ms
+
     def _xbuffers(self, mode):
+        if self.exchange == "auto":
+            self.pick_exchange(mode)
         nd = int(self.L.liw_batch_exchange_doubles(C.c_int(self.B), C.c_int(self.n), C.c_int(mode)))
         if (mode, "buf") not in self._xbuf:
             t = self.torch

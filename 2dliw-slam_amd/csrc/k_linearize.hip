@@ -71,7 +71,7 @@ constexpr int LASER_GMAX = 8;   // (window, frame) groups one wave may own
 // one free pose: [b_x b_y b_th0..2 r] (6, 21 pairs).  Every lane accumulates its blocks' pair products in
 // registers over all passes; one butterfly per group reduces them across the wave.
 template <bool BOTH>
-__device__ void laser_wave_local(const LinArgs& A, const DevParams& P, int G, int vblock) {
+__device__ __forceinline__ void laser_wave_local(const LinArgs& A, const DevParams& P, int G, int vblock) {
 #include "k_lin_laser_body.inc"
 }
 template <bool BOTH>
@@ -131,8 +131,17 @@ __device__ __forceinline__ V3<double> mulc(const double* m, int ld, const V3<dou
                       m[2 * ld] * v.x + m[2 * ld + 1] * v.y + m[2 * ld + 2] * v.z);
 }
 
-__device__ void imu_blocks(const LinArgs& A, const DevParams& P, int wave, double* lds) {
-    const int lane = threadIdx.x & 63, blk = lane / 3, g = lane % 3;
+// ND = derivative directions per lane: 3 (three lanes per block, 21 blocks per wave: the batched kernels — the value part of the chain
+// is evaluated once per three directions) or 1 (nine lanes per block, small batches: a lane's instruction stream is what a single
+// window waits for, and one direction instead of three shortens it by ~40 %).  f = the factor of the rotation chain this lane
+// differentiates (0: theta_i, 1: theta_j, 2: bw_i through gamma), eg = e0 + e its global direction.
+template <int ND>
+__device__ __forceinline__ void imu_blocks(const LinArgs& A, const DevParams& P, int wave, double* lds) {
+    constexpr int LPB = 9 / ND;
+    constexpr int MAXB = 63 / LPB;
+    typedef LJN<ND> JN;
+    const int lane = threadIdx.x & 63, blk = lane / LPB, g = lane % LPB;
+    const int f = g / (LPB / 3), e0 = ND == 3 ? 0 : g % 3;
     const int n = A.n, nb = n - 1, ipw = A.small_per_wave;   // blocks per wave: IMU_PER_WAVE for throughput, fewer for latency
     // blocks are indexed over the windows that are still iterating (compacted list), so finished windows cost no lanes
     const long total = (long)(A.active ? A.active[0] : A.B) * nb, gb0 = (long)wave * ipw;
@@ -142,9 +151,31 @@ __device__ void imu_blocks(const LinArgs& A, const DevParams& P, int wave, doubl
     const int wi = on ? (int)(gb / nb) : 0, k = on ? (int)(gb % nb) : 0;
     const int b = A.active ? A.active[1 + wi] : wi;
     if (on && !A.active) on = window_live(A, b);
-    double* rec = lds + (blk < IMU_PER_WAVE ? blk : 0) * IMU_REC;
+    double* rec = lds + (blk < MAXB ? blk : 0) * IMU_REC;
     const int sel_lane = (on && A.lm) ? (A.candidate ? 1 - A.lm[b].cur : A.lm[b].cur) : 0;   // partial buffer of this lane's block
     const int fk_lane = on ? b * nb + k : 0;                                                   // its record in the input / partial arrays
+    // sqrt_info operands of the matrix-core part below (A[i = ml][k = mk + 4c]) are fetched for a whole group of blocks at once, the next
+    // group's fetch in flight while this group runs on the matrix cores: three memory round trips per wave instead of one per block.
+    // The one-direction instantiation (a wave per block: latency) issues its fetch HERE, ahead of the dual-number part.
+    const int ml = lane & 15, mk = lane >> 4;
+    const int nblk = (int)min((long)ipw, total - gb0);
+    constexpr int GRP = ND == 3 ? 7 : 1;
+    auto load_sop = [&](int gq, double* o) {
+        const int fq = __shfl(fk_lane, gq < nblk ? LPB * gq : 0, 64);
+        const double* S = A.imu_sqrtP + (size_t)fq * 225;
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            const int kk = mk + 4 * c;
+            const bool in = ml < 15 && kk < 15;
+            const double v = S[in ? ml * 15 + kk : 0];
+            o[c] = in ? v : 0.0;
+        }
+    };
+    double sop[GRP][4], sopn[GRP][4];
+    if constexpr (ND == 1) {
+#pragma unroll
+        for (int q = 0; q < GRP; ++q) load_sop(q, sop[q]);
+    }
     LSTAMP(300);
     if (on) {
         const size_t fk = (size_t)b * nb + k;   // record of this block in the (uncompacted) input / partial arrays
@@ -156,20 +187,23 @@ __device__ void imu_blocks(const LinArgs& A, const DevParams& P, int wave, doubl
         const V3<double> thi = cast_v3<double>(si_ + 3), thj = cast_v3<double>(sj_ + 3);
         const V3<double> dba = cast_v3<double>(si_ + 9) - cast_v3<double>(X0 + 9), dbw = cast_v3<double>(si_ + 12) - cast_v3<double>(X0 + 12);
         const V3<double> gam = cast_v3<double>(X0 + 6) + mulc(Jp + 6 * 15 + 12, 15, dbw);
-        // this lane's differentiated rotation: lane 0 exp(-theta_i), lane 1 exp(theta_j), lane 2 exp(-gamma); seeds = d(arg)/d(direction)
-        V3<J3> arg;
+        // this lane's differentiated rotation: f = 0 exp(-theta_i), 1 exp(theta_j), 2 exp(-gamma); seeds = d(arg)/d(direction)
+        V3<JN> arg;
         {
-            const double av[3] = {g == 0 ? -thi.x : (g == 1 ? thj.x : -gam.x), g == 0 ? -thi.y : (g == 1 ? thj.y : -gam.y),
-                                  g == 0 ? -thi.z : (g == 1 ? thj.z : -gam.z)};
-            J3* ac[3] = {&arg.x, &arg.y, &arg.z};
+            const double av[3] = {f == 0 ? -thi.x : (f == 1 ? thj.x : -gam.x), f == 0 ? -thi.y : (f == 1 ? thj.y : -gam.y),
+                                  f == 0 ? -thi.z : (f == 1 ? thj.z : -gam.z)};
+            JN* ac[3] = {&arg.x, &arg.y, &arg.z};
 #pragma unroll
             for (int c = 0; c < 3; ++c) {
                 ac[c]->v = av[c];
 #pragma unroll
-                for (int e = 0; e < 3; ++e) ac[c]->d[e] = g == 0 ? (c == e ? -1.0 : 0.0) : (g == 1 ? (c == e ? 1.0 : 0.0) : -Jp[(6 + c) * 15 + 12 + e]);
+                for (int e = 0; e < ND; ++e) {
+                    const int eg = e0 + e;
+                    ac[c]->d[e] = f == 0 ? (c == eg ? -1.0 : 0.0) : (f == 1 ? (c == eg ? 1.0 : 0.0) : -Jp[(6 + c) * 15 + 12 + eg]);
+                }
             }
         }
-        const M3<J3> Md = exp_so3(arg);
+        const M3<JN> Md = exp_so3(arg);
         const M3<double> Rt = exp_so3(-thi);                                      // bk_R_w
         __builtin_amdgcn_sched_barrier(0);
         // ---- alpha, beta, ba, bw rows
@@ -181,22 +215,23 @@ __device__ void imu_blocks(const LinArgs& A, const DevParams& P, int wave, doubl
             const V3<double> ra = cast_v3<double>(X0) + mulc(Jp + 9, 15, dba) + mulc(Jp + 12, 15, dbw) - mul(Rt, va);
             const V3<double> rb = cast_v3<double>(X0 + 3) + mulc(Jp + 3 * 15 + 9, 15, dba) + mulc(Jp + 3 * 15 + 12, 15, dbw) - mul(Rt, vb);
 #pragma unroll
-            for (int e = 0; e < 3; ++e) {
-                // lane 0: -(dR_i^T / d theta_i_e) v ; lane 2: the bias Jacobian column ; lane 1: nothing
+            for (int e = 0; e < ND; ++e) {
+                // f = 0: -(dR_i^T / d theta_i_e) v ; f = 2: the bias Jacobian column ; f = 1: nothing
+                const int eg = e0 + e;
                 M3<double> dM;
 #pragma unroll
                 for (int q = 0; q < 9; ++q) dM.m[q] = Md.m[q].d[e];
                 const V3<double> da = mul(dM, va), db = mul(dM, vb);
-                const double ca[3] = {g == 0 ? -da.x : (g == 2 ? Jp[0 * 15 + 12 + e] : 0.0), g == 0 ? -da.y : (g == 2 ? Jp[1 * 15 + 12 + e] : 0.0),
-                                      g == 0 ? -da.z : (g == 2 ? Jp[2 * 15 + 12 + e] : 0.0)};
-                const double cb[3] = {g == 0 ? -db.x : (g == 2 ? Jp[3 * 15 + 12 + e] : 0.0), g == 0 ? -db.y : (g == 2 ? Jp[4 * 15 + 12 + e] : 0.0),
-                                      g == 0 ? -db.z : (g == 2 ? Jp[5 * 15 + 12 + e] : 0.0)};
+                const double ca[3] = {f == 0 ? -da.x : (f == 2 ? Jp[0 * 15 + 12 + eg] : 0.0), f == 0 ? -da.y : (f == 2 ? Jp[1 * 15 + 12 + eg] : 0.0),
+                                      f == 0 ? -da.z : (f == 2 ? Jp[2 * 15 + 12 + eg] : 0.0)};
+                const double cb[3] = {f == 0 ? -db.x : (f == 2 ? Jp[3 * 15 + 12 + eg] : 0.0), f == 0 ? -db.y : (f == 2 ? Jp[4 * 15 + 12 + eg] : 0.0),
+                                      f == 0 ? -db.z : (f == 2 ? Jp[5 * 15 + 12 + eg] : 0.0)};
 #pragma unroll
                 for (int r = 0; r < 3; ++r) {
-                    rec[r * IR_XS + 3 * g + e] = ca[r];
-                    rec[(3 + r) * IR_XS + 3 * g + e] = cb[r];
-                    rec[(9 + r) * IR_XS + 3 * g + e] = 0.0;                                   // res_ba has no non-linear direction
-                    rec[(12 + r) * IR_XS + 3 * g + e] = (g == 2 && r == e) ? -1.0 : 0.0;      // d res_bw / d bw_i
+                    rec[r * IR_XS + 3 * f + eg] = ca[r];
+                    rec[(3 + r) * IR_XS + 3 * f + eg] = cb[r];
+                    rec[(9 + r) * IR_XS + 3 * f + eg] = 0.0;                                   // res_ba has no non-linear direction
+                    rec[(12 + r) * IR_XS + 3 * f + eg] = (f == 2 && r == eg) ? -1.0 : 0.0;     // d res_bw / d bw_i
                 }
             }
             if (g == 0) {
@@ -227,15 +262,15 @@ __device__ void imu_blocks(const LinArgs& A, const DevParams& P, int wave, doubl
 #pragma unroll
             for (int q = 0; q < 9; ++q) {
                 const double id = (q % 4 == 0) ? 1.0 : 0.0;
-                Lm.m[q] = g == 2 ? id : (g == 1 ? EgRt.m[q] : Eg.m[q]);
-                Rm.m[q] = g == 0 ? Rj.m[q] : (g == 1 ? id : RtRj.m[q]);
+                Lm.m[q] = f == 2 ? id : (f == 1 ? EgRt.m[q] : Eg.m[q]);
+                Rm.m[q] = f == 0 ? Rj.m[q] : (f == 1 ? id : RtRj.m[q]);
             }
             const M3<double> Ev = mul(Eg, RtRj);
-            M3<J3> E;
+            M3<JN> E;
 #pragma unroll
             for (int q = 0; q < 9; ++q) E.m[q].v = Ev.m[q];
 #pragma unroll
-            for (int e = 0; e < 3; ++e) {
+            for (int e = 0; e < ND; ++e) {
                 M3<double> dM;
 #pragma unroll
                 for (int q = 0; q < 9; ++q) dM.m[q] = Md.m[q].d[e];
@@ -244,12 +279,12 @@ __device__ void imu_blocks(const LinArgs& A, const DevParams& P, int wave, doubl
                 for (int q = 0; q < 9; ++q) E.m[q].d[e] = dE.m[q];
             }
             __builtin_amdgcn_sched_barrier(0);
-            const V3<J3> rg = log_SO3(E);
-            const J3* rr[3] = {&rg.x, &rg.y, &rg.z};
+            const V3<JN> rg = log_SO3(E);
+            const JN* rr[3] = {&rg.x, &rg.y, &rg.z};
 #pragma unroll
             for (int r = 0; r < 3; ++r) {
 #pragma unroll
-                for (int e = 0; e < 3; ++e) rec[(6 + r) * IR_XS + 3 * g + e] = rr[r]->d[e];
+                for (int e = 0; e < ND; ++e) rec[(6 + r) * IR_XS + 3 * f + e0 + e] = rr[r]->d[e];
                 if (g == 0) rec[(6 + r) * IR_XS + 9] = rr[r]->v;
             }
         }
@@ -259,7 +294,6 @@ __device__ void imu_blocks(const LinArgs& A, const DevParams& P, int wave, doubl
     LSTAMP(304);
     // ---- matrix-core part, one block at a time (the whole wave cooperates).  Operand entry codes of this lane: x0 = column ml of
     // [J_raw wrt x_i | r_raw], x1 = column ml of [J_raw wrt x_j] for the four k-chunks (row kk = mk + 4c)
-    const int ml = lane & 15, mk = lane >> 4;
     int code0[4], code1[4];
     double cst0[4], cst1[4];
 #pragma unroll
@@ -267,25 +301,11 @@ __device__ void imu_blocks(const LinArgs& A, const DevParams& P, int wave, doubl
         code0[c] = imu_entry_code(mk + 4 * c, ml, &cst0[c]);
         code1[c] = imu_entry_code(mk + 4 * c, ml < 15 ? 16 + ml : 31, &cst1[c]);
     }
-    const int nblk = (int)min((long)ipw, total - gb0);
-    const unsigned long long onmask = __ballot(on);           // lane 3 q = block q is live (in range, window still iterating)
-    // sqrt_info operands (A[i = ml][k = mk + 4c]) are fetched for a whole group of blocks at once, the next group's fetch in flight
-    // while this group runs on the matrix cores: three memory round trips per wave instead of one per block
-    constexpr int GRP = 7;
-    auto load_sop = [&](int gq, double* o) {
-        const int fq = __shfl(fk_lane, gq < nblk ? 3 * gq : 0, 64);
-        const double* S = A.imu_sqrtP + (size_t)fq * 225;
+    const unsigned long long onmask = __ballot(on);           // lane LPB q = block q is live (in range, window still iterating)
+    if constexpr (ND == 3) {
 #pragma unroll
-        for (int c = 0; c < 4; ++c) {
-            const int kk = mk + 4 * c;
-            const bool in = ml < 15 && kk < 15;
-            const double v = S[in ? ml * 15 + kk : 0];
-            o[c] = in ? v : 0.0;
-        }
-    };
-    double sop[GRP][4], sopn[GRP][4];
-#pragma unroll
-    for (int q = 0; q < GRP; ++q) load_sop(q, sop[q]);
+        for (int q = 0; q < GRP; ++q) load_sop(q, sop[q]);
+    }
     for (int g0 = 0; g0 < nblk; g0 += GRP) {
         __builtin_amdgcn_sched_barrier(0);
         if (g0 + GRP < nblk) {
@@ -296,7 +316,7 @@ __device__ void imu_blocks(const LinArgs& A, const DevParams& P, int wave, doubl
 #pragma unroll
         for (int q = 0; q < GRP; ++q) {
             const int gq = g0 + q;
-            if (gq >= nblk || !((onmask >> (3 * gq)) & 1ull)) continue;
+            if (gq >= nblk || !((onmask >> (LPB * gq)) & 1ull)) continue;
             const double* R_ = lds + gq * IMU_REC;
             d4 y0 = {0.0, 0.0, 0.0, 0.0}, y1 = {0.0, 0.0, 0.0, 0.0};
 #pragma unroll
@@ -315,9 +335,9 @@ __device__ void imu_blocks(const LinArgs& A, const DevParams& P, int wave, doubl
                 g01 = __builtin_amdgcn_mfma_f64_16x16x4f64(y0[c], y1[c], g01, 0, 0, 0);
                 g11 = __builtin_amdgcn_mfma_f64_16x16x4f64(y1[c], y1[c], g11, 0, 0, 0);
             }
-            const size_t fg = (size_t)__shfl(fk_lane, 3 * gq, 64);
-            const int sel = __shfl(sel_lane, 3 * gq, 64);
-            double* out = A.PI[sel] + fg * PIS;
+            const size_t fg = (size_t)__shfl(fk_lane, LPB * gq, 64);
+            const int sel = __shfl(sel_lane, LPB * gq, 64);
+            double* out = (sel ? A.PI[1] : A.PI[0]) + fg * PIS;   // (a select, not an indexed load: an indexed kernel argument sends the whole struct through scratch)
             // tile (0,0) = [ii | gradient_i ; . | cost], tile (0,1) = [ij ; gradient_j], tile (1,1) = jj: one masked store per tile row group
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
@@ -359,15 +379,20 @@ __device__ void imu_blocks(const LinArgs& A, const DevParams& P, int wave, doubl
 // gets its derivative parts as  L * dM_e * R  with lane-selected double matrices; only log_SO3 and the scalar tail of the residual
 // run on LJN<3>.
 constexpr int WHEEL_PER_WAVE = 21;
-__device__ void wheel_blocks(const LinArgs& A, const DevParams& P, int wave, double* lds) {
-    const int lane = threadIdx.x & 63, blk = lane / 3, g = lane % 3;
+template <int ND>   // directions per lane: 3 (three lanes per block) or 1 (nine lanes per block, small batches), as in imu_blocks
+__device__ __forceinline__ void wheel_blocks(const LinArgs& A, const DevParams& P, int wave, double* lds) {
+    constexpr int LPB = 9 / ND;
+    constexpr int MAXB = 63 / LPB;
+    typedef LJN<ND> JN;
+    const int lane = threadIdx.x & 63, blk = lane / LPB, g = lane % LPB;
+    const int f = g / (LPB / 3), e0 = ND == 3 ? 0 : g % 3;   // f: 0 theta_i, 1 theta_j, 2 the relative translation; eg = e0 + e
     const int n = A.n, nb = n - 1;
     const long total = (long)(A.active ? A.active[0] : A.B) * nb, gb = (long)wave * A.small_per_wave + blk;   // over the windows still iterating
     bool on = blk < A.small_per_wave && gb < total;
     const int wi = on ? (int)(gb / nb) : 0, k = on ? (int)(gb % nb) : 0;
     const int b = A.active ? A.active[1 + wi] : wi;
     if (on && !A.active) on = window_live(A, b);
-    double* Y = lds + (blk < WHEEL_PER_WAVE ? blk : 0) * 64;   // [3][13] then Dp [3][3] at 40, R_wi [3][3] at 49
+    double* Y = lds + (blk < MAXB ? blk : 0) * 64;   // [3][13] then Dp [3][3] at 40, R_wi [3][3] at 49
     const size_t fk = on ? (size_t)b * nb + k : 0;
     if (on) {
         const double* si_ = A.x + ((size_t)b * n + k) * 15;
@@ -375,14 +400,18 @@ __device__ void wheel_blocks(const LinArgs& A, const DevParams& P, int wave, dou
         const double* T12 = A.wheel_T + fk * 12;
         const double* sq9 = A.wheel_sqrtP + fk * 9;
         const V3<double> thi = cast_v3<double>(si_ + 3), thj = cast_v3<double>(sj_ + 3);
-        V3<J3> arg;   // the rotation this lane differentiates (lane 2: R_i with zero seeds)
+        V3<JN> arg;   // the rotation this lane differentiates (f = 2: R_i with zero seeds)
         {
-            J3* ac[3] = {&arg.x, &arg.y, &arg.z};
-            const double av[3] = {g == 1 ? thj.x : thi.x, g == 1 ? thj.y : thi.y, g == 1 ? thj.z : thi.z};
+            JN* ac[3] = {&arg.x, &arg.y, &arg.z};
+            const double av[3] = {f == 1 ? thj.x : thi.x, f == 1 ? thj.y : thi.y, f == 1 ? thj.z : thi.z};
 #pragma unroll
-            for (int c = 0; c < 3; ++c) { *ac[c] = J3(av[c]); if (g < 2) ac[c]->d[c] = 1.0; }
+            for (int c = 0; c < 3; ++c) {
+                *ac[c] = JN(av[c]);
+#pragma unroll
+                for (int e = 0; e < ND; ++e) if (f < 2 && c == e0 + e) ac[c]->d[e] = 1.0;
+            }
         }
-        const M3<J3> Md = exp_so3(arg);
+        const M3<JN> Md = exp_so3(arg);
         const M3<double> Ri = exp_so3(thi), Rj = exp_so3(thj), Riw = cast_m3<double>(P.Riw);
         const V3<double> tiw(P.tiw[0], P.tiw[1], P.tiw[2]);
         const M3<double> Rwi = mul(Ri, Riw);                      // tf_i.R
@@ -392,67 +421,69 @@ __device__ void wheel_blocks(const LinArgs& A, const DevParams& P, int wave, dou
         const V3<double> w(Rjt.x + sj_[0] - si_[0], Rjt.y + sj_[1] - si_[1], Rjt.z + sj_[2] - si_[2]);
         const M3<double> Rrel = mul(Am, RjRiw);
         const V3<double> trel = mul(Am, w) - mulT(Riw, tiw);
-        M3<J3> E;
-        V3<J3> p;
+        M3<JN> E;
+        V3<JN> p;
 #pragma unroll
-        for (int q = 0; q < 9; ++q) E.m[q] = J3(Rrel.m[q]);
-        p.x = J3(trel.x); p.y = J3(trel.y); p.z = J3(trel.z);
+        for (int q = 0; q < 9; ++q) E.m[q] = JN(Rrel.m[q]);
+        p.x = JN(trel.x); p.y = JN(trel.y); p.z = JN(trel.z);
         {
             const M3<double> RiwT = transpose(Riw);
             M3<double> Lm, Rm;
 #pragma unroll
-            for (int q = 0; q < 9; ++q) { Lm.m[q] = g == 0 ? RiwT.m[q] : Am.m[q]; Rm.m[q] = g == 0 ? RjRiw.m[q] : Riw.m[q]; }
-            const V3<double> wv(g == 0 ? w.x : tiw.x, g == 0 ? w.y : tiw.y, g == 0 ? w.z : tiw.z);
+            for (int q = 0; q < 9; ++q) { Lm.m[q] = f == 0 ? RiwT.m[q] : Am.m[q]; Rm.m[q] = f == 0 ? RjRiw.m[q] : Riw.m[q]; }
+            const V3<double> wv(f == 0 ? w.x : tiw.x, f == 0 ? w.y : tiw.y, f == 0 ? w.z : tiw.z);
 #pragma unroll
-            for (int e = 0; e < 3; ++e) {
-                M3<double> X;   // lane 0: (dR_i / d theta_i_e)^T, lane 1: dR_j / d theta_j_e
+            for (int e = 0; e < ND; ++e) {
+                const int eg = e0 + e;
+                M3<double> X;   // f = 0: (dR_i / d theta_i_e)^T, f = 1: dR_j / d theta_j_e
 #pragma unroll
                 for (int r = 0; r < 3; ++r)
 #pragma unroll
-                    for (int c = 0; c < 3; ++c) X(r, c) = g == 0 ? Md(c, r).d[e] : Md(r, c).d[e];
+                    for (int c = 0; c < 3; ++c) X(r, c) = f == 0 ? Md(c, r).d[e] : Md(r, c).d[e];
                 const M3<double> LX = mul(Lm, X);
                 const M3<double> dR = mul(LX, Rm);
                 const V3<double> dt = mul(LX, wv);
 #pragma unroll
-                for (int q = 0; q < 9; ++q) E.m[q].d[e] = g < 2 ? dR.m[q] : 0.0;
-                p.x.d[e] = g < 2 ? dt.x : (e == 0 ? 1.0 : 0.0);
-                p.y.d[e] = g < 2 ? dt.y : (e == 1 ? 1.0 : 0.0);
-                p.z.d[e] = g < 2 ? dt.z : (e == 2 ? 1.0 : 0.0);
+                for (int q = 0; q < 9; ++q) E.m[q].d[e] = f < 2 ? dR.m[q] : 0.0;
+                p.x.d[e] = f < 2 ? dt.x : (eg == 0 ? 1.0 : 0.0);
+                p.y.d[e] = f < 2 ? dt.y : (eg == 1 ? 1.0 : 0.0);
+                p.z.d[e] = f < 2 ? dt.z : (eg == 2 ? 1.0 : 0.0);
             }
         }
         __builtin_amdgcn_sched_barrier(0);
         // wheel_odom_factor::operator() from (p, q) on (wheel_factor.h:36-70)
-        const V3<J3> q = log_SO3(E);
+        const V3<JN> q = log_SO3(E);
         const V3<double> oq = log_SO3(cast_m3<double>(T12));      // log_SE3 of the constant odometry increment: plain doubles
         const double opx = T12[9], opy = T12[10];
         const double o_len = sqrt(opx * opx + opy * opy);
-        const J3 len = dsqrt(p.x * p.x + p.y * p.y);
-        J3 res[3];
-        J3 angle(0.0);
+        const JN len = dsqrt(p.x * p.x + p.y * p.y);
+        JN res[3];
+        JN angle(0.0);
         if (o_len > 0.0001 && len.v > 0.0001) {
             const double odx = opx / o_len, ody = opy / o_len;     // normalized(o_dir)
-            const J3 dx = p.x / len, dy = p.y / len;
+            const JN dx = p.x / len, dy = p.y / len;
             // |cross(o_dir, dir)| with both in the plane: |o_x d_y - o_y d_x| through norm() = sqrt(z^2), as the reference computes it
-            const J3 cz = dy * odx - dx * ody;
+            const JN cz = dy * odx - dx * ody;
             angle = dasin(dsqrt(cz * cz));
         } else {
             angle = len;
         }
         if (len.v < 0.0001 || o_len < 0.0001) res[0] = len * sq9[0];
-        else res[0] = (J3(o_len) - len) * sq9[0];
+        else res[0] = (JN(o_len) - len) * sq9[0];
         res[1] = angle * sq9[4];
-        const J3 nq = norm(q);
+        const JN nq = norm(q);
         const double noq = sqrt(oq.x * oq.x + oq.y * oq.y + oq.z * oq.z);
         if (nq.v < 0.001 || noq < 0.001) res[2] = nq * sq9[8];
-        else res[2] = (J3(noq) - nq) * sq9[8];
+        else res[2] = (JN(noq) - nq) * sq9[8];
 #pragma unroll
-        for (int e = 0; e < 3; ++e) {
-            // lane 0 -> columns theta_i (3..5), lane 1 -> theta_j (9..11), lane 2 -> Dp
-            const int col = g == 0 ? 3 + e : (g == 1 ? 9 + e : 0);
+        for (int e = 0; e < ND; ++e) {
+            // f = 0 -> columns theta_i (3..5), f = 1 -> theta_j (9..11), f = 2 -> Dp
+            const int eg = e0 + e;
+            const int col = f == 0 ? 3 + eg : (f == 1 ? 9 + eg : 0);
 #pragma unroll
             for (int r = 0; r < 3; ++r) {
-                if (g < 2) Y[r * 13 + col] = res[r].d[e];
-                else Y[40 + r * 3 + e] = res[r].d[e];
+                if (f < 2) Y[r * 13 + col] = res[r].d[e];
+                else Y[40 + r * 3 + eg] = res[r].d[e];
             }
         }
         if (g == 0) {
@@ -463,7 +494,7 @@ __device__ void wheel_blocks(const LinArgs& A, const DevParams& P, int wave, dou
         }
     }
     lds_sync();
-    if (on) {   // position columns: Y[r][p_j c] = sum_k Dp[r][k] R_wi[c][k],  Y[r][p_i c] = -Y[r][p_j c]   (row r = g of this lane)
+    if (on && g < 3) {   // position columns: Y[r][p_j c] = sum_k Dp[r][k] R_wi[c][k],  Y[r][p_i c] = -Y[r][p_j c]   (row r = g of this lane)
 #pragma unroll
         for (int c = 0; c < 3; ++c) {
             const double v = Y[40 + g * 3] * Y[49 + c * 3] + Y[40 + g * 3 + 1] * Y[49 + c * 3 + 1] + Y[40 + g * 3 + 2] * Y[49 + c * 3 + 2];
@@ -475,12 +506,12 @@ __device__ void wheel_blocks(const LinArgs& A, const DevParams& P, int wave, dou
     if (on && g == 0 && A.dbg_wheel_res)
         for (int r = 0; r < 3; ++r) A.dbg_wheel_res[fk * 3 + r] = Y[r * 13 + 12];
     if (on && A.dbg_wheel_jac)
-        for (int e = g; e < 36; e += 3) A.dbg_wheel_jac[fk * 36 + e] = Y[(e / 12) * 13 + e % 12];
+        for (int e = g; e < 36; e += LPB) A.dbg_wheel_jac[fk * 36 + e] = Y[(e / 12) * 13 + e % 12];
     // G = Y^T Y (13 x 13 per block), written with consecutive lanes on consecutive addresses: the blocks of a wave are consecutive
     // records of the partial buffer, so the wave's output is one contiguous region (a lane-per-pair scatter doubled the HBM write
     // traffic of this role)
     int* meta = reinterpret_cast<int*>(lds + WHEEL_PER_WAVE * 64);   // per block: partial buffer (0 / 1) or -1 = skip; then its record index
-    if (g == 0 && blk < WHEEL_PER_WAVE) {
+    if (g == 0 && blk < MAXB) {
         meta[blk] = on ? (A.lm ? (A.candidate ? 1 - A.lm[b].cur : A.lm[b].cur) : 0) : -1;
         meta[32 + blk] = (int)fk;
     }
@@ -494,7 +525,7 @@ __device__ void wheel_blocks(const LinArgs& A, const DevParams& P, int wave, dou
             const double* Yq = lds + q * 64;
             const int r = e / 13, c = e % 13;
             const double v = e < 169 ? Yq[r] * Yq[c] + Yq[13 + r] * Yq[13 + c] + Yq[26 + r] * Yq[26 + c] : 0.0;
-            A.PW[sel][(size_t)meta[32 + q] * PWS + e] = v;
+            (sel ? A.PW[1] : A.PW[0])[(size_t)meta[32 + q] * PWS + e] = v;
         }
     }
 }
@@ -504,7 +535,7 @@ __device__ void wheel_blocks(const LinArgs& A, const DevParams& P, int wave, dou
 // tf_w_o = make_tf(p, theta) * T_imu_to_wheel
 // 32 frames per wave, two lanes each: lane 0 the 3 directions of p, lane 1 of theta
 constexpr int GROUND_PER_WAVE = 32;
-__device__ void ground_frames(const LinArgs& A, const DevParams& P, int wave, double* lds) {
+__device__ __forceinline__ void ground_frames(const LinArgs& A, const DevParams& P, int wave, double* lds) {
     const int lane = threadIdx.x & 63, sub = lane >> 1, g = lane & 1;
     const int n = A.n;
     const long total = (long)(A.active ? A.active[0] : A.B) * n, gf = (long)wave * GROUND_PER_WAVE + sub;
@@ -548,7 +579,7 @@ __device__ void ground_frames(const LinArgs& A, const DevParams& P, int wave, do
             const double* Yq = lds + q * 16;
             const int r = e / 7, c = e % 7;
             const double v = e < 49 ? mult * (Yq[r] * Yq[c] + Yq[7 + r] * Yq[7 + c]) : 0.0;
-            A.PG[sel][(size_t)meta[32 + q] * PGS + e] = v;
+            (sel ? A.PG[1] : A.PG[0])[(size_t)meta[32 + q] * PGS + e] = v;
         }
     }
 }
@@ -559,19 +590,20 @@ __device__ void ground_frames(const LinArgs& A, const DevParams& P, int wave, do
 __host__ __device__ inline int imu_wave_count(int B, int n, int per_wave) { return n > 1 ? (int)(((long)B * (n - 1) + per_wave - 1) / per_wave) : 0; }
 __host__ __device__ inline int wheel_wave_count(int B, int n, int per_wave) { return imu_wave_count(B, n, per_wave); }
 __host__ __device__ inline int ground_wave_count(int B, int n) { return (int)(((long)B * n + GROUND_PER_WAVE - 1) / GROUND_PER_WAVE); }
-__device__ void small_role(const LinArgs& A, const DevParams& P, int vblock, double* lds) {
+template <int ND>
+__device__ __forceinline__ void small_role(const LinArgs& A, const DevParams& P, int vblock, double* lds) {
     const int nw = wheel_wave_count(A.B, A.n, A.small_per_wave);
-    if (vblock < nw) wheel_blocks(A, P, vblock, lds);
+    if (vblock < nw) wheel_blocks<ND>(A, P, vblock, lds);
     else ground_frames(A, P, vblock - nw, lds);
 }
 constexpr int SMALL_LDS = WHEEL_PER_WAVE * 64 + 32;   // + 64 per-block meta words; >= GROUND_PER_WAVE * 16 + 32
 __global__ __launch_bounds__(64, 2) void k_lin_imu(LinArgs A, DevParams P) {
     __shared__ double lds[IMU_PER_WAVE * IMU_REC];
-    imu_blocks(A, P, (int)blockIdx.x, lds);
+    imu_blocks<3>(A, P, (int)blockIdx.x, lds);
 }
 __global__ __launch_bounds__(64, 2) void k_lin_small(LinArgs A, DevParams P) {
     __shared__ double lds[SMALL_LDS];
-    small_role(A, P, (int)blockIdx.x, lds);
+    small_role<3>(A, P, (int)blockIdx.x, lds);
 }
 // Small batches (a single tracking window): every role in ONE launch, the role of a wave follows from its block index —
 // one kernel and no fork / join events per linearisation, which is what a latency-bound 2-frame window pays for.
@@ -580,8 +612,11 @@ __global__ __launch_bounds__(64, 2) void k_lin_all(LinArgs A, DevParams P, int G
     __shared__ double lds[IMU_PER_WAVE * IMU_REC];   // IMU / small roles (>= SMALL_LDS); the laser role brings its own static LDS
     const int v = (int)blockIdx.x;
     if (v < n_laser) laser_wave_local<BOTH>(A, P, G, v);
-    else if (v < n_laser + n_imu) imu_blocks(A, P, v - n_laser, lds);
-    else small_role(A, P, v - n_laser - n_imu, lds);
+    else if (A.small_nd == 1) {   // (uniform) one direction per lane: the short instruction stream a single window waits for
+        if (v < n_laser + n_imu) imu_blocks<1>(A, P, v - n_laser, lds); else small_role<1>(A, P, v - n_laser - n_imu, lds);
+    } else {
+        if (v < n_laser + n_imu) imu_blocks<3>(A, P, v - n_laser, lds); else small_role<3>(A, P, v - n_laser - n_imu, lds);
+    }
 }
 
 // ids of the windows that are still iterating, in window order (deterministic): active[0] = count, active[1 ..] = ids.  One work-group:
@@ -632,11 +667,15 @@ void launch_linearize(const LinArgs& A_, const DevParams& P, hipStream_t s, cons
     LinArgs A = A_;
     const int n = A.n, B = A.B;
     // IMU / wheel blocks per wave: 21 (all 63 lanes) once the batch fills the chip; small batches spread their blocks over more,
-    // shorter waves (the matrix-core stage of a wave is serial over its blocks)
+    // shorter waves (the matrix-core stage of a wave is serial over its blocks); a few windows (everything in ONE k_lin_all launch
+    // with a wave per block) also switch to one derivative direction per lane
+    A.small_nd = 3;
     {
         const long blocks = (long)B * (n > 1 ? n - 1 : 0);
         int pw = IMU_PER_WAVE;
         while (pw > 3 && (blocks + pw - 1) / pw < 512) pw = (pw + 1) / 2;   // 21 -> 11 -> 6 -> 3
+        static const bool nd3 = getenv("LIW_SMALL_ND3") != nullptr;          // profiling aid: keep three directions per lane everywhere
+        if (A.eval_small && !nd3 && (long)B * n + 2 * blocks + ground_wave_count(B, n) <= 256) { pw = 1; A.small_nd = 1; }
         A.small_per_wave = pw;
     }
     // groups per wave: one for small batches (latency), up to LASER_GMAX for large ones (no ragged last pass per group)

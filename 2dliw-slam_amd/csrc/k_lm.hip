@@ -29,16 +29,12 @@ __device__ long long g_span[3 * 16384];   // per window: start, end (s_memtime),
 #define STAMP(id) do { if (b == 0 && lane == 0 && iteration_dbg == LIW_CLK_IT) g_clk[(id)] = clock64(); } while (0)
 #define STAMPE(id) do { if (b == 0 && lane == 0 && iteration == LIW_CLK_IT) g_clk[(id)] = clock64(); } while (0)   // before iteration_dbg exists
 #define STAMPM(id) do { if (b == 0 && lane == 0) g_clk[(id)] = clock64(); } while (0)                              // marginalisation kernel
-#define STAMPQ(id) do { if (lane == 0) g_clk[(id)] = clock64(); } while (0)
-#define COUNTQ(id, v) do { if (lane == 0) g_clk[(id)] = (v); } while (0)
 #define SPAN(k) do { if (lane == 0 && iteration_dbg == LIW_CLK_IT && b < 16384) { g_span[3 * b + (k)] = clock64(); \
                      if ((k) == 0) g_span[3 * b + 2] = __builtin_amdgcn_s_getreg((4 << 0) | (0 << 6) | (31 << 11)); } } while (0)
 #else
 #define STAMP(id) do { } while (0)
 #define STAMPE(id) do { } while (0)
 #define STAMPM(id) do { } while (0)
-#define STAMPQ(id) do { } while (0)
-#define COUNTQ(id, v) do { } while (0)
 #define SPAN(k) do { } while (0)
 #endif
 
@@ -1465,127 +1461,9 @@ __global__ __launch_bounds__(64) void k_export_dense(ExportArgs a) {
 }
 
 // ---------------------------------------------------------------------------------------------------
-// Symmetric eigen-decomposition of a 15x15 matrix by ONE wave (solver.cpp:390-402 uses Eigen::SelfAdjointEigenSolver):
-// Householder tridiagonalisation — lane r keeps row r of the matrix and of the accumulated reflections in registers, reflection
-// vectors travel by v_readlane — then implicit-shift QL on the tridiagonal form (tql2): diagonal / sub-diagonal one entry per
-// lane, plane rotations applied to the eigenvector matrix in LDS (column-major: lane r only ever touches row r, no barriers).
-// About 250 rotations with ~150 cycles on the dependent chain, against 8 cyclic-Jacobi sweeps x 15 rounds x 3 LDS hand-offs
-// (51 us of the 65 us k_marg_schur took on a tracking window in round 1).
-// In: A (LDS, ld 16, symmetric).  Out: return value = eigenvalue `lane` (lane < 15, unsorted), Vc[c * 16 + r] = component r of
-// eigenvector c.
-__device__ __noinline__ double eig15_ql(const double* A, double* Vc, int lane) {
-    const bool row = lane < 15;
-    const int rl = row ? lane : 15;                      // lanes beyond the matrix work on the unused row 15 of the 16 x 16 tiles
-    double a[15], q[15];
-#pragma unroll
-    for (int c = 0; c < 15; ++c) { a[c] = row ? A[rl * 16 + c] : 0.0; q[c] = (row && c == lane) ? 1.0 : 0.0; }
-    double e = 0.0;   // lane j: T[j][j+1]
-#pragma unroll
-    for (int k = 0; k < 13; ++k) {
-        // column k below the diagonal, taken from ROW k (lane k) as wave-uniform values: the reflection vector needs no further broadcasts
-        double x[15];
-        double sigma = 0.0;
-#pragma unroll
-        for (int c = k + 1; c < 15; ++c) { x[c] = rdlane(a[c], k); if (c > k + 1) sigma = __builtin_fma(x[c], x[c], sigma); }
-        const double x0 = x[k + 1];
-        if (sigma == 0.0) { if (lane == k) e = x0; continue; }             // column already reduced (wave-uniform)
-        sigma = __builtin_fma(x0, x0, sigma);
-        const double nrm = sigma * fast_rsqrt(sigma);
-        const double alpha = x0 >= 0.0 ? -nrm : nrm;
-        x[k + 1] = x0 - alpha;                                             // v (uniform); v^T v = 2 (sigma - alpha x0)
-        const double beta = fast_rcp(sigma - alpha * x0);
-        double v = 0.0;                                                    // this lane's entry of v
-#pragma unroll
-        for (int c = k + 1; c < 15; ++c) v = lane == c ? x[c] : v;
-        double p0 = 0.0, p1 = 0.0;
-#pragma unroll
-        for (int c = k + 1; c < 15; ++c) { if ((c - k) & 1) p0 = __builtin_fma(a[c], x[c], p0); else p1 = __builtin_fma(a[c], x[c], p1); }
-        const double p = lane > k ? (p0 + p1) * beta : 0.0;
-        const double Kc = 0.5 * beta * rdlane(row_sum(v * p), 0);
-        const double w = p - Kc * v;
-#pragma unroll
-        for (int c = k + 1; c < 15; ++c) a[c] -= v * rdlane(w, c) + w * x[c];
-        if (lane > k) a[k] = lane == k + 1 ? alpha : 0.0;
-        if (lane == k) {
-            a[k + 1] = alpha;
-#pragma unroll
-            for (int c = k + 2; c < 15; ++c) a[c] = 0.0;
-            e = alpha;
-        }
-        double t0 = 0.0, t1 = 0.0;                                         // Q <- Q (I - beta v v^T)
-#pragma unroll
-        for (int c = k + 1; c < 15; ++c) { if ((c - k) & 1) t0 = __builtin_fma(q[c], x[c], t0); else t1 = __builtin_fma(q[c], x[c], t1); }
-        const double t = (t0 + t1) * beta;
-#pragma unroll
-        for (int c = k + 1; c < 15; ++c) q[c] = __builtin_fma(-t, x[c], q[c]);
-    }
-    STAMPQ(5020);
-    if (lane == 13) e = a[14];
-    double d = 0.0;
-#pragma unroll
-    for (int c = 0; c < 15; ++c) d = lane == c ? a[c] : d;
-#pragma unroll
-    for (int c = 0; c < 15; ++c) Vc[c * 16 + rl] = q[c];
-    STAMPQ(5021);
-    // ---- implicit QL.  One rotation per inner iteration on the dependent chain g -> r -> (s, c) -> g; everything that does not
-    // depend on the chain (the eigenvector column, e_i, d_i of the NEXT rotation) is fetched one rotation ahead: a wave issues in
-    // order, so an LDS round trip (72 cycles) waited for inside the chain is paid in full.  What is left is bound by the ~43
-    // instructions per rotation this one wave issues at 4 cycles each (measured ~300 cycles per rotation, ~240 rotations).
-    long long nrot = 0, nsweep = 0, tin = 0;
-    for (int l = 0; l < 15; ++l) {
-        for (int iter = 0; iter < 60; ++iter) {
-            const double dn = dpp64<0x101>(d);                                  // row_shl:1 = d of lane + 1
-            const bool small = lane < 14 && fabs(e) <= 1.11e-16 * (fabs(d) + fabs(dn));
-            unsigned long long mask = __ballot(small) | (1ull << 14);
-            mask &= ~((1ull << l) - 1ull);
-            const int m = __builtin_ctzll(mask);
-            if (m == l) break;
-            const double dl = rdlane(d, l), el = rdlane(e, l), dm = rdlane(d, m);
-            double g = (rdlane(d, l + 1) - dl) * (0.5 * fast_rcp(el));            // the shift only steers convergence: no IEEE division needed
-            const double h = __builtin_fma(g, g, 1.0);
-            const double r0 = h * fast_rsqrt(h);
-            g = dm - dl + el * fast_rcp(g + (g >= 0.0 ? r0 : -r0));
-            double s = 1.0, c = 1.0, p = 0.0;
-            double carry = Vc[m * 16 + rl];                                     // column i+1 of the eigenvector matrix, row `lane`
-            int i = m - 1;
-            double vi = Vc[i * 16 + rl], ei = rdlane(e, i), di = rdlane(d, i), di1 = dm;
-            nsweep += 1; nrot += m - l;
-#ifdef LIW_CLK
-            const long long tq0 = clock64();
-#endif
-            for (; i >= l; --i) {
-                const int in = i > l ? i - 1 : l;
-                const double vn = Vc[in * 16 + rl], en = rdlane(e, in), dnx = rdlane(d, in);
-                const double f = s * ei, bq = c * ei;
-                const double h2 = fmax(__builtin_fma(f, f, g * g), 1e-300);      // f = g = 0 needs an underflow (tqli guards it)
-                const double rinv = fast_rsqrt(h2);
-                e = lane == i + 1 ? h2 * rinv : e;
-                s = f * rinv; c = g * rinv;
-                g = di1 - p;
-                const double r = __builtin_fma(di - g, s, (c + c) * bq);
-                p = s * r;
-                d = lane == i + 1 ? g + p : d;
-                g = __builtin_fma(c, r, -bq);
-                Vc[(i + 1) * 16 + rl] = __builtin_fma(s, vi, c * carry);
-                carry = __builtin_fma(c, vi, -s * carry);
-                vi = vn; ei = en; di1 = di; di = dnx;
-            }
-#ifdef LIW_CLK
-            tin += clock64() - tq0;
-#endif
-            Vc[l * 16 + rl] = carry;
-            if (lane == l) { d -= p; e = g; }
-            if (lane == m) e = 0.0;
-        }
-    }
-    STAMPQ(5022); COUNTQ(5023, nrot); COUNTQ(5024, nsweep); COUNTQ(5025, tin);
-    return d;
-}
-
-// ---------------------------------------------------------------------------------------------------
 // marginalisation: chain Schur complement of frames 0..n-2 onto frame n-1 (marginalization_matrix,
 // solver.cpp:4-40, on the block tri-diagonal H), eigen square root (solver.cpp:390-402), prior update (:407-441)
-__device__ __forceinline__ void marg_schur_body(const MargArgs& a, const int b, LdsTiles& T, double* V, double* Am) {
+__device__ __forceinline__ void marg_schur_body(const MargArgs& a, const int b, LdsTiles& T, double* V, double* Am, double* rot) {
     const int lane = threadIdx.x & 63, n = a.n;
     if (a.gate && !a.gate[b].done) { if (a.status && lane == 0) a.status[b] = 2; return; }
     double* oX = a.out_X ? a.out_X : a.prior_X; double* oJ = a.out_J ? a.out_J : a.prior_J; double* oR = a.out_R ? a.out_R : a.prior_R;
@@ -1666,32 +1544,95 @@ __device__ __forceinline__ void marg_schur_body(const MargArgs& a, const int b, 
     if (a.Delta_H) for (int e = lane; e < 225; e += 64) a.Delta_H[(size_t)b * 225 + e] = T.D[(e / 15) * 16 + e % 15];
     if (a.Delta_g && lane < 15) a.Delta_g[(size_t)b * 15 + lane] = -T.g[lane];
     STAMPM(5001);
-    // ---- symmetric eigen-decomposition (15x15): Am -> eigenvalue `lane` in wl, eigenvectors in the columns of V (column-major)
+    // ---- symmetric eigen-decomposition by cyclic Jacobi (15x15), A -> Am, eigenvectors -> V (columns).
+    // Jacobi, not tridiagonalisation + QL: Delta_H is graded over 1e11 (pose rows) ... 1e2 (bias rows), and only Jacobi keeps the small
+    // blocks accurate RELATIVE to their own scale (a QL variant was 15 % faster, normwise-accurate like Eigen's solver in the reference,
+    // and moved the tracking solve on the resulting prior by 1e-6 at cond(H_mm) = 1e7 — tests/soak/soak_batch.py found it).
     for (int e = lane; e < 256; e += 64) {
         const int r = e >> 4, cc = e & 15;
         Am[e] = (r < 15 && cc < 15) ? 0.5 * (T.D[r * 16 + cc] + T.D[cc * 16 + r]) : 0.0;
+        V[e] = r == cc ? 1.0 : 0.0;
     }
     lds_sync();
-    const double wl = eig15_ql(Am, V, lane);
-    lds_sync();
+    for (int sweep = 0; sweep < 60; ++sweep) {
+        double off = 0.0, dgn = 0.0;
+        for (int e = lane; e < 225; e += 64) {
+            const int r = e / 15, cc = e % 15;
+            const double v = Am[r * 16 + cc];
+            if (cc > r) off += v * v;
+            if (cc == r) dgn += v * v;
+        }
+        off = wave_sum(off); dgn = wave_sum(dgn);
+        if (off <= 1e-34 * dgn || off == 0.0) break;   // sums of squares: off-diagonal below 1e-17 of the diagonal
+        // parallel (round-robin) ordering: 15 rounds of 7 disjoint index pairs; the 7 plane rotations of a round are
+        // computed from the same A and applied together (columns of A and V, then rows of A), 105 independent element
+        // pairs per phase spread over the wave.  The pair (p, q) of slot i in round rnd is recomputed from the indices by every lane
+        // (a few integer operations instead of an LDS round trip), only cos / sin travel through LDS.
+        for (int rnd = 0; rnd < 15; ++rnd) {
+            auto pair_of = [&](int i, int& p, int& q) {
+                const int k = i + 1;
+                p = rnd + k; p = p >= 15 ? p - 15 : p;
+                q = rnd + 15 - k; q = q >= 15 ? q - 15 : q;
+                if (p > q) { const int t_ = p; p = q; q = t_; }
+            };
+            if (lane < 7) {
+                int p, q;
+                pair_of(lane, p, q);
+                const double apq = Am[p * 16 + q];
+                double cs = 1.0, sn = 0.0;
+                if (apq != 0.0) {
+                    // t = sgn(tau) / (|tau| + sqrt(1 + tau^2)) with tau = (aqq - app) / (2 apq), written without the division by apq;
+                    // square root, reciprocal and reciprocal square root from the hardware estimates + Newton steps (the rotation only
+                    // has to be orthogonal to working precision: cs^2 + sn^2 = 1 holds by construction)
+                    const double d = Am[q * 16 + q] - Am[p * 16 + p], h = 2.0 * apq;
+                    const double qq = d * d + h * h;
+                    const double t = (d >= 0.0 ? h : -h) * fast_rcp(fabs(d) + qq * fast_rsqrt(qq));
+                    cs = fast_rsqrt(1.0 + t * t); sn = t * cs;
+                }
+                rot[lane * 2] = cs; rot[lane * 2 + 1] = sn;
+            }
+            lds_sync();
+            for (int it = lane; it < 105; it += 64) {   // columns p,q of A and V: (row k, pair i)
+                const int k = it / 7, i = it - 7 * k;
+                int p, q;
+                pair_of(i, p, q);
+                const double cs = rot[i * 2], sn = rot[i * 2 + 1];
+                const double akp = Am[k * 16 + p], akq = Am[k * 16 + q];
+                const double vkp = V[k * 16 + p], vkq = V[k * 16 + q];
+                Am[k * 16 + p] = cs * akp - sn * akq;
+                Am[k * 16 + q] = sn * akp + cs * akq;
+                V[k * 16 + p] = cs * vkp - sn * vkq;
+                V[k * 16 + q] = sn * vkp + cs * vkq;
+            }
+            lds_sync();
+            for (int it = lane; it < 105; it += 64) {   // rows p,q of A: (pair i, column k)
+                const int k = it / 7, i = it - 7 * k;
+                int p, q;
+                pair_of(i, p, q);
+                const double cs = rot[i * 2], sn = rot[i * 2 + 1];
+                const double apk = Am[p * 16 + k], aqk = Am[q * 16 + k];
+                Am[p * 16 + k] = cs * apk - sn * aqk;
+                Am[q * 16 + k] = sn * apk + cs * aqk;
+            }
+            lds_sync();
+        }
+    }
     STAMPM(5002);
     // sort ascending (rank by counting; ties by index), sign convention: largest |component| positive
-    int rank = 0;
-#pragma unroll
-    for (int k = 0; k < 15; ++k) { const double wk = rdlane(wl, k); if (wk < wl || (wk == wl && k < lane)) ++rank; }
     if (lane < 15) {
-        const double w = wl;
-        const double* Vl = V + lane * 16;               // eigenvector `lane`
+        const double w = Am[lane * 16 + lane];
+        int rank = 0;
+        for (int k = 0; k < 15; ++k) { const double wk = Am[k * 16 + k]; if (wk < w || (wk == w && k < lane)) ++rank; }
         int m = 0;
-        for (int k = 1; k < 15; ++k) if (fabs(Vl[k]) > fabs(Vl[m])) m = k;
-        const double sg = Vl[m] < 0.0 ? -1.0 : 1.0;
+        for (int k = 1; k < 15; ++k) if (fabs(V[k * 16 + lane]) > fabs(V[m * 16 + lane])) m = k;
+        const double sg = V[m * 16 + lane] < 0.0 ? -1.0 : 1.0;
         const double eps = 1e-8;
         const double S = w > eps ? w : 0.0, Sinv = w > eps ? 1.0 / w : 0.0;
         const double ssq = sqrt(S), sisq = sqrt(Sinv);
         double dotg = 0.0;
-        for (int k = 0; k < 15; ++k) dotg += sg * Vl[k] * (-T.g[k]);   // V^T Delta_g
+        for (int k = 0; k < 15; ++k) dotg += sg * V[k * 16 + lane] * (-T.g[k]);   // V^T Delta_g
         // linearized_jacobians row `rank` = sqrt(S) v^T ; linearized_residuals[rank] = -(S^-1/2 v^T Delta_g)
-        for (int k = 0; k < 15; ++k) oJ[(size_t)b * 225 + rank * 15 + k] = ssq * sg * Vl[k];
+        for (int k = 0; k < 15; ++k) oJ[(size_t)b * 225 + rank * 15 + k] = ssq * sg * V[k * 16 + lane];
         oR[(size_t)b * 15 + rank] = -(sisq * dotg);
     }
     wave_mem_sync();
@@ -1703,8 +1644,8 @@ __device__ __forceinline__ void marg_schur_body(const MargArgs& a, const int b, 
 }
 __global__ __launch_bounds__(64, 2) void k_marg_schur(MargArgs a) {
     __shared__ LdsTiles T;
-    __shared__ double V[256], Am[256];
-    marg_schur_body(a, (int)blockIdx.x, T, V, Am);
+    __shared__ double V[256], Am[256], rot[16];
+    marg_schur_body(a, (int)blockIdx.x, T, V, Am, rot);
 }
 
 #ifdef LIW_CLK

@@ -82,6 +82,7 @@ struct LinArgs {
     const LmState* gate;        // non-null: linearise window b only if gate[b].done (a marginalisation enqueued speculatively behind a solve)
     int candidate;              // 1: write the small-factor partials of window b into buffer 1 - lm[b].cur
     int small_per_wave;         // IMU / wheel blocks per wave (set by launch_linearize)
+    int small_nd;               // derivative directions per lane of the IMU / wheel roles: 3 (batches) or 1 (k_lin_all on a few windows)
     int* active;                // [1 + B]: number of windows still iterating, then their ids (built per linearisation when lm != null)
     // optional per-factor outputs (liw_eval_factors)
     double* dbg_laser_res; double* dbg_laser_jac; double* dbg_imu_res; double* dbg_imu_jac;

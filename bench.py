@@ -467,6 +467,8 @@ def main():
                     sharded["allreduce_bytes_per_iteration"] = res["exchange_bytes_per_rank"]
                 else:
                     sharded["oneshot_exchange"] = res
+                if world > 1 and xi == 1:   # what exchange="auto" would keep on this machine at this record size (collective + sum, timed once)
+                    sharded["auto_exchange_pick"] = {k: (round(v, 4) if isinstance(v, float) else v) for k, v in sb.pick_exchange(liw.LIW_MODE_INIT).items()}
                 sb.close()
         except Exception as e:   # never lose the headline line because of the secondary measurement
             import traceback

@@ -163,7 +163,7 @@ def test_exchange_variants_bit_identical_and_early_exit(liw, synth, pyoracle, en
     assert np.array_equal(plain.states(), forced.states())
     assert [s["iterations"] for s in plain.summaries()] == [s["iterations"] for s in forced.summaries()]
     out = {}
-    for xch in ("allreduce", "oneshot"):
+    for xch in ("allreduce", "oneshot", "auto"):
         comms = liw.batch.LockstepComm.make(2)
         ranks = [liw.BatchSolver(prm, ws, rank=r, world=2, exchange=xch, comm=comms[r]) for r in range(2)]
         th = [threading.Thread(target=lambda rk=rk: rk.solve(liw.LIW_MODE_INIT, 50)) for rk in ranks]
@@ -174,6 +174,9 @@ def test_exchange_variants_bit_identical_and_early_exit(liw, synth, pyoracle, en
         torch.cuda.synchronize()
         assert np.array_equal(ranks[0].states(), ranks[1].states())
         out[xch] = (ranks[0].states(), [s["iterations"] for s in ranks[0].summaries()])
-    assert np.array_equal(out["allreduce"][0], out["oneshot"][0])
+        if xch == "auto":                               # timed both once, every rank kept the same (faster) transport
+            assert ranks[0].exchange in ("allreduce", "oneshot") and ranks[0].exchange == ranks[1].exchange
+            assert ranks[0].exchange_pick["picked"] == ranks[0].exchange and ranks[0].exchange_pick == ranks[1].exchange_pick
+    assert np.array_equal(out["allreduce"][0], out["oneshot"][0]) and np.array_equal(out["allreduce"][0], out["auto"][0])
     assert out["allreduce"][1] == [s["iterations"] for s in plain.summaries()]
     assert rel_inf(out["allreduce"][0], plain.states()) <= 1e-9

@@ -50,4 +50,9 @@ for i in (1, 0):
     print(" frame", i, "assemble", t[1] - t[0], "diag/gmax", t[2] - t[1], "colload", t[3] - t[2], "chol", t[4] - t[3], "ldsW", t[5] - t[4],
           "mfma+record+C", (clk[10 + (i - 1) * 8] if i else clk[1]) - t[5])
 print("k_marg_schur: chain %d | eigen %d | tail %d" % (d(5000, 5001), d(5001, 5002), d(5002, 5003)))
-print("eig15_ql: load+tridiag %d | store Q %d | QL %d  (rotations %d, sweeps %d, inner loops %d ticks)" % (d(5001, 5020), d(5020, 5021), d(5021, 5022), clk[5023], clk[5024], clk[5025]))
+# IMU role of the single-launch linearisation (k_lin_all: work-group n_laser + 0 is the IMU wave; LSTAMP picks gridDim / 2 = it at n = 2)
+slv.linearize(liw.LIW_MODE_TRACK)
+cl = np.zeros(512, dtype=np.int64)
+liw.lib().liw_debug_clk_lin(cl.ctypes.data_as(C.c_void_p), C.c_int(512))
+print("imu role (1 block): alpha/beta rows + dual exp %d | gamma rows (dE products, log_SO3) %d | sync %d | MFMA + stores %d | total %d"
+      % (cl[302] - cl[300], cl[303] - cl[302], cl[304] - cl[303], cl[311] - cl[304], cl[311] - cl[300]))
