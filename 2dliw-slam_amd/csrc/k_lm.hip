@@ -649,6 +649,7 @@ __device__ __forceinline__ void lm_step_body(const StepArgs& a, const int b, Lds
     const Tiles<1> TM{T.M, nullptr, nullptr, nullptr};
     AsmRegs areg;
     PriorRegs preg;
+    const double inv_radius = 1.0 / radius;   // (one division per step instead of one per frame; 1 ulp from diagonal / radius)
     if constexpr (LIW_PF1) areg = asm_issue(c, n - 1, scl, dgl);
     for (int i = n - 1; i >= 0; --i) {
         STAMP(10 + i * 8 + 0);
@@ -687,6 +688,14 @@ __device__ __forceinline__ void lm_step_body(const StepArgs& a, const int b, Lds
         else if (ln >= 16 && ln < 31) slane = i >= 1 ? s_m : 0.0;
         else if (ln >= 32 && ln < 38) slane = i >= 2 ? s_0 : 0.0;
         else if (ln == 40) slane = 1.0;
+        // LM damping and the unit pivots of constant entries go into the carried-terms tile BEFORE the columns are read: patching
+        // col[ln] afterwards is a dynamic register index = 7 instructions per row.  (A constant entry's row / column of M and of
+        // the carried terms is zero, and the hub accumulators only exist in the init topology, which has no constants.)
+        if (ln < 15) {
+            double& cd = T.C[ln * MS + ln];
+            cd = cstl ? 1.0 : cd + dgv * inv_radius;
+        }
+        lds_sync();
         double col[15];
         const int lc = ln < MS ? ln : MS - 1;   // lanes beyond the last column read a valid word they never use
 #pragma unroll
@@ -711,11 +720,6 @@ __device__ __forceinline__ void lm_step_body(const StepArgs& a, const int b, Lds
 #pragma unroll
                 for (int r = 0; r < 6; ++r) col[r] += T.g0acc[r];
             }
-        }
-        if (ln < 15) {
-            const double dmp = cstl ? 0.0 : dgv / radius;
-#pragma unroll
-            for (int r = 0; r < 15; ++r) if (r == ln) col[r] = cstl ? 1.0 : col[r] + dmp;
         }
         STAMP(10 + i * 8 + 3);
         // software pipeline: the next frame's loads are in flight while this one is factorised
