@@ -177,6 +177,11 @@ __device__ __forceinline__ AsmRegs asm_issue(const AsmCtx& c, int i, const doubl
     const double* PIp = PIb + (size_t)(hasp ? i : 0) * PIS;       // IMU block (i, i+1)
     const double* PWm = PWb + (size_t)(hasm ? i - 1 : 0) * PWS;
     const double* PWp = PWb + (size_t)(hasp ? i : 0) * PWS;
+    // frame-level bases are wave-uniform (SGPR pairs), the lane-dependent part of every address is an unsigned 32-bit element offset:
+    // global_load with scalar base + vector offset instead of a 64-bit vector address per load (148 of the kernel's 236 loads)
+    const double* PLi = PLb + (size_t)i * LP;
+    const double* PL1 = PLb + (size_t)(n > 1 ? 1 : 0) * LP;
+    const double* PGi = PGb + (size_t)i * PGS;
     AsmRegs R;
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
@@ -184,46 +189,46 @@ __device__ __forceinline__ AsmRegs asm_issue(const AsmCtx& c, int i, const doubl
         const bool valid = r < 15 && cc < 15;
         const int rs = valid ? r : 0, cs = valid ? cc : 0;
         const int tq = pi_tri(rs, cs);
-        R.v5[q] = PIm[PI_JJ + tq];
-        R.v6[q] = PIp[PI_II + tq];
-        R.v7[q] = up ? PIp[PI_IJ + cs * 15 + rs] : PIm[PI_IJ + rs * 15 + cs];   // (row r = neighbour's entry, column cc = frame i's)
+        R.v5[q] = PIm[(unsigned)(PI_JJ + tq)];
+        R.v6[q] = PIp[(unsigned)(PI_II + tq)];
+        R.v7[q] = up ? PIp[(unsigned)(PI_IJ + cs * 15 + rs)] : PIm[(unsigned)(PI_IJ + rs * 15 + cs)];   // (row r = neighbour's entry, column cc = frame i's)
     }
     {   // the 6x6 pose block terms: one element per lane (lanes 0..35)
         const bool pl = lane < 36;
         const int r = pl ? lane / 6 : 0, cc = pl ? lane % 6 : 0;
-        R.t1 = PLb[(size_t)i * LP + 36 + r * 6 + cc];
-        R.t2 = PWm[(6 + r) * 13 + 6 + cc];
-        R.t3 = PWp[r * 13 + cc];
-        R.t4 = PGb[(size_t)i * PGS + r * 7 + cc];
-        R.t8 = up ? PWp[cc * 13 + 6 + r] : PWm[r * 13 + 6 + cc];
-        R.e2 = up ? PWm[r * 13 + 6 + cc] : 0.0;
-        R.t9 = PLb[(size_t)(n > 1 ? 1 : 0) * LP + 72 + r * 6 + cc];
-        R.t10 = PLb[(size_t)i * LP + 72 + r * 6 + cc];
+        R.t1 = PLi[(unsigned)(36 + r * 6 + cc)];
+        R.t2 = PWm[(unsigned)((6 + r) * 13 + 6 + cc)];
+        R.t3 = PWp[(unsigned)(r * 13 + cc)];
+        R.t4 = PGi[(unsigned)(r * 7 + cc)];
+        R.t8 = up ? PWp[(unsigned)(cc * 13 + 6 + r)] : PWm[(unsigned)(r * 13 + 6 + cc)];
+        R.e2 = up ? PWm[(unsigned)(r * 13 + 6 + cc)] : 0.0;
+        R.t9 = PL1[(unsigned)(72 + r * 6 + cc)];
+        R.t10 = PLi[(unsigned)(72 + r * 6 + cc)];
     }
     {
         const int r = lane < 15 ? lane : 0, r6 = r < 6 ? r : 0;
-        R.g1 = PLb[(size_t)i * LP + 114 + r6];
-        R.g2 = PWm[(6 + r6) * 13 + 12];
-        R.g3 = PWp[r6 * 13 + 12];
-        R.g4 = PGb[(size_t)i * PGS + r6 * 7 + 6];
-        R.g5 = PIm[PI_G + 15 + r];
-        R.g6 = PIp[PI_G + r];
+        R.g1 = PLi[(unsigned)(114 + r6)];
+        R.g2 = PWm[(unsigned)((6 + r6) * 13 + 12)];
+        R.g3 = PWp[(unsigned)(r6 * 13 + 12)];
+        R.g4 = PGi[(unsigned)(r6 * 7 + 6)];
+        R.g5 = PIm[(unsigned)(PI_G + 15 + r)];
+        R.g6 = PIp[(unsigned)(PI_G + r)];
     }
     const int nbf = up ? (hasp ? i + 1 : i) : (hasm ? i - 1 : i);   // the sweep neighbour (or i itself at the end of the chain)
     {   // states (rotation vectors of frames i, its neighbour, 0 for the so3 Plus Jacobian test) and the LM scales
         int idx = i * 15 + (lane < 15 ? lane : 0);
         if (lane >= 16 && lane < 19) idx = nbf * 15 + 3 + (lane - 16);
         if (lane >= 20 && lane < 23) idx = 3 + (lane - 20);
-        R.xq = c.x[idx];
+        R.xq = c.x[(unsigned)idx];
         const int v = lane < 15 ? lane : 0;
-        R.sc_i = scl ? scl[i * 15 + v] : 1.0;
-        R.sc_m = scl ? scl[nbf * 15 + v] : 1.0;
-        R.dg_i = dgl ? dgl[i * 15 + v] : 0.0;
+        R.sc_i = scl ? scl[(unsigned)(i * 15 + v)] : 1.0;
+        R.sc_m = scl ? scl[(unsigned)(nbf * 15 + v)] : 1.0;
+        R.dg_i = dgl ? dgl[(unsigned)(i * 15 + v)] : 0.0;
     }
 #pragma unroll
     for (int q = 0; q < 2; ++q) {   // rows 0..5 (pose of frame i-1) of the IMU block (i-1, i): element e = r * 15 + c < 90
         const int e = lane + 64 * q;
-        R.e1[q] = up ? PIm[PI_IJ + (e < 90 ? e : 0)] : 0.0;
+        R.e1[q] = up ? PIm[(unsigned)(PI_IJ + (e < 90 ? e : 0))] : 0.0;
     }
     return R;
 }
@@ -547,7 +552,10 @@ __device__ __forceinline__ void lm_step_body(const StepArgs& a, const int b, Lds
     c.prior_on = a.mode == LIW_MODE_TRACK && a.has_prior[b] && !a.fast_mode;
 
     double radius = st.radius, dec = st.decrease_factor, x_cost = st.x_cost, x_norm = st.x_norm;
-    int reuse = st.reuse_diagonal, iteration = st.iteration, cur = st.cur;
+    // wave-uniform by construction, but loaded with vector loads: made scalar explicitly, so that the partial-buffer base pointers
+    // selected by `cur` (and everything derived from them in the frame loop) stay in SGPRs instead of 64-bit VALU address arithmetic
+    int reuse = __builtin_amdgcn_readfirstlane(st.reuse_diagonal), iteration = __builtin_amdgcn_readfirstlane(st.iteration),
+        cur = __builtin_amdgcn_readfirstlane(st.cur);
     bool last_successful = true;
     bool fresh = false;
     STAMPE(4000);
