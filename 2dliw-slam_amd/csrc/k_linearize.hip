@@ -611,12 +611,19 @@ template <bool BOTH>
 __global__ __launch_bounds__(64, 2) void k_lin_all(LinArgs A, DevParams P, int G, int n_laser, int n_imu) {
     __shared__ double lds[IMU_PER_WAVE * IMU_REC];   // IMU / small roles (>= SMALL_LDS); the laser role brings its own static LDS
     const int v = (int)blockIdx.x;
+#ifdef LIW_CLK
+    if ((threadIdx.x & 63) == 0 && v < 40) g_clk_lin[400 + 2 * v] = clock64();
+#endif
     if (v < n_laser) laser_wave_local<BOTH>(A, P, G, v);
     else if (A.small_nd == 1) {   // (uniform) one direction per lane: the short instruction stream a single window waits for
         if (v < n_laser + n_imu) imu_blocks<1>(A, P, v - n_laser, lds); else small_role<1>(A, P, v - n_laser - n_imu, lds);
     } else {
         if (v < n_laser + n_imu) imu_blocks<3>(A, P, v - n_laser, lds); else small_role<3>(A, P, v - n_laser - n_imu, lds);
     }
+#ifdef LIW_CLK
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+    if ((threadIdx.x & 63) == 0 && v < 40) g_clk_lin[401 + 2 * v] = clock64();
+#endif
 }
 
 // ids of the windows that are still iterating, in window order (deterministic): active[0] = count, active[1 ..] = ids.  One work-group:
