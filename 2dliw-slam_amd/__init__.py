@@ -233,9 +233,10 @@ class Solver:
         return out
 
     def marginalization(self):
-        sH, dH, dg = np.zeros(36), np.zeros(225), np.zeros(15)
-        self._chk(self.L.liw_marginalize(self.h, _p(sH), _p(dH), _p(dg)))
-        return dict(sqrt_H=sH.reshape(6, 6), Delta_H=dH.reshape(15, 15), Delta_g=dg)
+        out = np.zeros(36 + 225 + 15)      # one allocation: the call is ~10 us of a 0.24 ms tracking frame
+        base = out.ctypes.data
+        self._chk(self.L.liw_marginalize(self.h, C.cast(base, dp), C.cast(base + 36 * 8, dp), C.cast(base + 261 * 8, dp)))
+        return dict(sqrt_H=out[:36].reshape(6, 6), Delta_H=out[36:261].reshape(15, 15), Delta_g=out[261:])
 
     def get_prior(self):
         X, J, R = np.zeros(15), np.zeros(225), np.zeros(15)

@@ -885,7 +885,7 @@ __device__ __forceinline__ void lm_step_body(const StepArgs& a, const int b, Lds
                 if (!cst) {
                     sn2 += (xold - xnew) * (xold - xnew);
                     ytg += t * gsv;
-                    dsum += dgv / radius * t * t;
+                    dsum += dgv * inv_radius * t * t;
                 }
             }
             if (LIW_PF2) cur = nxt;
