@@ -204,7 +204,19 @@ __device__ __forceinline__ void imu_blocks(const LinArgs& A, const DevParams& P,
             }
         }
         const M3<JN> Md = exp_so3(arg);
-        const M3<double> Rt = exp_so3(-thi);                                      // bk_R_w
+        // The three rotations of the chain as VALUES are the value parts of the three lanes' differentiated factors: fetched from the
+        // first lane of each factor (two ds_bpermute per entry) instead of three more exp_so3 per lane (~750 instructions).
+        M3<double> Rt, Rj, Eg;                                                    // exp(-theta_i) = bk_R_w, exp(theta_j), exp(-gamma)
+        {
+            const int l0 = lane - g;                                              // first lane of this block
+#pragma unroll
+            for (int q = 0; q < 9; ++q) {
+                const double mv = Md.m[q].v;
+                Rt.m[q] = __shfl(mv, l0, 64);
+                Rj.m[q] = __shfl(mv, l0 + LPB / 3, 64);
+                Eg.m[q] = __shfl(mv, l0 + 2 * (LPB / 3), 64);
+            }
+        }
         __builtin_amdgcn_sched_barrier(0);
         // ---- alpha, beta, ba, bw rows
         {
@@ -256,7 +268,6 @@ __device__ __forceinline__ void imu_blocks(const LinArgs& A, const DevParams& P,
         __builtin_amdgcn_sched_barrier(0);
         // ---- gamma rows: log( exp(-gamma^) R_i^T R_j )
         {
-            const M3<double> Rj = exp_so3(thj), Eg = exp_so3(-gam);
             const M3<double> RtRj = mul(Rt, Rj), EgRt = mul(Eg, Rt);
             M3<double> Lm, Rm;   // dE_e = Lm * dM_e * Rm
 #pragma unroll
@@ -412,7 +423,18 @@ __device__ __forceinline__ void wheel_blocks(const LinArgs& A, const DevParams& 
             }
         }
         const M3<JN> Md = exp_so3(arg);
-        const M3<double> Ri = exp_so3(thi), Rj = exp_so3(thj), Riw = cast_m3<double>(P.Riw);
+        // R_i, R_j as values = the value parts of the differentiated rotations of the f = 0 (and f = 2: same argument) / f = 1 lanes
+        M3<double> Ri, Rj;
+        {
+            const int l0 = lane - g;
+#pragma unroll
+            for (int q = 0; q < 9; ++q) {
+                const double mv = Md.m[q].v;
+                Ri.m[q] = __shfl(mv, l0, 64);
+                Rj.m[q] = __shfl(mv, l0 + LPB / 3, 64);
+            }
+        }
+        const M3<double> Riw = cast_m3<double>(P.Riw);
         const V3<double> tiw(P.tiw[0], P.tiw[1], P.tiw[2]);
         const M3<double> Rwi = mul(Ri, Riw);                      // tf_i.R
         const M3<double> Am = transpose(Rwi);                     // R_iw^T R_i^T
