@@ -703,7 +703,7 @@ void launch_linearize(const LinArgs& A_, const DevParams& P, hipStream_t s, cons
         const long blocks = (long)B * (n > 1 ? n - 1 : 0);
         int pw = IMU_PER_WAVE;
         while (pw > 3 && (blocks + pw - 1) / pw < 512) pw = (pw + 1) / 2;   // 21 -> 11 -> 6 -> 3
-        static const bool nd3 = getenv("LIW_SMALL_ND3") != nullptr;          // profiling aid: keep three directions per lane everywhere
+        const bool nd3 = getenv("LIW_SMALL_ND3") != nullptr;                 // profiling / test aid (read per launch): three directions per lane everywhere
         if (A.eval_small && !nd3 && (long)B * n + 2 * blocks + ground_wave_count(B, n) <= 256) { pw = 1; A.small_nd = 1; }
         A.small_per_wave = pw;
     }

@@ -26,9 +26,17 @@ def setup(liw, synth, pyoracle):
     return prm, orc, slv
 
 
+@pytest.mark.parametrize("nd3", [False, True])
 @pytest.mark.parametrize("n,L,seed", [(4, 37, 3), (10, 300, 5)])
-def test_factor_residuals_and_jacobians(liw, synth, pyoracle, setup, n, L, seed):
+def test_factor_residuals_and_jacobians(liw, synth, pyoracle, setup, monkeypatch, n, L, seed, nd3):
+    """Per-factor residuals and ambient Jacobians against the oracle's Jets.  A single window runs the IMU / wheel roles with ONE
+    derivative direction per lane (nine lanes per block); LIW_SMALL_ND3 (read per launch) forces the three-directions-per-lane
+    instantiation the batched kernels use, so both are pinned factor by factor."""
     prm, orc, slv = setup
+    if nd3:
+        monkeypatch.setenv("LIW_SMALL_ND3", "1")
+    else:
+        monkeypatch.delenv("LIW_SMALL_ND3", raising=False)
     d = synth.make_window(orc, prm, seed=seed, n=n, L=L)
     slv.set_window(liw.Window(d))
     f = slv.eval_factors(liw.LIW_MODE_INIT)
