@@ -54,6 +54,7 @@ struct liw_ctx {
     // speculative marginalisation (TRACK solves): next prior + packed result record
     DevBuf priorn_X, priorn_J, priorn_R, has_priorn, result, marg_status;
     bool spec_marg = true, spec_valid = false;
+    bool reattach = true;         // recognise a window whose bytes the device already holds (LIW_NO_REATTACH: always upload)
     double spec_out[36 + 225 + 15];
     liw_batch sb{};
     liw_ws_layout lay{};
@@ -161,6 +162,7 @@ liw_ctx* liw_create(const liw_params* prm) {
                     c->have_fork = true;
                 if (std::getenv("LIW_SERIAL_ROLES")) c->have_fork = false;   // profiling aid: role kernels back to back
                 if (std::getenv("LIW_NO_SPEC_MARG")) c->spec_marg = false;   // profiling / test aid: marginalise only when asked
+                if (std::getenv("LIW_NO_REATTACH")) c->reattach = false;     // test aid: every liw_set_window uploads
                 (void)hipEventCreateWithFlags(&c->ev_upload, hipEventDisableTiming);
             } else {
                 c->err = std::string("device is ") + props.gcnArchName + ", this library is built for gfx950 only";
@@ -601,7 +603,7 @@ int liw_set_window(liw_ctx* c, const liw_window* w) {
     }
     // the same bytes as the device already holds (the lvio_2d::solver shim flattens the frames again for marginalization()):
     // nothing to upload, and what liw_solve left behind — history, the speculative marginalisation — stays valid
-    bool same = c->img_valid && c->n == n && c->L == L;
+    bool same = c->reattach && c->img_valid && c->n == n && c->L == L;
     if (same) {
         const char* cur = (const char*)c->pinned + (size_t)c->img_cur * c->img_cap;
         for (int k = 0; k < 12 && same; ++k)
