@@ -1477,11 +1477,9 @@ __global__ __launch_bounds__(64) void k_export_dense(ExportArgs a) {
 // ---------------------------------------------------------------------------------------------------
 // marginalisation: chain Schur complement of frames 0..n-2 onto frame n-1 (marginalization_matrix,
 // solver.cpp:4-40, on the block tri-diagonal H), eigen square root (solver.cpp:390-402), prior update (:407-441)
-__device__ __forceinline__ void marg_schur_body(const MargArgs& a, const int b, LdsTiles& T, double* V, double* Am, double* rot) {
+// chain Schur complement of one window by ONE wave: Delta_H -> T.D (ld 16), Delta_g(+J^T R convention) -> T.g, outputs, status; false = a pivot failed
+__device__ __forceinline__ bool marg_chain(const MargArgs& a, const int b, LdsTiles& T) {
     const int lane = threadIdx.x & 63, n = a.n;
-    if (a.gate && !a.gate[b].done) { if (a.status && lane == 0) a.status[b] = 2; return; }
-    double* oX = a.out_X ? a.out_X : a.prior_X; double* oJ = a.out_J ? a.out_J : a.prior_J; double* oR = a.out_R ? a.out_R : a.prior_R;
-    int* oHas = a.out_has ? a.out_has : a.has_prior;
     AsmCtx c;
     c.n = n; c.mode = LIW_MODE_MARG; c.fast = 0; c.b = b; c.buf = 0;
     c.PL = a.w.PL[0]; c.PI = a.w.PI[0]; c.PW = a.w.PW[0]; c.PG = a.w.PG[0];
@@ -1553,11 +1551,16 @@ __device__ __forceinline__ void marg_schur_body(const MargArgs& a, const int b, 
         lds_sync();
     }
     if (a.status && lane == 0) a.status[b] = ok ? 0 : 1;
-    if (!ok) return;
+    if (!ok) return false;
     // Delta_H = T.D (15x15), Delta_g = -T.g  (g = -J^T R in the reference)
     if (a.Delta_H) for (int e = lane; e < 225; e += 64) a.Delta_H[(size_t)b * 225 + e] = T.D[(e / 15) * 16 + e % 15];
     if (a.Delta_g && lane < 15) a.Delta_g[(size_t)b * 15 + lane] = -T.g[lane];
-    STAMPM(5001);
+    return true;
+}
+
+// cyclic Jacobi by ONE wave (large batches: a wave per window): T.D -> eigenvalues on the diagonal of Am, eigenvectors in the columns of V
+__device__ __forceinline__ void jacobi15_wave(LdsTiles& T, double* V, double* Am, double* rot) {
+    const int lane = threadIdx.x & 63;
     // ---- symmetric eigen-decomposition by cyclic Jacobi (15x15), A -> Am, eigenvectors -> V (columns).
     // Jacobi, not tridiagonalisation + QL: Delta_H is graded over 1e11 (pose rows) ... 1e2 (bias rows), and only Jacobi keeps the small
     // blocks accurate RELATIVE to their own scale (a QL variant was 15 % faster, normwise-accurate like Eigen's solver in the reference,
@@ -1631,6 +1634,14 @@ __device__ __forceinline__ void marg_schur_body(const MargArgs& a, const int b, 
             lds_sync();
         }
     }
+}
+
+// eigen square root and prior write-back (solver.cpp:390-441) by ONE wave: Am (eigenvalues on the diagonal), V (eigenvectors in columns)
+__device__ __forceinline__ void marg_tail(const MargArgs& a, const int b, LdsTiles& T, const double* V, const double* Am) {
+    const int lane = threadIdx.x & 63, n = a.n;
+    double* oX = a.out_X ? a.out_X : a.prior_X; double* oJ = a.out_J ? a.out_J : a.prior_J; double* oR = a.out_R ? a.out_R : a.prior_R;
+    int* oHas = a.out_has ? a.out_has : a.has_prior;
+    const double* xw = a.x + (size_t)b * n * 15;
     STAMPM(5002);
     // sort ascending (rank by counting; ties by index), sign convention: largest |component| positive
     if (lane < 15) {
@@ -1651,11 +1662,92 @@ __device__ __forceinline__ void marg_schur_body(const MargArgs& a, const int b, 
     }
     wave_mem_sync();
     __threadfence_block();
-    if (lane < 15) oX[(size_t)b * 15 + lane] = c.x[(size_t)(n - 1) * 15 + lane];
+    if (lane < 15) oX[(size_t)b * 15 + lane] = xw[(size_t)(n - 1) * 15 + lane];
     if (a.sqrt_H) for (int e = lane; e < 36; e += 64) a.sqrt_H[(size_t)b * 36 + e] = oJ[(size_t)b * 225 + (e / 6) * 15 + e % 6];
     if (lane == 0) oHas[b] = 1;
     STAMPM(5003);
 }
+__device__ __forceinline__ void marg_schur_body(const MargArgs& a, const int b, LdsTiles& T, double* V, double* Am, double* rot) {
+    const int lane = threadIdx.x & 63;
+    if (a.gate && !a.gate[b].done) { if (a.status && lane == 0) a.status[b] = 2; return; }
+    if (!marg_chain(a, b, T)) return;
+    STAMPM(5001);
+    jacobi15_wave(T, V, Am, rot);
+    marg_tail(a, b, T, V, Am);
+}
+// Cyclic Jacobi by a work-group of FOUR waves (a few windows: the marginalisation behind a tracking solve is on the caller's critical
+// path): one matrix element per thread.  Same rotations in the same round-robin order as jacobi15_wave; but the parameters of the (at
+// most two) rotations that touch element (r, c) are recomputed by the element's own thread from the current matrix, the two-sided update
+//   A'[r][c] = gr (A[r][c] gc + A[r][c'] sc) + sr (A[r'][c] gc + A[r'][c'] sc),   V'[r][c] = V[r][c] gc + V[r][c'] sc
+// reads the current buffer and writes the other one, so a round is ONE work-group barrier instead of three LDS hand-offs with 7 of 64
+// lanes computing parameters.  A2 / V2: two 16x16 buffers each; returns the index (0 / 1) of the buffer that holds the result.
+__device__ __forceinline__ int jacobi15_block(const double* D, double* A2, double* V2, double* red) {
+    const int t = threadIdx.x, r = t >> 4, c = t & 15, lane = t & 63, wave = t >> 6;
+    const bool in = r < 15 && c < 15;
+    A2[t] = in ? 0.5 * (D[r * 16 + c] + D[c * 16 + r]) : 0.0;
+    V2[t] = r == c ? 1.0 : 0.0;
+    __syncthreads();
+    int cur = 0;
+    // coefficients of index i in round rnd: new_i = g * x_i + s * x_partner.  partner = (2 rnd - i) mod 15 (the pairs of a round are the
+    // index pairs that sum to 2 rnd), none for i = rnd and for the padding index 15.
+    auto coeff = [&](const double* A, int i, int rnd, int& partner, double& g, double& sg) {
+        partner = i; g = 1.0; sg = 0.0;
+        if (i >= 15) return;
+        int pr = 2 * rnd - i; pr += pr < 0 ? 15 : 0; pr -= pr >= 15 ? 15 : 0;
+        if (pr == i) return;
+        const int P = i < pr ? i : pr, Q = i < pr ? pr : i;
+        const double apq = A[P * 16 + Q];
+        partner = pr;
+        if (apq == 0.0) return;
+        const double d = A[Q * 16 + Q] - A[P * 16 + P], h = 2.0 * apq;
+        const double qq = d * d + h * h;
+        const double tt = (d >= 0.0 ? h : -h) * fast_rcp(fabs(d) + qq * fast_rsqrt(qq));
+        const double cs = fast_rsqrt(1.0 + tt * tt), sn = tt * cs;
+        g = cs; sg = i == P ? -sn : sn;
+    };
+    for (int sweep = 0; sweep < 60; ++sweep) {
+        const double* A = A2 + 256 * cur;
+        const double v = in ? A[t] : 0.0;
+        double off = c > r ? v * v : 0.0, dgn = c == r ? v * v : 0.0;
+        off = wave_sum(off); dgn = wave_sum(dgn);
+        if (lane == 0) { red[wave] = off; red[4 + wave] = dgn; }
+        __syncthreads();
+        off = (red[0] + red[1]) + (red[2] + red[3]); dgn = (red[4] + red[5]) + (red[6] + red[7]);
+        __syncthreads();
+        if (off <= 1e-34 * dgn || off == 0.0) break;   // (uniform) sums of squares: off-diagonal below 1e-17 of the diagonal
+        for (int rnd = 0; rnd < 15; ++rnd) {
+            const double* Ac = A2 + 256 * cur; const double* Vc = V2 + 256 * cur;
+            double* An = A2 + 256 * (1 - cur); double* Vn = V2 + 256 * (1 - cur);
+            int rp, cp;
+            double gr, sr, gc, sc;
+            coeff(Ac, r, rnd, rp, gr, sr);
+            coeff(Ac, c, rnd, cp, gc, sc);
+            const double b0 = gc * Ac[r * 16 + c] + sc * Ac[r * 16 + cp];      // (A G)[r][c]
+            const double b1 = gc * Ac[rp * 16 + c] + sc * Ac[rp * 16 + cp];    // (A G)[r'][c]
+            An[t] = gr * b0 + sr * b1;
+            Vn[t] = gc * Vc[r * 16 + c] + sc * Vc[r * 16 + cp];
+            __syncthreads();
+            cur = 1 - cur;
+        }
+    }
+    return cur;
+}
+
+// small batches: four waves per window — wave 0 the chain and the eigen square root, all four the Jacobi sweeps in between
+__global__ __launch_bounds__(256, 1) void k_marg_schur4(MargArgs a) {
+    __shared__ LdsTiles T;
+    __shared__ double A2[512], V2[512], red[8];
+    __shared__ int okf;
+    const int b = blockIdx.x, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    if (a.gate && !a.gate[b].done) { if (a.status && threadIdx.x == 0) a.status[b] = 2; return; }   // (uniform)
+    if (wave == 0) { const bool ok = marg_chain(a, b, T); if (lane == 0) okf = ok ? 1 : 0; }
+    STAMPM(5001);
+    __syncthreads();
+    if (!okf) return;
+    const int cur = jacobi15_block(T.D, A2, V2, red);
+    if (wave == 0) marg_tail(a, b, T, V2 + 256 * cur, A2 + 256 * cur);
+}
+
 __global__ __launch_bounds__(64, 2) void k_marg_schur(MargArgs a) {
     __shared__ LdsTiles T;
     __shared__ double V[256], Am[256], rot[16];
@@ -1685,6 +1777,11 @@ void launch_lm_step(const StepArgs& a, hipStream_t s) {
 }
 void launch_lm_finish(const StepArgs& a, hipStream_t s) { hipLaunchKernelGGL(k_lm_finish, dim3((a.B * a.n * 6 + 255) / 256), dim3(256), 0, s, a); }
 void launch_export_dense(const ExportArgs& a, hipStream_t s) { hipLaunchKernelGGL(k_export_dense, dim3(a.B), dim3(64), 0, s, a); }
-void launch_marg_schur(const MargArgs& a, hipStream_t s) { hipLaunchKernelGGL(k_marg_schur, dim3(a.B), dim3(64), 0, s, a); }
+void launch_marg_schur(const MargArgs& a, hipStream_t s) {
+    static const char* env = getenv("LIW_MARG_WAVES");   // 1 / 4: force the one-wave / four-wave kernel (profiling / test aid)
+    const bool four = env ? env[0] == '4' : a.B <= 256;  // four waves per window while that takes no CUs away from other windows
+    if (four) hipLaunchKernelGGL(k_marg_schur4, dim3(a.B), dim3(256), 0, s, a);
+    else hipLaunchKernelGGL(k_marg_schur, dim3(a.B), dim3(64), 0, s, a);
+}
 
 }  // namespace liw
