@@ -1481,8 +1481,9 @@ __global__ __launch_bounds__(64) void k_export_dense(ExportArgs a) {
 __device__ __forceinline__ bool marg_chain(const MargArgs& a, const int b, LdsTiles& T) {
     const int lane = threadIdx.x & 63, n = a.n;
     AsmCtx c;
-    c.n = n; c.mode = LIW_MODE_MARG; c.fast = 0; c.b = b; c.buf = 0;
-    c.PL = a.w.PL[0]; c.PI = a.w.PI[0]; c.PW = a.w.PW[0]; c.PG = a.w.PG[0];
+    const int sel = a.use_cur ? __builtin_amdgcn_readfirstlane(a.w.lm[b].cur) : 0;
+    c.n = n; c.mode = LIW_MODE_MARG; c.fast = 0; c.b = b; c.buf = sel;
+    c.PL = sel ? a.w.PL[1] : a.w.PL[0]; c.PI = sel ? a.w.PI[1] : a.w.PI[0]; c.PW = sel ? a.w.PW[1] : a.w.PW[0]; c.PG = sel ? a.w.PG[1] : a.w.PG[0];
     c.x = a.x + (size_t)b * n * 15;
     c.pJ = a.prior_J + (size_t)b * 225; c.pX = a.prior_X + (size_t)b * 15;
     c.prior_on = a.has_prior[b] != 0;

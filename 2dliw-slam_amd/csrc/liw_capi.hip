@@ -712,7 +712,7 @@ int liw_solve(liw_ctx* c, int mode, int max_iters, liw_summary* summary) {
             ma.prior_X = b->prior_X; ma.prior_J = b->prior_J; ma.prior_R = b->prior_R; ma.has_prior = b->has_prior;
             ma.out_X = c->priorn_X.as<double>(); ma.out_J = c->priorn_J.as<double>(); ma.out_R = c->priorn_R.as<double>(); ma.out_has = c->has_priorn.as<int>();
             ma.w = v; ma.sqrt_H = marg_out; ma.Delta_H = marg_out + 36; ma.Delta_g = marg_out + 36 + 225; ma.status = c->marg_status.as<int>();
-            ma.gate = v.lm;
+            ma.gate = v.lm; ma.use_cur = 1;
         }
         // (linearise, step) pairs: pair 0 linearises at the initial point, pair j > 0 at the candidate of step j.  K + 1 pairs in all
         // (the last step takes the last candidate / meets the iteration cap); a solve of `it` iterations is done after it + 1 pairs.
@@ -723,8 +723,10 @@ int liw_solve(liw_ctx* c, int mode, int max_iters, liw_summary* summary) {
             for (int i = 0; i < m; ++i) { lin(k + i > 0 ? 1 : 0); launch_lm_step(st, s); }
             k += m;
             if (spec) {
-                LinArgs A = lin_args(b, LIW_MODE_MARG, b->x, v, 0, false);
-                A.gate = v.lm;
+                // the current LM buffer of a finished TRACK solve IS the marginalisation's linearisation (same states, same kernels) except
+                // for the laser records of the older frames, which the tracking topology leaves out: only those are evaluated again
+                LinArgs A = lin_args(b, LIW_MODE_MARG, b->x, v, 0, true);
+                A.active = nullptr; A.gate = v.lm; A.eval_small = 0; A.older_only = 1;
                 launch_linearize(A, c->dp, s, c->have_fork ? &c->fork : nullptr);
                 launch_marg_schur(ma, s);
             }

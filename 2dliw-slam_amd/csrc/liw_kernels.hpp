@@ -80,6 +80,8 @@ struct LinArgs {
     double* PL[2]; double* PI[2]; double* PW[2]; double* PG[2];   // partial buffers: window b writes buffer lm[b].cur (candidate: the other one)
     const LmState* lm;          // null (buffer 0, no skipping), or per-window state: done windows skip
     const LmState* gate;        // non-null: linearise window b only if gate[b].done (a marginalisation enqueued speculatively behind a solve)
+    int older_only;             // 1: the laser role leaves out frame n-1 (marginalisation behind a TRACK solve: the current buffer already
+                                //    holds that frame's record and every small role's partials, at the very states being marginalised)
     int candidate;              // 1: write the small-factor partials of window b into buffer 1 - lm[b].cur
     int small_per_wave;         // IMU / wheel blocks per wave (set by launch_linearize)
     int small_nd;               // derivative directions per lane of the IMU / wheel roles: 3 (batches) or 1 (k_lin_all on a few windows)
@@ -194,6 +196,7 @@ struct MargArgs {
     // before the caller asks for it), else in place; gate: run window b only if its solve has terminated, status 2 otherwise
     double* out_X; double* out_J; double* out_R; int* out_has;
     const LmState* gate;
+    int use_cur;                  // 1: read the partial sums of window b from its current LM buffer (lm[b].cur) instead of buffer 0
 };
 constexpr int LIW_RESULT_HDR = 8;   // doubles: 4 ints, then liw_summary (32 bytes), padded
 struct PackArgs {
