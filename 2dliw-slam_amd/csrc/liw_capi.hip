@@ -701,7 +701,10 @@ int liw_solve(liw_ctx* c, int mode, int max_iters, liw_summary* summary) {
             LinArgs A = lin_args(b, mode, cand ? v.x_cand : b->x, v, cand, true);
             launch_linearize(A, c->dp, s, c->have_fork ? &c->fork : nullptr);
         };
-        double* res = c->result.as<double>();
+        // the read-back record is written straight into the page-locked host block (device-visible under the same address): the packing
+        // kernel's stores cross PCIe, no separate device-to-host copy command (LIW_NO_ZEROCOPY: device buffer + copy, the round-2 start)
+        static const bool zero_copy = std::getenv("LIW_NO_ZEROCOPY") == nullptr;
+        double* res = zero_copy ? (double*)rb : c->result.as<double>();
         double* marg_out = res + LIW_RESULT_HDR + (size_t)c->n * 27;
         PackArgs pk{};
         pk.n = c->n; pk.mode = mode; pk.lm = v.lm; pk.info = v.info; pk.x = b->x; pk.match_pose = b->match_pose; pk.has_match = b->has_match;
@@ -732,7 +735,7 @@ int liw_solve(liw_ctx* c, int mode, int max_iters, liw_summary* summary) {
             }
             launch_pack_result(pk, s);
             HIPCHK(c, hipGetLastError());
-            HIPCHK(c, hipMemcpyAsync(rb, res, sizeof(double) * rdoubles, hipMemcpyDeviceToHost, s));
+            if (!zero_copy) HIPCHK(c, hipMemcpyAsync(rb, res, sizeof(double) * rdoubles, hipMemcpyDeviceToHost, s));
             HIPCHK(c, hipStreamSynchronize(s));
             done = ((const int*)rb)[0] != 0;
             if (!done && k >= K + 1) return fail(c, LIW_EHIP, "liw_solve: the window did not terminate within its iteration cap");
