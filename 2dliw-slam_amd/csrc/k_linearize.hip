@@ -627,12 +627,20 @@ __global__ __launch_bounds__(64, 2) void k_lin_small(LinArgs A, DevParams P) {
     __shared__ double lds[SMALL_LDS];
     small_role<3>(A, P, (int)blockIdx.x, lds);
 }
+__global__ void k_lm_reset(int B, LmState* lm, int max_iters) {
+    const int b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b < B) lm_reset(lm[b], max_iters);
+}
 // Small batches (a single tracking window): every role in ONE launch, the role of a wave follows from its block index —
 // one kernel and no fork / join events per linearisation, which is what a latency-bound 2-frame window pays for.
 template <bool BOTH>
-__global__ __launch_bounds__(64, 2) void k_lin_all(LinArgs A, DevParams P, int G, int n_laser, int n_imu) {
+__global__ __launch_bounds__(64, 2) void k_lin_all(LinArgs A, DevParams P, int G, int n_laser, int n_imu, int n_roles) {
     __shared__ double lds[IMU_PER_WAVE * IMU_REC];   // IMU / small roles (>= SMALL_LDS); the laser role brings its own static LDS
     const int v = (int)blockIdx.x;
+    if (v >= n_roles) {   // the extra work-group of a solve's first linearisation: LM state reset (the role waves of this launch do not read it)
+        for (int b = threadIdx.x; b < A.B; b += 64) lm_reset(A.reset_lm[b], A.reset_iters);
+        return;
+    }
 #ifdef LIW_CLK
     if ((threadIdx.x & 63) == 0 && v < 40) g_clk_lin[400 + 2 * v] = clock64();
 #endif
@@ -718,11 +726,13 @@ void launch_linearize(const LinArgs& A_, const DevParams& P, hipStream_t s, cons
     const bool compact = A.lm && A.active && A.eval_small && B >= 512 && B <= COMPACT_MAX && !no_compact;
     if (!compact) A.active = nullptr;
     if (A.eval_small && laser_waves + imu_waves + small_waves <= 256) {
-        const unsigned tot = (unsigned)(laser_waves + imu_waves + small_waves);
-        if (A.mode == LIW_MODE_INIT) hipLaunchKernelGGL(k_lin_all<true>, dim3(tot), dim3(64), 0, s, A, P, G, laser_waves, imu_waves);
-        else hipLaunchKernelGGL(k_lin_all<false>, dim3(tot), dim3(64), 0, s, A, P, G, laser_waves, imu_waves);
+        const int roles = laser_waves + imu_waves + small_waves;
+        const unsigned tot = (unsigned)(roles + (A.reset_lm ? 1 : 0));
+        if (A.mode == LIW_MODE_INIT) hipLaunchKernelGGL(k_lin_all<true>, dim3(tot), dim3(64), 0, s, A, P, G, laser_waves, imu_waves, roles);
+        else hipLaunchKernelGGL(k_lin_all<false>, dim3(tot), dim3(64), 0, s, A, P, G, laser_waves, imu_waves, roles);
         return;
     }
+    if (A.reset_lm) hipLaunchKernelGGL(k_lm_reset, dim3((B + 63) / 64), dim3(64), 0, s, B, A.reset_lm, A.reset_iters);
     const bool fork = fk && fk->side[0] && A.eval_small;
     if (fork) {
         hipEventRecord(fk->ev_fork, s);

@@ -1362,31 +1362,9 @@ __global__ __launch_bounds__(256, 1) void k_lm_step_tw(StepArgs a) {
 __global__ void k_lm_begin(int B, int n, LmState* lm, int max_iters) {
     const int b = blockIdx.x * blockDim.x + threadIdx.x;
     if (b >= B) return;
-    LmState& s = lm[b];
-    s.radius = kInitRadius; s.decrease_factor = 2.0; s.x_cost = 0.0; s.x_norm = 0.0; s.minimum_cost = 0.0;
-    s.cand_step_norm = 0.0; s.model_cost_change = 0.0; s.reuse_diagonal = 0; s.iteration = 0; s.done = 0; s.termination = 0;
-    s.successful = 0; s.cur = 0; s.invalid_steps = 0; s.have_candidate = 0; s.initial_cost = 0.0; s.max_iters = max_iters; s.pad_ = 0;
+    lm_reset(lm[b], max_iters);
 }
 
-// single-window entry (liw_solve): laser group offsets (k_group_offsets) and the LM state reset in one launch
-__global__ void k_begin_all(int B, int n, const int* laser_off, const int* laser_frame, int* group_off, LmState* lm, int max_iters) {
-    const int t = blockIdx.x * blockDim.x + threadIdx.x;
-    if (t < B * (n + 1)) {
-        const int b = t / (n + 1), i = t % (n + 1);
-        int lo = laser_off[b], hi = laser_off[b + 1];
-        while (lo < hi) {
-            const int mid = (lo + hi) >> 1;
-            if (laser_frame[mid] < i) lo = mid + 1; else hi = mid;
-        }
-        group_off[t] = lo;
-    }
-    if (t < B) {
-        LmState& s = lm[t];
-        s.radius = kInitRadius; s.decrease_factor = 2.0; s.x_cost = 0.0; s.x_norm = 0.0; s.minimum_cost = 0.0;
-        s.cand_step_norm = 0.0; s.model_cost_change = 0.0; s.reuse_diagonal = 0; s.iteration = 0; s.done = 0; s.termination = 0;
-        s.successful = 0; s.cur = 0; s.invalid_steps = 0; s.have_candidate = 0; s.initial_cost = 0.0; s.max_iters = max_iters; s.pad_ = 0;
-    }
-}
 // everything liw_solve reads back, gathered into ONE record (one device-to-host copy per chunk of iterations):
 // [done, marg status, -, - | liw_summary | states n*15 | match_pose n*12 | sqrt_H 36, Delta_H 225, Delta_g 15]
 __device__ __forceinline__ void pack_result_body(const PackArgs& a) {   // the whole work-group
@@ -1759,10 +1737,6 @@ __global__ __launch_bounds__(64, 2) void k_marg_schur(MargArgs a) {
 extern "C" void liw_debug_clk(long long* out, int nn) { hipMemcpyFromSymbol(out, HIP_SYMBOL(g_clk), sizeof(long long) * nn); }
 extern "C" void liw_debug_span(long long* out, int nn) { hipMemcpyFromSymbol(out, HIP_SYMBOL(g_span), sizeof(long long) * nn); }
 #endif
-void launch_begin_all(int B, int n, const int* laser_off, const int* laser_frame, int* group_off, LmState* lm, int max_iters, hipStream_t s) {
-    const int tot = B * (n + 1);
-    hipLaunchKernelGGL(k_begin_all, dim3((tot + 255) / 256), dim3(256), 0, s, B, n, laser_off, laser_frame, group_off, lm, max_iters);
-}
 void launch_pack_result(const PackArgs& a, hipStream_t s) { hipLaunchKernelGGL(k_pack_result, dim3(1), dim3(512), 0, s, a); }
 void launch_lm_begin(int B, int n, LmState* lm, int max_iters, hipStream_t s) {
     hipLaunchKernelGGL(k_lm_begin, dim3((B + 63) / 64), dim3(64), 0, s, B, n, lm, max_iters);

@@ -48,7 +48,7 @@ struct liw_ctx {
     size_t pinned_cap = 0, img_cap = 0, readback_cap = 0;
     int img_cur = 0;
     bool img_valid = false;
-    size_t part_off[12] = {0}, part_bytes[12] = {0};
+    size_t part_off[13] = {0}, part_bytes[13] = {0};
     hipEvent_t ev_upload = nullptr;   // completion of the last host-to-device copy (liw_set_window does not wait for it)
     DevBuf prior_X, prior_J, prior_R, has_prior, ws, scratch;
     // speculative marginalisation (TRACK solves): next prior + packed result record
@@ -570,16 +570,19 @@ int liw_set_window(liw_ctx* c, const liw_window* w) {
     // bytes: a dozen pageable copies cost more than the solve); the copy is ordered before the solve on the ctx stream, nobody waits
     struct Part { const void* src; size_t bytes; };
     int off2[2] = {0, L};
-    const Part parts[12] = {
+    int goff[65];   // laser block range of every frame (what k_group_offsets computes for the batched path): first block owned by a frame >= i
+    for (int i = 0, j = 0; i <= n; ++i) { while (j < L && w->laser_frame[j] < i) ++j; goff[i] = j; }
+    const Part parts[13] = {
         {w->states, sizeof(double) * n * 15}, {off2, sizeof(off2)}, {w->laser_frame, sizeof(int) * (size_t)L},
         {nullptr, sizeof(double) * 12 * (size_t)L},   // laser_pts: transposed to component-major below
         {w->match_pose, sizeof(double) * n * 12}, {w->has_match, (size_t)n},
         {w->imu_X, sizeof(double) * (n - 1) * 15}, {w->imu_J, sizeof(double) * (n - 1) * 225},
         {w->imu_sqrtP, sizeof(double) * (n - 1) * 225}, {w->imu_Dt, sizeof(double) * (n - 1)},
         {w->wheel_T, sizeof(double) * (n - 1) * 12}, {w->wheel_sqrtP, sizeof(double) * (n - 1) * 9},
+        {goff, sizeof(int) * (size_t)(n + 1)},
     };
-    size_t off[12], tot = 0;
-    for (int k = 0; k < 12; ++k) { off[k] = tot; tot = al256(tot + (parts[k].bytes ? parts[k].bytes : 8)); }
+    size_t off[13], tot = 0;
+    for (int k = 0; k < 13; ++k) { off[k] = tot; tot = al256(tot + (parts[k].bytes ? parts[k].bytes : 8)); }
     const size_t readback = al256(sizeof(double) * (LIW_RESULT_HDR + (size_t)n * 27 + 276));
     if (c->img_cap < tot || c->readback_cap < readback) {
         (void)hipStreamSynchronize(c->stream);   // an upload out of the old block may still be in flight
@@ -593,7 +596,7 @@ int liw_set_window(liw_ctx* c, const liw_window* w) {
     char* stage = (char*)c->pinned + (size_t)stage_id * c->img_cap;
     // `stage` was the source of the upload two calls ago; uploads are ordered on the ctx stream and the latest one carries ev_upload
     if (c->ev_upload) (void)hipEventSynchronize(c->ev_upload);
-    for (int k = 0; k < 12; ++k) {
+    for (int k = 0; k < 13; ++k) {
         if (k == 3) {
             double* soa = (double*)(stage + off[k]);
             for (int j = 0; j < L; ++j) for (int q = 0; q < 12; ++q) soa[(size_t)q * L + j] = w->laser_pts[(size_t)j * 12 + q];
@@ -606,7 +609,7 @@ int liw_set_window(liw_ctx* c, const liw_window* w) {
     bool same = c->reattach && c->img_valid && c->n == n && c->L == L;
     if (same) {
         const char* cur = (const char*)c->pinned + (size_t)c->img_cur * c->img_cap;
-        for (int k = 0; k < 12 && same; ++k)
+        for (int k = 0; k < 13 && same; ++k)
             if (parts[k].bytes && std::memcmp(stage + off[k], cur + off[k], parts[k].bytes) != 0) same = false;
     }
     if (same) { c->hw = *w; c->have_window = true; return LIW_OK; }
@@ -617,7 +620,7 @@ int liw_set_window(liw_ctx* c, const liw_window* w) {
     HIPCHK(c, hipMemcpyAsync(c->arena.p, stage, tot, hipMemcpyHostToDevice, c->stream));
     if (c->ev_upload) HIPCHK(c, hipEventRecord(c->ev_upload, c->stream));
     c->img_cur = stage_id; c->img_valid = true;
-    for (int k = 0; k < 12; ++k) { c->part_off[k] = off[k]; c->part_bytes[k] = parts[k].bytes; }
+    for (int k = 0; k < 13; ++k) { c->part_off[k] = off[k]; c->part_bytes[k] = parts[k].bytes; }
     char* dev = (char*)c->arena.p;
     bool fresh_prior = c->prior_X.p == nullptr;
     if (c->prior_X.ensure(sizeof(double) * 15) || c->prior_J.ensure(sizeof(double) * 225) || c->prior_R.ensure(sizeof(double) * 15) ||
@@ -695,10 +698,15 @@ int liw_solve(liw_ctx* c, int mode, int max_iters, liw_summary* summary) {
         const liw_batch* b = &c->sb;
         hipStream_t s = c->stream;
         WsView v = make_view(c->ws.p, 1, c->n, b->history_records);
-        launch_begin_all(1, c->n, b->laser_off, b->laser_frame, v.group_off, v.lm, K, s);
+        v.group_off = (int*)((char*)c->arena.p + c->part_off[12]);   // computed on the host by liw_set_window, uploaded with the window
         StepArgs st = step_args(c, b, mode, K, v);
+        bool first = true;
         auto lin = [&](int cand) {
-            LinArgs A = lin_args(b, mode, cand ? v.x_cand : b->x, v, cand, true);
+            // the first linearisation of a solve needs no LM state (buffer 0, window live): its launch carries the state reset as one
+            // more work-group instead of a k_lm_begin launch in front of it
+            LinArgs A = lin_args(b, mode, cand ? v.x_cand : b->x, v, cand, !first);
+            if (first) { A.reset_lm = v.lm; A.reset_iters = K; first = false; }
+            A.active = nullptr;
             launch_linearize(A, c->dp, s, c->have_fork ? &c->fork : nullptr);
         };
         // the read-back record is written straight into the page-locked host block (device-visible under the same address): the packing

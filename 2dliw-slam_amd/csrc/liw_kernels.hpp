@@ -48,6 +48,13 @@ struct LmState {
     double diagonal[15 * 64];
 };
 
+// state of a window at the start of a solve (k_lm_begin; the first k_lin_all of a single-window solve)
+__device__ __forceinline__ void lm_reset(LmState& s, int max_iters) {
+    s.radius = 1e4; s.decrease_factor = 2.0; s.x_cost = 0.0; s.x_norm = 0.0; s.minimum_cost = 0.0;
+    s.cand_step_norm = 0.0; s.model_cost_change = 0.0; s.reuse_diagonal = 0; s.iteration = 0; s.done = 0; s.termination = 0;
+    s.successful = 0; s.cur = 0; s.invalid_steps = 0; s.have_candidate = 0; s.initial_cost = 0.0; s.max_iters = max_iters; s.pad_ = 0;
+}
+
 struct WsView {
     // all device pointers into the caller's workspace
     // every role has two partial buffers: the current one of window b is lm[b].cur, its candidate linearisation goes to the other
@@ -80,6 +87,8 @@ struct LinArgs {
     double* PL[2]; double* PI[2]; double* PW[2]; double* PG[2];   // partial buffers: window b writes buffer lm[b].cur (candidate: the other one)
     const LmState* lm;          // null (buffer 0, no skipping), or per-window state: done windows skip
     const LmState* gate;        // non-null: linearise window b only if gate[b].done (a marginalisation enqueued speculatively behind a solve)
+    LmState* reset_lm;          // non-null (single-window liw_solve, first linearisation, lm == null): one more work-group of k_lin_all resets
+    int reset_iters;            //    the LM state of every window (iteration cap reset_iters) — k_lm_begin without a launch of its own
     int older_only;             // 1: the laser role leaves out frame n-1 (marginalisation behind a TRACK solve: the current buffer already
                                 //    holds that frame's record and every small role's partials, at the very states being marginalised)
     int candidate;              // 1: write the small-factor partials of window b into buffer 1 - lm[b].cur
@@ -210,7 +219,6 @@ void launch_linearize_join(hipStream_t s, const LinFork* fk);
 void launch_exchange_pack(int B, int n, bool both, const double* PL0, const double* PL1, int candidate, const LmState* lm, double* buf, hipStream_t s);
 void launch_exchange_unpack(int B, int n, bool both, int world, size_t stride, const double* buf, double* PL0, double* PL1, int candidate, const LmState* lm, hipStream_t s);
 void launch_group_offsets(int B, int n, const int* laser_off, const int* laser_frame, int* group_off, hipStream_t s);
-void launch_begin_all(int B, int n, const int* laser_off, const int* laser_frame, int* group_off, LmState* lm, int max_iters, hipStream_t s);
 void launch_pack_result(const PackArgs& a, hipStream_t s);
 void launch_lm_begin(int B, int n, LmState* lm, int max_iters, hipStream_t s);
 void launch_lm_step(const StepArgs& a, hipStream_t s);
