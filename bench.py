@@ -386,7 +386,7 @@ def main():
                 o["laser_pts"] = np.asarray(d3["laser_pts"])[m].copy()
                 return o
             slv = liw.Solver(prm)
-            reps, tg, it_g = 20, 0.0, 0
+            reps, tg, it_g = 200, 0.0, 0
             for rep in range(reps + 2):
                 slv.set_prior(None)
                 slv.set_window(liw.Window(sub(0)))
