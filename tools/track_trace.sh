@@ -1,6 +1,6 @@
 cd $GRAFT_REPO_ROOT; export TMPDIR=/tmp
-python tools/track_latency.py
-rocprofv3 --kernel-trace --stats -d gpurun_out/prof_t -o t -- python tools/track_latency.py > gpurun_out/trk.log 2>&1
+python tools/track_probe.py 100
+rocprofv3 --kernel-trace --stats -d gpurun_out/prof_t -o t -- python tools/track_probe.py 100 > gpurun_out/trk.log 2>&1
 db=$(find gpurun_out/prof_t -name "*.db" | head -1); python tools/rocprof_summary.py $db gpurun_out/trk_stats.csv
 python - <<'PY'
 import sqlite3,glob
