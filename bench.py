@@ -420,6 +420,64 @@ def main():
         except Exception as e:   # a latency side-measurement must never take the headline line down
             tracking = {"error": str(e)[:200]}
 
+    # ---- the same frame with the keep-N window policy of BASELINE config C3 (corridor replay, 30-KF window): tracking solve of a
+    #      30-frame window (laser blocks of the newest frame, 29 IMU + 29 wheel blocks, prior on frame 28) + marginalisation of all 30
+    #      frames (2 000 laser blocks), host buffers in and out, CPU oracle beside it
+    keepn = None
+    if rank == 0 and world == 1 and not args.no_single:
+        try:
+            hp = liw.HostPreint(prm)
+            NK = 30
+            dk = synth.make_window(hp, prm, seed=616, n=NK + 1, L=2000 + 67, laser_on_frame0=False)
+
+            def subk(lo):
+                o = dict(dk)
+                o["n"] = NK
+                for k in ("states", "match_pose"):
+                    o[k] = np.asarray(dk[k]).reshape(NK + 1, -1)[lo:lo + NK].copy()
+                o["has_match"] = np.asarray(dk["has_match"])[lo:lo + NK].copy()
+                for k in ("imu_X", "imu_J", "imu_sqrtP", "imu_Dt", "wheel_T", "wheel_sqrtP", "wheel_Dt"):
+                    o[k] = np.asarray(dk[k])[lo:lo + NK - 1].copy()
+                m = (np.asarray(dk["laser_frame"]) >= lo) & (np.asarray(dk["laser_frame"]) < lo + NK)
+                o["laser_frame"] = (np.asarray(dk["laser_frame"])[m] - lo).astype(np.int32)
+                o["laser_pts"] = np.asarray(dk["laser_pts"])[m].copy()
+                return o
+            slv = liw.Solver(prm)
+            reps, tg, it_g = 20, 0.0, 0
+            for rep in range(reps + 2):
+                slv.set_prior(None)
+                slv.set_window(liw.Window(subk(0)))
+                slv.solve()
+                slv.marginalization()
+                wk = liw.Window(subk(1))
+                t0_ = time.perf_counter()
+                slv.set_window(wk)
+                sg = slv.solve()
+                slv.marginalization()
+                if rep >= 2:
+                    tg += time.perf_counter() - t0_
+                    it_g = sg["iterations"]
+            keepn = {"ms_per_frame": round(1e3 * tg / reps, 3), "lm_iterations": it_g,
+                     "window": "n=%d tracking topology (C3 shape), %d laser blocks in the window, prior on frame %d" % (NK, int(len(subk(1)["laser_frame"])), NK - 2)}
+            if not args.no_cpu_baseline:
+                from oracle import pyoracle
+                orc3 = pyoracle.Oracle(prm)
+                tc, rc = 0.0, 3
+                for rep in range(rc):
+                    orc3.set_prior(None)
+                    w0 = pyoracle.Window(subk(0))
+                    orc3.solve(w0)
+                    orc3.marginalization(w0)
+                    w1 = pyoracle.Window(subk(1))
+                    t0_ = time.perf_counter()
+                    orc3.solve(w1)
+                    orc3.marginalization(w1)
+                    tc += time.perf_counter() - t0_
+                keepn["cpu_oracle_ms_per_frame"] = round(1e3 * tc / rc, 3)
+                keepn["cpu_oracle_lm_iterations"] = orc3.summary()["iterations"]
+        except Exception as e:   # a latency side-measurement must never take the headline line down
+            keepn = {"error": str(e)[:200]}
+
     # ---- factor-sharded mode (north_star's multi-GPU mode): C4-shaped windows, the laser blocks of every window split over the ranks,
     #      the compact laser record (45 pair totals per (window, frame)) exchanged once per LM iteration on the main stream while the
     #      IMU / wheel / ground roles still run on side streams.  Same total work at every N (strong scaling); N = 1 is the un-sharded
@@ -507,6 +565,8 @@ def main():
             out["single_window_latency"] = single
         if tracking:
             out["tracking_frame_latency"] = tracking
+        if keepn:
+            out["keep30_tracking_frame_latency"] = keepn
         if sharded:
             out["factor_sharded"] = sharded
         print(json.dumps(out))
