@@ -1253,9 +1253,21 @@ __global__ __launch_bounds__(256, 1) void k_lm_step_tw(StepArgs a) {
     if (producer) prepare(0);
     __syncthreads();
     for (int s_ = 0; s_ < NS; ++s_) {
+#ifdef LIW_CLK
+        const long long tw0 = clock64();
+#endif
         if (producer) { if (s_ + 1 < nsteps) prepare(s_ + 1); }
         else if (s_ < nsteps) eliminate(s_);
+#ifdef LIW_CLK
+        const long long tw1 = clock64();
+#endif
         __syncthreads();
+#ifdef LIW_CLK
+        if (b == 0 && (threadIdx.x & 63) == 0 && s_ < 40) {   // per wave and step: busy, then waiting at the barrier
+            g_clk[7000 + 100 * (int)(threadIdx.x >> 6) + 2 * s_] = tw1 - tw0;
+            g_clk[7001 + 100 * (int)(threadIdx.x >> 6) + 2 * s_] = clock64() - tw1;
+        }
+#endif
     }
     gmax = wave_max(gmax);
     if (lane == 0) { S.red[w][3] = gmax; if (!producer) S.ctl[3 + sd] = solved ? 1 : 0; }

@@ -1,22 +1,27 @@
-"""s_memtime stamps of the two-wave step kernel (k_lm_step_tw, LIW_CLK=1 build): per wave, per step phases of LM iteration 3."""
-import importlib, sys, ctypes as C
-sys.path.insert(0, '/root/repo')
-import numpy as np, torch
-liw = importlib.import_module('2dliw-slam_amd'); synth = importlib.import_module('2dliw-slam_amd.synth')
-prm = synth.office_params(); hp = liw.HostPreint(prm)
-n = int(sys.argv[1]) if len(sys.argv) > 1 else 30
-w = [synth.make_window(hp, prm, seed=20240, n=n, L=2000)]
-bs = liw.BatchSolver(prm, w)
-bs.solve(liw.LIW_MODE_INIT, 6); torch.cuda.synchronize()
+"""Per-step busy / barrier-wait cycles of the four waves of k_lm_step_tw (eliminators 0 / 1, producers 2 / 3) on one C2 window.
+Needs a stamp build (LIW_CLK=1).  usage: python tools/clk_probe_tw.py [mode: init|track]"""
+import ctypes as C
+import importlib
+import os
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+liw = importlib.import_module("2dliw-slam_amd")
+synth = importlib.import_module("2dliw-slam_amd.synth")
+prm = synth.office_params()
+hp = liw.HostPreint(prm)
+d = synth.make_window(hp, prm, seed=20240, n=30, L=2000)
+slv = liw.Solver(prm)
+slv.set_window(liw.Window(d))
+slv.init_solve(6)
 clk = np.zeros(8192, dtype=np.int64)
 liw.lib().liw_debug_clk(clk.ctypes.data_as(C.c_void_p), C.c_int(8192))
-t0 = clk[4000]
-for wv in (0, 1):
-    c = clk[4000 + 1000 * wv:5000 + 1000 * wv]
-    print('wave', wv, 'prologue+barrier', c[1] - t0, 'sweep', c[2] - c[1], 'to backsub', c[3] - c[2], 'backsub', c[4] - c[3], 'total', c[4] - t0)
-    m = (n + 1) // 2
-    ns = (n - 1 - m + 2) if wv == 0 else m
-    for s in list(range(min(ns, 3))) + [ns - 2, ns - 1]:
-        t = c[10 + s * 8:10 + s * 8 + 7]
-        nxt = c[10 + (s + 1) * 8] if s + 1 < ns else c[2]
-        print('  step', s, 'barrier', t[1] - t[0], 'commit', t[2] - t[1], 'diag', t[3] - t[2], 'col', t[4] - t[3], 'issue+chol', t[5] - t[4], 'tiles+rec', t[6] - t[5], 'schur', nxt - t[6])
+for w, name in enumerate(("eliminator down", "eliminator up", "producer down", "producer up")):
+    busy = clk[7000 + 100 * w:7000 + 100 * w + 40:2]
+    wait = clk[7001 + 100 * w:7001 + 100 * w + 40:2]
+    k = int((busy + wait > 0).sum())
+    print("%-16s busy %s" % (name, [int(v) for v in busy[:k]]))
+    print("%-16s wait %s  | sums: busy %d wait %d" % ("", [int(v) for v in wait[:k]], busy[:k].sum(), wait[:k].sum()))
