@@ -13,7 +13,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 pytestmark = pytest.mark.skipif(torch.cuda.is_available(), reason="CPU-box behaviour (the GPU twin is tests/test_gpu_bench_contract.py)")
 
 
-def run(args, env_extra=None, timeout=240):
+def run(args, env_extra=None, timeout=900):   # a fresh container pages torch in for a minute or two
     env = dict(os.environ)
     for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
         env.pop(k, None)
