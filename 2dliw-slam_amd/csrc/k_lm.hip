@@ -414,8 +414,12 @@ __device__ void assemble_frame(const AsmCtx& c, int i, const Tiles<LAYOUT>& T_, 
     asm_commit<LAYOUT>(c, i, R, T_, tmp, ex);
 }
 
-// cost = 1/2 sum r^2 over the residual blocks ceres keeps (blocks whose parameters are all constant are dropped)
-__device__ double window_cost(const AsmCtx& c) {
+// cost = 1/2 sum r^2 over the residual blocks ceres keeps (blocks whose parameters are all constant are dropped).
+// *gchk (optional): a checksum over every gradient slot J^T r of the same partial sums.  Ceres rejects an evaluation whose residuals
+// or Jacobians hold a non-finite value (ResidualBlock::Evaluate -> IsEvaluationValid); any such entry makes its block's J^T r
+// non-finite (NaN * r = NaN, Inf * 0 = NaN), so isfinite(cost) && isfinite(*gchk) is that test on the fused partial sums — e.g. the
+// NaN derivative of norm() at an exactly stationary wheel increment (wheel_factor.h:52,58,63).
+__device__ double window_cost(const AsmCtx& c, double* gchk = nullptr) {
     const int lane = threadIdx.x & 63;
     const int n = c.n;
     const double* PLb = c.PL + (size_t)c.b * n * LP;
@@ -423,16 +427,35 @@ __device__ double window_cost(const AsmCtx& c) {
     const double* PWb = c.PW + (size_t)c.b * (n - 1) * PWS;
     const double* PGb = c.PG + (size_t)c.b * n * PGS;
     const bool track = c.mode == LIW_MODE_TRACK;
-    double s = 0.0;
+    double s = 0.0, gs = 0.0;
     for (int i = lane; i < n; i += 64) {
         s += PLb[(size_t)i * LP + 120];
-        if (!(track && i < n - 1)) s += PGb[(size_t)i * PGS + 48];
+        const bool gon = !(track && i < n - 1);
+        if (gon) s += PGb[(size_t)i * PGS + 48];
+        if (gchk) {
+#pragma unroll
+            for (int k = 0; k < 12; ++k) gs += PLb[(size_t)i * LP + 108 + k];
+            if (gon) {
+#pragma unroll
+                for (int k = 0; k < 6; ++k) gs += PGb[(size_t)i * PGS + k * 7 + 6];
+            }
+        }
     }
     for (int k = lane; k < n - 1; k += 64) {
         s += PIb[(size_t)k * PIS + PI_C];
-        if (!(track && k < n - 2)) s += PWb[(size_t)k * PWS + 12 * 13 + 12];
+        const bool won = !(track && k < n - 2);
+        if (won) s += PWb[(size_t)k * PWS + 12 * 13 + 12];
+        if (gchk) {
+#pragma unroll
+            for (int e = 0; e < 30; ++e) gs += PIb[(size_t)k * PIS + PI_G + e];
+            if (won) {
+#pragma unroll
+                for (int e = 0; e < 12; ++e) gs += PWb[(size_t)k * PWS + e * 13 + 12];
+            }
+        }
     }
     if (c.prior_on && lane < 15) { const double r = prior_r(c, lane); s += r * r; }
+    if (gchk) *gchk = wave_sum(gs);
     return 0.5 * wave_sum(s);
 }
 
@@ -565,11 +588,20 @@ __device__ __forceinline__ void lm_step_body(const StepArgs& a, const int b, Lds
     if (iteration == 0 && !st.have_candidate) {
         // ---- iteration 0: cost at the initial point
         c.buf = cur; c.PL = a.w.PL[cur]; c.PI = a.w.PI[cur]; c.PW = a.w.PW[cur]; c.PG = a.w.PG[cur]; c.x = xw;
-        x_cost = window_cost(c);
-        double s = 0.0;
-        for (int e = lane; e < n * 15; e += 64) if (!var_is_const(a.mode, a.fast_mode, n, e / 15, e % 15)) s += xw[e] * xw[e];
-        x_norm = sqrt(wave_sum(s));
+        double gchk;
+        x_cost = window_cost(c, &gchk);
         if (lane == 0) { st.initial_cost = x_cost; st.minimum_cost = x_cost; }
+        if (!isfinite(x_cost) || !isfinite(gchk)) {   // IterationZero: "Residual and Jacobian evaluation failed." -> FAILURE, nothing applied
+            if (lane == 0) { st.done = 1; st.termination = 6; st.x_cost = x_cost; }
+            return;
+        }
+        double s = 0.0;
+        for (int e = lane; e < n * 15; e += 64) {
+            const double xv = xw[e];
+            st.x0[e] = xv;
+            if (!var_is_const(a.mode, a.fast_mode, n, e / 15, e % 15)) s += xv * xv;
+        }
+        x_norm = sqrt(wave_sum(s));
         fresh = true;
         if (a.w.history && a.w.history_records > 0)
             for (int e = lane; e < n * 15; e += 64) a.w.history[((size_t)b) * n * 15 + e] = xw[e];
@@ -577,7 +609,8 @@ __device__ __forceinline__ void lm_step_body(const StepArgs& a, const int b, Lds
         // ---- candidate evaluated by the previous linearise launch
         const int cb = 1 - cur;
         c.buf = cb; c.PL = a.w.PL[cb]; c.PI = a.w.PI[cb]; c.PW = a.w.PW[cb]; c.PG = a.w.PG[cb]; c.x = xc;
-        double cand_cost = window_cost(c);
+        double cand_gchk;
+        double cand_cost = window_cost(c, &cand_gchk);
         STAMPE(4001);
         if (!isfinite(cand_cost)) cand_cost = 1.7976931348623157e308;
         int term = 0;
@@ -590,6 +623,15 @@ __device__ __forceinline__ void lm_step_body(const StepArgs& a, const int b, Lds
             return;
         }
         const double rho = (x_cost - cand_cost) / st.model_cost_change;
+        if (rho > kMinRelDec && !isfinite(cand_gchk)) {
+            // HandleSuccessfulStep -> EvaluateGradientAndJacobian fails at the accepted point: FAILURE, the iteration is not recorded and
+            // the solve hands back the states it started from
+            if (st.successful > 0)
+                for (int e = lane; e < n * 15; e += 64) xw[e] = st.x0[e];
+            wave_mem_sync();
+            if (lane == 0) { st.done = 1; st.termination = 6; st.iteration = iteration - 1; st.x_cost = st.initial_cost; st.have_candidate = 0; }
+            return;
+        }
         if (rho > kMinRelDec) {
             for (int e = lane; e < n * 15; e += 64) xw[e] = xc[e];
             cur = cb;
@@ -898,6 +940,13 @@ __device__ __forceinline__ void lm_step_body(const StepArgs& a, const int b, Lds
         model_cost_change = 0.5 * (wave_sum(ytg) + wave_sum(dsum));
         valid = model_cost_change > 0.0 && isfinite(model_cost_change);
     }
+    // max_num_consecutive_invalid_steps reached: FAILURE, which hands back the states the solve started from
+    const bool fail5 = !valid && st.invalid_steps + 1 >= 5;
+    if (fail5 && st.successful > 0) {
+        for (int e = lane; e < n * 15; e += 64) xw[e] = st.x0[e];
+        x_cost = st.initial_cost;
+    }
+    wave_mem_sync();   // (every lane has read st.invalid_steps / st.successful before lane 0 updates the state)
     if (lane == 0) {
         st.iteration = iteration; st.cur = cur; st.x_cost = x_cost; st.x_norm = x_norm;
         if (valid) {
@@ -906,7 +955,7 @@ __device__ __forceinline__ void lm_step_body(const StepArgs& a, const int b, Lds
         } else {
             st.invalid_steps += 1;
             st.have_candidate = 0;
-            if (st.invalid_steps >= 5) { st.done = 1; st.termination = 6; st.iteration = iteration - 1; }
+            if (fail5) { st.done = 1; st.termination = 6; st.iteration = iteration - 1; }
             st.radius = radius / dec; st.decrease_factor = dec * 2.0; st.reuse_diagonal = 1;
         }
     }
@@ -980,29 +1029,45 @@ __global__ __launch_bounds__(256, 1) void k_lm_step_tw(StepArgs a) {
         int proceed = 1;
         if (iteration == 0 && !st.have_candidate) {
             c.buf = cur; c.PL = a.w.PL[cur]; c.PI = a.w.PI[cur]; c.PW = a.w.PW[cur]; c.PG = a.w.PG[cur]; c.x = xw;
-            x_cost = window_cost(c);
-            double sq = 0.0;
-            for (int e = lane; e < n * 15; e += 64) if (!var_is_const(a.mode, a.fast_mode, n, e / 15, e % 15)) sq += xw[e] * xw[e];
-            x_norm = sqrt(wave_sum(sq));
+            double gchk;
+            x_cost = window_cost(c, &gchk);
             if (lane == 0) { st.initial_cost = x_cost; st.minimum_cost = x_cost; }
+            double sq = 0.0;
+            for (int e = lane; e < n * 15; e += 64) {
+                const double xv = xw[e];
+                st.x0[e] = xv;
+                if (!var_is_const(a.mode, a.fast_mode, n, e / 15, e % 15)) sq += xv * xv;
+            }
+            x_norm = sqrt(wave_sum(sq));
             fresh = true;
             if (a.w.history && a.w.history_records > 0)
                 for (int e = lane; e < n * 15; e += 64) a.w.history[((size_t)b) * n * 15 + e] = xw[e];
+            if (!isfinite(x_cost) || !isfinite(gchk)) {   // IterationZero: evaluation failed -> FAILURE, nothing applied (see k_lm_step)
+                if (lane == 0) { st.done = 1; st.termination = 6; st.x_cost = x_cost; }
+                proceed = 0;
+            }
         } else if (st.have_candidate) {
             const int cb = 1 - cur;
             c.buf = cb; c.PL = a.w.PL[cb]; c.PI = a.w.PI[cb]; c.PW = a.w.PW[cb]; c.PG = a.w.PG[cb]; c.x = xc;
-            double cand_cost = window_cost(c);
+            double cand_gchk;
+            double cand_cost = window_cost(c, &cand_gchk);
             if (!isfinite(cand_cost)) cand_cost = 1.7976931348623157e308;
             int term = 0;
             if (st.cand_step_norm <= kParamTol * (x_norm + kParamTol)) term = 3;
             else if (fabs(x_cost - cand_cost) <= kFuncTol * x_cost) term = 2;
+            const double rho = term ? 0.0 : (x_cost - cand_cost) / st.model_cost_change;
             if (term) {
                 if (a.w.history && iteration < a.w.history_records)
                     for (int e = lane; e < n * 15; e += 64) a.w.history[((size_t)iteration * a.B + b) * n * 15 + e] = xw[e];
                 if (lane == 0) { st.done = 1; st.termination = term; }
                 proceed = 0;
+            } else if (rho > kMinRelDec && !isfinite(cand_gchk)) {   // evaluation failed at the accepted point -> FAILURE (see k_lm_step)
+                if (st.successful > 0)
+                    for (int e = lane; e < n * 15; e += 64) xw[e] = st.x0[e];
+                wave_mem_sync();
+                if (lane == 0) { st.done = 1; st.termination = 6; st.iteration = iteration - 1; st.x_cost = st.initial_cost; st.have_candidate = 0; }
+                proceed = 0;
             } else {
-                const double rho = (x_cost - cand_cost) / st.model_cost_change;
                 if (rho > kMinRelDec) {
                     for (int e = lane; e < n * 15; e += 64) xw[e] = xc[e];
                     cur = cb;
@@ -1365,7 +1430,10 @@ __global__ __launch_bounds__(256, 1) void k_lm_step_tw(StepArgs a) {
         } else {
             st.invalid_steps += 1;
             st.have_candidate = 0;
-            if (st.invalid_steps >= 5) { st.done = 1; st.termination = 6; st.iteration = iteration - 1; }
+            if (st.invalid_steps >= 5) {   // FAILURE hands back the states the solve started from (rare: one lane copies)
+                st.done = 1; st.termination = 6; st.iteration = iteration - 1;
+                if (st.successful > 0) { for (int e = 0; e < n * 15; ++e) xw[e] = st.x0[e]; st.x_cost = st.initial_cost; }
+            }
             st.radius = radius / dec; st.decrease_factor = dec * 2.0; st.reuse_diagonal = 1;
         }
     }

@@ -46,6 +46,8 @@ struct LmState {
     double initial_cost;
     double scale[15 * 64];      // Jacobi scaling, up to n = 64 frames
     double diagonal[15 * 64];
+    double x0[15 * 64];         // the states the solve started from: a FAILURE termination hands them back (Ceres solver.cc Minimize():
+                                // StateVectorToParameterBlocks(IsSolutionUsable() ? reduced : original_reduced_parameters))
 };
 
 // state of a window at the start of a solve (k_lm_begin; the first k_lin_all of a single-window solve)

@@ -81,21 +81,51 @@ def normalize_extrinsic(T16):
 
 
 # ---------------------------------------------------------------- trajectory ground truth
+MOTIONS = ("arc", "stationary", "rotate", "translate", "standstill_then_go")
+
+
 class _Truth:
-    def __init__(self, prm, yaw_rate=0.3, radius=5.0):
+    """Ground-truth base (wheel / odom frame) trajectory T_w_o(t).
+
+    motion: "arc" (default; circle of `radius`, yaw rate `yaw_rate`), "stationary" (the robot does not move at all),
+    "rotate" (turning on the spot: the wheel frame's origin stays put, so the translation of the relative wheel pose is 0 — the arm of
+    reference src/factor/wheel_factor.h:52,58 with |dp| < 1e-4), "translate" (straight line, no rotation: the arm of :63 with
+    |dq| < 1e-3), "standstill_then_go" (at rest until t_go, then the arc with a smooth start: the first frames of a log recorded from a
+    parked robot).  The path parameter s(t) carries all time dependence, so a standstill is exactly constant."""
+
+    def __init__(self, prm, yaw_rate=0.3, radius=5.0, motion="arc", t_go=2.0, speed=1.5):
+        assert motion in MOTIONS, motion
         self.T_i_o = normalize_extrinsic(prm["T_imu_to_wheel"])
         self.T_o_i = inv_se3(self.T_i_o)
         self.T_i_l = normalize_extrinsic(prm["T_imu_to_laser"])
         self.w = yaw_rate
         self.r = radius
         self.g = prm["g"]
+        self.motion = motion
+        self.t_go = t_go
+        self.speed = speed
+
+    def s(self, t):
+        if self.motion == "stationary":
+            return 0.0
+        if self.motion == "standstill_then_go":
+            u, tau = t - self.t_go, 0.5
+            if u <= 0.0:
+                return 0.0
+            return u * u / (2.0 * tau) if u < tau else u - 0.5 * tau
+        return t
 
     def T_w_o(self, t):
-        psi = self.w * t
-        roll = 1e-3 * np.sin(2.0 * t)
-        pitch = 1e-3 * np.cos(1.5 * t)
+        s = self.s(t)
+        if self.motion == "translate":
+            return se3(np.eye(3), np.array([self.speed * s, 0.0, 0.0]))
+        psi = self.w * s
+        if self.motion == "rotate":
+            return se3(exp_so3(np.array([0.0, 0.0, psi])), np.zeros(3))
+        roll = 1e-3 * np.sin(2.0 * s)
+        pitch = 1e-3 * np.cos(1.5 * s)
         R = exp_so3(np.array([0.0, 0.0, psi])) @ exp_so3(np.array([roll, pitch, 0.0]))
-        p = np.array([self.r * np.sin(psi), self.r * (1.0 - np.cos(psi)), 1e-3 * np.sin(3.0 * t)])
+        p = np.array([self.r * np.sin(psi), self.r * (1.0 - np.cos(psi)), 1e-3 * np.sin(3.0 * s)])
         return se3(R, p)
 
     def T_w_i(self, t):
@@ -115,18 +145,25 @@ class _Truth:
 
 
 def make_window(preint, prm=None, seed=20240, n=30, L=2000, frame_dt=0.1, imu_rate=200.0, wheel_period=0.0505,
-                laser_on_frame0=False, state_noise=1.0):
+                laser_on_frame0=False, state_noise=1.0, motion="arc", state_motion=None, odom_noise=2e-4,
+                state_p_sigma=0.02, state_q_sigma=np.deg2rad(0.5), t0=1.0):
     """Returns a dict of numpy arrays in the flat `liw_window` layout (+ 'truth_states').
 
     preint: object with imu_preint(samples[N,7], t_start, t_end, bias6) -> (X15, J15x15, sqrtP15x15, Dt)
             and wheel_preint(samples[N,13], t_start, t_end) -> (T12, sqrtP3x3, Dt)   (row-major matrices).
     laser blocks are spread over frames 1..n-1 (init topology ties them to frame 0; frame 0 owns none
     unless laser_on_frame0) and sorted by owning frame.
+
+    motion / state_motion (see _Truth): the sensors (IMU, wheel odometry, matched lines) follow `motion`; the frame STATES the solver
+    starts from are the truth of `state_motion` (default: the same) + N(0, state_noise * [state_p_sigma, state_q_sigma]).  Different
+    values give the mixed arms of reference src/factor/wheel_factor.h:45-66: the odometry increment at rest while the states move
+    (motion="stationary", state_motion="arc") and the mirror.  odom_noise: position noise of the odometry samples (0 for the
+    identical readings of a parked robot).
     """
     prm = prm or office_params()
     rng = np.random.default_rng(seed)
-    tr = _Truth(prm)
-    t0 = 1.0
+    tr = _Truth(prm, motion=motion)
+    trs = tr if state_motion in (None, motion) else _Truth(prm, motion=state_motion)
     times = t0 + frame_dt * np.arange(n)
 
     # ---- frame states: truth + perturbation
@@ -134,13 +171,13 @@ def make_window(preint, prm=None, seed=20240, n=30, L=2000, frame_dt=0.1, imu_ra
     truth = np.zeros((n, 15))
     states = np.zeros((n, 15))
     for k in range(n):
-        T = tr.T_w_i(times[k])
+        T = trs.T_w_i(times[k])
         truth[k, 0:3] = T[:3, 3]
         truth[k, 3:6] = log_so3(T[:3, :3])
-        truth[k, 6:9] = tr.vel(times[k])
+        truth[k, 6:9] = trs.vel(times[k])
         truth[k, 9:15] = true_bias
-        Rn = T[:3, :3] @ exp_so3(rng.normal(0.0, np.deg2rad(0.5) * state_noise, 3))
-        states[k, 0:3] = T[:3, 3] + rng.normal(0.0, 0.02 * state_noise, 3)
+        Rn = T[:3, :3] @ exp_so3(rng.normal(0.0, state_q_sigma * state_noise, 3))
+        states[k, 0:3] = T[:3, 3] + rng.normal(0.0, state_p_sigma * state_noise, 3)
         states[k, 3:6] = log_so3(Rn)
         states[k, 6:9] = truth[k, 6:9] + rng.normal(0.0, 0.05 * state_noise, 3)
         states[k, 9:15] = rng.normal(0.0, 1e-3, 6)
@@ -166,7 +203,7 @@ def make_window(preint, prm=None, seed=20240, n=30, L=2000, frame_dt=0.1, imu_ra
             T = tr.T_w_o(t)
             ws[i, 0] = t
             ws[i, 1:10] = T[:3, :3].reshape(9)
-            ws[i, 10:13] = T[:3, 3] + rng.normal(0.0, 2e-4, 3)
+            ws[i, 10:13] = T[:3, 3] + rng.normal(0.0, 1.0, 3) * odom_noise
         # samples before times[k] only establish the twist; the accumulator is reset at times[k] (trajectory.cpp:176-184)
         T12, P9, Dtw = preint.wheel_preint(ws, times[k], times[k + 1])
         wheel_T[k], wheel_P[k], wheel_Dt[k] = T12, np.asarray(P9).reshape(9), Dtw

@@ -121,9 +121,13 @@ public:
             else for (int k = 0; k < b.size; ++k) xout[b.amb_off + k] = xin[b.amb_off + k] + delta[b.tan_off + k];
         }
     }
-    // cost (and optionally H, g) at ambient point xv
+    // cost (and optionally H, g) at ambient point xv.  eval_ok = false when a residual (or, with_jac, a Jacobian entry of a
+    // non-constant block) is not finite: Ceres' ResidualBlock::Evaluate -> IsEvaluationValid rejects the evaluation then
+    // (internal/ceres/residual_block.cc, array_utils.cc IsArrayValid).
+    bool eval_ok = true;
     double evaluate(const std::vector<double>& xv, bool with_jac) {
         double cost = 0.0;
+        eval_ok = true;
         if (with_jac) { H = DMat(n_tan, n_tan); g.assign(n_tan, 0.0); }
         std::vector<double> res, jbuf;
         std::vector<double> local(9 * 1);
@@ -143,6 +147,11 @@ public:
                 int o = 0;
                 for (int b = 0; b < nb; ++b) { jp[b] = jbuf.data() + size_t(rb.n_res) * o; o += pr.pblocks[rb.blocks[b]].size; }
                 rb.eval(pp.data(), res.data(), jp.data());
+                for (int b = 0; b < nb; ++b) {
+                    auto& pb = pr.pblocks[rb.blocks[b]];
+                    if (pb.constant) continue;
+                    for (int e = 0; e < rb.n_res * pb.size; ++e) if (!std::isfinite(jp[b][e])) eval_ok = false;
+                }
                 // local parameterisation: J <- J * dPlus/ddelta
                 for (int b = 0; b < nb; ++b) {
                     auto& pb = pr.pblocks[rb.blocks[b]];
@@ -177,7 +186,7 @@ public:
                     }
                 }
             }
-            for (int i = 0; i < rb.n_res; ++i) cost += res[i] * res[i];
+            for (int i = 0; i < rb.n_res; ++i) { cost += res[i] * res[i]; if (!std::isfinite(res[i])) eval_ok = false; }
         }
         return 0.5 * cost;
     }
@@ -223,6 +232,14 @@ public:
         std::vector<double> diagonal(n_tan, 0.0);
         double x_cost = evaluate(x, true);
         sum->initial_cost = x_cost;
+        // TrustRegionMinimizer::IterationZero -> EvaluateGradientAndJacobian fails: "Residual and Jacobian evaluation failed.",
+        // termination FAILURE, no iteration recorded; Solver then hands the ORIGINAL parameters back (see restore_user below)
+        if (!eval_ok) { sum->termination = 6; sum->final_cost = x_cost; sum->num_iterations = 0; return; }
+        const std::vector<double> x_initial = x;
+        // solver.cc Minimize(): StateVectorToParameterBlocks(IsSolutionUsable() ? reduced_parameters : original_reduced_parameters):
+        // a FAILURE termination (evaluation failure after a successful step, or max_num_consecutive_invalid_steps) is not "usable"
+        // and restores the parameters the solve started from, whatever progress was written back before
+        auto restore_user = [&]() { x = x_initial; write_back(); };
         scale.assign(n_tan, 1.0);
         if (opt.jacobi_scaling)
             for (int i = 0; i < n_tan; ++i) scale[i] = 1.0 / (1.0 + std::sqrt(H(i, i)));
@@ -300,7 +317,7 @@ public:
             rec.step_is_valid = valid;
             if (!valid) {
                 // HandleInvalidStep
-                if (++num_consecutive_invalid_steps >= opt.max_num_consecutive_invalid_steps) { sum->termination = 6; --iteration; break; }
+                if (++num_consecutive_invalid_steps >= opt.max_num_consecutive_invalid_steps) { sum->termination = 6; --iteration; restore_user(); x_cost = sum->initial_cost; break; }
                 radius = radius / decrease_factor; decrease_factor *= 2.0; reuse_diagonal = true;   // StepIsInvalid -> StepRejected(0)
                 rec.cost = x_cost; rec.radius = radius; rec.step_is_successful = false;
                 snapshot(rec);
@@ -316,7 +333,8 @@ public:
             plus(x, delta, cand);
             double candidate_cost = evaluate(cand, false);
             rec.candidate_cost = candidate_cost;
-            if (!std::isfinite(candidate_cost)) candidate_cost = std::numeric_limits<double>::max();
+            // "Step failed to evaluate. Treating it as a step with infinite cost" (a non-finite residual fails the evaluation)
+            if (!eval_ok || !std::isfinite(candidate_cost)) candidate_cost = std::numeric_limits<double>::max();
 
             // ---- ParameterToleranceReached
             double step_norm = 0.0;
@@ -346,6 +364,8 @@ public:
                 for (auto& b : pr.pblocks) if (!b.constant) for (int k = 0; k < b.size; ++k) x_norm += x[b.amb_off + k] * x[b.amb_off + k];
                 x_norm = std::sqrt(x_norm);
                 x_cost = evaluate(x, true);
+                // HandleSuccessfulStep -> EvaluateGradientAndJacobian fails: FAILURE, returned before the iteration is recorded
+                if (!eval_ok) { sum->termination = 6; --iteration; restore_user(); x_cost = sum->initial_cost; break; }
                 gmax = gradient_max_norm();
                 radius = radius / std::max(1.0 / 3.0, 1.0 - std::pow(2.0 * relative_decrease - 1.0, 3));
                 radius = std::min(opt.max_trust_region_radius, radius);

@@ -57,3 +57,23 @@ def block_rel_errors(A, Ao, bs=3):
                 continue
             worst = max(worst, float(np.abs(b - bo).max() / s))
     return worst
+
+
+def wheel_arms(synth, prm, d, k):
+    """Which arms of reference src/factor/wheel_factor.h the wheel block k (frames k, k+1) of window `d` takes at its states,
+    recomputed in numpy (independent of oracle and product):
+      moving45 : :45  both o_dir.norm() and dir.norm() > 1e-4   -> angle = asin|o_dir x dir|, else angle = dir.norm()
+      moving58 : :58  neither len nor o_len < 1e-4               -> res[0] = w (o_len - len),   else w len
+      moving63 : :63  neither |q| nor |oq| < 1e-3                -> res[2] = w (|oq| - |q|),    else w |q|
+    plus the four magnitudes (len, o_len, |q|, |oq|) so a test can keep clear of the thresholds."""
+    T_i_w = synth.normalize_extrinsic(prm["T_imu_to_wheel"])
+    st = np.asarray(d["states"]).reshape(-1, 15)
+    tfi = synth.se3(synth.exp_so3(st[k, 3:6]), st[k, 0:3]) @ T_i_w
+    tfj = synth.se3(synth.exp_so3(st[k + 1, 3:6]), st[k + 1, 0:3]) @ T_i_w
+    rel = synth.inv_se3(tfi) @ tfj
+    p, q = rel[:3, 3], synth.log_so3(rel[:3, :3])
+    T12 = np.asarray(d["wheel_T"])[k]
+    op, oq = T12[9:12], synth.log_so3(T12[:9].reshape(3, 3))
+    ln, oln, nq, noq = float(np.hypot(p[0], p[1])), float(np.hypot(op[0], op[1])), float(np.linalg.norm(q)), float(np.linalg.norm(oq))
+    return dict(moving45=bool(oln > 1e-4 and ln > 1e-4), moving58=bool(not (ln < 1e-4 or oln < 1e-4)),
+                moving63=bool(not (nq < 1e-3 or noq < 1e-3)), len=ln, o_len=oln, q=nq, oq=noq)
