@@ -62,10 +62,13 @@ def cast_scan_moving(segs, pose_of_time, t0, n_rays, fov, time_increment, noise,
     return ranges, np.float32(angle_min), np.float32(inc)
 
 
-def make_log(prm, duration=3.0, seed=0, imu_rate=200.0, wheel_rate=20.0, laser_rate=10.0, n_rays=720, scan_time=0.04):
-    """-> list of messages (dicts with 'type', 'time', ...), strictly increasing distinct stamps."""
+def make_log(prm, duration=3.0, seed=0, imu_rate=200.0, wheel_rate=20.0, laser_rate=10.0, n_rays=720, scan_time=0.04,
+             motion="arc", odom_noise=2e-4, **truth_kw):
+    """-> list of messages (dicts with 'type', 'time', ...), strictly increasing distinct stamps.
+    motion / truth_kw: synth._Truth (e.g. "standstill_then_go" with t_go, "stop_and_go" with t_stop / pause); odom_noise = 0 gives the
+    bit-identical odometry readings of a robot at rest."""
     rng = np.random.default_rng(seed)
-    tr = synth._Truth(prm)
+    tr = synth._Truth(prm, motion=motion, **truth_kw)
     room = replay_room()
     bias = rng.normal(0.0, 1e-3, 6)
     msgs = []
@@ -76,7 +79,7 @@ def make_log(prm, duration=3.0, seed=0, imu_rate=200.0, wheel_rate=20.0, laser_r
     for k in range(int(duration * wheel_rate)):
         t = k / wheel_rate + 3e-4
         T = tr.T_w_o(t)
-        msgs.append(dict(type=1, time=t, R=T[:3, :3].copy(), t=T[:3, 3] + rng.normal(0, 2e-4, 3)))
+        msgs.append(dict(type=1, time=t, R=T[:3, :3].copy(), t=T[:3, 3] + rng.normal(0, 1.0, 3) * odom_noise))
     T_i_l = tr.T_i_l
     tinc = scan_time / n_rays
     for k in range(int(duration * laser_rate)):

@@ -81,7 +81,7 @@ def normalize_extrinsic(T16):
 
 
 # ---------------------------------------------------------------- trajectory ground truth
-MOTIONS = ("arc", "stationary", "rotate", "translate", "standstill_then_go")
+MOTIONS = ("arc", "stationary", "rotate", "translate", "standstill_then_go", "stop_and_go")
 
 
 class _Truth:
@@ -91,9 +91,10 @@ class _Truth:
     "rotate" (turning on the spot: the wheel frame's origin stays put, so the translation of the relative wheel pose is 0 — the arm of
     reference src/factor/wheel_factor.h:52,58 with |dp| < 1e-4), "translate" (straight line, no rotation: the arm of :63 with
     |dq| < 1e-3), "standstill_then_go" (at rest until t_go, then the arc with a smooth start: the first frames of a log recorded from a
-    parked robot).  The path parameter s(t) carries all time dependence, so a standstill is exactly constant."""
+    parked robot), "stop_and_go" (the arc, braking to a halt at t_stop, at rest for `pause` seconds, then on: a standstill while
+    TRACKING).  The path parameter s(t) carries all time dependence, so a standstill is exactly constant."""
 
-    def __init__(self, prm, yaw_rate=0.3, radius=5.0, motion="arc", t_go=2.0, speed=1.5):
+    def __init__(self, prm, yaw_rate=0.3, radius=5.0, motion="arc", t_go=2.0, speed=1.5, t_stop=3.0, pause=2.0):
         assert motion in MOTIONS, motion
         self.T_i_o = normalize_extrinsic(prm["T_imu_to_wheel"])
         self.T_o_i = inv_se3(self.T_i_o)
@@ -104,6 +105,8 @@ class _Truth:
         self.motion = motion
         self.t_go = t_go
         self.speed = speed
+        self.t_stop = t_stop
+        self.pause = pause
 
     def s(self, t):
         if self.motion == "stationary":
@@ -113,6 +116,18 @@ class _Truth:
             if u <= 0.0:
                 return 0.0
             return u * u / (2.0 * tau) if u < tau else u - 0.5 * tau
+        if self.motion == "stop_and_go":      # speed 1 -> linear ramp to 0 over tau before t_stop -> 0 for `pause` -> ramp up over tau
+            tau, a, b = 0.5, self.t_stop - 0.5, self.t_stop + self.pause
+            if t <= a:
+                return t
+            s_stop = a + 0.5 * tau
+            if t <= self.t_stop:
+                u = t - a
+                return a + u - u * u / (2.0 * tau)
+            if t <= b:
+                return s_stop
+            u = t - b
+            return s_stop + (u * u / (2.0 * tau) if u < tau else u - 0.5 * tau)
         return t
 
     def T_w_o(self, t):

@@ -170,6 +170,44 @@ def test_keep_n_window_replay_matches_oracle(liw, synth, pyoracle, tmp_path, kee
     print("keep=%d: %d tracking solves (up to %d frames, %d laser blocks) reproduced: %s" % (keep, len(caps), keep + 1, max(c["L"] for c in caps), worst))
 
 
+@pytest.mark.parametrize("name,kw,duration", [
+    ("parked_2s_then_drive", dict(motion="standstill_then_go", t_go=2.0), 6.0),
+    ("stop_2s_while_tracking_noisy_odometry", dict(motion="stop_and_go", t_stop=3.0, pause=2.0), 7.0),
+    ("stop_2s_while_tracking_identical_odometry", dict(motion="stop_and_go", t_stop=3.0, pause=2.0, odom_noise=0.0), 7.0)])
+def test_replay_with_a_standstill(liw, synth, pyoracle, tmp_path, name, kw, duration):
+    """Logs with a 2 s standstill.  Parked at the start: the INITIALIZING gate drops the scans of a robot at rest
+    (reference trajectory.cpp:163), the state machine must agree.  A stop while TRACKING: the tracking solves of those frames take the
+    stationary arms of wheel_odom_factor (wheel_factor.h:45/:58/:63; asserted from the captured inputs) — every one re-run on the
+    MI355X from the oracle's input: states 1e-6, iteration counts, Delta_H / Delta_g, the new prior."""
+    import importlib
+    from parity_util import wheel_arms
+    replay = importlib.import_module("2dliw-slam_amd.replay")
+    prm = synth.office_params()
+    lp = liw.laser.office_laser_params(prm)
+    msgs, truth = replay.make_log(prm, duration=duration, seed=4, **kw)
+    replay.write_log(str(tmp_path / "log.bin"), msgs)
+    out = str(tmp_path) + "/"
+    r = subprocess.run([build_replay(liw), str(tmp_path / "log.bin"), out], capture_output=True)
+    assert r.returncode == 0, r.stderr.decode()
+    orc = oracle_replay(pyoracle, prm, lp, msgs, capture=True)
+    frames, tracked, got = _check_free_running(out, orc, replay, min_tracked=20, lead=8)
+    caps = orc.captures()
+    assert len(caps) == tracked
+    arms = []
+    for c in caps:
+        d = dict(c)
+        d["states"], d["wheel_T"] = np.asarray(c["states"]).reshape(c["n"], 15), np.asarray(c["wheel_T"]).reshape(c["n"] - 1, 12)
+        a = wheel_arms(synth, prm, d, c["n"] - 2)
+        arms.append((a["moving45"], a["moving63"]))
+    at_rest = sum(1 for a in arms if not a[1])
+    if kw["motion"] == "stop_and_go":
+        assert at_rest >= 15, arms                                    # ~2 s of 10 Hz scans with |oq| < 1e-3
+        if kw.get("odom_noise", 1.0) == 0.0:
+            assert sum(1 for a in arms if a == (False, False)) >= 15, arms   # identical odometry readings: o_len = 0 too
+    worst = _teacher_forced_tracking(liw, pyoracle, prm, caps)
+    print("%s: %d tracking solves (%d in the stationary arms) reproduced: %s" % (name, len(caps), at_rest, worst))
+
+
 def test_c5_shape_replay_with_pose_graph_backend(liw, synth, pyoracle, tmp_path):
     """BASELINE C5 end to end in shape: 50-frame tracking windows, key frames leaving the window go to the back-end
     (include/lvio_2d_keyframe_manager.hpp: sequential edges, loop edges from a schedule standing in for loop detection,
