@@ -15,6 +15,7 @@
 // (src/factor/factor_common.h:41-53).  Marginalisation restates solver.cpp:4-40 and :390-402 on the same
 // block structure (chain elimination 0..n-2, eigen floor 1e-8).
 #include "liw_kernels.hpp"
+#include "k_lm_common.hpp"
 
 namespace liw {
 
@@ -38,71 +39,6 @@ __device__ long long g_span[3 * 16384];   // per window: start, end (s_memtime),
 #define SPAN(k) do { } while (0)
 #endif
 
-
-constexpr double kMinDiag = 1e-6, kMaxDiag = 1e32, kMinRelDec = 1e-3, kFuncTol = 1e-6, kGradTol = 1e-10, kParamTol = 1e-8;
-constexpr double kMaxRadius = 1e16, kMinRadius = 1e-32, kInitRadius = 1e4;
-constexpr double kPi = 3.141592653589793238462643383279, kTwoPi = 6.283185307179586476925286766559;
-
-// Cross-lane reductions on DPP row operations (v_mov_b32_dpp on both halves of the double): a row of 16 lanes in 4 steps, the four
-// rows joined by row_bcast:15 / :31, result broadcast from lane 63 — 175 cycles measured (tools/ubench/dpp.hip) against 460 for six
-// ds_bpermute butterflies; the step kernels are single waves whose run time is the sum of such latencies.
-template <int CTRL, int ROWMASK = 0xF>
-__device__ __forceinline__ double dpp64(double v, double old = 0.0) {   // lanes without a source / outside ROWMASK: `old`
-    int lo = __double2loint(v), hi = __double2hiint(v);
-    lo = __builtin_amdgcn_update_dpp(__double2loint(old), lo, CTRL, ROWMASK, 0xF, false);
-    hi = __builtin_amdgcn_update_dpp(__double2hiint(old), hi, CTRL, ROWMASK, 0xF, false);
-    return __hiloint2double(hi, lo);
-}
-__device__ __forceinline__ double row_sum(double v) {   // every lane: the sum over its row of 16 lanes
-    v += dpp64<0xB1>(v); v += dpp64<0x4E>(v); v += dpp64<0x141>(v); v += dpp64<0x140>(v);   // quad_perm [1,0,3,2], [2,3,0,1], row_half_mirror, row_mirror
-    return v;
-}
-__device__ __forceinline__ double rdlane(double v, int l);
-__device__ __forceinline__ double wave_sum(double v) {
-    v = row_sum(v);
-    v += dpp64<0x142, 0xA>(v);   // row_bcast:15 into rows 1 and 3
-    v += dpp64<0x143, 0xC>(v);   // row_bcast:31 into rows 2 and 3
-    return rdlane(v, 63);
-}
-__device__ __forceinline__ double wave_max(double v) {
-    v = fmax(v, dpp64<0xB1>(v, v)); v = fmax(v, dpp64<0x4E>(v, v)); v = fmax(v, dpp64<0x141>(v, v)); v = fmax(v, dpp64<0x140>(v, v));
-    v = fmax(v, dpp64<0x142, 0xA>(v, v));
-    v = fmax(v, dpp64<0x143, 0xC>(v, v));
-    return rdlane(v, 63);
-}
-
-__device__ __forceinline__ double rdlane(double v, int l) {   // v_readlane_b32 x2: broadcast lane l's value (l uniform)
-    int lo = __double2loint(v), hi = __double2hiint(v);
-    lo = __builtin_amdgcn_readlane(lo, l);
-    hi = __builtin_amdgcn_readlane(hi, l);
-    return __hiloint2double(hi, lo);
-}
-
-// so3 Plus and its Jacobian at delta = 0 (factor_common.h:41-53 through AutoDiffLocalParameterization)
-__device__ __forceinline__ void so3_plus(const double* x, const double* d, double* out) {
-    const double a0 = x[0] + d[0], a1 = x[1] + d[1], a2 = x[2] + d[2];
-    // normalize_so3 returns its argument unchanged unless |a| > pi: clearly below that (|a|^2 < 9.8 < pi^2 = 9.8696) the
-    // square root of the norm is skipped; the callers pass wave-uniform values, so the branch does not diverge
-    if (a0 * a0 + a1 * a1 + a2 * a2 < 9.8) { out[0] = a0; out[1] = a1; out[2] = a2; return; }
-    V3<double> r = normalize_so3(V3<double>(a0, a1, a2));
-    out[0] = r.x; out[1] = r.y; out[2] = r.z;
-}
-__device__ __forceinline__ bool so3_plus_jac(const double* x, double* P9) {
-    const double a = sqrt(x[0] * x[0] + x[1] * x[1] + x[2] * x[2]);
-    if (!(a > kPi)) return false;  // identity
-    const double k = floor((a + kPi) / kTwoPi);
-    const double c = kTwoPi * k / a;
-    const double u[3] = {x[0] / a, x[1] / a, x[2] / a};
-    for (int i = 0; i < 3; ++i)
-        for (int j = 0; j < 3; ++j) P9[i * 3 + j] = (i == j ? 1.0 : 0.0) - c * ((i == j ? 1.0 : 0.0) - u[i] * u[j]);
-    return true;
-}
-
-__device__ __forceinline__ bool var_is_const(int mode, int fast, int n, int i, int v) {
-    if (mode != LIW_MODE_TRACK) return false;
-    if (i >= n - 1) return false;
-    return v < 6 || (fast && v >= 9);
-}
 
 struct AsmCtx {
     int n, mode, fast, b, buf;
@@ -567,6 +503,7 @@ __device__ __forceinline__ void lm_step_body(const StepArgs& a, const int b, Lds
     const int lane = threadIdx.x & 63;
     LmState& st = a.w.lm[b];
     if (st.done) return;
+    if (a.only_slow && !lm_window_is_slow(a, b)) return;   // this window was stepped by k_lm_step_quad in the launch before
     const int n = a.n;
     double* xw = a.x + (size_t)b * n * 15;
     double* xc = a.w.x_cand + (size_t)b * n * 15;
@@ -588,11 +525,10 @@ __device__ __forceinline__ void lm_step_body(const StepArgs& a, const int b, Lds
     if (iteration == 0 && !st.have_candidate) {
         // ---- iteration 0: cost at the initial point
         c.buf = cur; c.PL = a.w.PL[cur]; c.PI = a.w.PI[cur]; c.PW = a.w.PW[cur]; c.PG = a.w.PG[cur]; c.x = xw;
-        double gchk;
-        x_cost = window_cost(c, &gchk);
+        x_cost = window_cost(c);
         if (lane == 0) { st.initial_cost = x_cost; st.minimum_cost = x_cost; }
-        if (!isfinite(x_cost) || !isfinite(gchk)) {   // IterationZero: "Residual and Jacobian evaluation failed." -> FAILURE, nothing applied
-            if (lane == 0) { st.done = 1; st.termination = 6; st.x_cost = x_cost; }
+        if (!isfinite(x_cost)) {   // IterationZero: "Residual and Jacobian evaluation failed." -> FAILURE, nothing applied (non-finite residual;
+            if (lane == 0) { st.done = 1; st.termination = 6; st.x_cost = x_cost; }   // a non-finite Jacobian is caught in the pass below)
             return;
         }
         double s = 0.0;
@@ -609,8 +545,7 @@ __device__ __forceinline__ void lm_step_body(const StepArgs& a, const int b, Lds
         // ---- candidate evaluated by the previous linearise launch
         const int cb = 1 - cur;
         c.buf = cb; c.PL = a.w.PL[cb]; c.PI = a.w.PI[cb]; c.PW = a.w.PW[cb]; c.PG = a.w.PG[cb]; c.x = xc;
-        double cand_gchk;
-        double cand_cost = window_cost(c, &cand_gchk);
+        double cand_cost = window_cost(c);
         STAMPE(4001);
         if (!isfinite(cand_cost)) cand_cost = 1.7976931348623157e308;
         int term = 0;
@@ -623,15 +558,6 @@ __device__ __forceinline__ void lm_step_body(const StepArgs& a, const int b, Lds
             return;
         }
         const double rho = (x_cost - cand_cost) / st.model_cost_change;
-        if (rho > kMinRelDec && !isfinite(cand_gchk)) {
-            // HandleSuccessfulStep -> EvaluateGradientAndJacobian fails at the accepted point: FAILURE, the iteration is not recorded and
-            // the solve hands back the states it started from
-            if (st.successful > 0)
-                for (int e = lane; e < n * 15; e += 64) xw[e] = st.x0[e];
-            wave_mem_sync();
-            if (lane == 0) { st.done = 1; st.termination = 6; st.iteration = iteration - 1; st.x_cost = st.initial_cost; st.have_candidate = 0; }
-            return;
-        }
         if (rho > kMinRelDec) {
             for (int e = lane; e < n * 15; e += 64) xw[e] = xc[e];
             cur = cb;
@@ -695,7 +621,7 @@ __device__ __forceinline__ void lm_step_body(const StepArgs& a, const int b, Lds
     const double sc0reg = scl[lane < 15 ? lane : 0];           // scale of frame 0 (rows of the arrow block)
     lds_sync();
     bool solved = true;
-    double gmax = 0.0;
+    double gmax = 0.0, gsum = 0.0;
     const int iteration_dbg = iteration; (void)iteration_dbg;
     STAMP(0); SPAN(0);
     const Tiles<1> TM{T.M, nullptr, nullptr, nullptr};
@@ -716,6 +642,7 @@ __device__ __forceinline__ void lm_step_body(const StepArgs& a, const int b, Lds
         // LM diagonal of this frame (LevenbergMarquardtStrategy::ComputeStep), |x - Plus(x,-g)|
         const bool cstl = ln < 15 && var_is_const(a.mode, a.fast_mode, n, i, ln);
         const double gl = ln < 15 ? T.M[ln * MS + 40] : 0.0;          // tangent gradient entry of this lane
+        gsum += gl;
         double dgv = ex.dg_i;
         if (ln < 15) {
             if (!reuse) { dgv = fmin(fmax(T.M[ln * MS + ln] * ex.sc_i * ex.sc_i, kMinDiag), kMaxDiag); dgl[i * 15 + ln] = dgv; }
@@ -838,6 +765,25 @@ __device__ __forceinline__ void lm_step_body(const StepArgs& a, const int b, Lds
     }
     STAMP(1);
     gmax = wave_max(gmax);
+    // ---- was the evaluation this linearisation came from valid?  Ceres rejects residuals / Jacobians with a non-finite entry
+    //      (ResidualBlock::Evaluate -> IsEvaluationValid); any such entry makes its block's J^T r non-finite (NaN * r = NaN, Inf * 0 = NaN),
+    //      i.e. the assembled gradient that just went through this wave — e.g. the NaN derivative of norm() at an exactly stationary wheel
+    //      increment (wheel_factor.h:52,58,63).  A sweep cut short by a failed pivot re-reads the gradient slots of every frame instead.
+    {
+        double gchk = wave_sum(gsum);
+        if (!solved) (void)window_cost(c, &gchk);
+        if (!isfinite(gchk)) {
+            // IterationZero / HandleSuccessfulStep: "Residual and Jacobian evaluation failed." -> FAILURE: the iteration is not recorded and
+            // the solve hands back the states it started from
+            if (!fresh) for (int e = lane; e < n * 15; e += 64) xw[e] = st.x0[e];
+            wave_mem_sync();
+            if (lane == 0) {
+                st.done = 1; st.termination = 6; st.have_candidate = 0; st.cur = cur;
+                if (!fresh) { st.iteration = iteration - 1; st.x_cost = st.initial_cost; }
+            }
+            return;
+        }
+    }
     // ---- FinalizeIterationAndCheck, part 2
     {
         int term = 0;
@@ -1822,10 +1768,21 @@ void launch_lm_begin(int B, int n, LmState* lm, int max_iters, hipStream_t s) {
     hipLaunchKernelGGL(k_lm_begin, dim3((B + 63) / 64), dim3(64), 0, s, B, n, lm, max_iters);
 }
 void launch_lm_step(const StepArgs& a, hipStream_t s) {
-    static const char* env = getenv("LIW_STEP_VARIANT");   // 0 / 1 / 2: force the one-wave latency / throughput / two-wave variant (profiling aid)
+    // LIW_STEP_VARIANT (read per launch) 0 / 1 / 2 / 3: force the one-wave latency / one-wave throughput / four-wave / quad variant (profiling, tests)
+    const char* env = getenv("LIW_STEP_VARIANT");
     const bool tp = env ? env[0] == '1' : a.B > 2048;
     // two waves per window while that does not take CUs away from other windows, and the chain is long enough to be worth cutting
     const bool tw = (env ? env[0] == '2' : a.B <= 256) && a.n >= 6;
+    // four windows per wave (k_lm_quad.hip) once the batch is large enough to fill the chip that way; the windows it leaves out
+    // (a rotation vector outside the |theta| <= pi ball) are stepped by the one-wave kernel right behind it
+    const bool quad = (env ? env[0] == '3' : a.B > 2048) && a.mode == LIW_MODE_INIT && lm_step_quad_fits(a);
+    if (quad) {
+        launch_lm_step_quad(a, s);
+        StepArgs a2 = a;
+        a2.only_slow = 1;
+        hipLaunchKernelGGL(k_lm_step<true>, dim3(a.B), dim3(64), 0, s, a2);
+        return;
+    }
     if (tw) hipLaunchKernelGGL(k_lm_step_tw, dim3(a.B), dim3(256), 0, s, a);
     else if (tp) hipLaunchKernelGGL(k_lm_step<true>, dim3(a.B), dim3(64), 0, s, a);
     else hipLaunchKernelGGL(k_lm_step<false>, dim3(a.B), dim3(64), 0, s, a);

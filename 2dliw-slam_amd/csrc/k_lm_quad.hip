@@ -1,0 +1,616 @@
+// k_lm_quad.hip — the LM step for LARGE batches: FOUR windows per wavefront, one 16-lane DPP row per window (gfx950, fp64).
+//
+// k_lm_step (k_lm.hip) gives a whole wave to one window and broadcasts every L[r][k] of the 15x15 eliminations with two
+// v_readlane + one FMA: at 12 288 windows it is bound by the NUMBER of instructions it issues (profiles/r02_v9: 54 k per window and
+// iteration, 91 % of the SIMD's issue cycles, 11 % MFMA-busy).  Here a window lives in ONE ROW of 16 lanes: lane j < 15 owns column j
+// of the damped diagonal tile D, of O^T (coupling to frame i-1) and, j < 6, of R^T (arrow to frame 0's pose) — three register sets
+// in the same lanes — and lane 15 rides along in the O^T set with the gradient.  The broadcast of L[r][k] inside a row is the
+// DP-ALU's DPP operand (row_newbcast:r, the only DPP control 64-bit instructions take on gfx90a+):
+//     v_fmac_f64_dpp  a[r], -wk (row_newbcast:r), wk        ==   a[r] -= L[r][k] * wk     for 4 windows x 16 lanes in ONE instruction
+// at half the plain FMA rate (tools/ubench/dpp64.hip: 8.2 cycles), i.e. 2 cycles per window and row update instead of 12.  Rank-1
+// updates, the Schur products W^T W (next frame's tiles come out directly in the lane layout: no LDS, no MFMA operand tiles) and the
+// back-substitution operators L^-T W all take that form; nothing leaves the registers between assembly and the factor record.
+//
+// Same algorithm and the same per-launch protocol as k_lm_step (candidate test -> accept / reject -> eliminate frames n-1 .. 0 ->
+// back substitution -> candidate states; Ceres' TrustRegionMinimizer restated, see k_lm.hip), so the two kernels can serve different
+// windows of one batch: windows whose rotation vector left the |theta| <= pi ball (so3 Plus Jacobian != I, rare: Plus normalises) and
+// the TRACK topology (constant blocks, prior) stay on k_lm_step.  Reference call sites: src/factor/solver.cpp:161-168.
+#include <cstddef>
+#include <type_traits>
+
+#include "liw_kernels.hpp"
+#include "k_lm_common.hpp"
+
+namespace liw {
+
+template <int B_, int E_, class F> __device__ __forceinline__ void sfor(F&& f) {
+    if constexpr (B_ < E_) { f(std::integral_constant<int, B_>{}); sfor<B_ + 1, E_>(f); }
+}
+#define KI(K) (std::remove_reference_t<decltype(K)>::value)
+
+// ---- DP-ALU DPP primitives.  volatile: they must execute with all 64 lanes enabled (a DPP read of a disabled lane is not a read), so
+// the compiler may neither sink them into divergent code nor reorder them against each other; program order below is written for ILP
+// (consecutive instructions hit different accumulators).  A VGPR written by a VALU instruction needs 2 wait states before a DPP
+// instruction reads it (the hazard recogniser does not look inside inline asm): fresh DPP sources are produced by mul_nop().
+template <int L> __device__ __forceinline__ double bc(double v) {            // value of lane L of this lane's row
+    double r;
+    asm volatile("v_mov_b64_dpp %0, %1 row_newbcast:%2 row_mask:0xf bank_mask:0xf" : "=v"(r) : "v"(v), "n"(L));
+    return r;
+}
+template <int L> __device__ __forceinline__ void fnma_bc(double& acc, double src, double mul) {   // acc -= src@L * mul
+    asm volatile("v_fmac_f64_dpp %0, -%1, %2 row_newbcast:%3 row_mask:0xf bank_mask:0xf" : "+v"(acc) : "v"(src), "v"(mul), "n"(L));
+}
+template <int L> __device__ __forceinline__ double mul_bc(double src, double mul) {              // src@L * mul
+    double r;
+    asm volatile("v_mul_f64_dpp %0, %1, %2 row_newbcast:%3 row_mask:0xf bank_mask:0xf" : "=v"(r) : "v"(src), "v"(mul), "n"(L));
+    return r;
+}
+__device__ __forceinline__ double mul_nop(double x, double y) {              // x * y, safe as a DPP source right away
+    double r;
+    asm volatile("v_mul_f64 %0, %1, %2\n s_nop 1" : "=v"(r) : "v"(x), "v"(y));
+    return r;
+}
+__device__ __forceinline__ void dpp_fence() { asm volatile("s_nop 1"); }    // before the first DPP read of values written by plain code
+
+__device__ __forceinline__ double row_max(double v) {
+    v = fmax(v, dpp64<0xB1>(v, v)); v = fmax(v, dpp64<0x4E>(v, v)); v = fmax(v, dpp64<0x141>(v, v)); v = fmax(v, dpp64<0x140>(v, v));
+    return v;
+}
+
+// phase stamps (tools/clk_probe_quad.py): s_memtime of one wave at one frame of one LM iteration; dormant unless switched on
+__device__ long long g_qclk[64];
+__device__ int g_qclk_on[4];   // on, block, frame, iteration
+#define QSTAMP(id) do { if (clk_on && i == clk_frame) { if (lane == 0) g_qclk[(id)] = clock64(); } } while (0)
+
+constexpr int QTOT = 4 * (PIS + 86 + PWS + PGS);   // LDS doubles per wave: the prefetched partial records of its four rows (25.8 kB -> 6 waves per CU)
+
+// offset of entry (r, j) inside a packed upper triangle of order 15, r a compile-time constant
+template <int R> __device__ __forceinline__ int tri_rc(int j, int cj) {   // cj = 14 j - j (j - 1) / 2
+    constexpr int cR = 14 * R - (R * (R - 1)) / 2;
+    return R <= j ? cR + j : cj + R;
+}
+
+__global__ __launch_bounds__(64, 1) void k_lm_step_quad(StepArgs a) {
+    __shared__ double S[QTOT];
+    const int lane = threadIdx.x & 63, j = lane & 15, w = lane >> 4;
+    const int n = a.n;
+    int b = (int)blockIdx.x * 4 + w;
+    bool act = b < a.B;
+    b = act ? b : a.B - 1;
+    // Row-dependent addresses are wave-uniform bases (kernel arguments, SGPR pairs) + unsigned 32-bit element offsets (one VGPR each);
+    // launch_lm_step_quad checks that every offset fits.
+    double* const X = a.x;
+    double* const XC = a.w.x_cand;
+    double* const LMD = reinterpret_cast<double*>(a.w.lm);                // LmState as doubles
+    constexpr unsigned LMS = sizeof(LmState) / 8, LM_SCALE = offsetof(LmState, scale) / 8, LM_DIAG = offsetof(LmState, diagonal) / 8,
+                       LM_X0 = offsetof(LmState, x0) / 8;
+    const unsigned oX = (unsigned)b * (unsigned)(n * 15), oLM = (unsigned)b * LMS;
+    LmState& st = a.w.lm[b];
+    act = act && !st.done;
+    const int have_cand = st.have_candidate;
+    {
+        const double sl = quad_slow_lane(X + oX, XC + oX, have_cand, n, j, 16) ? 1.0 : 0.0;
+        act = act && !(row_max(sl) > 0.0);
+    }
+    if (!__any(act)) return;
+
+    int reuse = st.reuse_diagonal, cur = st.cur;
+    const int iteration = st.iteration;
+    bool proceed = act, last_successful = true;
+    const bool fresh = iteration == 0 && !have_cand;
+    const bool clk_k = g_qclk_on[0] && (int)blockIdx.x == g_qclk_on[1] && iteration == g_qclk_on[3] && lane == 0;
+    if (clk_k) g_qclk[12] = clock64();
+    double inv_radius;
+    // ---------------------------------------------------------------- prologue: cost of the initial point / the pending candidate,
+    //      accept / reject, Ceres' termination tests (k_lm_step's prologue, statement for statement, per row)
+    {
+        double radius = st.radius, dec = st.decrease_factor, x_cost = st.x_cost, x_norm = st.x_norm;
+        const int max_iters = st.max_iters, successful0 = st.successful;
+        int successful = successful0;
+        const double model0 = st.model_cost_change, cand_step_norm = st.cand_step_norm, initial_cost0 = st.initial_cost;
+        double minimum_cost = st.minimum_cost, initial_cost = initial_cost0;
+        const int cb = (fresh || !have_cand) ? cur : 1 - cur;
+        double cost;
+        {
+            const double* PLb = (cb ? a.w.PL[1] : a.w.PL[0]) + (size_t)b * n * LP;
+            const double* PIb = (cb ? a.w.PI[1] : a.w.PI[0]) + (size_t)b * (n - 1) * PIS;
+            const double* PWb = (cb ? a.w.PW[1] : a.w.PW[0]) + (size_t)b * (n - 1) * PWS;
+            const double* PGb = (cb ? a.w.PG[1] : a.w.PG[0]) + (size_t)b * n * PGS;
+            double s = 0.0;
+            for (int i = j; i < n; i += 16) {
+                s += PLb[(size_t)i * LP + 120];
+                s += PGb[(size_t)i * PGS + 48];
+            }
+            for (int k = j; k < n - 1; k += 16) {
+                s += PIb[(size_t)k * PIS + PI_C];
+                s += PWb[(size_t)k * PWS + 12 * 13 + 12];
+            }
+            cost = 0.5 * row_sum(s);
+        }
+        int term = 0;
+        bool accept = false, fail_eval = false;
+        if (fresh) {
+            x_cost = cost; initial_cost = cost; minimum_cost = cost;
+            fail_eval = !isfinite(cost);          // IterationZero: non-finite residual -> FAILURE, nothing applied (Jacobians: after the sweep below)
+        } else if (have_cand) {
+            const double cand_cost = isfinite(cost) ? cost : 1.7976931348623157e308;
+            if (cand_step_norm <= kParamTol * (x_norm + kParamTol)) term = 3;
+            else if (fabs(x_cost - cand_cost) <= kFuncTol * x_cost) term = 2;
+            if (!term) {
+                const double rho = (x_cost - cand_cost) / model0;
+                accept = rho > kMinRelDec;
+                if (accept) {
+                    cur = cb; x_cost = cand_cost;
+                    const double t3 = 2.0 * rho - 1.0;
+                    radius = fmin(kMaxRadius, radius / fmax(1.0 / 3.0, 1.0 - t3 * t3 * t3));
+                    dec = 2.0; reuse = 0; successful += 1;
+                    if (x_cost < minimum_cost) minimum_cost = x_cost;
+                } else {
+                    radius = radius / dec; dec *= 2.0; reuse = 1; last_successful = false;
+                }
+            }
+        } else {
+            last_successful = false;   // previous step was invalid
+        }
+        // states: accepted candidate -> live states; a failed evaluation hands back the states the solve started from; x0 / x_norm
+        {
+            double s2 = 0.0;
+            const bool restore = act && fail_eval && !fresh && successful0 > 0;
+            const bool hist = act && a.w.history && iteration < a.w.history_records && !fail_eval;
+            for (int e0 = j; e0 < n * 15; e0 += 16 * 8) {      // eight entries per lane at a time: their loads are in flight together
+                double xv[8];
+#pragma unroll
+                for (int q = 0; q < 8; ++q) {
+                    const int e = e0 + 16 * q;
+                    const unsigned ee = (unsigned)(e < n * 15 ? e : j);
+                    xv[q] = restore ? LMD[oLM + LM_X0 + ee] : (accept ? XC[oX + ee] : X[oX + ee]);
+                }
+#pragma unroll
+                for (int q = 0; q < 8; ++q) {
+                    const int e = e0 + 16 * q;
+                    if (e < n * 15) {
+                        if (act && (accept || restore)) X[oX + (unsigned)e] = xv[q];
+                        if (act && fresh) LMD[oLM + LM_X0 + (unsigned)e] = xv[q];
+                        s2 += xv[q] * xv[q];
+                        if (hist) a.w.history[((size_t)iteration * a.B + b) * (size_t)(n * 15) + e] = xv[q];
+                    }
+                }
+            }
+            s2 = row_sum(s2);
+            if (fresh || accept) x_norm = sqrt(s2);
+        }
+        if (act && (fail_eval || term)) {
+            if (j == 0) {
+                st.done = 1; st.termination = fail_eval ? 6 : term;
+                if (fail_eval) { st.x_cost = fresh ? cost : initial_cost0; st.have_candidate = 0; if (!fresh) st.iteration = iteration - 1; }
+                if (fresh) { st.initial_cost = initial_cost; st.minimum_cost = minimum_cost; }
+            }
+            proceed = false;
+        }
+        const bool cap = proceed && iteration >= max_iters && !fresh;
+        // the LM state as k_lm_step leaves it when a launch ends after the prologue; the tail below re-reads radius / decrease_factor
+        if (proceed && j == 0) {
+            st.radius = radius; st.decrease_factor = dec; st.x_cost = x_cost; st.x_norm = x_norm; st.cur = cur;
+            st.successful = successful; st.minimum_cost = minimum_cost;
+            if (fresh) st.initial_cost = initial_cost;
+            if (cap) { st.done = 1; st.termination = 4; st.reuse_diagonal = reuse; st.have_candidate = 0; }
+        }
+        if (cap) proceed = false;
+        inv_radius = 1.0 / radius;
+    }
+    if (!__any(proceed)) return;
+
+    // current linearisation of this row's window
+    const double* const PL0 = a.w.PL[0];
+    const double* const PI0 = a.w.PI[0];
+    const double* const PW0 = a.w.PW[0];
+    const double* const PG0 = a.w.PG[0];
+    const unsigned oPL = (unsigned)b * (unsigned)(n * LP) + (cur ? (unsigned)(a.w.PL[1] - a.w.PL[0]) : 0u);
+    const unsigned oPI = (unsigned)b * (unsigned)((n - 1) * PIS) + (cur ? (unsigned)(a.w.PI[1] - a.w.PI[0]) : 0u);
+    const unsigned oPW = (unsigned)b * (unsigned)((n - 1) * PWS) + (cur ? (unsigned)(a.w.PW[1] - a.w.PW[0]) : 0u);
+    const unsigned oPG = (unsigned)b * (unsigned)(n * PGS) + (cur ? (unsigned)(a.w.PG[1] - a.w.PG[0]) : 0u);
+    const unsigned oWS = (unsigned)b * (unsigned)(n * SOLVE_WS);
+    double* const WS = a.w.solve_ws;
+    const unsigned oSC = oLM + LM_SCALE, oDG = oLM + LM_DIAG;
+    const int jc = j < 15 ? j : 0;            // clamped column for addresses
+    const int cj = 14 * jc - (jc * (jc - 1)) / 2;
+    const bool l6 = j < 6, l15 = j == 15, lm = j < 15;
+    const int j6 = l6 ? j : 0;
+
+    if (__any(proceed && fresh)) {   // Jacobi scaling 1 / (1 + sqrt(H_jj)), once per solve (same sums, same order as k_lm_step's frame_diag)
+        for (int i = 0; i < n; ++i) {
+            double dd = 0.0;
+            if (l6) {
+                dd += PL0[oPL + (unsigned)(i * LP + 36 + jc * 7)];
+                if (i == 0) for (int f = 0; f < n; ++f) dd += PL0[oPL + (unsigned)(f * LP + jc * 7)];
+                if (i >= 1) dd += PW0[oPW + (unsigned)((i - 1) * PWS + (6 + jc) * 14)];
+                if (i <= n - 2) dd += PW0[oPW + (unsigned)(i * PWS + jc * 14)];
+                dd += PG0[oPG + (unsigned)(i * PGS + jc * 8)];
+            }
+            if (i >= 1) dd += PI0[oPI + (unsigned)((i - 1) * PIS + PI_JJ + pi_tri(jc, jc))];
+            if (i <= n - 2) dd += PI0[oPI + (unsigned)(i * PIS + PI_II + pi_tri(jc, jc))];
+            if (proceed && fresh && lm) LMD[oSC + (unsigned)(i * 15 + j)] = 1.0 / (1.0 + sqrt(dd));
+        }
+    }
+    const double sc0 = l6 ? LMD[oSC + (unsigned)jc] : 0.0;           // scale of frame 0's pose entry j (columns of the arrow block)
+
+    // Everything frame f needs from HBM is fetched ONE FRAME AHEAD, behind the elimination of frame f+1: the partial records by LDS-DMA
+    // (global_load_lds: no VGPRs, no waits; LDS destination = uniform base + lane * 16 bytes, so every instruction fills a lane-linear
+    // piece of one row's area), the Jacobi scale / LM diagonal / state entry of this lane in three registers.
+    //   S_IMU[w][496]  IMU partial of block (f-1, f)            4 pieces per row
+    //   S_PL[w][86]    PL_f[36 .. 122): Hbb, Hab, ga, gb         1 piece per row (43 lanes)
+    //   S_PW[w][172]   wheel partial of block (f-1, f)           2 pieces per row (64 + 22 lanes)
+    //   S_PG[w][52]    ground partial of frame f                 1 piece per two rows (26 lanes each)
+    constexpr int S_IMU = 0, S_PL = 4 * PIS, S_PW = S_PL + 4 * 86, S_PG = S_PW + 4 * PWS;
+    static_assert(S_PG + 4 * PGS <= QTOT, "LDS layout");
+    const unsigned rPL[4] = {(unsigned)__builtin_amdgcn_readlane(oPL, 0), (unsigned)__builtin_amdgcn_readlane(oPL, 16), (unsigned)__builtin_amdgcn_readlane(oPL, 32), (unsigned)__builtin_amdgcn_readlane(oPL, 48)};
+    const unsigned rPI[4] = {(unsigned)__builtin_amdgcn_readlane(oPI, 0), (unsigned)__builtin_amdgcn_readlane(oPI, 16), (unsigned)__builtin_amdgcn_readlane(oPI, 32), (unsigned)__builtin_amdgcn_readlane(oPI, 48)};
+    const unsigned rPW[4] = {(unsigned)__builtin_amdgcn_readlane(oPW, 0), (unsigned)__builtin_amdgcn_readlane(oPW, 16), (unsigned)__builtin_amdgcn_readlane(oPW, 32), (unsigned)__builtin_amdgcn_readlane(oPW, 48)};
+    const unsigned rPG[4] = {(unsigned)__builtin_amdgcn_readlane(oPG, 0), (unsigned)__builtin_amdgcn_readlane(oPG, 16), (unsigned)__builtin_amdgcn_readlane(oPG, 32), (unsigned)__builtin_amdgcn_readlane(oPG, 48)};
+    typedef __attribute__((address_space(3))) void* lds_t;
+    const int j_ = j;
+    double scm_n = 1.0, dg_n = 0.0, xq_n = 0.0;     // prefetched: scale of frame f-1, LM diagonal and state entry of frame f (lane j)
+    auto prefetch = [&](int f) {                    // f >= 0: the frame eliminated next
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // the LDS reads of the current frame have returned
+        const int k = f - 1;                        // its block towards the frame before
+        // the lane's 16-byte slot of a piece, in doubles: the ONLY lane-dependent part of an address.  Laundered, so that the per-lane
+        // pointers are formed right here (one 64-bit add each) and never kept across the frame loop — as hoisted loop invariants they
+        // spilled, and every reload inside this burst waited (vmcnt) for the pieces already in flight
+        int lane2 = lane * 2;
+        asm volatile("" : "+v"(lane2));
+#pragma unroll
+        for (int ws = 0; ws < 4; ++ws) {
+            if (k >= 0) {
+                const double* gI = PI0 + rPI[ws] + (unsigned)(k * PIS) + lane2;
+                const double* gW = PW0 + rPW[ws] + (unsigned)(k * PWS) + lane2;
+                lds_t lI = (lds_t)(S + S_IMU + ws * PIS), lW = (lds_t)(S + S_PW + ws * PWS);
+                // (the immediate offset moves the global AND the LDS address)
+                __builtin_amdgcn_global_load_lds(gI, lI, 16, 0, 0);
+                __builtin_amdgcn_global_load_lds(gI, lI, 16, 1024, 0);
+                __builtin_amdgcn_global_load_lds(gI, lI, 16, 2048, 0);
+                if (lane < (PIS - 3 * 128) / 2) __builtin_amdgcn_global_load_lds(gI, lI, 16, 3072, 0);
+                __builtin_amdgcn_global_load_lds(gW, lW, 16, 0, 0);
+                if (lane < 22) __builtin_amdgcn_global_load_lds(gW, lW, 16, 1024, 0);
+            }
+            const double* gL = PL0 + rPL[ws] + (unsigned)(f * LP + 36) + lane2;
+            if (lane < 43) __builtin_amdgcn_global_load_lds(gL, (lds_t)(S + S_PL + ws * 86), 16, 0, 0);
+        }
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {               // two rows per piece: lanes 0..25 row 2h, 26..51 row 2h+1
+            const unsigned ob = (lane < 26 ? rPG[2 * h] : rPG[2 * h + 1] - 52u) + (unsigned)(f * PGS);
+            if (lane < 52) __builtin_amdgcn_global_load_lds(PG0 + ob + lane2, (lds_t)(S + S_PG + h * 2 * PGS), 16, 0, 0);
+        }
+        const int jq = j_ < 15 ? j_ : 0;
+        scm_n = (j_ < 15 && f >= 1) ? LMD[oSC + (unsigned)((f - 1) * 15 + jq)] : 1.0;
+        dg_n = LMD[oDG + (unsigned)(f * 15 + jq)];
+        xq_n = X[oX + (unsigned)(f * 15 + jq)];
+    };
+    const double* SI = S + S_IMU + w * PIS;
+    const double* SL = S + S_PL + w * 86;         // SL[e] = PL_f[36 + e]
+    const double* SW = S + S_PW + w * PWS;
+    const double* SG = S + S_PG + w * PGS;
+
+    double d[15], o[15], rr[15], cd[15], cr[15], D0[6];
+    double g0 = 0.0, gm = 0.0, ytg = 0.0, pdiag = 0.0, gsum = 0.0;
+    bool solved = true;
+    sfor<0, 15>([&](auto R) { constexpr int r = KI(R); cd[r] = 0.0; cr[r] = 0.0; });
+    sfor<0, 6>([&](auto R) { D0[KI(R)] = 0.0; });
+    const bool clk_on = g_qclk_on[0] && (int)blockIdx.x == g_qclk_on[1] && iteration == g_qclk_on[3];
+    const int clk_frame = g_qclk_on[2];
+    if (clk_k) g_qclk[13] = clock64();
+    prefetch(n - 1);
+    double sci_carry = (j_ < 15) ? LMD[oSC + (unsigned)((n - 1) * 15 + (j_ < 15 ? j_ : 0))] : 1.0;   // scale of frame n-1; later frames reuse scm
+    for (int i = n - 1; i >= 0; --i) {
+        QSTAMP(0);
+        // the lane id is laundered once per frame: lane-derived addresses and masks are recomputed (a few integer ops) instead of being
+        // hoisted out of the loop into registers that then spill (the same trick as in k_lm_step)
+        int j = j_;
+        asm volatile("" : "+v"(j));
+        const int jc = j < 15 ? j : 0, cj = 14 * jc - (jc * (jc - 1)) / 2, j6 = j < 6 ? j : 0;
+        const bool l6 = j < 6, l15 = j == 15, lm = j < 15;
+        const bool hasm = i >= 1;
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this frame's records have landed in LDS (and the row's earlier stores are done)
+        QSTAMP(1);
+        const double sci = sci_carry, scm = scm_n, dg_old = dg_n, xq = xq_n;
+        sci_carry = scm;
+        // ---- pose-block partials: lanes j < 6 the 6x6 blocks, lane 15 the gradient slots
+        double tS[6], oW[6], rL[6];
+        sfor<0, 6>([&](auto R) {
+            constexpr int r = KI(R);
+            const double aD = SL[l15 ? 114 - 36 + r : r * 6 + j6];
+            const double cD = SG[l15 ? r * 7 + 6 : r * 7 + j6];
+            const double bD = SW[l15 ? (6 + r) * 13 + 12 : (6 + r) * 13 + 6 + j6];
+            oW[r] = SW[j6 * 13 + 6 + r];
+            rL[r] = SL[72 - 36 + j6 * 6 + r];
+            tS[r] = aD + (hasm ? bD : 0.0) + cD;
+        });
+        if (i == 0) {   // every laser frame's Haa / ga lands on frame 0's pose
+            double hA[6];
+            sfor<0, 6>([&](auto R) { hA[KI(R)] = 0.0; });
+            for (int f = 0; f < n; ++f) {
+                const unsigned oLf = oPL + (unsigned)(f * LP);
+                sfor<0, 6>([&](auto R) { constexpr int r = KI(R); hA[r] += PL0[oLf + (unsigned)(l15 ? 108 + r : r * 6 + j6)]; });
+            }
+            sfor<0, 6>([&](auto R) { tS[KI(R)] += hA[KI(R)]; });
+        }
+        // ---- IMU block (i-1, i): jj -> D, ij -> O^T, g_j -> gradient (lane 15); ii / g_i are frame i-1's share (-> cd below)
+        if (hasm) {
+            sfor<0, 15>([&](auto R) {
+                constexpr int r = KI(R);
+                d[r] = SI[PI_JJ + tri_rc<r>(jc, cj)];
+                o[r] = SI[l15 ? PI_G + 15 + r : PI_IJ + jc * 15 + r];
+            });
+        } else {
+            sfor<0, 15>([&](auto R) { constexpr int r = KI(R); d[r] = 0.0; o[r] = 0.0; });
+        }
+        sfor<0, 15>([&](auto R) { rr[KI(R)] = 0.0; });
+        sfor<0, 6>([&](auto R) {
+            constexpr int r = KI(R);
+            d[r] += l6 ? tS[r] : 0.0;
+            o[r] += l15 ? tS[r] : ((l6 && hasm) ? oW[r] : 0.0);
+            rr[r] = (l6 && hasm) ? rL[r] : 0.0;
+        });
+        QSTAMP(2);
+        // ---- gradient max-norm of this frame, |x - Plus(x, -g)| (lane 15's registers hold the unscaled tangent gradient)
+        QSTAMP(3);
+        {
+            // (lane 15: o = the share of block (i-1, i) + the pose blocks, cr = the share of block (i, i+1) stashed by the previous step)
+            dpp_fence();
+            const double q0 = bc<3>(xq), q1 = bc<4>(xq), q2 = bc<5>(xq);
+            const double g3 = o[3] + cr[3], g4 = o[4] + cr[4], g5 = o[5] + cr[5];
+            const double a0 = q0 - g3, a1 = q1 - g4, a2 = q2 - g5;
+            double m3 = fabs(g3), m4 = fabs(g4), m5 = fabs(g5);     // |q - (q - g)| when Plus does not wrap
+            if (__any(proceed && l15 && !(a0 * a0 + a1 * a1 + a2 * a2 < 9.8))) {
+                const V3<double> nq = normalize_so3(V3<double>(a0, a1, a2));
+                m3 = fabs(q0 - nq.x); m4 = fabs(q1 - nq.y); m5 = fabs(q2 - nq.z);
+            }
+            double m = fmax(fmax(fabs(o[0] + cr[0]), fabs(o[1] + cr[1])), fabs(o[2] + cr[2]));
+            m = fmax(m, fmax(fmax(m3, m4), m5));
+            sfor<6, 15>([&](auto R) { constexpr int r = KI(R); m = fmax(m, fabs(o[r] + cr[r])); });
+            gm = fmax(gm, m);
+            // checksum of the assembled gradient (lane 15): a non-finite residual or Jacobian entry anywhere in the evaluation makes it non-finite
+            gsum += ((g3 + g4) + g5) + ((o[0] + cr[0]) + (o[1] + cr[1]) + (o[2] + cr[2]));
+            sfor<6, 15>([&](auto R) { constexpr int r = KI(R); gsum += o[r] + cr[r]; });
+        }
+        // ---- LM diagonal (LevenbergMarquardtStrategy::ComputeStep): clamp(S H S, 1e-6, 1e32) at the last accepted point
+        double dmp;
+        {
+            double mjj = d[0];
+            sfor<1, 15>([&](auto R) { constexpr int r = KI(R); mjj = (j == r) ? d[r] : mjj; });
+            double dgv = dg_old;
+            if (!reuse) {
+                dgv = fmin(fmax(__builtin_fma(mjj, sci * sci, pdiag), kMinDiag), kMaxDiag);   // (pdiag: the diagonal of block (i, i+1)'s share, already scaled)
+                if (proceed && lm) LMD[oDG + (unsigned)(i * 15 + j)] = dgv;
+            }
+            dmp = dgv * inv_radius;
+        }
+        // ---- Jacobi scaling, carried Schur terms, damping
+        QSTAMP(4);
+        dpp_fence();
+        sfor<0, 15>([&](auto R) {
+            constexpr int r = KI(R);
+            const double rs = bc<r>(sci);
+            d[r] = __builtin_fma(d[r], rs * sci, cd[r]) + ((j == r) ? dmp : 0.0);
+            o[r] = __builtin_fma(o[r], rs * scm, l15 ? cd[r] : 0.0);
+            rr[r] = __builtin_fma(rr[r], rs * sc0, l15 ? 0.0 : cr[r]);
+        });
+        if (i == 1) {   // frame 0 is both the chain neighbour and the arrow target: fold R^T into O^T
+            sfor<0, 15>([&](auto R) { constexpr int r = KI(R); o[r] += rr[r]; rr[r] = 0.0; });
+        }
+        if (i == 0) {   // the hub: Schur terms every laser frame left on frame 0's pose
+            dpp_fence();
+            sfor<0, 6>([&](auto R) {
+                constexpr int r = KI(R);
+                const double gr = bc<r>(g0);
+                d[r] += D0[r];
+                o[r] += l15 ? gr : 0.0;
+            });
+        }
+        // ---- frame i-1's share of block (i-1, i), in scaled space, starts its carried terms
+        QSTAMP(5);
+        if (hasm) {
+            dpp_fence();
+            sfor<0, 15>([&](auto R) {
+                constexpr int r = KI(R);
+                const double rs = bc<r>(scm);
+                double fi = SI[l15 ? PI_G + r : PI_II + tri_rc<r>(jc, cj)];
+                if constexpr (r < 6) fi += (l6 || l15) ? SW[l15 ? r * 13 + 12 : r * 13 + j6] : 0.0;
+                cd[r] = fi * (rs * scm);
+                cr[r] = l15 ? fi : 0.0;            // lane 15 of the R^T set is idle: it carries frame i-1's unscaled gradient share (gradient max-norm)
+                pdiag = (j == r) ? cd[r] : pdiag;  // ... and this is its diagonal (LM diagonal of frame i-1)
+            });
+        }
+        if (i >= 1) prefetch(i - 1);       // this frame is in registers: the next one streams in behind the elimination
+        QSTAMP(6);
+        // ---- right-looking Cholesky of D fused with the forward substitution of O^T | g and R^T: pivot k broadcasts L_kk, every lane
+        //      forms w_k = a[k] / L_kk of its three columns and updates a[r] -= L[r][k] w_k with L[r][k] = w_k of lane r (DPP operand).
+        //      Lane 15 keeps 1 / L_kk in its (otherwise unused) D registers for the back substitution.
+        sfor<0, 15>([&](auto K) {
+            constexpr int k = KI(K);
+            const double piv = bc<k>(d[k]);
+            if (k == 14) solved = solved && (piv > 0.0) && isfinite(piv);   // a bad pivot poisons every later one: testing the last tests all
+            const double inv = fast_rsqrt(piv);
+            const double wkd = mul_nop(d[k], inv);
+            const double wko = o[k] * inv, wkr = rr[k] * inv;
+            d[k] = l15 ? inv : wkd;
+            o[k] = wko; rr[k] = wkr;
+            sfor<k + 1, 15>([&](auto R) {
+                constexpr int r = KI(R);
+                fnma_bc<r>(d[r], wkd, wkd);
+                fnma_bc<r>(o[r], wkd, wko);
+                fnma_bc<r>(rr[r], wkd, wkr);
+            });
+        });
+        QSTAMP(7);
+        // y' g_s of the model decrease: (A + D^2) y = g_s eliminated block by block is the Cholesky of the whole system, so
+        // y' g_s = |L^-1 g_s|^2 = the sum over the frames of |z|^2, z = this frame's forward-substituted gradient (lane 15)
+        sfor<0, 15>([&](auto K) { constexpr int k = KI(K); ytg = __builtin_fma(o[k], o[k], ytg); });
+        // ---- Schur terms [Wo|z]^T [Wo|z], Wr^T [Wo|z], Wr^T Wr straight into the lane layout of frame i-1 / the hub accumulators
+        if (hasm) {
+            dpp_fence();
+            sfor<0, 15>([&](auto K) {
+                constexpr int k = KI(K);
+                sfor<0, 15>([&](auto C) { constexpr int c = KI(C); fnma_bc<c>(cd[c], o[k], o[k]); });
+            });
+            if (i >= 2) {
+                sfor<0, 15>([&](auto K) {
+                    constexpr int k = KI(K);
+                    sfor<0, 15>([&](auto C) { constexpr int c = KI(C); fnma_bc<c>(cr[c], o[k], rr[k]); });
+                    sfor<0, 6>([&](auto C) { constexpr int c = KI(C); fnma_bc<c>(D0[c], rr[k], rr[k]); });
+                    fnma_bc<15>(g0, o[k], rr[k]);
+                });
+            }
+        }
+        QSTAMP(8);
+        // ---- back-substitution operators [Yo | yz] = L^-T [Wo | z], Yr = L^-T Wr in place (right-looking: once row r is final, every
+        //      earlier row k < r takes its L[r][k] y[r], L[r][k] = d[k] of lane r), then the 22-column record
+        dpp_fence();
+        sfor<0, 15>([&](auto T_) {
+            constexpr int r = 14 - KI(T_);
+            const double ir = bc<15>(d[r]);
+            o[r] *= ir; rr[r] *= ir;
+            sfor<0, r>([&](auto K) {
+                constexpr int k = KI(K);
+                fnma_bc<r>(o[k], d[k], o[r]);
+                fnma_bc<r>(rr[k], d[k], rr[r]);
+            });
+        });
+        QSTAMP(9);
+        if (proceed) {
+            const unsigned of = oWS + (unsigned)(i * SOLVE_WS);
+            sfor<0, 15>([&](auto K) {
+                constexpr int k = KI(K);
+                WS[of + (unsigned)(k * REC_LD + (l15 ? 21 : j))] = o[k];
+                if (l6) WS[of + (unsigned)(k * REC_LD + 15 + j)] = rr[k];
+            });
+        }
+        QSTAMP(10);
+    }
+    if (clk_k) g_qclk[14] = clock64();
+    dpp_fence();
+    const double gmax = bc<15>(gm);
+    ytg = bc<15>(ytg);
+    // ---- was the evaluation this linearisation came from valid?  (see k_lm_step: Ceres' IsEvaluationValid on the fused partial sums)
+    {
+        const bool bad = !isfinite(bc<15>(gsum));
+        if (proceed && bad) {   // IterationZero / HandleSuccessfulStep: evaluation failed -> FAILURE, the states the solve started from are handed back
+            if (!fresh) for (int e = j; e < n * 15; e += 16) X[oX + (unsigned)e] = LMD[oLM + LM_X0 + (unsigned)e];
+            if (j == 0) {
+                st.done = 1; st.termination = 6; st.have_candidate = 0;
+                if (!fresh) { st.iteration = iteration - 1; st.x_cost = st.initial_cost; }
+            }
+            proceed = false;
+        }
+    }
+    // ---- FinalizeIterationAndCheckIfMinimizerCanContinue, part 2
+    {
+        int t2 = 0;
+        if (fresh) { if (gmax <= kGradTol) t2 = 1; }
+        else if (last_successful && gmax <= kGradTol) t2 = 1;
+        if (!t2 && !(1.0 > kMinRadius * inv_radius)) t2 = 5;     // radius > min_trust_region_radius
+        if (proceed && t2) {
+            if (j == 0) { st.done = 1; st.termination = t2; st.reuse_diagonal = reuse; st.have_candidate = 0; }
+            proceed = false;
+        }
+    }
+    if (!__any(proceed)) return;
+
+    // ---------------------------------------------------------------- back substitution, frame 0 first; lane r owns unknown r
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the records written above are read by other lanes of the row
+    double sn2 = 0.0, dsum = 0.0, yprev = 0.0, y0v = 0.0;
+    // the sweep is a chain of small matrix-vector products (21 DPP FMAs per frame) fed by 2.6 kB of record per frame and window: four
+    // frames of loads are kept in flight (a set is refilled as soon as it has been consumed)
+    struct BsRow { double row[22], xold, scv, dgv; };
+    auto fetch = [&](int i) {
+        BsRow R;
+        const double2* f2 = reinterpret_cast<const double2*>(WS + oWS + (unsigned)(i * SOLVE_WS + jc * REC_LD));
+#pragma unroll
+        for (int k = 0; k < 11; ++k) { const double2 v = f2[k]; R.row[2 * k] = v.x; R.row[2 * k + 1] = v.y; }
+        R.xold = X[oX + (unsigned)(i * 15 + jc)]; R.scv = LMD[oSC + (unsigned)(i * 15 + jc)]; R.dgv = LMD[oDG + (unsigned)(i * 15 + jc)];
+        return R;
+    };
+    auto solve_frame = [&](const BsRow& R, int i) {
+        double t = R.row[21];
+        dpp_fence();
+        if (i >= 1) sfor<0, 15>([&](auto K) { constexpr int k = KI(K); fnma_bc<k>(t, yprev, R.row[k]); });
+        if (i >= 2) sfor<0, 6>([&](auto K) { constexpr int k = KI(K); fnma_bc<k>(t, y0v, R.row[15 + k]); });
+        yprev = t;
+        if (i == 0) y0v = t;
+        const double del = lm ? -t * R.scv : 0.0;
+        double xnew = R.xold + del;
+        {
+            dpp_fence();
+            const double a0 = bc<3>(xnew), a1 = bc<4>(xnew), a2 = bc<5>(xnew);
+            if (__any(proceed && !(a0 * a0 + a1 * a1 + a2 * a2 < 9.8))) {   // so3 Plus = normalize_so3(x + d) (factor_common.h:41-53)
+                const V3<double> nq = normalize_so3(V3<double>(a0, a1, a2));
+                if (j == 3) xnew = nq.x;
+                if (j == 4) xnew = nq.y;
+                if (j == 5) xnew = nq.z;
+            }
+        }
+        if (lm) {
+            if (proceed) XC[oX + (unsigned)(i * 15 + j)] = xnew;
+            sn2 += (R.xold - xnew) * (R.xold - xnew);
+            dsum += R.dgv * inv_radius * t * t;
+        }
+    };
+    BsRow R0 = fetch(0), R1 = fetch(n > 1 ? 1 : 0), R2 = fetch(n > 2 ? 2 : 0), R3 = fetch(n > 3 ? 3 : 0);
+    for (int i0 = 0; i0 < n; i0 += 4) {
+        __builtin_amdgcn_sched_barrier(0);
+        solve_frame(R0, i0);
+        if (i0 + 4 < n) R0 = fetch(i0 + 4);
+        __builtin_amdgcn_sched_barrier(0);
+        if (i0 + 1 < n) { solve_frame(R1, i0 + 1); if (i0 + 5 < n) R1 = fetch(i0 + 5); }
+        __builtin_amdgcn_sched_barrier(0);
+        if (i0 + 2 < n) { solve_frame(R2, i0 + 2); if (i0 + 6 < n) R2 = fetch(i0 + 6); }
+        __builtin_amdgcn_sched_barrier(0);
+        if (i0 + 3 < n) { solve_frame(R3, i0 + 3); if (i0 + 7 < n) R3 = fetch(i0 + 7); }
+    }
+    if (clk_k) g_qclk[15] = clock64();
+    const double step_norm = sqrt(row_sum(sn2));
+    // model cost change -(s'g_s + s'A s/2) with s = -y and (A + D^2) y = g_s  ==  (y'g_s + y'D^2 y)/2
+    const double model_cost_change = 0.5 * (ytg + row_sum(dsum));
+    const bool valid = solved && model_cost_change > 0.0 && isfinite(model_cost_change);
+    const int invalid0 = st.invalid_steps, successful = st.successful;
+    const bool fail5 = !valid && invalid0 + 1 >= 5;
+    if (proceed && fail5 && successful > 0) {   // max_num_consecutive_invalid_steps: FAILURE hands back the states the solve started from
+        for (int e = j; e < n * 15; e += 16) X[oX + (unsigned)e] = LMD[oLM + LM_X0 + (unsigned)e];
+    }
+    if (proceed && j == 0) {
+        const double radius = st.radius, dec = st.decrease_factor;
+        st.iteration = iteration + 1;
+        if (fail5 && successful > 0) st.x_cost = st.initial_cost;
+        if (valid) {
+            st.reuse_diagonal = 1;
+            st.model_cost_change = model_cost_change; st.cand_step_norm = step_norm; st.have_candidate = 1; st.invalid_steps = 0;
+        } else {
+            st.invalid_steps = invalid0 + 1;
+            st.have_candidate = 0;
+            if (fail5) { st.done = 1; st.termination = 6; st.iteration = iteration; }
+            st.radius = radius / dec; st.decrease_factor = dec * 2.0; st.reuse_diagonal = 1;
+        }
+    }
+}
+
+// every row-dependent address of the kernel is a base + unsigned 32-bit element offset
+bool lm_step_quad_fits(const StepArgs& a) {
+    const unsigned long long lim = 0xFFFFFFFFull - 4096;
+    auto span = [&](const double* p0, const double* p1, unsigned long long per) {
+        const unsigned long long d = p1 >= p0 ? (unsigned long long)(p1 - p0) : ~0ull;
+        return d <= lim && d + (unsigned long long)a.B * per <= lim;
+    };
+    const int nm = a.n > 1 ? a.n - 1 : 1;
+    return a.n >= 1 && a.mode == LIW_MODE_INIT && span(a.w.PL[0], a.w.PL[1], (unsigned long long)a.n * LP) && span(a.w.PI[0], a.w.PI[1], (unsigned long long)nm * PIS) &&
+           span(a.w.PW[0], a.w.PW[1], (unsigned long long)nm * PWS) && span(a.w.PG[0], a.w.PG[1], (unsigned long long)a.n * PGS) &&
+           (unsigned long long)a.B * (sizeof(LmState) / 8) <= lim && (unsigned long long)a.B * a.n * SOLVE_WS <= lim;
+}
+extern "C" void liw_debug_quad_clk(int on, int block, int frame, int iteration, long long* out) {
+    const int v[4] = {on, block, frame, iteration};
+    (void)hipMemcpyToSymbol(HIP_SYMBOL(g_qclk_on), v, sizeof(v));
+    if (out) (void)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_qclk), sizeof(long long) * 64);
+}
+void launch_lm_step_quad(const StepArgs& a, hipStream_t s) {
+    hipLaunchKernelGGL(k_lm_step_quad, dim3((a.B + 3) / 4), dim3(64), 0, s, a);
+}
+
+}  // namespace liw

@@ -191,6 +191,7 @@ struct StepArgs {
     const unsigned char* has_match;
     const double* prior_X; const double* prior_J; const int* has_prior;
     WsView w;
+    int only_slow;               // 1: k_lm_step handles only the windows k_lm_step_quad leaves out in this launch (|theta| > pi somewhere)
 };
 struct ExportArgs {
     int B, n, mode, fast_mode, buf;
@@ -224,6 +225,8 @@ void launch_group_offsets(int B, int n, const int* laser_off, const int* laser_f
 void launch_pack_result(const PackArgs& a, hipStream_t s);
 void launch_lm_begin(int B, int n, LmState* lm, int max_iters, hipStream_t s);
 void launch_lm_step(const StepArgs& a, hipStream_t s);
+void launch_lm_step_quad(const StepArgs& a, hipStream_t s);   // k_lm_quad.hip: four windows per wave (INIT topology, large batches)
+bool lm_step_quad_fits(const StepArgs& a);
 void launch_lm_finish(const StepArgs& a, hipStream_t s);
 void launch_export_dense(const ExportArgs& a, hipStream_t s);
 void launch_marg_schur(const MargArgs& a, hipStream_t s);
