@@ -8,6 +8,9 @@ import ctypes as C
 import numpy as np
 
 
+XFN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p)   # liw_exchange_fn (include/liw_window.h)
+
+
 def shard_laser(win, rank, world):
     """Factor-parallel partition of ONE window: rank r keeps a contiguous slice of the (frame-sorted) laser blocks;
     states, IMU / wheel blocks and poses are replicated.  Union over ranks = all blocks, slices are disjoint."""
@@ -236,24 +239,34 @@ class BatchSolver:
                 return
             self._chk(self.L.liw_batch_solve(self.h, C.byref(self.b), C.c_int(mode), C.c_int(max_iters), self._wsp(), self._stream(), C.c_int(0)))
             return
-        # factor-sharded loop.  Per LM iteration: step -> linearise (laser role on this stream, small roles on the ctx's side
-        # streams) -> exchange of the compact laser record on this stream, overlapping the small roles -> join.  Every rank holds
-        # bit-identical sums, so states and `done` flags stay identical across ranks; the number of windows still iterating rides
+        # factor-sharded: the loop lives in the library (liw_batch_solve_sharded, shared with C++ hosts: tests/cpp/sharded_driver.cpp); this
+        # side supplies the collective as a callback.  Per LM iteration: step -> linearise (laser role on this stream, small roles on the
+        # ctx's side streams) -> exchange of the compact laser record on this stream, overlapping the small roles -> join.  Every rank
+        # holds bit-identical sums, so states and `done` flags stay identical across ranks; the number of windows still iterating rides
         # in the exchanged buffer (identical everywhere by construction) and is read back between growing chunks for the early exit.
-        K = self.lm_begin(mode, max_iters)
-        self._lin_exchange(mode, 0)
-        k, chunk = 0, 4
-        while k < K:
-            m = min(chunk, K - k)
-            for _ in range(m):
-                self.lm_step(mode)
-                self._lin_exchange(mode, 1)
-            k += m
-            if k < K and self.active_windows(mode) == 0:
-                break
-            chunk *= 2
-        self.lm_step(mode)
-        self.lm_finish(mode)
+        buf, allb, nd = self._xbuffers(mode)
+        oneshot = self.exchange == "oneshot"
+        err = []
+
+        def _cb(user, pbuf, pall, doubles, stream):
+            try:
+                if oneshot:
+                    self.comm.all_gather_(allb, buf)
+                    return max(self.world, 1)
+                self.comm.all_reduce_sum_(buf)
+                return 1
+            except BaseException as e:   # never unwind through the C frames
+                err.append(e)
+                return -1
+        cb = XFN(_cb)
+        self._chk(self.L.liw_batch_exchange_timing(self.h, C.c_int(1 if self.time_exchange else 0), None, None))
+        r = self.L.liw_batch_solve_sharded(self.h, C.byref(self.b), C.c_int(mode), C.c_int(max_iters), self._wsp(), self._stream(),
+                                           C.c_void_p(buf.data_ptr()), C.c_void_p(allb.data_ptr()) if allb is not None else None,
+                                           C.c_int(max(self.world, 1)), cb, None)
+        if err:
+            raise err[0]
+        self._chk(r)
+        self._last_x = allb[0] if oneshot else buf
 
     def pick_exchange(self, mode, reps=3):
         """exchange="auto": time `reps` all-reduces and `reps` all-gather + rank-order sums of this batch's compact record (collective +
@@ -342,7 +355,10 @@ class BatchSolver:
         self.torch.cuda.synchronize(self.dev)
         ms = [a.elapsed_time(b) for a, b in self._xev]
         self._xev = []
-        return (sum(ms) / len(ms) if ms else 0.0), len(ms)
+        avg, cnt = C.c_double(0.0), C.c_int(0)
+        self._chk(self.L.liw_batch_exchange_timing(self.h, C.c_int(1 if self.time_exchange else 0), C.byref(avg), C.byref(cnt)))
+        tot, num = sum(ms) + avg.value * cnt.value, len(ms) + cnt.value
+        return (tot / num if num else 0.0), num
 
     # the launch pieces of one solve (what liw_batch_solve chains); a factor-sharded driver puts its exchange of
     # self.PL[candidate] between lm_linearize and lm_step

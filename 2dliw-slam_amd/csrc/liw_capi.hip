@@ -63,8 +63,11 @@ struct liw_ctx {
     int solved_records = 0;       // history records of the last completed liw_solve on the current window (0: none)
     // timing
     bool timing = false;
-    std::vector<hipEvent_t> ev_lin, ev_step;
-    size_t ev_lin_used = 0, ev_step_used = 0;
+    std::vector<hipEvent_t> ev_lin, ev_step, ev_x;
+    size_t ev_lin_used = 0, ev_step_used = 0, xev_used = 0;
+    bool time_exchange = false;         // liw_batch_exchange_timing
+    const double* last_x = nullptr;     // the exchanged buffer of the last liw_batch_solve_sharded exchange (active-window trailer)
+    int last_x_copies = 1;
     LinFork fork{};
     bool have_fork = false;
     // graph cache
@@ -184,6 +187,7 @@ void liw_destroy(liw_ctx* c) {
         for (DevBuf* b : bufs) b->release();
         for (auto e : c->ev_lin) (void)hipEventDestroy(e);
         for (auto e : c->ev_step) (void)hipEventDestroy(e);
+        for (auto e : c->ev_x) (void)hipEventDestroy(e);
         if (c->gexec) (void)hipGraphExecDestroy(c->gexec);
         if (c->have_fork) {
             (void)hipStreamDestroy(c->fork.side[0]); (void)hipStreamDestroy(c->fork.side[1]);
@@ -357,6 +361,84 @@ int liw_batch_exchange_unpack(liw_ctx* c, const liw_batch* b, int mode, int cand
     const size_t stride = (size_t)liw_batch_exchange_doubles(b->B, b->n, mode);
     launch_exchange_unpack(b->B, b->n, mode == LIW_MODE_INIT, copies, stride, buf, v.PL[0], v.PL[1], candidate, mode == LIW_MODE_MARG ? nullptr : v.lm, (hipStream_t)stream);
     HIPCHK(c, hipGetLastError());
+    return LIW_OK;
+}
+static hipEvent_t next_event(std::vector<hipEvent_t>& pool, size_t& used);
+/* The factor-sharded LM solve (reference caller src/trajectory/trajectory.cpp:446 -> solver::init_solve): the chunked
+ * early-exit loop, owned by the library so that C++ and Python hosts share one implementation.  See include/liw_window.h. */
+int liw_batch_solve_sharded(liw_ctx* c, const liw_batch* b, int mode, int max_iters, void* ws, void* stream,
+                            double* xbuf, double* xall, int world, liw_exchange_fn exchange, void* user) {
+    NEEDDEV(c);
+    if (int r = check_batch(c, b, min_frames(mode))) return r;
+    if (mode != LIW_MODE_INIT && mode != LIW_MODE_TRACK) return fail(c, LIW_EINVAL, "liw_batch_solve_sharded: mode must be INIT or TRACK");
+    if (!xbuf || !exchange || world < 1) return fail(c, LIW_EINVAL, "liw_batch_solve_sharded: exchange buffer / callback / world");
+    const int K = resolve_iters(c, mode, max_iters);
+    const size_t nd = (size_t)liw_batch_exchange_doubles(b->B, b->n, mode);
+    hipStream_t s = (hipStream_t)stream;
+    c->xev_used = 0;
+    auto lin_exchange = [&](int cand) -> int {
+        if (int r = liw_batch_lm_linearize_async(c, b, mode, cand, ws, stream)) return r;
+        if (c->time_exchange) (void)hipEventRecord(next_event(c->ev_x, c->xev_used), s);
+        if (int r = liw_batch_exchange_pack(c, b, mode, cand, ws, xbuf, stream)) return r;
+        // the host's collective, ordered on `stream`: the elementwise sum over the ranks left in xbuf (returns 1), or the `world` images in
+        // rank order in xall (returns world: the one-shot exchange; liw_batch_exchange_unpack adds them in that order on every rank)
+        const int copies = exchange(user, xbuf, xall, nd, stream);
+        if (copies != 1 && !(copies == world && xall)) return fail(c, LIW_EINVAL, "liw_batch_solve_sharded: the exchange callback must return 1 (sum in buf) or world (images in all)");
+        c->last_x = copies == 1 ? xbuf : xall;
+        c->last_x_copies = copies;
+        if (int r = liw_batch_exchange_unpack(c, b, mode, cand, ws, c->last_x, copies, stream)) return r;
+        if (c->time_exchange) (void)hipEventRecord(next_event(c->ev_x, c->xev_used), s);
+        return liw_batch_lm_join(c, stream);
+    };
+    // windows still iterating at the last exchange: the trailer went through the same exchange, so every rank reads the same number and
+    // takes the same decision without a second collective (blocking 8-byte read-backs, one per image)
+    auto active = [&](long* out) -> int {
+        double tot = 0.0;
+        for (int k = 0; k < c->last_x_copies; ++k) {
+            double v = 0.0;
+            HIPCHK(c, hipMemcpyAsync(&v, c->last_x + (size_t)k * nd + (nd - 1), sizeof(double), hipMemcpyDeviceToHost, s));
+            HIPCHK(c, hipStreamSynchronize(s));
+            tot += v;
+        }
+        *out = (long)(tot + 0.5) / world;
+        return LIW_OK;
+    };
+    if (int r = liw_batch_lm_begin(c, b, mode, K, ws, stream)) return r;
+    if (int r = lin_exchange(0)) return r;
+    int k = 0, chunk = 4;
+    while (k < K) {
+        const int m = std::min(chunk, K - k);
+        for (int i = 0; i < m; ++i) {
+            if (int r = liw_batch_lm_step(c, b, mode, ws, stream)) return r;
+            if (int r = lin_exchange(1)) return r;
+        }
+        k += m;
+        if (k < K) {
+            long act = 0;
+            if (int r = active(&act)) return r;
+            if (act == 0) break;
+        }
+        chunk *= 2;
+    }
+    if (int r = liw_batch_lm_step(c, b, mode, ws, stream)) return r;
+    return liw_batch_lm_finish(c, b, mode, ws, stream);
+}
+/* average device time (ms) of one exchange (pack + collective + unpack) of the last liw_batch_solve_sharded, and their number */
+int liw_batch_exchange_timing(liw_ctx* c, int enable, double* avg_ms, int* count) {
+    NEEDDEV(c);
+    if (avg_ms || count) {
+        double tot = 0.0;
+        int cnt = 0;
+        for (size_t i = 0; i + 1 < c->xev_used; i += 2) {
+            float ms = 0.f;
+            (void)hipEventSynchronize(c->ev_x[i + 1]);
+            if (hipEventElapsedTime(&ms, c->ev_x[i], c->ev_x[i + 1]) == hipSuccess) { tot += ms; ++cnt; }
+        }
+        if (avg_ms) *avg_ms = cnt ? tot / cnt : 0.0;
+        if (count) *count = cnt;
+        c->xev_used = 0;
+    }
+    c->time_exchange = enable != 0;
     return LIW_OK;
 }
 int liw_batch_lm_step(liw_ctx* c, const liw_batch* b, int mode, void* ws, void* stream) {

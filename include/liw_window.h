@@ -201,6 +201,21 @@ int liw_batch_lm_finish(liw_ctx* ctx, const liw_batch* b, int mode, void* ws, vo
  *   liw_batch_lm_join            : `stream` waits for the side roles; then liw_batch_lm_step */
 int liw_batch_lm_linearize_async(liw_ctx* ctx, const liw_batch* b, int mode, int candidate, void* ws, void* stream);
 int liw_batch_lm_join(liw_ctx* ctx, void* stream);
+/* The whole factor-sharded solve as ONE call (round 3; the loop lived in 2dliw-slam_amd/batch.py before): lm_begin, then per LM iteration
+ *   step -> linearise (laser role on `stream`, small roles on the ctx's side streams) -> pack -> exchange -> unpack -> join
+ * in growing chunks (4, 8, 16 ...) with the early exit read from the exchanged active-window count, then lm_finish.  The caller supplies
+ * the collective: `exchange(user, buf, all, doubles, stream)` is called once per linearisation, in `stream` order, with this rank's
+ * packed record in `buf` (device, `doubles` = liw_batch_exchange_doubles()); it must enqueue on `stream` either the elementwise SUM over
+ * all ranks into `buf` and return 1 (e.g. ncclAllReduce(buf, buf, doubles, ncclDouble, ncclSum, comm, stream)), or the `world` images in
+ * rank order into `all` (device, world * doubles; e.g. ncclAllGather) and return `world` — the one-shot exchange, added up in rank order
+ * by liw_batch_exchange_unpack so that every rank forms identical bits.  Anything else is LIW_EINVAL.  `all` may be NULL for a
+ * sum-only callback.  Replaces, on the reference side, nothing: the reference is single-process (INTEGRATION.md 5 shows the driver). */
+typedef int (*liw_exchange_fn)(void* user, double* buf, double* all, size_t doubles, void* stream);
+int liw_batch_solve_sharded(liw_ctx* ctx, const liw_batch* b, int mode, int max_iters, void* ws, void* stream,
+                            double* xbuf, double* xall, int world, liw_exchange_fn exchange, void* user);
+/* enable != 0: time every exchange (pack + collective + unpack, HIP events on `stream`); avg_ms / count (either may be NULL) return the
+ * figures gathered since the last call */
+int liw_batch_exchange_timing(liw_ctx* ctx, int enable, double* avg_ms, int* count);
 int liw_batch_exchange_doubles(int B, int n, int mode);
 int liw_batch_exchange_pack(liw_ctx* ctx, const liw_batch* b, int mode, int candidate, void* ws, double* buf, void* stream);
 int liw_batch_exchange_unpack(liw_ctx* ctx, const liw_batch* b, int mode, int candidate, void* ws, const double* buf, int copies, void* stream);
