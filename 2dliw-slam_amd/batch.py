@@ -271,8 +271,12 @@ class BatchSolver:
     def pick_exchange(self, mode, reps=3):
         """exchange="auto": time `reps` all-reduces and `reps` all-gather + rank-order sums of this batch's compact record (collective +
         unpack, HIP events), take the maximum over the ranks of each (one small all-reduce: every rank sees the same two numbers)
-        and keep the faster transport.  Returns {"allreduce": ms, "oneshot": ms, "picked": name}."""
+        and keep the faster transport.  Returns {"allreduce": ms, "oneshot": ms, "picked": name}; the pick is kept in self.exchange /
+        self.exchange_pick for the life of this object.  NOT run-to-run reproducible: a ring all-reduce and the rank-order sum of gathered
+        images differ in the low-order bits, so a sharded solve is bit-identical across ranks but, with "auto", not necessarily across
+        runs or machines — pass exchange="allreduce" / "oneshot" when that matters."""
         t = self.torch
+        reps = max(1, int(reps))
         nd = int(self.L.liw_batch_exchange_doubles(C.c_int(self.B), C.c_int(self.n), C.c_int(mode)))
         buf = t.zeros(nd, dtype=t.float64, device=self.dev)
         allb = t.zeros((max(self.world, 1), nd), dtype=t.float64, device=self.dev)

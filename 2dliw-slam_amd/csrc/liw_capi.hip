@@ -701,7 +701,9 @@ int liw_set_window(liw_ctx* c, const liw_window* w) {
     if (c->arena.ensure(tot)) return fail(c, LIW_ENOMEM, "hipMalloc");
     HIPCHK(c, hipMemcpyAsync(c->arena.p, stage, tot, hipMemcpyHostToDevice, c->stream));
     if (c->ev_upload) HIPCHK(c, hipEventRecord(c->ev_upload, c->stream));
-    c->img_cur = stage_id; c->img_valid = true;
+    // the mirror image only counts once EVERYTHING below has succeeded: a failed allocation further down must not leave an
+    // image marked valid, or the next call with the same bytes would re-attach to device pointers that were never (re)established
+    c->img_valid = false;
     for (int k = 0; k < 13; ++k) { c->part_off[k] = off[k]; c->part_bytes[k] = parts[k].bytes; }
     char* dev = (char*)c->arena.p;
     bool fresh_prior = c->prior_X.p == nullptr;
@@ -720,6 +722,7 @@ int liw_set_window(liw_ctx* c, const liw_window* w) {
     FullLayout f = full_layout(1, n, c->hist_records);
     if (c->ws.ensure(f.bytes)) return fail(c, LIW_ENOMEM, "hipMalloc workspace");
     c->hw = *w; c->have_window = true; c->n = n; c->L = L;
+    c->img_cur = stage_id; c->img_valid = true;
     liw_batch& b = c->sb;
     b.B = 1; b.n = n; b.Ltot = L;
     b.x = (double*)(dev + off[0]); b.laser_off = (int*)(dev + off[1]); b.laser_frame = (int*)(dev + off[2]);
