@@ -700,6 +700,10 @@ __global__ void k_group_offsets(int B, int n, const int* laser_off, const int* l
 // overlaps the fp64 VALU work of the laser kernel on the same CUs.  Small batches: one launch for everything (k_lin_all).
 // defer_join: the laser role stays on `s`, the IMU / small roles on the side streams, and the join is left to launch_linearize_join —
 // a factor-sharded driver puts its exchange of the laser partial sums on `s` in between, so that it overlaps the small roles.
+bool lin_builds_active_list(int B, int eval_small) {
+    static const bool no_compact = getenv("LIW_NO_COMPACT") != nullptr;   // profiling aid: index the small roles over all windows
+    return eval_small && B >= 512 && B <= COMPACT_MAX && !no_compact;
+}
 void launch_linearize(const LinArgs& A_, const DevParams& P, hipStream_t s, const LinFork* fk, bool defer_join) {
     LinArgs A = A_;
     const int n = A.n, B = A.B;
@@ -722,8 +726,7 @@ void launch_linearize(const LinArgs& A_, const DevParams& P, hipStream_t s, cons
     const int imu_waves = A.eval_small ? imu_wave_count(B, n, A.small_per_wave) : 0;
     const int small_waves = A.eval_small ? wheel_wave_count(B, n, A.small_per_wave) + ground_wave_count(B, n) : 0;
     // large batches only: a single window gains nothing from the list and would pay one more launch per LM iteration
-    static const bool no_compact = getenv("LIW_NO_COMPACT") != nullptr;   // profiling aid: index the small roles over all windows
-    const bool compact = A.lm && A.active && A.eval_small && B >= 512 && B <= COMPACT_MAX && !no_compact;
+    const bool compact = A.lm && A.active && lin_builds_active_list(B, A.eval_small);
     if (!compact) A.active = nullptr;
     if (A.eval_small && laser_waves + imu_waves + small_waves <= 256) {
         const int roles = laser_waves + imu_waves + small_waves;

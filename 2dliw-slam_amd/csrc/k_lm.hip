@@ -503,7 +503,11 @@ __device__ __forceinline__ void lm_step_body(const StepArgs& a, const int b, Lds
     const int lane = threadIdx.x & 63;
     LmState& st = a.w.lm[b];
     if (st.done) return;
-    if (a.only_slow && !lm_window_is_slow(a, b)) return;   // this window was stepped by k_lm_step_quad in the launch before
+    if (a.only_slow) {   // behind k_lm_step_quad: that kernel marked the windows it stepped; the others (a rotation vector outside |theta| <= pi) are this one's
+        const int taken = st.pad_;
+        wave_mem_sync();
+        if (taken) { if (lane == 0) st.pad_ = 0; return; }
+    }
     const int n = a.n;
     double* xw = a.x + (size_t)b * n * 15;
     double* xc = a.w.x_cand + (size_t)b * n * 15;

@@ -72,7 +72,7 @@ __device__ __forceinline__ bool var_is_const(int mode, int fast, int n, int i, i
 }
 
 // Is this window outside what the quad kernel handles in this launch?  Pure function of memory at launch start, evaluated identically
-// by k_lm_step<.., ONLY_SLOW> (64 lanes per window) and here (16): a rotation vector with |theta|^2 > 9.6 (pi^2 = 9.87) among the current
+// at the start of k_lm_step_quad (which marks the windows it takes in LmState::pad_ for the one-wave kernel launched behind it): a rotation vector with |theta|^2 > 9.6 (pi^2 = 9.87) among the current
 // states or, when a candidate is pending, the candidate states.
 __device__ __forceinline__ bool quad_slow_lane(const double* xw, const double* xc, int have_cand, int n, int first, int stride) {
     bool slow = false;
@@ -86,12 +86,4 @@ __device__ __forceinline__ bool quad_slow_lane(const double* xw, const double* x
     }
     return slow;
 }
-// the 64-lane form for k_lm_step
-__device__ __forceinline__ bool lm_window_is_slow(const StepArgs& a, int b) {
-    const LmState& st = a.w.lm[b];
-    const bool s = quad_slow_lane(a.x + (size_t)b * a.n * 15, a.w.x_cand + (size_t)b * a.n * 15, st.have_candidate, a.n, threadIdx.x & 63, 64);
-    return __any(s) != 0;
-}
-
-
 }  // namespace liw

@@ -74,9 +74,17 @@ __global__ __launch_bounds__(64, 1) void k_lm_step_quad(StepArgs a) {
     __shared__ double S[QTOT];
     const int lane = threadIdx.x & 63, j = lane & 15, w = lane >> 4;
     const int n = a.n;
+    // row -> window: over the compacted list of the windows still iterating when the last linearisation built one (k_compact_active:
+    // exactly the windows this step has to take), so that finished windows do not leave rows of a wave idle; else by index
     int b = (int)blockIdx.x * 4 + w;
-    bool act = b < a.B;
-    b = act ? b : a.B - 1;
+    bool act;
+    if (a.use_active) {
+        act = b < a.w.active[0];
+        b = act ? a.w.active[1 + b] : 0;
+    } else {
+        act = b < a.B;
+        b = act ? b : a.B - 1;
+    }
     // Row-dependent addresses are wave-uniform bases (kernel arguments, SGPR pairs) + unsigned 32-bit element offsets (one VGPR each);
     // launch_lm_step_quad checks that every offset fits.
     double* const X = a.x;
@@ -92,6 +100,9 @@ __global__ __launch_bounds__(64, 1) void k_lm_step_quad(StepArgs a) {
         const double sl = quad_slow_lane(X + oX, XC + oX, have_cand, n, j, 16) ? 1.0 : 0.0;
         act = act && !(row_max(sl) > 0.0);
     }
+    // windows this launch steps are marked: the one-wave kernel launched behind it (only_slow) takes exactly the unmarked ones — it cannot
+    // repeat the test above, because by then this kernel has written new candidates
+    if (act && j == 0) st.pad_ = 1;
     if (!__any(act)) return;
 
     int reuse = st.reuse_diagonal, cur = st.cur;
@@ -277,8 +288,10 @@ __global__ __launch_bounds__(64, 1) void k_lm_step_quad(StepArgs a) {
         }
 #pragma unroll
         for (int h = 0; h < 2; ++h) {               // two rows per piece: lanes 0..25 row 2h, 26..51 row 2h+1
-            const unsigned ob = (lane < 26 ? rPG[2 * h] : rPG[2 * h + 1] - 52u) + (unsigned)(f * PGS);
-            if (lane < 52) __builtin_amdgcn_global_load_lds(PG0 + ob + lane2, (lds_t)(S + S_PG + h * 2 * PGS), 16, 0, 0);
+            // (signed lane part: row 2h+1's lanes start 52 doubles into the piece, and its window's offset may be 0)
+            const unsigned ob = lane < 26 ? rPG[2 * h] : rPG[2 * h + 1];
+            const long lo = (long)(f * PGS) + (lane < 26 ? lane2 : lane2 - 52);
+            if (lane < 52) __builtin_amdgcn_global_load_lds(PG0 + ob + lo, (lds_t)(S + S_PG + h * 2 * PGS), 16, 0, 0);
         }
         const int jq = j_ < 15 ? j_ : 0;
         scm_n = (j_ < 15 && f >= 1) ? LMD[oSC + (unsigned)((f - 1) * 15 + jq)] : 1.0;

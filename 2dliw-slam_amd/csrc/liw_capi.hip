@@ -294,6 +294,7 @@ static StepArgs step_args(liw_ctx* c, const liw_batch* b, int mode, int max_iter
     a.x = b->x; a.match_pose = b->match_pose; a.has_match = b->has_match;
     a.prior_X = b->prior_X; a.prior_J = b->prior_J; a.has_prior = b->has_prior;
     a.w = v;
+    a.use_active = lin_builds_active_list(b->B, b->eval_small) ? 1 : 0;   // every step launch follows a linearisation with LM state
     return a;
 }
 static int resolve_iters(liw_ctx* c, int mode, int max_iters) {

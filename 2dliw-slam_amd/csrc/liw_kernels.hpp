@@ -192,6 +192,7 @@ struct StepArgs {
     const double* prior_X; const double* prior_J; const int* has_prior;
     WsView w;
     int only_slow;               // 1: k_lm_step handles only the windows k_lm_step_quad leaves out in this launch (|theta| > pi somewhere)
+    int use_active;              // 1: w.active holds the windows still iterating (built by the linearisation in front of this step)
 };
 struct ExportArgs {
     int B, n, mode, fast_mode, buf;
@@ -227,6 +228,7 @@ void launch_lm_begin(int B, int n, LmState* lm, int max_iters, hipStream_t s);
 void launch_lm_step(const StepArgs& a, hipStream_t s);
 void launch_lm_step_quad(const StepArgs& a, hipStream_t s);   // k_lm_quad.hip: four windows per wave (INIT topology, large batches)
 bool lm_step_quad_fits(const StepArgs& a);
+bool lin_builds_active_list(int B, int eval_small);   // k_linearize.hip: does launch_linearize (with LM state) compact the active windows?
 void launch_lm_finish(const StepArgs& a, hipStream_t s);
 void launch_export_dense(const ExportArgs& a, hipStream_t s);
 void launch_marg_schur(const MargArgs& a, hipStream_t s);
