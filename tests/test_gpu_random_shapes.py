@@ -60,3 +60,69 @@ def test_random_window_init_then_track(liw, synth, pyoracle, seed):
     sg2 = slv.solve()
     assert (sg2["iterations"], sg2["termination"]) == (so2["iterations"], so2["termination"]), (n, L, sg2, so2)
     assert rel(wg2["states"], wo2["states"]) <= 1e-6
+
+
+@pytest.mark.parametrize("seed", [641, 693])
+def test_soak_outliers_are_within_the_problems_own_round_off_sensitivity(liw, synth, pyoracle, seed):
+    """Two of the ten seeds (of 29 988, tests/soak/soak_random_shapes.py) whose tracking solve misses the 1e-6 bar: 40-50-iteration crawls
+    along the ground_factor_q cone.  Referee: the ORACLE against itself with the pre-integrated IMU means scaled by
+    1 + 1e-13 N(0,1) — the size of the round-off difference between two correct implementations.  The product must be no further from the
+    oracle than three times what that perturbation moves the oracle itself (and agree to 1e-9 for the first 20 iterations)."""
+    rng = np.random.default_rng(1000 + seed)
+    prm = synth.office_params()
+    if seed % 4 == 3:
+        prm = dict(prm, fast_mode=True)
+    orc, slv = pyoracle.Oracle(prm), liw.Solver(prm)
+    n = int(rng.integers(2, 25))
+    L = int(rng.integers(0, 301))
+    cap = int(rng.choice([1, 3, 8, 20]))
+    d = synth.make_window(orc, prm, seed=3000 + seed, n=n, L=L, state_noise=float(rng.choice([0.2, 1.0])))
+    if L > 20 and seed % 2:
+        keep = d["laser_frame"] != int(rng.integers(1, n))
+        d["laser_frame"], d["laser_pts"] = d["laser_frame"][keep], d["laser_pts"][keep]
+    wo = pyoracle.Window(d)
+    orc.set_prior(None)
+    orc.set_max_iterations(cap)
+    orc.init_solve(wo)
+    orc.marginalization(wo)
+    prior = orc.get_prior()
+    sub = dict(d)
+    sub["n"] = 2
+    for k in ("states", "match_pose"):
+        sub[k] = np.asarray(wo[k]).reshape(n, -1)[n - 2:n].copy()
+    sub["has_match"] = np.asarray(d["has_match"])[n - 2:n].copy()
+    for k in ("imu_X", "imu_J", "imu_sqrtP", "imu_Dt", "wheel_T", "wheel_sqrtP", "wheel_Dt"):
+        sub[k] = np.asarray(d[k])[n - 2:n - 1].copy()
+    m = np.asarray(d["laser_frame"]) >= n - 2
+    sub["laser_frame"] = (np.asarray(d["laser_frame"])[m] - (n - 2)).astype(np.int32)
+    sub["laser_pts"] = np.asarray(d["laser_pts"])[m].copy()
+    sub["states"][1, 0:3] += rng.normal(0, 0.01, 3)
+
+    def oracle_track(win):
+        o2 = pyoracle.Oracle(prm)
+        if not prm.get("fast_mode"):
+            o2.set_prior(prior)
+        w = pyoracle.Window(win)
+        o2.set_max_iterations(50)
+        o2.solve(w)
+        return w["states"].reshape(2, 15).copy(), o2.summary(), [h["x"].copy() for h in o2.iterations()]
+    xo, so, ho = oracle_track(sub)
+    if not prm.get("fast_mode"):
+        slv.set_prior(prior)
+    wg = liw.Window(sub)
+    slv.set_window(wg)
+    sg = slv.solve()
+    hg = slv.history()
+    err = rel(wg["states"], xo)
+    sens, rp = 0.0, np.random.default_rng(7)
+    for _ in range(3):
+        alt = dict(sub)
+        alt["imu_X"] = np.asarray(sub["imu_X"]) * (1.0 + 1e-13 * rp.standard_normal(np.asarray(sub["imu_X"]).shape))
+        xa, _, _ = oracle_track(alt)
+        sens = max(sens, rel(xa, xo))
+    lead = min(20, len(ho), len(hg))
+    early = max(float(np.abs(hg[k].reshape(-1) - ho[k].reshape(-1)).max() / max(np.abs(ho[k]).max(), 1e-12)) for k in range(lead))
+    print("seed %d: n=%d L=%d, %d / %d iterations; product vs oracle %.2e (first %d iterations %.2e); oracle vs itself with 1e-13 IMU noise %.2e"
+          % (seed, n, L, sg["iterations"], so["iterations"], err, lead, early, sens))
+    assert early <= 1e-9
+    assert err <= max(1e-6, 3.0 * sens), (err, sens)
