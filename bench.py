@@ -175,7 +175,7 @@ def main():
     ap.add_argument("--gate-windows", type=int, default=4, help="windows of the timed batch whose results are checked against the oracle (parity gate)")
     ap.add_argument("--cpu-procs", type=int, default=64, help="processes of the all-cores CPU baseline leg (capped at the core count)")
     ap.add_argument("--skip-sharded", action="store_true")
-    ap.add_argument("--converging-scale", type=float, default=0.01, help="initial state error of the `converging_c2` side measurement, as a fraction of the C2 perturbation")
+    ap.add_argument("--converging-scale", type=float, default=0.1, help="initial state error of the `converging_c2` side measurement, as a fraction of the C2 perturbation")
     ap.add_argument("--no-single", action="store_true", help="skip the B=1 latency measurement (clean per-kernel profiles)")
     ap.add_argument("--record-md", default=None, help="after the timed region, write a reference-shaped `record` table (labels "
                     "'solve' / 'marginalization', src/utilies/record.h) of per-batch durations to this path")
