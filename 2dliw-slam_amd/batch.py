@@ -48,7 +48,7 @@ def allgather_(out, t, group=None):
     return out
 
 
-EXCHANGES = ("allreduce", "oneshot", "auto")
+EXCHANGES = ("allreduce", "oneshot", "auto", "p2p")
 
 
 class TorchComm:
@@ -149,8 +149,10 @@ class BatchSolver:
         #   "allreduce": RCCL all-reduce(SUM) of the compact record; "oneshot": all-gather of every rank's compact record
         #   (each GPU pushes its image to all peers once) + local sum in rank order; "auto": both are timed once on the record size
         #   of this batch (pick_exchange, at the first sharded solve) and the faster one is used — SURVEY 8e's "pick per size", decided
-        #   by measurement on the machine at hand and agreed between the ranks.  force_exchange runs the pack / exchange / unpack
-        #   path even with one rank (tests).
+        #   by measurement on the machine at hand and agreed between the ranks; "p2p": the native one-shot exchange (every rank writes
+        #   its record straight into every peer's receive area, flag-synchronised kernels, no collective: include/liw_window.h) — the areas
+        #   have to be attached first (p2p_attach_local for rank objects of one process, p2p_attach_ipc across processes).
+        #   force_exchange runs the pack / exchange / unpack path even with one rank (tests).
         self.exchange, self.sharded = exchange, (world > 1 or force_exchange)
         self.comm = comm if comm is not None else TorchComm(group)
         self.exchange_ms, self.exchange_calls, self._xev, self._xbuf = 0.0, 0, [], {}
@@ -245,6 +247,13 @@ class BatchSolver:
         # holds bit-identical sums, so states and `done` flags stay identical across ranks; the number of windows still iterating rides
         # in the exchanged buffer (identical everywhere by construction) and is read back between growing chunks for the early exit.
         buf, allb, nd = self._xbuffers(mode)
+        if self.exchange == "p2p":
+            assert getattr(self, "_p2p", None) is not None and self._p2p["mode"] == mode, "attach the receive areas first (p2p_attach_local / p2p_attach_ipc)"
+            self._chk(self.L.liw_batch_exchange_timing(self.h, C.c_int(1 if self.time_exchange else 0), None, None))
+            self._chk(self.L.liw_batch_solve_sharded(self.h, C.byref(self.b), C.c_int(mode), C.c_int(max_iters), self._wsp(), self._stream(),
+                                                     C.c_void_p(buf.data_ptr()), None, C.c_int(max(self.world, 1)), XFN(0), None))
+            self._last_x = buf
+            return
         oneshot = self.exchange == "oneshot"
         err = []
 
@@ -353,6 +362,72 @@ class BatchSolver:
         if self.exchange == "oneshot":
             return int(round(float(allb[:, nd - 1].sum().item()))) // max(self.world, 1)
         return int(round(float(buf[nd - 1].item()))) // max(self.world, 1)
+
+    # ---- native peer-write exchange (liw_batch_p2p_setup): receive areas
+    def _p2p_alloc(self, mode):
+        t = self.torch
+        L = self.L
+        L.liw_batch_p2p_area_doubles.restype = C.c_size_t
+        nd = int(L.liw_batch_p2p_area_doubles(C.c_int(self.B), C.c_int(self.n), C.c_int(mode), C.c_int(max(self.world, 1))))
+        area = t.zeros(nd, dtype=t.float64, device=self.dev)
+        flags = t.zeros(max(self.world, 1), dtype=t.int64, device=self.dev)
+        return area, flags
+
+    def _p2p_set(self, mode, area_ptrs, flag_ptrs, keep):
+        w = max(self.world, 1)
+        A = (C.c_void_p * w)(*area_ptrs)
+        F = (C.c_void_p * w)(*flag_ptrs)
+        self._chk(self.L.liw_batch_p2p_setup(self.h, C.c_int(self.rank), C.c_int(w), A, F))
+        self._p2p = {"mode": mode, "keep": keep}
+
+    @staticmethod
+    def p2p_attach_local(ranks, mode):
+        """rank objects of ONE process (tests on a 1-GPU box; also `world` = 1): every rank's receive area is a torch allocation, all see all"""
+        bufs = [rk._p2p_alloc(mode) for rk in ranks]
+        for rk in ranks:
+            rk.torch.cuda.synchronize(rk.dev)
+            rk._p2p_set(mode, [a.data_ptr() for a, _ in bufs], [f.data_ptr() for _, f in bufs], bufs)
+
+    def p2p_attach_ipc(self, mode):
+        """one process per GPU: receive areas from hipMalloc, handles exchanged over torch.distributed, peers' areas mapped with hipIpc.
+        NOT exercised on the 1-GPU test box (hipIpcOpenMemHandle refuses a handle of the same process)."""
+        import torch.distributed as dist
+        hip = C.CDLL("libamdhip64.so")
+
+        class Handle(C.Structure):
+            _fields_ = [("reserved", C.c_byte * 64)]
+        L = self.L
+        L.liw_batch_p2p_area_doubles.restype = C.c_size_t
+        w = max(self.world, 1)
+        nd = int(L.liw_batch_p2p_area_doubles(C.c_int(self.B), C.c_int(self.n), C.c_int(mode), C.c_int(w)))
+        own = []
+        for nbytes in (8 * nd, 8 * w):
+            p = C.c_void_p()
+            assert hip.hipMalloc(C.byref(p), C.c_size_t(nbytes)) == 0
+            assert hip.hipMemset(p, 0, C.c_size_t(nbytes)) == 0
+            own.append(p)
+        hs = []
+        for p in own:
+            h = Handle()
+            assert hip.hipIpcGetMemHandle(C.byref(h), p) == 0
+            hs.append(bytes(h.reserved))
+        allh = [None] * w
+        dist.all_gather_object(allh, hs, group=self.group)
+        areas, flags = [], []
+        for r in range(w):
+            if r == self.rank:
+                areas.append(own[0].value); flags.append(own[1].value)
+                continue
+            ptrs = []
+            for raw in allh[r]:
+                h = Handle()
+                C.memmove(h.reserved, raw, 64)
+                q = C.c_void_p()
+                assert hip.hipIpcOpenMemHandle(C.byref(q), h, C.c_uint(1)) == 0      # hipIpcMemLazyEnablePeerAccess
+                ptrs.append(q.value)
+            areas.append(ptrs[0]); flags.append(ptrs[1])
+        dist.barrier(group=self.group)
+        self._p2p_set(mode, areas, flags, own)
 
     def exchange_timing(self):
         """average device time (ms) of one exchange (pack + collective + unpack) since the last call, and the count"""

@@ -780,7 +780,7 @@ __global__ void k_exchange_pack(int groups, int n, int np, LaserPackTable tb, co
     buf[t] = dead ? 0.0 : (tb.neg[p] ? -v : v);
 }
 template <bool BOTH>
-__global__ void k_exchange_unpack(int groups, int n, int np, int world, size_t stride, const double* buf, double* PL0, double* PL1, int candidate, const LmState* lm) {
+__global__ void k_exchange_unpack(int groups, int n, int np, int world, size_t stride, const double* buf, double* PL0, double* PL1, int candidate, const LmState* lm, int sysload) {
     const int t = blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= groups * LP) return;
     const int grp = t / LP, s = t % LP;
@@ -790,7 +790,10 @@ __global__ void k_exchange_unpack(int groups, int n, int np, int world, size_t s
     double v = 0.0;
     if (code >= 0) {
         const double* src = buf + (size_t)grp * np + (code & 63);
-        for (int r = 0; r < world; ++r) v += src[(size_t)r * stride];   // fixed rank order: every rank forms the same bits
+        // fixed rank order: every rank forms the same bits.  sysload: the images were written by OTHER devices (peer-write exchange):
+        // system-scope loads, which do not trust lines this device's caches may still hold from the exchange two steps back
+        for (int r = 0; r < world; ++r)
+            v += sysload ? __hip_atomic_load(src + (size_t)r * stride, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) : src[(size_t)r * stride];
         if (code & 64) v = -v;
     }
     PL[t] = v;
@@ -816,10 +819,49 @@ void launch_exchange_pack(int B, int n, bool both, const double* PL0, const doub
     hipLaunchKernelGGL(k_exchange_pack, dim3((groups * np + 255) / 256), dim3(256), 0, s, groups, n, np, tb, PL0, PL1, candidate, lm, buf);
     if (lm) hipLaunchKernelGGL(k_count_active, dim3(1), dim3(256), 0, s, B, lm, buf + (size_t)groups * np);
 }
-void launch_exchange_unpack(int B, int n, bool both, int world, size_t stride, const double* buf, double* PL0, double* PL1, int candidate, const LmState* lm, hipStream_t s) {
+void launch_exchange_unpack(int B, int n, bool both, int world, size_t stride, const double* buf, double* PL0, double* PL1, int candidate, const LmState* lm, hipStream_t s, bool sysload) {
     const int np = both ? 45 : 21, groups = B * n;
-    if (both) hipLaunchKernelGGL(k_exchange_unpack<true>, dim3((groups * LP + 255) / 256), dim3(256), 0, s, groups, n, np, world, stride, buf, PL0, PL1, candidate, lm);
-    else hipLaunchKernelGGL(k_exchange_unpack<false>, dim3((groups * LP + 255) / 256), dim3(256), 0, s, groups, n, np, world, stride, buf, PL0, PL1, candidate, lm);
+    if (both) hipLaunchKernelGGL(k_exchange_unpack<true>, dim3((groups * LP + 255) / 256), dim3(256), 0, s, groups, n, np, world, stride, buf, PL0, PL1, candidate, lm, sysload ? 1 : 0);
+    else hipLaunchKernelGGL(k_exchange_unpack<false>, dim3((groups * LP + 255) / 256), dim3(256), 0, s, groups, n, np, world, stride, buf, PL0, PL1, candidate, lm, sysload ? 1 : 0);
+}
+
+// ---- native one-shot exchange: instead of an all-gather collective every rank WRITES its packed record
+// straight into its slot of every peer's receive area (P-1 pushes over the P-1 dedicated xGMI links, one hop), raises its flag there, and
+// waits for the P flags of its own area before the rank-order sum.  Receive area of a rank: [2 parities][world images][nd doubles] +
+// [world] 64-bit flags; peers map each other's areas with hipIpc (one process per GPU) or share pointers (one process).  Exchange e uses
+// parity e & 1: a peer can only push exchange e + 2 after it has received this rank's e + 1, which this rank sends after it has summed e.
+__global__ void k_p2p_push(size_t nd, const double* buf, P2pPeers peers, int rank, int world, int parity) {
+    const size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= nd) return;
+    const double v = buf[t];
+    for (int p = 0; p < world; ++p)   // system-scope (write-through) stores: the payload leaves this device's caches as it is written
+        __hip_atomic_store(peers.area[p] + ((size_t)(parity * world + rank)) * nd + t, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+__global__ void k_p2p_signal(P2pPeers peers, int rank, int world, unsigned long long epoch) {   // launched behind k_p2p_push: its stores are complete
+    const int p = threadIdx.x;
+    if (p >= world) return;
+    __atomic_thread_fence(__ATOMIC_RELEASE);   // (system scope by default)
+    __hip_atomic_store(peers.flags[p] + rank, epoch, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+// ONE small work-group polls (a spinning grid could keep a peer's push off a shared device); bounded: a peer that never arrives ends
+// in an error word, not in a hung GPU
+__global__ void k_p2p_wait(const unsigned long long* flags, int world, unsigned long long epoch, long long max_polls, int* err) {
+    const int r = threadIdx.x;
+    if (r < world && *(volatile int*)err == 0) {   // (an exchange that already failed is not waited for again)
+        long long polls = 0;
+        while (__hip_atomic_load(flags + r, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) < epoch) {
+            __builtin_amdgcn_s_sleep(32);
+            if (++polls > max_polls) { atomicExch(err, 1 + r); break; }
+        }
+    }
+    __syncthreads();
+    __atomic_thread_fence(__ATOMIC_ACQUIRE);
+}
+void launch_p2p_exchange(size_t nd, const double* buf, const P2pPeers& peers, int rank, int world, unsigned long long epoch, int* err, hipStream_t s) {
+    const int parity = (int)(epoch & 1ull);
+    hipLaunchKernelGGL(k_p2p_push, dim3((unsigned)((nd + 255) / 256)), dim3(256), 0, s, nd, buf, peers, rank, world, parity);
+    hipLaunchKernelGGL(k_p2p_signal, dim3(1), dim3(64), 0, s, peers, rank, world, epoch);
+    hipLaunchKernelGGL(k_p2p_wait, dim3(1), dim3(64), 0, s, (const unsigned long long*)peers.flags[rank], world, epoch, (long long)4000000, err);
 }
 #ifdef LIW_CLK
 extern "C" void liw_debug_clk_lin(long long* out, int nn) { hipMemcpyFromSymbol(out, HIP_SYMBOL(g_clk_lin), sizeof(long long) * nn); }

@@ -68,6 +68,11 @@ struct liw_ctx {
     bool time_exchange = false;         // liw_batch_exchange_timing
     const double* last_x = nullptr;     // the exchanged buffer of the last liw_batch_solve_sharded exchange (active-window trailer)
     int last_x_copies = 1;
+    // native peer-write exchange (liw_batch_p2p_setup)
+    P2pPeers p2p{};
+    int p2p_rank = 0, p2p_world = 0;
+    unsigned long long p2p_epoch = 0;
+    DevBuf p2p_err;
     LinFork fork{};
     bool have_fork = false;
     // graph cache
@@ -372,7 +377,9 @@ int liw_batch_solve_sharded(liw_ctx* c, const liw_batch* b, int mode, int max_it
     NEEDDEV(c);
     if (int r = check_batch(c, b, min_frames(mode))) return r;
     if (mode != LIW_MODE_INIT && mode != LIW_MODE_TRACK) return fail(c, LIW_EINVAL, "liw_batch_solve_sharded: mode must be INIT or TRACK");
-    if (!xbuf || !exchange || world < 1) return fail(c, LIW_EINVAL, "liw_batch_solve_sharded: exchange buffer / callback / world");
+    const bool p2p = exchange == nullptr && c->p2p_world > 0;
+    if (!xbuf || (!exchange && !p2p) || world < 1) return fail(c, LIW_EINVAL, "liw_batch_solve_sharded: exchange buffer / callback (or liw_batch_p2p_setup) / world");
+    if (p2p && world != c->p2p_world) return fail(c, LIW_EINVAL, "liw_batch_solve_sharded: world differs from liw_batch_p2p_setup");
     const int K = resolve_iters(c, mode, max_iters);
     const size_t nd = (size_t)liw_batch_exchange_doubles(b->B, b->n, mode);
     hipStream_t s = (hipStream_t)stream;
@@ -381,6 +388,17 @@ int liw_batch_solve_sharded(liw_ctx* c, const liw_batch* b, int mode, int max_it
         if (int r = liw_batch_lm_linearize_async(c, b, mode, cand, ws, stream)) return r;
         if (c->time_exchange) (void)hipEventRecord(next_event(c->ev_x, c->xev_used), s);
         if (int r = liw_batch_exchange_pack(c, b, mode, cand, ws, xbuf, stream)) return r;
+        if (p2p) {   // native one-shot exchange: push into every peer's receive area, raise the flags, wait for the P flags of our own
+            const unsigned long long e = ++c->p2p_epoch;
+            launch_p2p_exchange(nd, xbuf, c->p2p, c->p2p_rank, world, e, c->p2p_err.as<int>(), s);
+            c->last_x = c->p2p.area[c->p2p_rank] + (size_t)(e & 1ull) * world * nd;
+            c->last_x_copies = world;
+            WsView v = make_view(ws, b->B, b->n, b->history_records);
+            launch_exchange_unpack(b->B, b->n, mode == LIW_MODE_INIT, world, nd, c->last_x, v.PL[0], v.PL[1], cand, v.lm, s, true);
+            HIPCHK(c, hipGetLastError());
+            if (c->time_exchange) (void)hipEventRecord(next_event(c->ev_x, c->xev_used), s);
+            return liw_batch_lm_join(c, stream);
+        }
         // the host's collective, ordered on `stream`: the elementwise sum over the ranks left in xbuf (returns 1), or the `world` images in
         // rank order in xall (returns world: the one-shot exchange; liw_batch_exchange_unpack adds them in that order on every rank)
         const int copies = exchange(user, xbuf, xall, nd, stream);
@@ -402,6 +420,12 @@ int liw_batch_solve_sharded(liw_ctx* c, const liw_batch* b, int mode, int max_it
             tot += v;
         }
         *out = (long)(tot + 0.5) / world;
+        if (p2p) {
+            int e = 0;
+            HIPCHK(c, hipMemcpyAsync(&e, c->p2p_err.p, sizeof(int), hipMemcpyDeviceToHost, s));
+            HIPCHK(c, hipStreamSynchronize(s));
+            if (e) return fail(c, LIW_EHIP, "peer-write exchange: a peer's flag never arrived (rank in p2p status)");
+        }
         return LIW_OK;
     };
     if (int r = liw_batch_lm_begin(c, b, mode, K, ws, stream)) return r;
@@ -423,6 +447,32 @@ int liw_batch_solve_sharded(liw_ctx* c, const liw_batch* b, int mode, int max_it
     }
     if (int r = liw_batch_lm_step(c, b, mode, ws, stream)) return r;
     return liw_batch_lm_finish(c, b, mode, ws, stream);
+}
+/* native peer-write exchange: see include/liw_window.h */
+size_t liw_batch_p2p_area_doubles(int B, int n, int mode, int world) {
+    if (world < 1 || world > P2P_MAX) return 0;
+    const int nd = liw_batch_exchange_doubles(B, n, mode);
+    return nd > 0 ? (size_t)2 * world * nd : 0;
+}
+int liw_batch_p2p_setup(liw_ctx* c, int rank, int world, double* const* areas, unsigned long long* const* flags) {
+    NEEDDEV(c);
+    if (world == 0) { c->p2p_world = 0; return LIW_OK; }
+    if (world < 1 || world > P2P_MAX || rank < 0 || rank >= world || !areas || !flags) return fail(c, LIW_EINVAL, "liw_batch_p2p_setup: rank / world / pointers");
+    for (int r = 0; r < world; ++r) {
+        if (!areas[r] || !flags[r]) return fail(c, LIW_EINVAL, "liw_batch_p2p_setup: null peer pointer");
+        c->p2p.area[r] = areas[r]; c->p2p.flags[r] = flags[r];
+    }
+    if (c->p2p_err.ensure(sizeof(int))) return fail(c, LIW_ENOMEM, "hipMalloc");
+    HIPCHK(c, hipMemset(c->p2p_err.p, 0, sizeof(int)));
+    c->p2p_rank = rank; c->p2p_world = world; c->p2p_epoch = 0;
+    return LIW_OK;
+}
+int liw_batch_p2p_status(liw_ctx* c, int* timed_out_rank_plus_1) {
+    NEEDDEV(c);
+    int e = 0;
+    if (c->p2p_err.p) HIPCHK(c, hipMemcpy(&e, c->p2p_err.p, sizeof(int), hipMemcpyDeviceToHost));
+    if (timed_out_rank_plus_1) *timed_out_rank_plus_1 = e;
+    return LIW_OK;
 }
 /* average device time (ms) of one exchange (pack + collective + unpack) of the last liw_batch_solve_sharded, and their number */
 int liw_batch_exchange_timing(liw_ctx* c, int enable, double* avg_ms, int* count) {

@@ -570,8 +570,15 @@ def main():
                                    "compact laser record per iteration%s" % (Bs, n, Ls, world, Ks, "" if world > 1 else " (none at 1 rank)"),
                        "scaling": "strong", "ranks": world,
                        "process_group": {"backend": dist.get_backend() if world > 1 else None, "world_size": dist.get_world_size() if world > 1 else 1}}
-            for xi, xch in enumerate(("allreduce", "oneshot") if world > 1 else ("allreduce",)):
+            # LIW_BENCH_P2P=1 (N > 1, real devices only): also time the native peer-write exchange (hipIpc areas + flag-synchronised kernels,
+            # include/liw_window.h) — off by default: it has never run across xGMI
+            xvars = ("allreduce", "oneshot") if world > 1 else ("allreduce",)
+            if world > 1 and not share and os.environ.get("LIW_BENCH_P2P") == "1":
+                xvars = xvars + ("p2p",)
+            for xi, xch in enumerate(xvars):
                 sb = liw.BatchSolver(prm, wl, device=dev, rank=rank, world=world, exchange=xch)
+                if xch == "p2p":
+                    sb.p2p_attach_ipc(liw.LIW_MODE_INIT)
                 xs0 = sb.t["x"].clone()
                 te = ts = 0.0
                 for rep in range(3):
@@ -600,6 +607,8 @@ def main():
                     sharded["exchange"] = xch if world > 1 else None
                     sharded["allreduce_ms_per_iteration"] = res["exchange_ms_per_iteration"]
                     sharded["allreduce_bytes_per_iteration"] = res["exchange_bytes_per_rank"]
+                elif xch == "p2p":
+                    sharded["p2p_exchange"] = res
                 else:
                     sharded["oneshot_exchange"] = res
                 if world > 1 and xi == 1:   # what exchange="auto" would keep on this machine at this record size (collective + sum, timed once)

@@ -213,6 +213,22 @@ int liw_batch_lm_join(liw_ctx* ctx, void* stream);
 typedef int (*liw_exchange_fn)(void* user, double* buf, double* all, size_t doubles, void* stream);
 int liw_batch_solve_sharded(liw_ctx* ctx, const liw_batch* b, int mode, int max_iters, void* ws, void* stream,
                             double* xbuf, double* xall, int world, liw_exchange_fn exchange, void* user);
+/* Native one-shot exchange (SURVEY 5 last row; OFF unless set up): instead of a collective, every rank WRITES its packed record into its
+ * slot of every peer's receive area (P-1 pushes over the P-1 dedicated xGMI links, one hop of latency), raises a flag there and waits for
+ * the P flags of its own area; liw_batch_exchange_unpack then adds the P images in rank order (identical bits on every rank).
+ *   receive area of a rank : liw_batch_p2p_area_doubles() = 2 (parities) x world x liw_batch_exchange_doubles() doubles, and `world`
+ *                            unsigned 64-bit flags, zero-initialised once; device memory other devices can write: hipMalloc + hipIpc handles
+ *                            between processes (fine-grained / uncached allocation recommended), plain pointers inside one process
+ *   liw_batch_p2p_setup    : areas[r] / flags[r] = rank r's area / flags AS MAPPED INTO THIS PROCESS (r = 0 .. world-1, own included);
+ *                            world = 0 switches the path off again
+ *   liw_batch_solve_sharded(..., exchange = NULL, user = NULL) then uses it (xall unused); a peer whose flag does not arrive within ~4 s
+ *   makes the solve return LIW_EHIP instead of hanging the device (liw_batch_p2p_status names the rank).
+ * Exercised on one device only (tests/test_gpu_p2p_exchange.py: one rank onto itself, two rank objects of one process on two streams);
+ * the cross-device visibility rules (system-scope stores / loads, release / acquire on the flags) are written per the ISA guide but have
+ * not run across xGMI. */
+size_t liw_batch_p2p_area_doubles(int B, int n, int mode, int world);
+int liw_batch_p2p_setup(liw_ctx* ctx, int rank, int world, double* const* areas, unsigned long long* const* flags);
+int liw_batch_p2p_status(liw_ctx* ctx, int* timed_out_rank_plus_1);
 /* enable != 0: time every exchange (pack + collective + unpack, HIP events on `stream`); avg_ms / count (either may be NULL) return the
  * figures gathered since the last call */
 int liw_batch_exchange_timing(liw_ctx* ctx, int enable, double* avg_ms, int* count);
