@@ -111,6 +111,11 @@ def _check_free_running(out, orc, replay, min_tracked, lead):
     err = np.abs(got[:, 1:] - ref[:, 1:]).max(axis=1) / max(1.0, np.abs(ref[:, 1:]).max())
     assert err[:lead].max() <= 1e-6, err[:lead]
     assert np.abs(got[:, 1:4] - ref[:, 1:4]).max() < 0.05
+    # tracked number: the first pose of the free-running trajectory that is further than 1e-6 from the oracle twin's —
+    # how long two correct implementations stay together before the driver's own sensitivity takes over
+    beyond = np.nonzero(err > 1e-6)[0]
+    print("free-running replay: %d tracked poses, first pose beyond 1e-6: %s (worst %.2e, position %.2e m)"
+          % (tracked, int(beyond[0]) if len(beyond) else "none", float(err.max()), float(np.abs(got[:, 1:4] - ref[:, 1:4]).max())))
     return frames, tracked, got
 
 
