@@ -1776,7 +1776,7 @@ void launch_lm_step(const StepArgs& a, hipStream_t s) {
     const char* env = getenv("LIW_STEP_VARIANT");
     const bool tp = env ? env[0] == '1' : a.B > 2048;
     // two waves per window while that does not take CUs away from other windows, and the chain is long enough to be worth cutting
-    const bool tw = (env ? env[0] == '2' : a.B <= 256) && a.n >= 6;
+    const bool tw = (env ? env[0] == '2' : a.B <= 512) && a.n >= 6;   // (tools/step_variant_sweep.py: 97 k vs 67 k solves/s at 256 windows, 120 k vs 116 k at 512)
     // four windows per wave (k_lm_quad.hip) once the batch is large enough to fill the chip that way; the windows it leaves out
     // (a rotation vector outside the |theta| <= pi ball) are stepped by the one-wave kernel right behind it
     const bool quad = (env ? env[0] == '3' : a.B > 2048) && a.mode == LIW_MODE_INIT && lm_step_quad_fits(a);

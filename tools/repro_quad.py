@@ -12,6 +12,4 @@ for rep in range(2):
     bs.t["x"].copy_(x0)
     bs.solve(liw.LIW_MODE_INIT, it)
     torch.cuda.synchronize()
-    import ctypes as C
-    out = (C.c_longlong * 64)(); liw.lib().liw_debug_quad_clk(0, 0, 0, 0, out); print("dbg", list(out[20:24]))
     print("solve ok", rep, np.bincount([s["iterations"] for s in bs.summaries()])[-5:], flush=True)
