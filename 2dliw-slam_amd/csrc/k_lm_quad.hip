@@ -261,42 +261,46 @@ __global__ __launch_bounds__(64, 1) void k_lm_step_quad(StepArgs a) {
     typedef __attribute__((address_space(3))) void* lds_t;
     const int j_ = j;
     double scm_n = 1.0, dg_n = 0.0, xq_n = 0.0;     // prefetched: scale of frame f-1, LM diagonal and state entry of frame f (lane j)
-    auto prefetch = [&](int f) {                    // f >= 0: the frame eliminated next
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // the LDS reads of the current frame have returned
-        const int k = f - 1;                        // its block towards the frame before
+    // one piece of frame f's prefetch, P = 0 .. 29 (compile-time: row, part and LDS destination are immediates)
+    auto piece = [&](auto PP, int f) {
+        constexpr int P = KI(PP);
+        const int k = f - 1;                        // frame f's block towards the frame before
         // the lane's 16-byte slot of a piece, in doubles: the ONLY lane-dependent part of an address.  Laundered, so that the per-lane
         // pointers are formed right here (one 64-bit add each) and never kept across the frame loop — as hoisted loop invariants they
-        // spilled, and every reload inside this burst waited (vmcnt) for the pieces already in flight
+        // spilled, and every reload inside a burst waited (vmcnt) for the pieces already in flight
         int lane2 = lane * 2;
         asm volatile("" : "+v"(lane2));
-#pragma unroll
-        for (int ws = 0; ws < 4; ++ws) {
-            if (k >= 0) {
-                const double* gI = PI0 + rPI[ws] + (unsigned)(k * PIS) + lane2;
-                const double* gW = PW0 + rPW[ws] + (unsigned)(k * PWS) + lane2;
-                lds_t lI = (lds_t)(S + S_IMU + ws * PIS), lW = (lds_t)(S + S_PW + ws * PWS);
-                // (the immediate offset moves the global AND the LDS address)
-                __builtin_amdgcn_global_load_lds(gI, lI, 16, 0, 0);
-                __builtin_amdgcn_global_load_lds(gI, lI, 16, 1024, 0);
-                __builtin_amdgcn_global_load_lds(gI, lI, 16, 2048, 0);
-                if (lane < (PIS - 3 * 128) / 2) __builtin_amdgcn_global_load_lds(gI, lI, 16, 3072, 0);
-                __builtin_amdgcn_global_load_lds(gW, lW, 16, 0, 0);
-                if (lane < 22) __builtin_amdgcn_global_load_lds(gW, lW, 16, 1024, 0);
-            }
-            const double* gL = PL0 + rPL[ws] + (unsigned)(f * LP + 36) + lane2;
-            if (lane < 43) __builtin_amdgcn_global_load_lds(gL, (lds_t)(S + S_PL + ws * 86), 16, 0, 0);
-        }
-#pragma unroll
-        for (int h = 0; h < 2; ++h) {               // two rows per piece: lanes 0..25 row 2h, 26..51 row 2h+1
+        if constexpr (P < 16) {                     // IMU partial: 4 pieces per row (the immediate offset moves the global AND the LDS address)
+            constexpr int ws = P >> 2, part = P & 3;
+            if (k >= 0 && (part < 3 || lane < (PIS - 3 * 128) / 2))
+                __builtin_amdgcn_global_load_lds(PI0 + rPI[ws] + (unsigned)(k * PIS) + lane2, (lds_t)(S + S_IMU + ws * PIS), 16, part * 1024, 0);
+        } else if constexpr (P < 24) {              // wheel partial: 2 pieces per row
+            constexpr int ws = (P - 16) >> 1, part = (P - 16) & 1;
+            if (k >= 0 && (part == 0 || lane < 22))
+                __builtin_amdgcn_global_load_lds(PW0 + rPW[ws] + (unsigned)(k * PWS) + lane2, (lds_t)(S + S_PW + ws * PWS), 16, part * 1024, 0);
+        } else if constexpr (P < 28) {              // laser group record, slots 36 .. 122
+            constexpr int ws = P - 24;
+            if (lane < 43)
+                __builtin_amdgcn_global_load_lds(PL0 + rPL[ws] + (unsigned)(f * LP + 36) + lane2, (lds_t)(S + S_PL + ws * 86), 16, 0, 0);
+        } else {                                    // ground partial, two rows per piece: lanes 0..25 row 2h, 26..51 row 2h+1
+            constexpr int h = P - 28;
             // (signed lane part: row 2h+1's lanes start 52 doubles into the piece, and its window's offset may be 0)
             const unsigned ob = lane < 26 ? rPG[2 * h] : rPG[2 * h + 1];
             const long lo = (long)(f * PGS) + (lane < 26 ? lane2 : lane2 - 52);
             if (lane < 52) __builtin_amdgcn_global_load_lds(PG0 + ob + lo, (lds_t)(S + S_PG + h * 2 * PGS), 16, 0, 0);
         }
+        asm volatile("" ::: "memory");              // keeps the piece where it was written
+    };
+    auto prefetch_regs = [&](int f) {
         const int jq = j_ < 15 ? j_ : 0;
         scm_n = (j_ < 15 && f >= 1) ? LMD[oSC + (unsigned)((f - 1) * 15 + jq)] : 1.0;
         dg_n = LMD[oDG + (unsigned)(f * 15 + jq)];
         xq_n = X[oX + (unsigned)(f * 15 + jq)];
+    };
+    auto prefetch = [&](int f) {                    // the whole frame at once (the first frame of the sweep)
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        sfor<0, 30>([&](auto PP) { piece(PP, f); });
+        prefetch_regs(f);
     };
     const double* SI = S + S_IMU + w * PIS;
     const double* SL = S + S_PL + w * 86;         // SL[e] = PL_f[36 + e]
@@ -423,17 +427,25 @@ __global__ __launch_bounds__(64, 1) void k_lm_step_quad(StepArgs a) {
         QSTAMP(5);
         if (hasm) {
             dpp_fence();
+            sfor<0, 15>([&](auto R) {           // (all LDS reads first: one round trip, not fifteen)
+                constexpr int r = KI(R);
+                cd[r] = SI[l15 ? PI_G + r : PI_II + tri_rc<r>(jc, cj)];
+                if constexpr (r < 6) cr[r] = SW[l15 ? r * 13 + 12 : r * 13 + j6];
+            });
+            __builtin_amdgcn_sched_barrier(0);
             sfor<0, 15>([&](auto R) {
                 constexpr int r = KI(R);
                 const double rs = bc<r>(scm);
-                double fi = SI[l15 ? PI_G + r : PI_II + tri_rc<r>(jc, cj)];
-                if constexpr (r < 6) fi += (l6 || l15) ? SW[l15 ? r * 13 + 12 : r * 13 + j6] : 0.0;
+                double fi = cd[r];
+                if constexpr (r < 6) fi += (l6 || l15) ? cr[r] : 0.0;
                 cd[r] = fi * (rs * scm);
                 cr[r] = l15 ? fi : 0.0;            // lane 15 of the R^T set is idle: it carries frame i-1's unscaled gradient share (gradient max-norm)
                 pdiag = (j == r) ? cd[r] : pdiag;  // ... and this is its diagonal (LM diagonal of frame i-1)
             });
         }
-        if (i >= 1) prefetch(i - 1);       // this frame is in registers: the next one streams in behind the elimination
+        // this frame is in registers: the next one streams in behind the elimination.  (Spreading the 30 pieces over the pivots of the
+        // elimination was measured: each piece still costs ~130 ticks of issue there, no gain over the burst.)
+        if (i >= 1) prefetch(i - 1);
         QSTAMP(6);
         // ---- right-looking Cholesky of D fused with the forward substitution of O^T | g and R^T: pivot k broadcasts L_kk, every lane
         //      forms w_k = a[k] / L_kk of its three columns and updates a[r] -= L[r][k] w_k with L[r][k] = w_k of lane r (DPP operand).
@@ -531,7 +543,7 @@ __global__ __launch_bounds__(64, 1) void k_lm_step_quad(StepArgs a) {
     // ---------------------------------------------------------------- back substitution, frame 0 first; lane r owns unknown r
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the records written above are read by other lanes of the row
     double sn2 = 0.0, dsum = 0.0, yprev = 0.0, y0v = 0.0;
-    // the sweep is a chain of small matrix-vector products (21 DPP FMAs per frame) fed by 2.6 kB of record per frame and window: four
+    // the sweep is a chain of small matrix-vector products (21 DPP FMAs per frame) fed by 2.6 kB of record per frame and window: BSD
     // frames of loads are kept in flight (a set is refilled as soon as it has been consumed)
     struct BsRow { double row[22], xold, scv, dgv; };
     auto fetch = [&](int i) {
@@ -567,17 +579,18 @@ __global__ __launch_bounds__(64, 1) void k_lm_step_quad(StepArgs a) {
             dsum += R.dgv * inv_radius * t * t;
         }
     };
-    BsRow R0 = fetch(0), R1 = fetch(n > 1 ? 1 : 0), R2 = fetch(n > 2 ? 2 : 0), R3 = fetch(n > 3 ? 3 : 0);
-    for (int i0 = 0; i0 < n; i0 += 4) {
-        __builtin_amdgcn_sched_barrier(0);
-        solve_frame(R0, i0);
-        if (i0 + 4 < n) R0 = fetch(i0 + 4);
-        __builtin_amdgcn_sched_barrier(0);
-        if (i0 + 1 < n) { solve_frame(R1, i0 + 1); if (i0 + 5 < n) R1 = fetch(i0 + 5); }
-        __builtin_amdgcn_sched_barrier(0);
-        if (i0 + 2 < n) { solve_frame(R2, i0 + 2); if (i0 + 6 < n) R2 = fetch(i0 + 6); }
-        __builtin_amdgcn_sched_barrier(0);
-        if (i0 + 3 < n) { solve_frame(R3, i0 + 3); if (i0 + 7 < n) R3 = fetch(i0 + 7); }
+    constexpr int BSD = 4;      // frames of record loads in flight (14 loads each: the 6-bit vmcnt cannot tell more than 63 apart, 8 measured no better)
+    BsRow RB[BSD];
+    sfor<0, BSD>([&](auto Q) { constexpr int q = KI(Q); RB[q] = fetch(q < n ? q : 0); });
+    for (int i0 = 0; i0 < n; i0 += BSD) {
+        sfor<0, BSD>([&](auto Q) {
+            constexpr int q = KI(Q);
+            __builtin_amdgcn_sched_barrier(0);
+            if (i0 + q < n) {
+                solve_frame(RB[q], i0 + q);
+                if (i0 + q + BSD < n) RB[q] = fetch(i0 + q + BSD);
+            }
+        });
     }
     if (clk_k) g_qclk[15] = clock64();
     const double step_norm = sqrt(row_sum(sn2));
