@@ -1410,7 +1410,7 @@ __device__ __forceinline__ void pack_result_body(const PackArgs& a) {   // the w
     }
     __syncthreads();
     int* hdr = reinterpret_cast<int*>(a.out);
-    if (t == 0) { hdr[0] = a.lm[0].done; hdr[1] = a.marg_status ? a.marg_status[0] : 3; hdr[2] = 0; hdr[3] = 0; }
+    if (t == 0) { hdr[0] = a.lm[0].done; hdr[1] = a.marg_status ? a.marg_status[0] : 3; hdr[2] = 0; }
     if (t == 1) {
         const LmState& st = a.lm[0];
         liw_summary o;
@@ -1425,6 +1425,10 @@ __device__ __forceinline__ void pack_result_body(const PackArgs& a) {   // the w
     for (int e = t; e < n * 12; e += blockDim.x) o[e] = a.match_pose[e];
     o += n * 12;
     if (a.marg) for (int e = t; e < 276; e += blockDim.x) o[e] = a.marg[e];
+    // the sequence word goes LAST, behind a system-scope fence: a host that polls it in the page-locked record (liw_solve, zero-copy)
+    // sees the whole record — and what earlier kernels of the stream stored there — without waiting for the stream's completion signal
+    __syncthreads();
+    if (t == 0) { __threadfence_system(); __hip_atomic_store(hdr + 3, a.seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM); }
 }
 __global__ void k_pack_result(PackArgs a) { pack_result_body(a); }
 

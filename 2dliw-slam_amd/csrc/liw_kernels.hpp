@@ -217,6 +217,7 @@ struct PackArgs {
     const LmState* lm; liw_summary* info; const double* x; double* match_pose; const unsigned char* has_match;
     const double* marg; const int* marg_status;   // null without a speculative marginalisation
     double* out;
+    int seq;                                      // written to header word 3 last (a polling host's completion signal)
 };
 void launch_linearize(const LinArgs& A, const DevParams& P, hipStream_t s, const LinFork* fk, bool defer_join = false);
 void launch_linearize_join(hipStream_t s, const LinFork* fk);
