@@ -74,6 +74,11 @@ __global__ __launch_bounds__(64, 1) void k_lm_step_quad(StepArgs a) {
     __shared__ double S[QTOT];
     const int lane = threadIdx.x & 63, j = lane & 15, w = lane >> 4;
     const int n = a.n;
+    // TRACK topology (solver.cpp:631-820): p, q of every frame but the newest are constant (fast mode: its biases too), laser blocks tie
+    // the newest frame to constant laser_match poses (no arrow), the prior block sits on frame n-2.  Uniform per launch.
+    const bool track = a.mode == LIW_MODE_TRACK;
+    const int fast = a.fast_mode;
+    auto is_const = [&](int i, int v) { return track && i < n - 1 && (v < 6 || (fast && v >= 9)); };
     // row -> window: over the compacted list of the windows still iterating when the last linearisation built one (k_compact_active:
     // exactly the windows this step has to take), so that finished windows do not leave rows of a wave idle; else by index
     int b = (int)blockIdx.x * 4 + w;
@@ -128,13 +133,22 @@ __global__ __launch_bounds__(64, 1) void k_lm_step_quad(StepArgs a) {
             const double* PWb = (cb ? a.w.PW[1] : a.w.PW[0]) + (size_t)b * (n - 1) * PWS;
             const double* PGb = (cb ? a.w.PG[1] : a.w.PG[0]) + (size_t)b * n * PGS;
             double s = 0.0;
-            for (int i = j; i < n; i += 16) {
+            for (int i = j; i < n; i += 16) {   // (blocks whose parameters are all constant are not in Ceres' problem)
                 s += PLb[(size_t)i * LP + 120];
-                s += PGb[(size_t)i * PGS + 48];
+                if (!(track && i < n - 1)) s += PGb[(size_t)i * PGS + 48];
             }
             for (int k = j; k < n - 1; k += 16) {
                 s += PIb[(size_t)k * PIS + PI_C];
-                s += PWb[(size_t)k * PWS + 12 * 13 + 12];
+                if (!(track && k < n - 2)) s += PWb[(size_t)k * PWS + 12 * 13 + 12];
+            }
+            if (track && !fast && a.has_prior[b] && j < 15) {   // marginalization_factor: r = linearized_J (x_{n-2} - linearized_X)  (:22-53)
+                const double* xs = ((fresh || !have_cand) ? X : XC) + oX + (unsigned)((n - 2) * 15);
+                const double* pJ = a.prior_J + (size_t)b * 225 + j * 15;
+                const double* pX = a.prior_X + (size_t)b * 15;
+                double r = 0.0;
+#pragma unroll
+                for (int q = 0; q < 15; ++q) r += pJ[q] * (xs[q] - pX[q]);
+                s += r * r;
             }
             cost = 0.5 * row_sum(s);
         }
@@ -182,7 +196,7 @@ __global__ __launch_bounds__(64, 1) void k_lm_step_quad(StepArgs a) {
                     if (e < n * 15) {
                         if (act && (accept || restore)) X[oX + (unsigned)e] = xv[q];
                         if (act && fresh) LMD[oLM + LM_X0 + (unsigned)e] = xv[q];
-                        s2 += xv[q] * xv[q];
+                        if (!is_const(e / 15, e % 15)) s2 += xv[q] * xv[q];
                         if (hist) a.w.history[((size_t)iteration * a.B + b) * (size_t)(n * 15) + e] = xv[q];
                     }
                 }
@@ -228,6 +242,7 @@ __global__ __launch_bounds__(64, 1) void k_lm_step_quad(StepArgs a) {
     const bool l6 = j < 6, l15 = j == 15, lm = j < 15;
     const int j6 = l6 ? j : 0;
 
+    const bool prior_row = track && !fast && a.has_prior[b] != 0;   // this row's window carries the prior block (frame n-2)
     if (__any(proceed && fresh)) {   // Jacobi scaling 1 / (1 + sqrt(H_jj)), once per solve (same sums, same order as k_lm_step's frame_diag)
         for (int i = 0; i < n; ++i) {
             double dd = 0.0;
@@ -240,7 +255,12 @@ __global__ __launch_bounds__(64, 1) void k_lm_step_quad(StepArgs a) {
             }
             if (i >= 1) dd += PI0[oPI + (unsigned)((i - 1) * PIS + PI_JJ + pi_tri(jc, jc))];
             if (i <= n - 2) dd += PI0[oPI + (unsigned)(i * PIS + PI_II + pi_tri(jc, jc))];
-            if (proceed && fresh && lm) LMD[oSC + (unsigned)(i * 15 + j)] = 1.0 / (1.0 + sqrt(dd));
+            if (prior_row && i == n - 2) {
+                double sp = 0.0;
+                for (int k = 0; k < 15; ++k) { const double v = a.prior_J[(size_t)b * 225 + k * 15 + jc]; sp += v * v; }
+                dd += sp;
+            }
+            if (proceed && fresh && lm) LMD[oSC + (unsigned)(i * 15 + j)] = is_const(i, j) ? 1.0 : 1.0 / (1.0 + sqrt(dd));
         }
     }
     const double sc0 = l6 ? LMD[oSC + (unsigned)jc] : 0.0;           // scale of frame 0's pose entry j (columns of the arrow block)
@@ -341,7 +361,7 @@ __global__ __launch_bounds__(64, 1) void k_lm_step_quad(StepArgs a) {
             rL[r] = SL[72 - 36 + j6 * 6 + r];
             tS[r] = aD + (hasm ? bD : 0.0) + cD;
         });
-        if (i == 0) {   // every laser frame's Haa / ga lands on frame 0's pose
+        if (i == 0 && !track) {   // every laser frame's Haa / ga lands on frame 0's pose (init topology)
             double hA[6];
             sfor<0, 6>([&](auto R) { hA[KI(R)] = 0.0; });
             for (int f = 0; f < n; ++f) {
@@ -367,6 +387,22 @@ __global__ __launch_bounds__(64, 1) void k_lm_step_quad(StepArgs a) {
             o[r] += l15 ? tS[r] : ((l6 && hasm) ? oW[r] : 0.0);
             rr[r] = (l6 && hasm) ? rL[r] : 0.0;
         });
+        if (track && i == n - 2 && __any(prior_row)) {
+            // marginalization_factor (marginalization_factor.h:22-53, linearized_R omitted there): r = J (x - X), H += J^T J, g += J^T r.
+            // Lane j holds column j of linearized_J; (J^T J)[r][j] = sum_k J[k][r] J[k][j] is one DPP FMA per (r, k).
+            double Jc[15];
+            const double dxl = (lm && prior_row) ? X[oX + (unsigned)((n - 2) * 15 + jc)] - a.prior_X[(size_t)b * 15 + jc] : 0.0;
+            sfor<0, 15>([&](auto K) { constexpr int k = KI(K); Jc[k] = (lm && prior_row) ? a.prior_J[(size_t)b * 225 + k * 15 + jc] : 0.0; });
+            double gp = 0.0;
+            sfor<0, 15>([&](auto K) { constexpr int k = KI(K); const double rp = row_sum(Jc[k] * dxl); gp = __builtin_fma(Jc[k], rp, gp); });
+            dpp_fence();
+            sfor<0, 15>([&](auto R) {
+                constexpr int r = KI(R);
+                sfor<0, 15>([&](auto K) { constexpr int k = KI(K); fnma_bc<r>(d[r], Jc[k], -Jc[k]); });
+                const double gr = bc<r>(gp);
+                o[r] += l15 ? gr : 0.0;
+            });
+        }
         QSTAMP(2);
         // ---- gradient max-norm of this frame, |x - Plus(x, -g)| (lane 15's registers hold the unscaled tangent gradient)
         QSTAMP(3);
@@ -383,7 +419,8 @@ __global__ __launch_bounds__(64, 1) void k_lm_step_quad(StepArgs a) {
             }
             double m = fmax(fmax(fabs(o[0] + cr[0]), fabs(o[1] + cr[1])), fabs(o[2] + cr[2]));
             m = fmax(m, fmax(fmax(m3, m4), m5));
-            sfor<6, 15>([&](auto R) { constexpr int r = KI(R); m = fmax(m, fabs(o[r] + cr[r])); });
+            if (is_const(i, 0)) m = 0.0;                                           // (constant pose: not a parameter of the problem)
+            sfor<6, 15>([&](auto R) { constexpr int r = KI(R); if (!is_const(i, r)) m = fmax(m, fabs(o[r] + cr[r])); });
             gm = fmax(gm, m);
             // checksum of the assembled gradient (lane 15): a non-finite residual or Jacobian entry anywhere in the evaluation makes it non-finite
             gsum += ((g3 + g4) + g5) + ((o[0] + cr[0]) + (o[1] + cr[1]) + (o[2] + cr[2]));
@@ -421,6 +458,18 @@ __global__ __launch_bounds__(64, 1) void k_lm_step_quad(StepArgs a) {
                 const double gr = bc<r>(g0);
                 d[r] += D0[r];
                 o[r] += l15 ? gr : 0.0;
+            });
+        }
+        // ---- constant parameter blocks (solver.cpp:787-794): their rows / columns leave the system — unit pivot, nothing coupled
+        if (track) {
+            const bool colc = lm && is_const(i, j);                   // this lane's column of D
+            const bool nbc = lm && hasm && is_const(i - 1, j);        // this lane's column of O^T (a variable of frame i-1)
+            sfor<0, 15>([&](auto R) {
+                constexpr int r = KI(R);
+                const bool rowc = is_const(i, r);                     // (uniform)
+                if (rowc || colc) d[r] = (j == r) ? 1.0 : 0.0;
+                if (rowc || nbc) o[r] = 0.0;                          // (lane 15: the gradient entry of a constant row)
+                if (rowc) rr[r] = 0.0;
             });
         }
         // ---- frame i-1's share of block (i-1, i), in scaled space, starts its carried terms
@@ -561,12 +610,13 @@ __global__ __launch_bounds__(64, 1) void k_lm_step_quad(StepArgs a) {
         if (i >= 2) sfor<0, 6>([&](auto K) { constexpr int k = KI(K); fnma_bc<k>(t, y0v, R.row[15 + k]); });
         yprev = t;
         if (i == 0) y0v = t;
-        const double del = lm ? -t * R.scv : 0.0;
+        const bool cst = is_const(i, j);
+        const double del = (lm && !cst) ? -t * R.scv : 0.0;
         double xnew = R.xold + del;
         {
             dpp_fence();
             const double a0 = bc<3>(xnew), a1 = bc<4>(xnew), a2 = bc<5>(xnew);
-            if (__any(proceed && !(a0 * a0 + a1 * a1 + a2 * a2 < 9.8))) {   // so3 Plus = normalize_so3(x + d) (factor_common.h:41-53)
+            if (!is_const(i, 3) && __any(proceed && !(a0 * a0 + a1 * a1 + a2 * a2 < 9.8))) {   // so3 Plus = normalize_so3(x + d) (factor_common.h:41-53)
                 const V3<double> nq = normalize_so3(V3<double>(a0, a1, a2));
                 if (j == 3) xnew = nq.x;
                 if (j == 4) xnew = nq.y;
@@ -575,8 +625,10 @@ __global__ __launch_bounds__(64, 1) void k_lm_step_quad(StepArgs a) {
         }
         if (lm) {
             if (proceed) XC[oX + (unsigned)(i * 15 + j)] = xnew;
-            sn2 += (R.xold - xnew) * (R.xold - xnew);
-            dsum += R.dgv * inv_radius * t * t;
+            if (!cst) {
+                sn2 += (R.xold - xnew) * (R.xold - xnew);
+                dsum += R.dgv * inv_radius * t * t;
+            }
         }
     };
     constexpr int BSD = 4;      // frames of record loads in flight (14 loads each: the 6-bit vmcnt cannot tell more than 63 apart, 8 measured no better)
@@ -626,7 +678,7 @@ bool lm_step_quad_fits(const StepArgs& a) {
         return d <= lim && d + (unsigned long long)a.B * per <= lim;
     };
     const int nm = a.n > 1 ? a.n - 1 : 1;
-    return a.n >= 1 && a.mode == LIW_MODE_INIT && span(a.w.PL[0], a.w.PL[1], (unsigned long long)a.n * LP) && span(a.w.PI[0], a.w.PI[1], (unsigned long long)nm * PIS) &&
+    return a.n >= 1 && (a.mode == LIW_MODE_INIT || (a.mode == LIW_MODE_TRACK && a.n >= 2)) && span(a.w.PL[0], a.w.PL[1], (unsigned long long)a.n * LP) && span(a.w.PI[0], a.w.PI[1], (unsigned long long)nm * PIS) &&
            span(a.w.PW[0], a.w.PW[1], (unsigned long long)nm * PWS) && span(a.w.PG[0], a.w.PG[1], (unsigned long long)a.n * PGS) &&
            (unsigned long long)a.B * (sizeof(LmState) / 8) <= lim && (unsigned long long)a.B * a.n * SOLVE_WS <= lim;
 }

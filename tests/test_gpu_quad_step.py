@@ -96,3 +96,43 @@ def test_quad_step_hands_wrapped_rotations_to_the_one_wave_kernel_and_fails_like
         assert (summ[k]["iterations"], summ[k]["termination"]) == (so["iterations"], so["termination"]), (k, summ[k], so)
         assert rel(got[k], wo["states"].reshape(n, 15)) <= 1e-6, k
     assert summ[2]["termination"] == 6 and summ[2]["iterations"] == 0 and np.array_equal(got[2], wins[2]["states"])
+
+
+@pytest.mark.parametrize("fast", [False, True])
+def test_quad_step_tracking_topology_with_prior(liw, synth, pyoracle, monkeypatch, fast):
+    """TRACK topology (solver.cpp:631-820) in the quad kernel: constant poses of the older frames (fast mode: their biases too), the prior
+    block on frame n-2 (absent in fast mode), no arrow.  init solve -> marginalisation -> tracking solve on the stored prior, forced
+    through k_lm_step_quad and through the one-wave kernel: same iteration counts, states 1e-8 apart, and both follow the oracle's chain."""
+    prm = dict(synth.office_params(), fast_mode=fast)
+    orc = pyoracle.Oracle(prm)
+    n, B, K = 6, 11, 8                                 # (fast mode caps the tracking solve at 10 iterations: solver.cpp:800-801)
+    base = [synth.make_window(orc, prm, seed=5310 + k, n=n, L=25 + 30 * k) for k in range(4)]
+    wins = [base[b % 4] for b in range(B)]
+    out = {}
+    for variant in ("1", "3"):
+        monkeypatch.setenv("LIW_STEP_VARIANT", variant)
+        bs = liw.BatchSolver(prm, wins)
+        bs.solve(liw.LIW_MODE_INIT, K)
+        bs.marginalize()
+        x = bs.states()
+        x[:, n - 1, 0:3] += 0.01                      # something for the tracker to do
+        bs.set_states(x)
+        bs.solve(liw.LIW_MODE_TRACK, 0 if fast else K)       # fast mode: the reference's own cap of 10 (the oracle applies it regardless)
+        out[variant] = (bs.states(), bs.summaries())
+        bs.close()
+    for b in range(B):
+        s1, s3 = out["1"][1][b], out["3"][1][b]
+        assert (s1["iterations"], s1["termination"]) == (s3["iterations"], s3["termination"]), (b, s1, s3)
+        assert rel(out["3"][0][b], out["1"][0][b]) <= 1e-8, b
+    for k in range(4):
+        wo = pyoracle.Window(base[k])
+        orc.set_prior(None)
+        orc.set_max_iterations(K)
+        orc.init_solve(wo)
+        orc.marginalization(wo)
+        wo["states"].reshape(n, 15)[n - 1, 0:3] += 0.01
+        orc.solve(wo)
+        so = orc.summary()
+        assert (out["3"][1][k]["iterations"], out["3"][1][k]["termination"]) == (so["iterations"], so["termination"]), (k, out["3"][1][k], so)
+        assert rel(out["3"][0][k], wo["states"].reshape(n, 15)) <= 1e-6, k
+    orc.set_max_iterations(50)
