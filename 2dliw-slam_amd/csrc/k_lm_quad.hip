@@ -13,8 +13,8 @@
 //
 // Same algorithm and the same per-launch protocol as k_lm_step (candidate test -> accept / reject -> eliminate frames n-1 .. 0 ->
 // back substitution -> candidate states; Ceres' TrustRegionMinimizer restated, see k_lm.hip), so the two kernels can serve different
-// windows of one batch: windows whose rotation vector left the |theta| <= pi ball (so3 Plus Jacobian != I, rare: Plus normalises) and
-// the TRACK topology (constant blocks, prior) stay on k_lm_step.  Reference call sites: src/factor/solver.cpp:161-168.
+// windows of one batch: windows whose rotation vector left the |theta| <= pi ball (so3 Plus Jacobian != I, rare: Plus normalises) stay
+// on k_lm_step.  INIT and TRACK topologies.  Reference call sites: src/factor/solver.cpp:161-168 (init), :795-802 (tracking).
 #include <cstddef>
 #include <type_traits>
 

@@ -306,8 +306,8 @@ def main():
                 "lm_step_kernel_avg_ms": round(tm["step_ms"], 5), "lm_step_launches": tm["step_launches"],
                 "linearize_only_windows_per_s": round(B / (tm["linearize_ms"] * 1e-3), 1) if tm["linearize_ms"] > 0 else None}
     # second kernel of the step: the LM step (assembly + elimination + back substitution).  Since round 3 batches above 2 048 windows run
-    # k_lm_step_quad (four windows per wave, DPP row broadcasts, one-frame-ahead LDS-DMA): it is HBM bound on the partial sums it reads and
-    # the back-substitution record it writes and reads.  `achieved` prices the analytic bytes of the kernel (step_model) over
+    # k_lm_step_quad (four windows per wave, DPP row broadcasts, one-frame-ahead LDS-DMA): it is bound by the issue rate of its one wave
+    # per SIMD while streaming the partial sums and its back-substitution record.  `achieved` prices the analytic bytes of the kernel (step_model) over
     # the windows that took the step, `achieved_counter_gbs` the PMC-counted bytes of profiles/pmc_traffic.json.
     sm = step_model(n)
     succ = np.array([s_["successful"] for s_ in summ])
@@ -315,7 +315,8 @@ def main():
     step_time_s = tm["step_ms"] * tm["step_launches"] * 1e-3
     step_bytes = (sm["read"] + sm["write"]) * step_window_launches
     step_roof = {"kernel": "k_lm_step_quad (normal-equation assembly + block-tridiagonal-arrow LM elimination + back substitution; four windows per wave)",
-                 "bound": "hbm", "avg_launch_ms": round(tm["step_ms"], 5), "launches": tm["step_launches"],
+                 "bound": "fp64 DP-ALU issue of one wave per SIMD (DPP-FMAs at half rate; DESIGN 4); the HBM figures below are what goes by meanwhile",
+                 "avg_launch_ms": round(tm["step_ms"], 5), "launches": tm["step_launches"],
                  "analytic_bytes_per_window_iteration": sm["read"] + sm["write"],
                  "achieved": round(step_bytes / step_time_s / 1e9, 2) if step_time_s > 0 else None, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                  "frac": round(step_bytes / step_time_s / 1e9 / HBM_PEAK_GBS, 4) if step_time_s > 0 else None,
