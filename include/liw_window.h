@@ -78,7 +78,10 @@ typedef struct liw_window {
 typedef struct liw_summary {
     int iterations;        /* LM iterations executed (iteration 0 excluded) */
     int successful_steps;
-    int termination;       /* 1 gradient tol, 2 function tol, 3 parameter tol, 4 max iterations, 5 min radius, 6 failure */
+    int termination;       /* 1 gradient tol, 2 function tol, 3 parameter tol, 4 max iterations, 5 min radius, 6 failure.
+                            * 6 = Ceres' FAILURE: a non-finite residual / Jacobian entry at the initial point or at an accepted point (e.g. the
+                            * NaN derivative of an exactly stationary wheel increment, wheel_factor.h:63), or 5 consecutive invalid steps; as in
+                            * Ceres (solver.cc: IsSolutionUsable()) the states are then handed back as they were before the solve */
     double initial_cost, final_cost;
 } liw_summary;
 

@@ -10,6 +10,13 @@
 // SURVEY.md Appendix B (Jacobi scaling computed at iteration 0; LM diagonal clamp
 // [1e-6,1e32]; rho-based radius update; the step that trips function/parameter tolerance is
 // NOT applied — parameters are only written back after successful steps).
+// Evaluation failure (round 3): a residual or a Jacobian entry of a non-constant block that is not finite fails the evaluation
+// (internal/ceres/residual_block.cc ResidualBlock::Evaluate -> IsEvaluationValid, array_utils.cc IsArrayValid); at iteration 0 and
+// after a successful step that ends the solve with termination FAILURE (trust_region_minimizer.cc IterationZero /
+// HandleSuccessfulStep -> EvaluateGradientAndJacobian), a failed candidate evaluation is a step of infinite cost; and a FAILURE
+// termination — also max_num_consecutive_invalid_steps — hands back the parameters the solve started from (solver.cc Minimize():
+// StateVectorToParameterBlocks(IsSolutionUsable() ? reduced_parameters : original_reduced_parameters)).  Restated from the published
+// Ceres 1.14 sources; exercised by the exactly stationary wheel interval (tests/test_oracle_stationary.py).
 // The linear solve is an exact dense Cholesky of the damped normal equations: both Schur
 // variants are exact solvers of the same system, so only round-off differs.
 #pragma once
