@@ -93,10 +93,15 @@ typedef LJN<3> J3;
 // and the pre-integration Jacobian; they are never materialised: the MFMA operand of the whitening  Y = sqrt_info [J_raw | r_raw]
 // (imu_factor.h:85-86) is composed per lane from the compact block record below, and  G = Y^T Y  follows on the matrix cores
 // (8 + 12 v_mfma_f64_16x16x4_f64 per block, the accumulator layout of Y being the operand layout of Y^T Y).
-constexpr int IMU_PER_WAVE = 21;
-// compact block record in LDS (doubles): Xc[15][10] = the 9 derivative columns (theta_i 0-2, theta_j 3-5, bw_i 6-8) + r_raw (9);
-// Rt[9] = R_i^T; RtDt[9]; Jb[18] = alpha_J_ba (9), beta_J_ba (9)
-constexpr int IR_XS = 10, IR_RT = 150, IR_RTDT = 159, IR_JB = 168, IMU_REC = 188;
+// Blocks per wave: 18 (54 of the 64 lanes in the dual-number part) x 132 doubles of LDS each = 19 kB per wave, so that EIGHT waves fit a
+// CU (two per SIMD, the register limit).  The role is bound by the latency of one wave's instruction stream (a block's 20 dependent
+// fp64 MFMAs + operand reads + stores: 3.1 k ticks, tools/clk_probe_imu.py), not by HBM: with 21 blocks x 188 doubles (31.6 kB, five
+// waves per CU) the kernel took 563 us per 12 288 C2 windows, with the packed inputs alone 3 % less.
+constexpr int IMU_PER_WAVE = 18;
+// compact block record in LDS (doubles): Xc[9][10] = rows alpha, beta, gamma: the 9 derivative columns (theta_i 0-2, theta_j 3-5,
+// bw_i 6-8) + r_raw (9); Rb[6] = r_raw of the bias rows (their derivative columns are constants); Rt[9] = R_i^T; RtDt[9];
+// Jb[18] = alpha_J_ba (9), beta_J_ba (9)
+constexpr int IR_XS = 10, IR_RB = 90, IR_RT = 96, IR_RTDT = 105, IR_JB = 114, IMU_REC = 132;
 
 // column `col` (0..30: x_i 15 | r_raw | x_j 15) of row kk of [J_raw | r_raw] as (record offset | negate flag) or a constant:
 // returns offset >= 0 (bit 30 = negated) or -1 with *cst set
@@ -104,22 +109,23 @@ __device__ __forceinline__ int imu_entry_code(int kk, int col, double* cst) {
     *cst = 0.0;
     if (kk >= 15 || col > 30) return -1;
     const int rg = kk / 3, rr = kk % 3;
-    if (col == 15) return kk * IR_XS + 9;
+    if (col == 15) return kk < 9 ? kk * IR_XS + 9 : IR_RB + kk - 9;
     const bool second = col > 15;
     const int c = second ? col - 16 : col, grp = c / 3, cc = c % 3;
     if (!second) {
         switch (grp) {
         case 0: return rg == 0 ? IR_RT + rr * 3 + cc : -1;                                            // d r_alpha / d p_i = R_i^T
-        case 1: return kk * IR_XS + cc;                                                              // theta_i
+        case 1: return kk < 9 ? kk * IR_XS + cc : -1;                                                // theta_i
         case 2: return rg == 0 ? IR_RTDT + rr * 3 + cc : (rg == 1 ? IR_RT + rr * 3 + cc : -1);       // v_i
         case 3: if (rg == 0) return IR_JB + rr * 3 + cc; if (rg == 1) return IR_JB + 9 + rr * 3 + cc;
                 if (rg == 3 && rr == cc) *cst = -1.0; return -1;                                     // ba_i
-        default: return kk * IR_XS + 6 + cc;                                                         // bw_i
+        default: if (kk < 9) return kk * IR_XS + 6 + cc;
+                 if (rg == 4 && rr == cc) *cst = -1.0; return -1;                                    // bw_i (d res_bw / d bw_i = -I)
         }
     }
     switch (grp) {
     case 0: return rg == 0 ? ((IR_RT + rr * 3 + cc) | (1 << 30)) : -1;                                // p_j: -R_i^T
-    case 1: return kk * IR_XS + 3 + cc;                                                              // theta_j
+    case 1: return kk < 9 ? kk * IR_XS + 3 + cc : -1;                                                // theta_j
     case 2: return rg == 1 ? ((IR_RT + rr * 3 + cc) | (1 << 30)) : -1;                                // v_j: -R_i^T
     case 3: if (rg == 3 && rr == cc) *cst = 1.0; return -1;                                          // ba_j
     default: if (rg == 4 && rr == cc) *cst = 1.0; return -1;                                         // bw_j
@@ -135,14 +141,16 @@ __device__ __forceinline__ V3<double> mulc(const double* m, int ld, const V3<dou
 // is evaluated once per three directions) or 1 (nine lanes per block, small batches: a lane's instruction stream is what a single
 // window waits for, and one direction instead of three shortens it by ~40 %).  f = the factor of the rotation chain this lane
 // differentiates (0: theta_i, 1: theta_j, 2: bw_i through gamma), eg = e0 + e its global direction.
-template <int ND>
+// PK: the block's inputs come from the packed records of the solve in progress (WsView::imu_pk, 1 536 B per block instead of the 3 728 B
+// of the caller's X / J / sqrt_inverse_P / Dt arrays: the role is HBM-bound, and those arrays are constant over the LM iterations).
+template <int ND, bool PK = false>
 __device__ __forceinline__ void imu_blocks(const LinArgs& A, const DevParams& P, int wave, double* lds) {
     constexpr int LPB = 9 / ND;
     constexpr int MAXB = 63 / LPB;
     typedef LJN<ND> JN;
     const int lane = threadIdx.x & 63, blk = lane / LPB, g = lane % LPB;
     const int f = g / (LPB / 3), e0 = ND == 3 ? 0 : g % 3;
-    const int n = A.n, nb = n - 1, ipw = A.small_per_wave;   // blocks per wave: IMU_PER_WAVE for throughput, fewer for latency
+    const int n = A.n, nb = n - 1, ipw = A.imu_per_wave;   // blocks per wave: IMU_PER_WAVE for throughput, fewer for latency
     // blocks are indexed over the windows that are still iterating (compacted list), so finished windows cost no lanes
     const long total = (long)(A.active ? A.active[0] : A.B) * nb, gb0 = (long)wave * ipw;
     if (gb0 >= total) return;
@@ -162,12 +170,12 @@ __device__ __forceinline__ void imu_blocks(const LinArgs& A, const DevParams& P,
     constexpr int GRP = ND == 3 ? 7 : 1;
     auto load_sop = [&](int gq, double* o) {
         const int fq = __shfl(fk_lane, gq < nblk ? LPB * gq : 0, 64);
-        const double* S = A.imu_sqrtP + (size_t)fq * 225;
+        const double* S = PK ? A.imu_pk + (size_t)fq * IMU_PK + IPK_S : A.imu_sqrtP + (size_t)fq * 225;
 #pragma unroll
         for (int c = 0; c < 4; ++c) {
             const int kk = mk + 4 * c;
-            const bool in = ml < 15 && kk < 15;
-            const double v = S[in ? ml * 15 + kk : 0];
+            const bool in = ml < 15 && kk < 15 && (!PK || kk >= ml);          // (packed: row ml of the upper triangle)
+            const double v = S[in ? (PK ? ml * 15 - (ml * (ml - 1)) / 2 + (kk - ml) : ml * 15 + kk) : 0];
             o[c] = in ? v : 0.0;
         }
     };
@@ -181,12 +189,15 @@ __device__ __forceinline__ void imu_blocks(const LinArgs& A, const DevParams& P,
         const size_t fk = (size_t)b * nb + k;   // record of this block in the (uncompacted) input / partial arrays
         const double* si_ = A.x + ((size_t)b * n + k) * 15;
         const double* sj_ = si_ + 15;
-        const double* Jp = A.imu_J + fk * 225;
-        const double* X0 = A.imu_X + fk * 15;
-        const double Dt = A.imu_Dt[fk];
+        // Jp[r * JLD + c], r < 9, 9 <= c < 15: the bias blocks of the pre-integration Jacobian (the only entries the factor reads)
+        constexpr int JLD = PK ? 6 : 15;
+        const double* pkr = PK ? A.imu_pk + fk * IMU_PK : nullptr;
+        const double* Jp = PK ? pkr + IPK_J - 9 : A.imu_J + fk * 225;
+        const double* X0 = PK ? pkr : A.imu_X + fk * 15;
+        const double Dt = PK ? pkr[IPK_DT] : A.imu_Dt[fk];
         const V3<double> thi = cast_v3<double>(si_ + 3), thj = cast_v3<double>(sj_ + 3);
         const V3<double> dba = cast_v3<double>(si_ + 9) - cast_v3<double>(X0 + 9), dbw = cast_v3<double>(si_ + 12) - cast_v3<double>(X0 + 12);
-        const V3<double> gam = cast_v3<double>(X0 + 6) + mulc(Jp + 6 * 15 + 12, 15, dbw);
+        const V3<double> gam = cast_v3<double>(X0 + 6) + mulc(Jp + 6 * JLD + 12, JLD, dbw);
         // this lane's differentiated rotation: f = 0 exp(-theta_i), 1 exp(theta_j), 2 exp(-gamma); seeds = d(arg)/d(direction)
         V3<JN> arg;
         {
@@ -199,7 +210,7 @@ __device__ __forceinline__ void imu_blocks(const LinArgs& A, const DevParams& P,
 #pragma unroll
                 for (int e = 0; e < ND; ++e) {
                     const int eg = e0 + e;
-                    ac[c]->d[e] = f == 0 ? (c == eg ? -1.0 : 0.0) : (f == 1 ? (c == eg ? 1.0 : 0.0) : -Jp[(6 + c) * 15 + 12 + eg]);
+                    ac[c]->d[e] = f == 0 ? (c == eg ? -1.0 : 0.0) : (f == 1 ? (c == eg ? 1.0 : 0.0) : -Jp[(6 + c) * JLD + 12 + eg]);
                 }
             }
         }
@@ -224,8 +235,8 @@ __device__ __forceinline__ void imu_blocks(const LinArgs& A, const DevParams& P,
             const double gD = P.g * Dt;
             const V3<double> va(pj.x - pi.x - vi.x * Dt, pj.y - pi.y - vi.y * Dt, pj.z - pi.z + 0.5 * gD * Dt - vi.z * Dt);
             const V3<double> vb(vj.x - vi.x, vj.y - vi.y, vj.z + gD - vi.z);
-            const V3<double> ra = cast_v3<double>(X0) + mulc(Jp + 9, 15, dba) + mulc(Jp + 12, 15, dbw) - mul(Rt, va);
-            const V3<double> rb = cast_v3<double>(X0 + 3) + mulc(Jp + 3 * 15 + 9, 15, dba) + mulc(Jp + 3 * 15 + 12, 15, dbw) - mul(Rt, vb);
+            const V3<double> ra = cast_v3<double>(X0) + mulc(Jp + 9, JLD, dba) + mulc(Jp + 12, JLD, dbw) - mul(Rt, va);
+            const V3<double> rb = cast_v3<double>(X0 + 3) + mulc(Jp + 3 * JLD + 9, JLD, dba) + mulc(Jp + 3 * JLD + 12, JLD, dbw) - mul(Rt, vb);
 #pragma unroll
             for (int e = 0; e < ND; ++e) {
                 // f = 0: -(dR_i^T / d theta_i_e) v ; f = 2: the bias Jacobian column ; f = 1: nothing
@@ -234,16 +245,15 @@ __device__ __forceinline__ void imu_blocks(const LinArgs& A, const DevParams& P,
 #pragma unroll
                 for (int q = 0; q < 9; ++q) dM.m[q] = Md.m[q].d[e];
                 const V3<double> da = mul(dM, va), db = mul(dM, vb);
-                const double ca[3] = {f == 0 ? -da.x : (f == 2 ? Jp[0 * 15 + 12 + eg] : 0.0), f == 0 ? -da.y : (f == 2 ? Jp[1 * 15 + 12 + eg] : 0.0),
-                                      f == 0 ? -da.z : (f == 2 ? Jp[2 * 15 + 12 + eg] : 0.0)};
-                const double cb[3] = {f == 0 ? -db.x : (f == 2 ? Jp[3 * 15 + 12 + eg] : 0.0), f == 0 ? -db.y : (f == 2 ? Jp[4 * 15 + 12 + eg] : 0.0),
-                                      f == 0 ? -db.z : (f == 2 ? Jp[5 * 15 + 12 + eg] : 0.0)};
+                const double ca[3] = {f == 0 ? -da.x : (f == 2 ? Jp[0 * JLD + 12 + eg] : 0.0), f == 0 ? -da.y : (f == 2 ? Jp[1 * JLD + 12 + eg] : 0.0),
+                                      f == 0 ? -da.z : (f == 2 ? Jp[2 * JLD + 12 + eg] : 0.0)};
+                const double cb[3] = {f == 0 ? -db.x : (f == 2 ? Jp[3 * JLD + 12 + eg] : 0.0), f == 0 ? -db.y : (f == 2 ? Jp[4 * JLD + 12 + eg] : 0.0),
+                                      f == 0 ? -db.z : (f == 2 ? Jp[5 * JLD + 12 + eg] : 0.0)};
 #pragma unroll
                 for (int r = 0; r < 3; ++r) {
                     rec[r * IR_XS + 3 * f + eg] = ca[r];
                     rec[(3 + r) * IR_XS + 3 * f + eg] = cb[r];
-                    rec[(9 + r) * IR_XS + 3 * f + eg] = 0.0;                                   // res_ba has no non-linear direction
-                    rec[(12 + r) * IR_XS + 3 * f + eg] = (f == 2 && r == eg) ? -1.0 : 0.0;     // d res_bw / d bw_i
+                    // (res_ba has no non-linear direction, d res_bw / d bw_i = -I: constants of imu_entry_code)
                 }
             }
             if (g == 0) {
@@ -252,15 +262,15 @@ __device__ __forceinline__ void imu_blocks(const LinArgs& A, const DevParams& P,
                 for (int r = 0; r < 3; ++r) {
                     rec[r * IR_XS + 9] = r3[0][r];
                     rec[(3 + r) * IR_XS + 9] = r3[1][r];
-                    rec[(9 + r) * IR_XS + 9] = sj_[9 + r] - si_[9 + r];                       // res_ba
-                    rec[(12 + r) * IR_XS + 9] = sj_[12 + r] - si_[12 + r];                    // res_bw
+                    rec[IR_RB + r] = sj_[9 + r] - si_[9 + r];                                 // res_ba
+                    rec[IR_RB + 3 + r] = sj_[12 + r] - si_[12 + r];                           // res_bw
                 }
 #pragma unroll
                 for (int q = 0; q < 9; ++q) {
                     rec[IR_RT + q] = Rt.m[q];
                     rec[IR_RTDT + q] = Rt.m[q] * Dt;
-                    rec[IR_JB + q] = Jp[(q / 3) * 15 + 9 + q % 3];                             // alpha_J_ba
-                    rec[IR_JB + 9 + q] = Jp[(3 + q / 3) * 15 + 9 + q % 3];                     // beta_J_ba
+                    rec[IR_JB + q] = Jp[(q / 3) * JLD + 9 + q % 3];                             // alpha_J_ba
+                    rec[IR_JB + 9 + q] = Jp[(3 + q / 3) * JLD + 9 + q % 3];                     // beta_J_ba
                 }
             }
         }
@@ -318,6 +328,7 @@ __device__ __forceinline__ void imu_blocks(const LinArgs& A, const DevParams& P,
         for (int q = 0; q < GRP; ++q) load_sop(q, sop[q]);
     }
     for (int g0 = 0; g0 < nblk; g0 += GRP) {
+        LSTAMP(305 + g0 / GRP);
         __builtin_amdgcn_sched_barrier(0);
         if (g0 + GRP < nblk) {
 #pragma unroll
@@ -621,7 +632,35 @@ __device__ __forceinline__ void small_role(const LinArgs& A, const DevParams& P,
 constexpr int SMALL_LDS = WHEEL_PER_WAVE * 64 + 32;   // + 64 per-block meta words; >= GROUND_PER_WAVE * 16 + 32
 __global__ __launch_bounds__(64, 2) void k_lin_imu(LinArgs A, DevParams P) {
     __shared__ double lds[IMU_PER_WAVE * IMU_REC];
-    imu_blocks<3>(A, P, (int)blockIdx.x, lds);
+    if (A.imu_pk && *A.imu_pk_bad == 0) imu_blocks<3, true>(A, P, (int)blockIdx.x, lds);   // (uniform)
+    else imu_blocks<3>(A, P, (int)blockIdx.x, lds);
+}
+// Packed IMU block records of a solve (IMU_PK doubles per block, liw_kernels.hpp): one thread per entry; `bad` is raised when a
+// sqrt_inverse_P has a non-zero entry below its diagonal (not what imu_preintegraption.h:149 produces: the role then reads the full arrays).
+__global__ void k_imu_pack(long blocks, const double* X, const double* J, const double* S, const double* Dt, double* pk, int* bad) {
+    const long t = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= blocks * 256) return;
+    const long fk = t >> 8;
+    const int e = (int)(t & 255);
+    if (e < IMU_PK) {
+        double v = 0.0;
+        if (e < 15) v = X[fk * 15 + e];
+        else if (e == IPK_DT) v = Dt[fk];
+        else if (e < IPK_S) { const int q = e - IPK_J; v = J[fk * 225 + (q / 6) * 15 + 9 + q % 6]; }
+        else if (e < IPK_S + 120) {
+            int r = 0, q = e - IPK_S;
+            while (q >= 15 - r) { q -= 15 - r; ++r; }
+            v = S[fk * 225 + r * 15 + r + q];
+        }
+        pk[fk * IMU_PK + e] = v;
+    }
+    if (e < 225 && e % 15 < e / 15 && S[fk * 225 + e] != 0.0) atomicOr(bad, 1);
+}
+void launch_imu_pack(int B, int n, const double* imu_X, const double* imu_J, const double* imu_sqrtP, const double* imu_Dt, double* pk, int* bad, hipStream_t s) {
+    (void)hipMemsetAsync(bad, 0, sizeof(int), s);
+    const long blocks = (long)B * (n - 1);
+    if (blocks <= 0) return;
+    hipLaunchKernelGGL(k_imu_pack, dim3((unsigned)blocks), dim3(256), 0, s, blocks, imu_X, imu_J, imu_sqrtP, imu_Dt, pk, bad);
 }
 __global__ __launch_bounds__(64, 2) void k_lin_small(LinArgs A, DevParams P) {
     __shared__ double lds[SMALL_LDS];
@@ -713,17 +752,18 @@ void launch_linearize(const LinArgs& A_, const DevParams& P, hipStream_t s, cons
     A.small_nd = 3;
     {
         const long blocks = (long)B * (n > 1 ? n - 1 : 0);
-        int pw = IMU_PER_WAVE;
+        int pw = WHEEL_PER_WAVE;
         while (pw > 3 && (blocks + pw - 1) / pw < 512) pw = (pw + 1) / 2;   // 21 -> 11 -> 6 -> 3
         const bool nd3 = getenv("LIW_SMALL_ND3") != nullptr;                 // profiling / test aid (read per launch): three directions per lane everywhere
         if (A.eval_small && !nd3 && (long)B * n + 2 * blocks + ground_wave_count(B, n) <= 256) { pw = 1; A.small_nd = 1; }
         A.small_per_wave = pw;
+        A.imu_per_wave = pw < IMU_PER_WAVE ? pw : IMU_PER_WAVE;
     }
     // groups per wave: one for small batches (latency), up to LASER_GMAX for large ones (no ragged last pass per group)
     int G = 1;
     if (A.mode != LIW_MODE_TRACK) while (G < LASER_GMAX && (long)B * ((n + 2 * G - 1) / (2 * G)) >= 4096) G *= 2;
     const int laser_waves = B * ((n + G - 1) / G);
-    const int imu_waves = A.eval_small ? imu_wave_count(B, n, A.small_per_wave) : 0;
+    const int imu_waves = A.eval_small ? imu_wave_count(B, n, A.imu_per_wave) : 0;
     const int small_waves = A.eval_small ? wheel_wave_count(B, n, A.small_per_wave) + ground_wave_count(B, n) : 0;
     // large batches only: a single window gains nothing from the list and would pay one more launch per LM iteration
     const bool compact = A.lm && A.active && lin_builds_active_list(B, A.eval_small);

@@ -164,8 +164,16 @@ liw_ctx* liw_create(const liw_params* prm) {
         if (hipSetDevice(prm->device) == hipSuccess && hipGetDeviceProperties(&props, prm->device) == hipSuccess) {
             if (std::strstr(props.gcnArchName, "gfx950") != nullptr) {
                 if (hipStreamCreate(&c->stream) == hipSuccess) c->have_device = true;
-                if (c->have_device && hipStreamCreateWithFlags(&c->fork.side[0], hipStreamNonBlocking) == hipSuccess &&
-                    hipStreamCreateWithFlags(&c->fork.side[1], hipStreamNonBlocking) == hipSuccess &&
+                auto side_stream = [](hipStream_t* st) {
+                    const char* pr = std::getenv("LIW_SIDE_PRIO");   // experiment: role streams at the highest dispatch priority
+                    if (pr && pr[0] == '1') {
+                        int lo = 0, hi = 0;
+                        if (hipDeviceGetStreamPriorityRange(&lo, &hi) == hipSuccess) return hipStreamCreateWithPriority(st, hipStreamNonBlocking, hi);
+                    }
+                    return hipStreamCreateWithFlags(st, hipStreamNonBlocking);
+                };
+                if (c->have_device && side_stream(&c->fork.side[0]) == hipSuccess &&
+                    side_stream(&c->fork.side[1]) == hipSuccess &&
                     hipEventCreateWithFlags(&c->fork.ev_fork, hipEventDisableTiming) == hipSuccess &&
                     hipEventCreateWithFlags(&c->fork.ev_join[0], hipEventDisableTiming) == hipSuccess &&
                     hipEventCreateWithFlags(&c->fork.ev_join[1], hipEventDisableTiming) == hipSuccess &&
@@ -222,7 +230,7 @@ int liw_get_extrinsics(const liw_ctx* c, double* A, double* Bm) {
 // ------------------------------------------------------------------------------------------ workspace
 static size_t al256(size_t v) { return (v + 255) & ~(size_t)255; }
 struct FullLayout {
-    size_t PL[2], PI[2], PW[2], PG[2], x_cand, group_off, lm, solve_ws, info, history, active, bytes;
+    size_t PL[2], PI[2], PW[2], PG[2], x_cand, group_off, lm, solve_ws, info, history, active, imu_pk, imu_pk_bad, bytes;
 };
 static FullLayout full_layout(int B, int n, int hist) {
     FullLayout f{};
@@ -240,6 +248,8 @@ static FullLayout full_layout(int B, int n, int hist) {
     f.info = o; o = al256(o + sizeof(liw_summary) * (size_t)B);
     f.history = hist > 0 ? o : 0;
     if (hist > 0) o = al256(o + sizeof(double) * (size_t)hist * B * n * 15);
+    f.imu_pk_bad = o; o = al256(o + sizeof(int));
+    f.imu_pk = o; o = al256(o + sizeof(double) * (size_t)B * nm * IMU_PK);
     f.bytes = o;
     return f;
 }
@@ -259,6 +269,8 @@ static WsView make_view(void* ws, int B, int n, int hist) {
     v.history = hist > 0 ? (double*)(base + f.history) : nullptr;
     v.history_records = hist;
     v.active = (int*)(base + f.active);
+    v.imu_pk = (double*)(base + f.imu_pk);
+    v.imu_pk_bad = (int*)(base + f.imu_pk_bad);
     return v;
 }
 
@@ -283,7 +295,8 @@ static int check_batch(liw_ctx* c, const liw_batch* b, int min_n = 1) {
     return LIW_OK;
 }
 static int min_frames(int mode) { return mode == LIW_MODE_INIT ? 1 : 2; }
-static LinArgs lin_args(const liw_batch* b, int mode, const double* x, const WsView& v, int candidate, bool use_lm) {
+// packed: the linearisation belongs to a solve opened by liw_batch_lm_begin (which packed the IMU block records into the workspace)
+static LinArgs lin_args(const liw_batch* b, int mode, const double* x, const WsView& v, int candidate, bool use_lm, bool packed = false) {
     LinArgs A{};
     A.B = b->B; A.n = b->n; A.mode = mode; A.eval_small = b->eval_small;
     A.x = x; A.group_off = v.group_off; A.laser_off = b->laser_off; A.laser_pts = b->laser_pts; A.Ltot = b->Ltot;
@@ -294,6 +307,7 @@ static LinArgs lin_args(const liw_batch* b, int mode, const double* x, const WsV
     A.lm = use_lm ? v.lm : nullptr;
     A.active = use_lm ? v.active : nullptr;
     A.candidate = candidate;
+    if (packed && b->n > 1 && b->eval_small) { A.imu_pk = v.imu_pk; A.imu_pk_bad = v.imu_pk_bad; }
     return A;
 }
 static StepArgs step_args(liw_ctx* c, const liw_batch* b, int mode, int max_iters, const WsView& v) {
@@ -321,6 +335,13 @@ int liw_batch_lm_begin(liw_ctx* c, const liw_batch* b, int mode, int max_iters, 
     hipStream_t s = (hipStream_t)stream;
     launch_group_offsets(b->B, b->n, b->laser_off, b->laser_frame, v.group_off, s);
     launch_lm_begin(b->B, b->n, v.lm, c->last_iters, s);
+    // IMU block records of this solve, packed once (the role kernel of large batches is HBM-bound; k_lin_all on a few windows reads the
+    // caller's arrays); *imu_pk_bad != 0 (set here on the device) sends the role back to the full arrays
+    if (b->n > 1 && b->eval_small) {
+        if ((long)b->B * (b->n - 1) >= 4096 && !std::getenv("LIW_NO_IMU_PACK"))
+            launch_imu_pack(b->B, b->n, b->imu_X, b->imu_J, b->imu_sqrtP, b->imu_Dt, v.imu_pk, v.imu_pk_bad, s);
+        else (void)hipMemsetAsync(v.imu_pk_bad, 0xff, sizeof(int), s);
+    }
     HIPCHK(c, hipGetLastError());
     return LIW_OK;
 }
@@ -328,7 +349,7 @@ int liw_batch_lm_linearize(liw_ctx* c, const liw_batch* b, int mode, int candida
     NEEDDEV(c);
     if (int r = check_batch(c, b, min_frames(mode))) return r;
     WsView v = make_view(ws, b->B, b->n, b->history_records);
-    LinArgs A = lin_args(b, mode, candidate ? v.x_cand : b->x, v, candidate != 0, true);
+    LinArgs A = lin_args(b, mode, candidate ? v.x_cand : b->x, v, candidate != 0, true, true);
     launch_linearize(A, c->dp, (hipStream_t)stream, c->have_fork ? &c->fork : nullptr);
     HIPCHK(c, hipGetLastError());
     return LIW_OK;
@@ -338,7 +359,7 @@ int liw_batch_lm_linearize_async(liw_ctx* c, const liw_batch* b, int mode, int c
     NEEDDEV(c);
     if (int r = check_batch(c, b, min_frames(mode))) return r;
     WsView v = make_view(ws, b->B, b->n, b->history_records);
-    LinArgs A = lin_args(b, mode, candidate ? v.x_cand : b->x, v, candidate != 0, true);
+    LinArgs A = lin_args(b, mode, candidate ? v.x_cand : b->x, v, candidate != 0, true, true);
     launch_linearize(A, c->dp, (hipStream_t)stream, c->have_fork ? &c->fork : nullptr, true);
     HIPCHK(c, hipGetLastError());
     return LIW_OK;
@@ -529,9 +550,12 @@ static int enqueue_solve(liw_ctx* c, const liw_batch* b, int mode, int K, void* 
     WsView v = make_view(ws, b->B, b->n, b->history_records);
     launch_group_offsets(b->B, b->n, b->laser_off, b->laser_frame, v.group_off, s);
     launch_lm_begin(b->B, b->n, v.lm, K, s);
+    // (a few windows go through k_lin_all, whose IMU role reads the caller's arrays: nothing to pack)
+    const bool pack = b->n > 1 && b->eval_small && !std::getenv("LIW_NO_IMU_PACK") && (long)b->B * (b->n - 1) >= 4096;
+    if (pack) launch_imu_pack(b->B, b->n, b->imu_X, b->imu_J, b->imu_sqrtP, b->imu_Dt, v.imu_pk, v.imu_pk_bad, s);
     StepArgs st = step_args(c, b, mode, K, v);
     auto lin = [&](int cand) {
-        LinArgs A = lin_args(b, mode, cand ? v.x_cand : b->x, v, cand, true);
+        LinArgs A = lin_args(b, mode, cand ? v.x_cand : b->x, v, cand, true, pack);
         if (timed) (void)hipEventRecord(next_event(c->ev_lin, c->ev_lin_used), s);
         launch_linearize(A, c->dp, s, c->have_fork ? &c->fork : nullptr);
         if (timed) (void)hipEventRecord(next_event(c->ev_lin, c->ev_lin_used), s);

@@ -71,7 +71,13 @@ struct WsView {
     double* history;      // [(records)][B][n][15] or null
     int history_records;
     int* active;          // [1 + B] compacted list of the windows still iterating (IMU / wheel / ground roles index their blocks over it)
+    double* imu_pk;       // [B][n-1][IMU_PK] packed IMU block records of the solve in progress (launch_imu_pack, from liw_batch_lm_begin)
+    int* imu_pk_bad;      // [1] != 0: some sqrt_inverse_P is not upper triangular -> the IMU role reads the caller's arrays
 };
+// Packed IMU block record (built once per solve: the block's inputs are constant over its LM iterations, and only 190 of their 466
+// doubles are ever used): observation X (15) | Dt | rows 0..8 x columns 9..14 of the pre-integration Jacobian (the bias blocks the
+// factor reads, imu_factor.h:40-85) | upper triangle of sqrt_inverse_P = LLT(P^-1).matrixL().transpose() (imu_preintegraption.h:149)
+constexpr int IMU_PK = 192, IPK_DT = 15, IPK_J = 16, IPK_S = 70;
 constexpr int REC_LD = 22;                 // rec[15][22]: back-substitution operators Yo (15), Yr (6), yz columns of a frame
 constexpr int REC_GS = 15 * REC_LD;       // + the scaled gradient (model decrease)
 constexpr int SOLVE_WS = REC_GS + 16;
@@ -94,9 +100,12 @@ struct LinArgs {
     int older_only;             // 1: the laser role leaves out frame n-1 (marginalisation behind a TRACK solve: the current buffer already
                                 //    holds that frame's record and every small role's partials, at the very states being marginalised)
     int candidate;              // 1: write the small-factor partials of window b into buffer 1 - lm[b].cur
-    int small_per_wave;         // IMU / wheel blocks per wave (set by launch_linearize)
+    int small_per_wave;         // wheel blocks per wave (set by launch_linearize)
+    int imu_per_wave;           // IMU blocks per wave (set by launch_linearize)
     int small_nd;               // derivative directions per lane of the IMU / wheel roles: 3 (batches) or 1 (k_lin_all on a few windows)
     int* active;                // [1 + B]: number of windows still iterating, then their ids (built per linearisation when lm != null)
+    const double* imu_pk;       // packed IMU block records (WsView::imu_pk) or null
+    const int* imu_pk_bad;      //   ... usable iff *imu_pk_bad == 0
     // optional per-factor outputs (liw_eval_factors)
     double* dbg_laser_res; double* dbg_laser_jac; double* dbg_imu_res; double* dbg_imu_jac;
     double* dbg_wheel_res; double* dbg_wheel_jac; double* dbg_ground_res; double* dbg_ground_jac;
@@ -227,6 +236,7 @@ constexpr int P2P_MAX = 16;
 struct P2pPeers { double* area[P2P_MAX]; unsigned long long* flags[P2P_MAX]; };   // device pointers to every rank's receive area / flags, as mapped here
 void launch_p2p_exchange(size_t nd, const double* buf, const P2pPeers& peers, int rank, int world, unsigned long long epoch, int* err, hipStream_t s);
 void launch_group_offsets(int B, int n, const int* laser_off, const int* laser_frame, int* group_off, hipStream_t s);
+void launch_imu_pack(int B, int n, const double* imu_X, const double* imu_J, const double* imu_sqrtP, const double* imu_Dt, double* pk, int* bad, hipStream_t s);
 void launch_pack_result(const PackArgs& a, hipStream_t s);
 void launch_lm_begin(int B, int n, LmState* lm, int max_iters, hipStream_t s);
 void launch_lm_step(const StepArgs& a, hipStream_t s);

@@ -101,3 +101,52 @@ def test_throughput_step_kernel_variant_matches_latency_variant_and_oracle(liw, 
         # tracking solve on its prior amplify that to ~1e-8 (measured 5e-10 .. 9e-9), the same factor by which either one moves
         # when its own summation order changes
         assert rel(gb[b], gs[k]) <= 1e-7, (k, b)
+
+
+def test_packed_imu_records_are_the_callers_arrays(liw, synth, pyoracle, monkeypatch):
+    """Large batches read the IMU block inputs from the packed records liw_batch_lm_begin builds (observation, Dt, the bias blocks of
+    the pre-integration Jacobian, the upper triangle of sqrt_inverse_P): same numbers, so the solve is bit-identical to the one that
+    reads the caller's arrays (LIW_NO_IMU_PACK=1).  A sqrt_inverse_P that is NOT upper triangular (not what
+    imu_preintegraption.h:149 produces, but the arrays are the caller's) sends the role back to the full arrays on the device."""
+    import copy
+    prm = synth.office_params()
+    orc = pyoracle.Oracle(prm)
+    n, B, K = 7, 800, 8                                        # 4 800 IMU blocks: above the packing threshold
+    base = [synth.make_window(orc, prm, seed=2210 + k, n=n, L=20 + 25 * k) for k in range(4)]
+    for w in base:
+        S = np.asarray(w["imu_sqrtP"]).reshape(-1, 15, 15)
+        assert np.all(np.tril(S, -1) == 0.0)                   # the synthetic windows follow the reference's construction
+
+    def run(windows, no_pack):
+        if no_pack:
+            monkeypatch.setenv("LIW_NO_IMU_PACK", "1")
+        else:
+            monkeypatch.delenv("LIW_NO_IMU_PACK", raising=False)
+        bs = liw.BatchSolver(prm, windows)
+        bs.solve(liw.LIW_MODE_INIT, K)
+        return bs.states().copy(), bs.summaries()
+
+    wins = [base[b % 4] for b in range(B)]
+    x_pk, s_pk = run(wins, False)
+    x_full, s_full = run(wins, True)
+    assert np.array_equal(x_pk, x_full)
+    assert [s["iterations"] for s in s_pk] == [s["iterations"] for s in s_full]
+    # oracle on the sampled windows
+    orc.set_max_iterations(K)
+    for k in range(4):
+        wo = pyoracle.Window(base[k])
+        orc.set_prior(None)
+        orc.init_solve(wo)
+        assert rel(x_pk[k], wo["states"].reshape(n, 15)) <= 1e-6, k
+    orc.set_max_iterations(50)
+    # one block of one window with a dense sqrt_inverse_P: the whole batch falls back, results = the full-array path
+    odd = copy.deepcopy(base[1])
+    S = np.array(odd["imu_sqrtP"], dtype=np.float64).reshape(-1, 15, 15)
+    S[2] = S[2] + 1e-3 * np.tril(np.ones((15, 15)), -1) * np.abs(S[2]).max()
+    odd["imu_sqrtP"] = S.reshape(np.asarray(odd["imu_sqrtP"]).shape)
+    wins2 = list(wins)
+    wins2[B - 3] = odd
+    y_pk, _ = run(wins2, False)
+    y_full, _ = run(wins2, True)
+    assert np.array_equal(y_pk, y_full)
+    assert not np.array_equal(y_pk[B - 3], x_pk[B - 3])         # (the dense block does change that window)
