@@ -695,30 +695,40 @@ __global__ __launch_bounds__(64, 2) void k_lin_all(LinArgs A, DevParams P, int G
 #endif
 }
 
-// ids of the windows that are still iterating, in window order (deterministic): active[0] = count, active[1 ..] = ids.  One work-group:
-// phase 1 pulls the `done` words (one cache line per window: LmState is 15 kB) with independent loads into LDS, phase 2 scans.
-constexpr int COMPACT_MAX = 16384;
-__global__ __launch_bounds__(1024) void k_compact_active(int B, const LmState* lm, int* active) {
-    __shared__ int flag[COMPACT_MAX];
-    __shared__ int cnt[1024];
-    const int t = threadIdx.x;
-#pragma unroll 8
-    for (int b = t; b < B; b += 1024) flag[b] = lm[b].done ? 0 : 1;
+// ids of the windows that are still iterating, in window order (deterministic): active[0] = count, active[1 ..] = ids; behind the list:
+// a ticket word and one flag byte per window.  Many SMALL work-groups: each pulls 256 `done` words (one cache line per window: LmState
+// is 15 kB) into the flag bytes, and the group that finishes last (ticket) scans the bytes and writes the list.  The first version was
+// ONE 1 024-thread group with 68 kB of LDS: behind the laser kernel (eight 17.5 kB waves per CU) it waited up to 0.9 ms for a CU to
+// drain, and the IMU / wheel / ground roles waited with it.
+constexpr int COMPACT_MAX = 1 << 20;
+__host__ __device__ inline size_t compact_list_bytes(int B) { return sizeof(int) * ((size_t)B + 2) + (((size_t)B + 3) & ~(size_t)3); }
+__global__ __launch_bounds__(256) void k_compact_active(int B, const LmState* lm, int* active) {
+    unsigned char* flags = reinterpret_cast<unsigned char*>(active + B + 2);
+    int* ticket = active + B + 1;
+    __shared__ int cnt[256];
+    __shared__ int last;
+    const int t = threadIdx.x, b0 = (int)blockIdx.x * 256 + t;
+    if (b0 < B) flags[b0] = lm[b0].done ? 0 : 1;
+    __threadfence();                        // release (agent scope: the groups sit on different XCDs / L2s)
     __syncthreads();
-    const int per = (B + 1023) / 1024, lo = t * per, hi = min(B, lo + per);
+    if (t == 0) last = __hip_atomic_fetch_add(ticket, 1, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT) == (int)gridDim.x - 1;
+    __syncthreads();
+    if (!last) return;
+    __threadfence();                        // acquire
+    const int per = (B + 255) / 256, lo = t * per, hi = min(B, lo + per);
     int c = 0;
-    for (int b = lo; b < hi; ++b) c += flag[b];
+    for (int b = lo; b < hi; ++b) c += flags[b];
     cnt[t] = c;
     __syncthreads();
-    for (int o = 1; o < 1024; o <<= 1) {   // inclusive scan
+    for (int o = 1; o < 256; o <<= 1) {     // inclusive scan
         const int v = t >= o ? cnt[t - o] : 0;
         __syncthreads();
         cnt[t] += v;
         __syncthreads();
     }
     int pos = cnt[t] - c;
-    for (int b = lo; b < hi; ++b) if (flag[b]) active[1 + pos++] = b;
-    if (t == 1023) active[0] = cnt[1023];
+    for (int b = lo; b < hi; ++b) if (flags[b]) active[1 + pos++] = b;
+    if (t == 255) { active[0] = cnt[255]; *ticket = 0; }
 }
 
 // laser block range of every (window, frame): first block of window b owned by a frame >= i
@@ -739,6 +749,7 @@ __global__ void k_group_offsets(int B, int n, const int* laser_off, const int* l
 // overlaps the fp64 VALU work of the laser kernel on the same CUs.  Small batches: one launch for everything (k_lin_all).
 // defer_join: the laser role stays on `s`, the IMU / small roles on the side streams, and the join is left to launch_linearize_join —
 // a factor-sharded driver puts its exchange of the laser partial sums on `s` in between, so that it overlaps the small roles.
+size_t compact_list_bytes_host(int B) { return compact_list_bytes(B); }
 bool lin_builds_active_list(int B, int eval_small) {
     static const bool no_compact = getenv("LIW_NO_COMPACT") != nullptr;   // profiling aid: index the small roles over all windows
     return eval_small && B >= 512 && B <= COMPACT_MAX && !no_compact;
@@ -777,16 +788,16 @@ void launch_linearize(const LinArgs& A_, const DevParams& P, hipStream_t s, cons
     }
     if (A.reset_lm) hipLaunchKernelGGL(k_lm_reset, dim3((B + 63) / 64), dim3(64), 0, s, B, A.reset_lm, A.reset_iters);
     const bool fork = fk && fk->side[0] && A.eval_small;
+    // the list of windows still iterating (read by the IMU / wheel / ground roles and by the next step kernel) is built IN FRONT of the
+    // fork: on a side stream its work-groups queued behind the laser kernel, whose waves hold every register of the chip, and the roles
+    // waiting for the list started up to 0.9 ms late
+    if (compact) hipLaunchKernelGGL(k_compact_active, dim3((unsigned)((B + 255) / 256)), dim3(256), 0, s, B, A.lm, A.active);
     if (fork) {
         hipEventRecord(fk->ev_fork, s);
         hipStreamWaitEvent(fk->side[0], fk->ev_fork, 0);
         hipStreamWaitEvent(fk->side[1], fk->ev_fork, 0);
     }
     hipStream_t s_imu = fork ? fk->side[0] : s, s_small = fork ? fk->side[1] : s;
-    if (compact) {   // only the IMU / wheel / ground roles read the list: off the laser role's stream when the roles are forked
-        hipLaunchKernelGGL(k_compact_active, dim3(1), dim3(1024), 0, s_imu, B, A.lm, A.active);
-        if (fork) { hipEventRecord(fk->ev_compact, s_imu); hipStreamWaitEvent(s_small, fk->ev_compact, 0); }
-    }
     if (A.mode == LIW_MODE_INIT) hipLaunchKernelGGL(k_lin_laser<true>, dim3((unsigned)laser_waves), dim3(64), 0, s, A, P, G);
     else hipLaunchKernelGGL(k_lin_laser<false>, dim3((unsigned)laser_waves), dim3(64), 0, s, A, P, G);
     if (imu_waves) hipLaunchKernelGGL(k_lin_imu, dim3((unsigned)imu_waves), dim3(64), 0, s_imu, A, P);
