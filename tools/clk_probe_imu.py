@@ -8,8 +8,7 @@ hp = liw.HostPreint(prm)
 w = [synth.make_window(hp, prm, seed=20240 + k, n=30, L=2000) for k in range(2)]
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 12288
 bs = liw.BatchSolver(prm, [w[k % 2] for k in range(B)])
-for _ in range(3):
-    bs.linearize(liw.LIW_MODE_INIT)
+bs.solve(liw.LIW_MODE_INIT, 3)      # (the linearisations of a solve read the packed IMU block records)
 torch.cuda.synchronize()
 clk = np.zeros(512, dtype=np.int64)
 liw.lib().liw_debug_clk_lin(clk.ctypes.data_as(C.c_void_p), C.c_int(512))
