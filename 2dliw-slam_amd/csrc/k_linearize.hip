@@ -656,6 +656,21 @@ __global__ void k_imu_pack(long blocks, const double* X, const double* J, const 
     }
     if (e < 225 && e % 15 < e / 15 && S[fk * 225 + e] != 0.0) atomicOr(bad, 1);
 }
+// *flag = 1 when any laser end point has a non-zero z component (planes 2, 5, 8, 11 of the [12][Ltot] block array); 2-D scans have none
+// (src/utilies/common.cpp:22-24) and the laser role then skips those planes.  Once per solve.
+__global__ void k_laser_z_scan(long Ltot, const double* pts, int* flag) {
+    const long t = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    bool nz = false;
+    for (long j = t; j < Ltot; j += (long)gridDim.x * blockDim.x)
+        nz = nz || pts[2 * Ltot + j] != 0.0 || pts[5 * Ltot + j] != 0.0 || pts[8 * Ltot + j] != 0.0 || pts[11 * Ltot + j] != 0.0;
+    if (__any(nz) && (threadIdx.x & 63) == 0) atomicOr(flag, 1);
+}
+void launch_laser_z_scan(long Ltot, const double* laser_pts, int* flag, hipStream_t s) {
+    (void)hipMemsetAsync(flag, 0, sizeof(int), s);
+    if (Ltot <= 0) return;
+    const long blocks = (Ltot + 1023) / 1024;
+    hipLaunchKernelGGL(k_laser_z_scan, dim3((unsigned)(blocks < 4096 ? blocks : 4096)), dim3(256), 0, s, Ltot, laser_pts, flag);
+}
 void launch_imu_pack(int B, int n, const double* imu_X, const double* imu_J, const double* imu_sqrtP, const double* imu_Dt, double* pk, int* bad, hipStream_t s) {
     (void)hipMemsetAsync(bad, 0, sizeof(int), s);
     const long blocks = (long)B * (n - 1);

@@ -248,7 +248,7 @@ static FullLayout full_layout(int B, int n, int hist) {
     f.info = o; o = al256(o + sizeof(liw_summary) * (size_t)B);
     f.history = hist > 0 ? o : 0;
     if (hist > 0) o = al256(o + sizeof(double) * (size_t)hist * B * n * 15);
-    f.imu_pk_bad = o; o = al256(o + sizeof(int));
+    f.imu_pk_bad = o; o = al256(o + 2 * sizeof(int));
     f.imu_pk = o; o = al256(o + sizeof(double) * (size_t)B * nm * IMU_PK);
     f.bytes = o;
     return f;
@@ -308,6 +308,7 @@ static LinArgs lin_args(const liw_batch* b, int mode, const double* x, const WsV
     A.active = use_lm ? v.active : nullptr;
     A.candidate = candidate;
     if (packed && b->n > 1 && b->eval_small) { A.imu_pk = v.imu_pk; A.imu_pk_bad = v.imu_pk_bad; }
+    if (packed) A.laser_hz = v.imu_pk_bad + 1;
     return A;
 }
 static StepArgs step_args(liw_ctx* c, const liw_batch* b, int mode, int max_iters, const WsView& v) {
@@ -343,6 +344,7 @@ int liw_batch_lm_begin(liw_ctx* c, const liw_batch* b, int mode, int max_iters, 
             launch_imu_pack(b->B, b->n, b->imu_X, b->imu_J, b->imu_sqrtP, b->imu_Dt, v.imu_pk, v.imu_pk_bad, s);
         else (void)hipMemsetAsync(v.imu_pk_bad, 0xff, sizeof(int), s);
     }
+    launch_laser_z_scan(b->Ltot, b->laser_pts, v.imu_pk_bad + 1, s);   // 2-D scans: the laser role skips the z planes
     HIPCHK(c, hipGetLastError());
     return LIW_OK;
 }
@@ -555,6 +557,7 @@ static int enqueue_solve(liw_ctx* c, const liw_batch* b, int mode, int K, void* 
     // (a few windows go through k_lin_all, whose IMU role reads the caller's arrays: nothing to pack)
     const bool pack = b->n > 1 && b->eval_small && !std::getenv("LIW_NO_IMU_PACK") && (long)b->B * (b->n - 1) >= 4096;
     if (pack) launch_imu_pack(b->B, b->n, b->imu_X, b->imu_J, b->imu_sqrtP, b->imu_Dt, v.imu_pk, v.imu_pk_bad, s);
+    if (pack) launch_laser_z_scan(b->Ltot, b->laser_pts, v.imu_pk_bad + 1, s);
     StepArgs st = step_args(c, b, mode, K, v);
     auto lin = [&](int cand) {
         LinArgs A = lin_args(b, mode, cand ? v.x_cand : b->x, v, cand, true, pack);

@@ -73,7 +73,8 @@ struct WsView {
     int* active;          // [1 + B] compacted list of the windows still iterating (IMU / wheel / ground roles index their blocks over it);
                           //    behind it the ticket word (zeroed by lm_begin) and flag bytes of k_compact_active
     double* imu_pk;       // [B][n-1][IMU_PK] packed IMU block records of the solve in progress (launch_imu_pack, from liw_batch_lm_begin)
-    int* imu_pk_bad;      // [1] != 0: some sqrt_inverse_P is not upper triangular -> the IMU role reads the caller's arrays
+    int* imu_pk_bad;      // [0] != 0: some sqrt_inverse_P is not upper triangular -> the IMU role reads the caller's arrays;
+                          // [1] != 0: some laser end point has a z component (launch_laser_z_scan)
 };
 // Packed IMU block record (built once per solve: the block's inputs are constant over its LM iterations, and only 190 of their 466
 // doubles are ever used): observation X (15) | Dt | rows 0..8 x columns 9..14 of the pre-integration Jacobian (the bias blocks the
@@ -107,6 +108,7 @@ struct LinArgs {
     int* active;                // [1 + B]: number of windows still iterating, then their ids (built per linearisation when lm != null)
     const double* imu_pk;       // packed IMU block records (WsView::imu_pk) or null
     const int* imu_pk_bad;      //   ... usable iff *imu_pk_bad == 0
+    const int* laser_hz;        // null, or -> 0 when no laser end point of the batch has a z component (2-D scans): the z planes are skipped
     // optional per-factor outputs (liw_eval_factors)
     double* dbg_laser_res; double* dbg_laser_jac; double* dbg_imu_res; double* dbg_imu_jac;
     double* dbg_wheel_res; double* dbg_wheel_jac; double* dbg_ground_res; double* dbg_ground_jac;
@@ -237,6 +239,7 @@ constexpr int P2P_MAX = 16;
 struct P2pPeers { double* area[P2P_MAX]; unsigned long long* flags[P2P_MAX]; };   // device pointers to every rank's receive area / flags, as mapped here
 void launch_p2p_exchange(size_t nd, const double* buf, const P2pPeers& peers, int rank, int world, unsigned long long epoch, int* err, hipStream_t s);
 void launch_group_offsets(int B, int n, const int* laser_off, const int* laser_frame, int* group_off, hipStream_t s);
+void launch_laser_z_scan(long Ltot, const double* laser_pts, int* flag, hipStream_t s);
 void launch_imu_pack(int B, int n, const double* imu_X, const double* imu_J, const double* imu_sqrtP, const double* imu_Dt, double* pk, int* bad, hipStream_t s);
 void launch_pack_result(const PackArgs& a, hipStream_t s);
 void launch_lm_begin(int B, int n, LmState* lm, int max_iters, hipStream_t s);

@@ -150,3 +150,44 @@ def test_packed_imu_records_are_the_callers_arrays(liw, synth, pyoracle, monkeyp
     y_full, _ = run(wins2, True)
     assert np.array_equal(y_pk, y_full)
     assert not np.array_equal(y_pk[B - 3], x_pk[B - 3])         # (the dense block does change that window)
+
+
+def test_laser_end_points_with_z_take_the_full_path(liw, synth, pyoracle):
+    """A batch solve scans the laser end points once: 2-D scans (z = 0 in the laser frame, src/utilies/common.cpp:22-24) let the laser
+    role skip the four z planes and their terms.  One end point with z != 0 anywhere in the batch switches the whole batch back to the
+    full evaluation: the window that carries it follows the oracle (which always uses z), and so do its z = 0 neighbours."""
+    prm = synth.office_params()
+    orc = pyoracle.Oracle(prm)
+    n, B, K = 7, 800, 8
+    base = [synth.make_window(orc, prm, seed=2310 + k, n=n, L=40 + 25 * k) for k in range(4)]
+    for w in base:
+        assert np.all(np.asarray(w["laser_pts"]).reshape(-1, 4, 3)[:, :, 2] == 0.0)
+    tilted = dict(base[2])
+    pts = np.array(tilted["laser_pts"], dtype=np.float64).reshape(-1, 4, 3)
+    pts[5:40, :, 2] = 0.05 * np.random.default_rng(5).normal(size=(35, 4))     # end points off the scan plane
+    tilted["laser_pts"] = pts.reshape(np.asarray(tilted["laser_pts"]).shape)
+    orc.set_max_iterations(K)
+
+    def oracle_states(w):
+        wo = pyoracle.Window(w)
+        orc.set_prior(None)
+        orc.init_solve(wo)
+        return wo["states"].reshape(n, 15).copy()
+
+    flat = [base[b % 4] for b in range(B)]
+    bs = liw.BatchSolver(prm, flat)
+    bs.solve(liw.LIW_MODE_INIT, K)
+    x_flat = bs.states().copy()
+    for k in range(4):
+        assert rel(x_flat[k], oracle_states(base[k])) <= 1e-6, k
+    mixed = list(flat)
+    mixed[B - 2] = tilted
+    bs2 = liw.BatchSolver(prm, mixed)
+    bs2.solve(liw.LIW_MODE_INIT, K)
+    x_mixed = bs2.states().copy()
+    ref_t = oracle_states(tilted)
+    assert rel(x_mixed[B - 2], ref_t) <= 1e-6
+    assert rel(x_mixed[B - 2], x_flat[B - 2]) > 1e-9                     # (the z components do matter to that window)
+    for k in range(4):                                                   # z = 0 windows: skipping the planes is exact up to the order of the sums
+        assert rel(x_mixed[k], x_flat[k]) <= 1e-9, k
+    orc.set_max_iterations(50)
