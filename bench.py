@@ -52,8 +52,15 @@ def step_model(n, arrow=True):
 
 
 def input_floor_bytes(n, L):
-    """what an LM iteration must read at least: the factor records and the states (2 000 x 104 + 29 x 3 728 + 29 x 208 + 30 x 120)"""
+    """what an LM iteration must read at least when it reads the caller's factor records and the states (2 000 x 104 +
+    29 x 3 728 + 29 x 208 + 30 x 120).  Since the end of round 3 the linearisation reads LESS than these arrays hold: the IMU role reads
+    per-solve packed block records (1 536 of the 3 728 B: the entries the factor uses) and the laser role skips the z planes of 2-D scans
+    (64 of 96 B per block) — input_floor_packed_bytes()."""
     return L * 104 + (n - 1) * (3728 + 208) + n * 120
+
+
+def input_floor_packed_bytes(n, L):
+    return L * 72 + (n - 1) * (1536 + 208) + n * 120
 
 
 def _free_port():
@@ -306,8 +313,8 @@ def main():
                 "lm_step_kernel_avg_ms": round(tm["step_ms"], 5), "lm_step_launches": tm["step_launches"],
                 "linearize_only_windows_per_s": round(B / (tm["linearize_ms"] * 1e-3), 1) if tm["linearize_ms"] > 0 else None}
     # second kernel of the step: the LM step (assembly + elimination + back substitution).  Since round 3 batches above 2 048 windows run
-    # k_lm_step_quad (four windows per wave, DPP row broadcasts, one-frame-ahead LDS-DMA): it is bound by the issue rate of its one wave
-    # per SIMD while streaming the partial sums and its back-substitution record.  `achieved` prices the analytic bytes of the kernel (step_model) over
+    # k_lm_step_quad (four windows per wave, DPP row broadcasts, one-frame-ahead LDS-DMA): one wave per SIMD, streaming the partial sums
+    # and its back-substitution record.  `achieved` prices the analytic bytes of the kernel (step_model) over
     # the windows that took the step, `achieved_counter_gbs` the PMC-counted bytes of profiles/pmc_traffic.json.
     sm = step_model(n)
     succ = np.array([s_["successful"] for s_ in summ])
@@ -315,7 +322,7 @@ def main():
     step_time_s = tm["step_ms"] * tm["step_launches"] * 1e-3
     step_bytes = (sm["read"] + sm["write"]) * step_window_launches
     step_roof = {"kernel": "k_lm_step_quad (normal-equation assembly + block-tridiagonal-arrow LM elimination + back substitution; four windows per wave)",
-                 "bound": "fp64 DP-ALU issue of one wave per SIMD (DPP-FMAs at half rate; DESIGN 4); the HBM figures below are what goes by meanwhile",
+                 "bound": "hbm: one wave per SIMD streams 30 KiB of partial records per frame through the CU's load path (first sweep, with the dependent pivot chains of the elimination exposed) and reads its back-substitution record back at ~4.8 TB/s chip-wide (second sweep); DESIGN 4",
                  "avg_launch_ms": round(tm["step_ms"], 5), "launches": tm["step_launches"],
                  "analytic_bytes_per_window_iteration": sm["read"] + sm["write"],
                  "achieved": round(step_bytes / step_time_s / 1e9, 2) if step_time_s > 0 else None, "peak": HBM_PEAK_GBS, "unit": "GB/s",
@@ -331,7 +338,7 @@ def main():
     floor = input_floor_bytes(n, L)
     lin_w = pmcj.get("k_linearize_hbm_bytes_per_window")
     stp_w = (pmcj.get("k_lm_step_hbm_bytes_per_launch", 0.0) / pmcj["windows"]) if pmcj.get("windows") else None
-    hbm_iter = {"input_floor": floor, "linearise_counter": int(lin_w) if lin_w else None, "step_counter": int(stp_w) if stp_w else None,
+    hbm_iter = {"input_floor": floor, "input_floor_packed": input_floor_packed_bytes(n, L), "linearise_counter": int(lin_w) if lin_w else None, "step_counter": int(stp_w) if stp_w else None,
                 "step_analytic": sm["read"] + sm["write"],
                 "total_counter": int(lin_w + stp_w) if (lin_w and stp_w) else None,
                 "ratio_to_floor": round((lin_w + stp_w) / floor, 3) if (lin_w and stp_w) else None,

@@ -5,8 +5,9 @@ profiles/pmc_traffic.json: HBM bytes per launch of the linearise (Jacobian-evalu
 Units / corrections (MI355X_MICROARCH.md §HBM): the counters are in KiB; WRITE_SIZE matches a known write
 volume 1:1 (k_lin_laser<false>: 61 440 groups x 1 024 B = 62.91 MB measured 62.91 MB); FETCH_SIZE under-reports
 coalesced streaming reads on gfx950 — calibrated here on the laser kernel, whose read volume is known exactly
-(96 B of end-points per block + 512 B of frame transforms per group): factor = known / reported.
-usage: pmc_traffic.py <fetch_csv> <write_csv> <windows> <frames> <laser_blocks_per_window> <out_json>
+(8 B per end-point component plane read — 8 planes for 2-D scans, whose four z planes the role skips, else 12 — per block + 512 B of
+frame transforms per group): factor = known / reported.
+usage: pmc_traffic.py <fetch_csv> <write_csv> <windows> <frames> <laser_blocks_per_window> <out_json> [planes = 8]
 """
 import collections
 import csv
@@ -46,13 +47,14 @@ def step_known_read(B, n):
 
 def main():
     fetch_csv, write_csv, B, n, L, out = sys.argv[1], sys.argv[2], int(sys.argv[3]), int(sys.argv[4]), int(sys.argv[5]), sys.argv[6]
+    planes = int(sys.argv[7]) if len(sys.argv) > 7 else 8   # bench.py's synthetic scans are 2-D (z = 0): the laser role reads 8 of the 12 planes
     f, w = per_kernel(fetch_csv, "FETCH_SIZE"), per_kernel(write_csv, "WRITE_SIZE")
     fx, wx = per_kernel_max(fetch_csv, "FETCH_SIZE"), per_kernel_max(write_csv, "WRITE_SIZE")
     # ---- per-kernel calibration of FETCH_SIZE.  The guide's prior for 16-byte-per-lane streaming reads is x2; the
     # factor depends on the access pattern, so it is fixed per kernel on a read volume that is known exactly:
-    #   k_lin_laser<true>: 96 B of end points per block + 512 B of frame states per group (8-byte-per-lane SoA loads)
+    #   k_lin_laser<true>: 8 B x planes of end points per block + 512 B of frame states per group (8-byte-per-lane SoA loads)
     #   k_lm_step_quad:    step_known_read() (LDS-DMA dwordx4 pieces + 128-bit record rows), on its launch with every window active
-    known_laser_read = B * L * 96.0 + B * n * 512.0
+    known_laser_read = B * L * 8.0 * planes + B * n * 512.0
     cal_laser = known_laser_read / pick(fx, "k_lin_laser<true>") if pick(fx, "k_lin_laser<true>") else None
     step_name = "k_lm_step_quad" if pick(fx, "k_lm_step_quad") else "k_lm_step"
     cal_step = step_known_read(B, n) / pick(fx, step_name) if step_name == "k_lm_step_quad" else cal_laser
@@ -67,7 +69,7 @@ def main():
     produced = sum(pick(wx, k) for k in names) + pick(wx, step_name) + B * 25e3
     step_read_full = pick(fx, step_name) * cal_step
     ok = step_read_full <= 1.10 * produced
-    res = {"windows": B, "frames": n, "laser_blocks": L, "fetch_calibration_factor": cal_laser, "fetch_calibration_factor_step": cal_step,
+    res = {"windows": B, "frames": n, "laser_blocks": L, "laser_planes_read": planes, "fetch_calibration_factor": cal_laser, "fetch_calibration_factor_step": cal_step,
            "step_kernel": step_name,
            "k_linearize_hbm_bytes_per_launch": sum(kern[k]["fetch_calibrated"] + kern[k]["write"] for k in names),
            "k_lm_step_hbm_bytes_per_launch": kern[step_name]["fetch_calibrated"] + kern[step_name]["write"], "kernels": kern,

@@ -2,7 +2,7 @@
 # End-of-round evidence pass on the MI355X box (run through gpurun): default bench line, kernel-trace stats with forked and
 # serial role kernels, PMC traffic passes (separate, kernel-trace only), per-kernel FETCH_SIZE calibration + consistency check
 # (tools/pmc_traffic.py) and the serial-roles roofline fraction.  Outputs under gpurun_out/$TAG_* and profiles/pmc_traffic.json.
-TAG=${1:-r03_v1}; B=${2:-12288}
+TAG=${1:-r03_v3}; B=${2:-12288}
 cd $GRAFT_REPO_ROOT; export TMPDIR=/tmp
 mkdir -p gpurun_out
 for d in a s; do
