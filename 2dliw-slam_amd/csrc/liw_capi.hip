@@ -164,16 +164,10 @@ liw_ctx* liw_create(const liw_params* prm) {
         if (hipSetDevice(prm->device) == hipSuccess && hipGetDeviceProperties(&props, prm->device) == hipSuccess) {
             if (std::strstr(props.gcnArchName, "gfx950") != nullptr) {
                 if (hipStreamCreate(&c->stream) == hipSuccess) c->have_device = true;
-                auto side_stream = [](hipStream_t* st) {
-                    const char* pr = std::getenv("LIW_SIDE_PRIO");   // experiment: role streams at the highest dispatch priority
-                    if (pr && pr[0] == '1') {
-                        int lo = 0, hi = 0;
-                        if (hipDeviceGetStreamPriorityRange(&lo, &hi) == hipSuccess) return hipStreamCreateWithPriority(st, hipStreamNonBlocking, hi);
-                    }
-                    return hipStreamCreateWithFlags(st, hipStreamNonBlocking);
-                };
-                if (c->have_device && side_stream(&c->fork.side[0]) == hipSuccess &&
-                    side_stream(&c->fork.side[1]) == hipSuccess &&
+                // (role streams at the highest dispatch priority were tried: the dispatcher takes no notice while the laser kernel's waves
+                // hold every register of the chip — same time line, tools/rocprof_timeline.py)
+                if (c->have_device && hipStreamCreateWithFlags(&c->fork.side[0], hipStreamNonBlocking) == hipSuccess &&
+                    hipStreamCreateWithFlags(&c->fork.side[1], hipStreamNonBlocking) == hipSuccess &&
                     hipEventCreateWithFlags(&c->fork.ev_fork, hipEventDisableTiming) == hipSuccess &&
                     hipEventCreateWithFlags(&c->fork.ev_join[0], hipEventDisableTiming) == hipSuccess &&
                     hipEventCreateWithFlags(&c->fork.ev_join[1], hipEventDisableTiming) == hipSuccess &&
