@@ -794,7 +794,10 @@ void launch_linearize(const LinArgs& A_, const DevParams& P, hipStream_t s, cons
     // large batches only: a single window gains nothing from the list and would pay one more launch per LM iteration
     const bool compact = A.lm && A.active && lin_builds_active_list(B, A.eval_small);
     if (!compact) A.active = nullptr;
-    if (A.eval_small && laser_waves + imu_waves + small_waves <= 256) {
+    // (also without the small roles — the older-frames laser evaluation of a marginalisation enqueued behind a tracking solve: the SAME
+    // compiled body as the one-launch linearisation it must agree with bit for bit; the stand-alone k_lin_laser is a second compilation of
+    // the body, whose FMA contraction may differ in the last bit)
+    if (laser_waves + imu_waves + small_waves <= 256) {
         const int roles = laser_waves + imu_waves + small_waves;
         const unsigned tot = (unsigned)(roles + (A.reset_lm ? 1 : 0));
         if (A.mode == LIW_MODE_INIT) hipLaunchKernelGGL(k_lin_all<true>, dim3(tot), dim3(64), 0, s, A, P, G, laser_waves, imu_waves, roles);
