@@ -183,7 +183,13 @@ int liw_batch_ws_layout(int B, int n, int history_records, liw_ws_layout* out);
 /* LM driver pieces (what ceres::Solve iterates, solver.cpp:168,802).  All launches go to `stream`
  * (a hipStream_t passed as void*); nothing synchronises.  Sequence for a solve:
  *   liw_batch_lm_begin -> liw_batch_lm_linearize(buf 0 at x) -> [ liw_batch_lm_step ; liw_batch_lm_linearize(candidate) ] x K
- *   -> liw_batch_lm_finish.   liw_batch_solve runs exactly that (optionally as one hipGraph). */
+ *   -> liw_batch_lm_finish.   liw_batch_solve runs exactly that (optionally as one hipGraph).
+ * The factor arrays of `b` are constants of a solve (as the frame_infos are for ceres::Solve): liw_batch_lm_begin reads them once — it
+ * packs the IMU block inputs the factor uses (imu_factor.h:40-85: observation, Dt, the bias blocks of the pre-integration Jacobian, the
+ * upper triangle of sqrt_inverse_P, imu_preintegraption.h:149) into the workspace and notes whether any laser end point has a z
+ * component (2-D scans have none, src/utilies/common.cpp:22-24) — and the linearisations up to liw_batch_lm_finish read those.  Arrays
+ * that do not fit the assumptions (a sqrt_inverse_P with entries below its diagonal, end points off the scan plane) are detected on the
+ * device and evaluated in full from the caller's arrays: same results either way. */
 int liw_batch_set_max_iters(liw_ctx* ctx, int mode, int max_iters); /* cap enforced by liw_batch_lm_step; returns it */
 /* stand-alone linearisation at b->x (partials "current", no LM state): what liw_linearize and the bench kernel
  * timing use */
