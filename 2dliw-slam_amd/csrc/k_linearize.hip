@@ -556,8 +556,11 @@ __device__ __forceinline__ void wheel_blocks(const LinArgs& A, const DevParams& 
             const int q = idx / PWS, e = idx % PWS, sel = meta[q];
             if (sel < 0) continue;
             const double* Yq = lds + q * 64;
-            const int r = e / 13, c = e % 13;
-            const double v = e < 169 ? Yq[r] * Yq[c] + Yq[13 + r] * Yq[13 + c] + Yq[26 + r] * Yq[26 + c] : 0.0;
+            // record entry e -> columns (r, c) of Y: ii | ij | jj | gradient | cost (liw_kernels.hpp)
+            const int blk6 = e / 36, w6 = e % 36;
+            const int r = e < 108 ? (blk6 == 2 ? 6 : 0) + w6 / 6 : (e < 120 ? e - 108 : 12);
+            const int c = e < 108 ? (blk6 == 0 ? 0 : 6) + w6 % 6 : 12;
+            const double v = e <= PW_C ? Yq[r] * Yq[c] + Yq[13 + r] * Yq[13 + c] + Yq[26 + r] * Yq[26 + c] : 0.0;
             (sel ? A.PW[1] : A.PW[0])[(size_t)meta[32 + q] * PWS + e] = v;
         }
     }

@@ -133,19 +133,19 @@ __device__ __forceinline__ AsmRegs asm_issue(const AsmCtx& c, int i, const doubl
         const bool pl = lane < 36;
         const int r = pl ? lane / 6 : 0, cc = pl ? lane % 6 : 0;
         R.t1 = PLi[(unsigned)(36 + r * 6 + cc)];
-        R.t2 = PWm[(unsigned)((6 + r) * 13 + 6 + cc)];
-        R.t3 = PWp[(unsigned)(r * 13 + cc)];
+        R.t2 = PWm[(unsigned)PW_JJ(r, cc)];
+        R.t3 = PWp[(unsigned)PW_II(r, cc)];
         R.t4 = PGi[(unsigned)(r * 7 + cc)];
-        R.t8 = up ? PWp[(unsigned)(cc * 13 + 6 + r)] : PWm[(unsigned)(r * 13 + 6 + cc)];
-        R.e2 = up ? PWm[(unsigned)(r * 13 + 6 + cc)] : 0.0;
+        R.t8 = up ? PWp[(unsigned)PW_IJ(cc, r)] : PWm[(unsigned)PW_IJ(r, cc)];
+        R.e2 = up ? PWm[(unsigned)PW_IJ(r, cc)] : 0.0;
         R.t9 = PL1[(unsigned)(72 + r * 6 + cc)];
         R.t10 = PLi[(unsigned)(72 + r * 6 + cc)];
     }
     {
         const int r = lane < 15 ? lane : 0, r6 = r < 6 ? r : 0;
         R.g1 = PLi[(unsigned)(114 + r6)];
-        R.g2 = PWm[(unsigned)((6 + r6) * 13 + 12)];
-        R.g3 = PWp[(unsigned)(r6 * 13 + 12)];
+        R.g2 = PWm[(unsigned)PW_G(6 + r6)];
+        R.g3 = PWp[(unsigned)PW_G(r6)];
         R.g4 = PGi[(unsigned)(r6 * 7 + 6)];
         R.g5 = PIm[(unsigned)(PI_G + 15 + r)];
         R.g6 = PIp[(unsigned)(PI_G + r)];
@@ -380,13 +380,13 @@ __device__ double window_cost(const AsmCtx& c, double* gchk = nullptr) {
     for (int k = lane; k < n - 1; k += 64) {
         s += PIb[(size_t)k * PIS + PI_C];
         const bool won = !(track && k < n - 2);
-        if (won) s += PWb[(size_t)k * PWS + 12 * 13 + 12];
+        if (won) s += PWb[(size_t)k * PWS + PW_C];
         if (gchk) {
 #pragma unroll
             for (int e = 0; e < 30; ++e) gs += PIb[(size_t)k * PIS + PI_G + e];
             if (won) {
 #pragma unroll
-                for (int e = 0; e < 12; ++e) gs += PWb[(size_t)k * PWS + e * 13 + 12];
+                for (int e = 0; e < 12; ++e) gs += PWb[(size_t)k * PWS + PW_G(e)];
             }
         }
     }
@@ -484,8 +484,8 @@ __device__ double frame_diag(const AsmCtx& c, int i, LdsStep& T) {
     if (r < 6) {
         d += PLb[(size_t)i * LP + 36 + r * 7];
         if (i == 0) for (int j = 0; j < n; ++j) d += PLb[(size_t)j * LP + r * 7];
-        if (i >= 1) d += PWb[(size_t)(i - 1) * PWS + (6 + r) * 14];
-        if (i <= n - 2) d += PWb[(size_t)i * PWS + r * 14];
+        if (i >= 1) d += PWb[(size_t)(i - 1) * PWS + PW_JJ(r, r)];
+        if (i <= n - 2) d += PWb[(size_t)i * PWS + PW_II(r, r)];
         d += PGb[(size_t)i * PGS + r * 8];
     }
     if (i >= 1) d += PIb[(size_t)(i - 1) * PIS + PI_JJ + pi_tri(r, r)];

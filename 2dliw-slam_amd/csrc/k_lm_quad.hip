@@ -139,7 +139,7 @@ __global__ __launch_bounds__(64, 1) void k_lm_step_quad(StepArgs a) {
             }
             for (int k = j; k < n - 1; k += 16) {
                 s += PIb[(size_t)k * PIS + PI_C];
-                if (!(track && k < n - 2)) s += PWb[(size_t)k * PWS + 12 * 13 + 12];
+                if (!(track && k < n - 2)) s += PWb[(size_t)k * PWS + PW_C];
             }
             if (track && !fast && a.has_prior[b] && j < 15) {   // marginalization_factor: r = linearized_J (x_{n-2} - linearized_X)  (:22-53)
                 const double* xs = ((fresh || !have_cand) ? X : XC) + oX + (unsigned)((n - 2) * 15);
@@ -249,8 +249,8 @@ __global__ __launch_bounds__(64, 1) void k_lm_step_quad(StepArgs a) {
             if (l6) {
                 dd += PL0[oPL + (unsigned)(i * LP + 36 + jc * 7)];
                 if (i == 0) for (int f = 0; f < n; ++f) dd += PL0[oPL + (unsigned)(f * LP + jc * 7)];
-                if (i >= 1) dd += PW0[oPW + (unsigned)((i - 1) * PWS + (6 + jc) * 14)];
-                if (i <= n - 2) dd += PW0[oPW + (unsigned)(i * PWS + jc * 14)];
+                if (i >= 1) dd += PW0[oPW + (unsigned)((i - 1) * PWS + PW_JJ(jc, jc))];
+                if (i <= n - 2) dd += PW0[oPW + (unsigned)(i * PWS + PW_II(jc, jc))];
                 dd += PG0[oPG + (unsigned)(i * PGS + jc * 8)];
             }
             if (i >= 1) dd += PI0[oPI + (unsigned)((i - 1) * PIS + PI_JJ + pi_tri(jc, jc))];
@@ -270,8 +270,9 @@ __global__ __launch_bounds__(64, 1) void k_lm_step_quad(StepArgs a) {
     // piece of one row's area), the Jacobi scale / LM diagonal / state entry of this lane in three registers.
     //   S_IMU[w][496]  IMU partial of block (f-1, f)            4 pieces per row
     //   S_PL[w][86]    PL_f[36 .. 122): Hbb, Hab, ga, gb         1 piece per row (43 lanes)
-    //   S_PW[w][172]   wheel partial of block (f-1, f)           2 pieces per row (64 + 22 lanes)
+    //   S_PW[w][122]   wheel partial of block (f-1, f)           1 piece per row (61 lanes; two until the record dropped its ji block)
     //   S_PG[w][52]    ground partial of frame f                 1 piece per two rows (26 lanes each)
+    constexpr int QPIECES = 26;                     // IMU 16, wheel 4, laser 4, ground 2
     constexpr int S_IMU = 0, S_PL = 4 * PIS, S_PW = S_PL + 4 * 86, S_PG = S_PW + 4 * PWS;
     static_assert(S_PG + 4 * PGS <= QTOT, "LDS layout");
     const unsigned rPL[4] = {(unsigned)__builtin_amdgcn_readlane(oPL, 0), (unsigned)__builtin_amdgcn_readlane(oPL, 16), (unsigned)__builtin_amdgcn_readlane(oPL, 32), (unsigned)__builtin_amdgcn_readlane(oPL, 48)};
@@ -281,7 +282,7 @@ __global__ __launch_bounds__(64, 1) void k_lm_step_quad(StepArgs a) {
     typedef __attribute__((address_space(3))) void* lds_t;
     const int j_ = j;
     double scm_n = 1.0, dg_n = 0.0, xq_n = 0.0;     // prefetched: scale of frame f-1, LM diagonal and state entry of frame f (lane j)
-    // one piece of frame f's prefetch, P = 0 .. 29 (compile-time: row, part and LDS destination are immediates)
+    // one piece of frame f's prefetch, P = 0 .. QPIECES-1 (compile-time: row, part and LDS destination are immediates)
     auto piece = [&](auto PP, int f) {
         constexpr int P = KI(PP);
         const int k = f - 1;                        // frame f's block towards the frame before
@@ -294,16 +295,17 @@ __global__ __launch_bounds__(64, 1) void k_lm_step_quad(StepArgs a) {
             constexpr int ws = P >> 2, part = P & 3;
             if (k >= 0 && (part < 3 || lane < (PIS - 3 * 128) / 2))
                 __builtin_amdgcn_global_load_lds(PI0 + rPI[ws] + (unsigned)(k * PIS) + lane2, (lds_t)(S + S_IMU + ws * PIS), 16, part * 1024, 0);
-        } else if constexpr (P < 24) {              // wheel partial: 2 pieces per row
-            constexpr int ws = (P - 16) >> 1, part = (P - 16) & 1;
-            if (k >= 0 && (part == 0 || lane < 22))
-                __builtin_amdgcn_global_load_lds(PW0 + rPW[ws] + (unsigned)(k * PWS) + lane2, (lds_t)(S + S_PW + ws * PWS), 16, part * 1024, 0);
-        } else if constexpr (P < 28) {              // laser group record, slots 36 .. 122
-            constexpr int ws = P - 24;
+        } else if constexpr (P < 20) {              // wheel partial: 1 piece per row
+            constexpr int ws = P - 16;
+            static_assert(PWS % 2 == 0 && PWS <= 128, "one piece");
+            if (k >= 0 && lane < PWS / 2)
+                __builtin_amdgcn_global_load_lds(PW0 + rPW[ws] + (unsigned)(k * PWS) + lane2, (lds_t)(S + S_PW + ws * PWS), 16, 0, 0);
+        } else if constexpr (P < 24) {              // laser group record, slots 36 .. 122
+            constexpr int ws = P - 20;
             if (lane < 43)
                 __builtin_amdgcn_global_load_lds(PL0 + rPL[ws] + (unsigned)(f * LP + 36) + lane2, (lds_t)(S + S_PL + ws * 86), 16, 0, 0);
         } else {                                    // ground partial, two rows per piece: lanes 0..25 row 2h, 26..51 row 2h+1
-            constexpr int h = P - 28;
+            constexpr int h = P - 24;
             // (signed lane part: row 2h+1's lanes start 52 doubles into the piece, and its window's offset may be 0)
             const unsigned ob = lane < 26 ? rPG[2 * h] : rPG[2 * h + 1];
             const long lo = (long)(f * PGS) + (lane < 26 ? lane2 : lane2 - 52);
@@ -319,7 +321,7 @@ __global__ __launch_bounds__(64, 1) void k_lm_step_quad(StepArgs a) {
     };
     auto prefetch = [&](int f) {                    // the whole frame at once (the first frame of the sweep)
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        sfor<0, 30>([&](auto PP) { piece(PP, f); });
+        sfor<0, QPIECES>([&](auto PP) { piece(PP, f); });
         prefetch_regs(f);
     };
     const double* SI = S + S_IMU + w * PIS;
@@ -356,8 +358,8 @@ __global__ __launch_bounds__(64, 1) void k_lm_step_quad(StepArgs a) {
             constexpr int r = KI(R);
             const double aD = SL[l15 ? 114 - 36 + r : r * 6 + j6];
             const double cD = SG[l15 ? r * 7 + 6 : r * 7 + j6];
-            const double bD = SW[l15 ? (6 + r) * 13 + 12 : (6 + r) * 13 + 6 + j6];
-            oW[r] = SW[j6 * 13 + 6 + r];
+            const double bD = SW[l15 ? PW_G(6 + r) : PW_JJ(r, j6)];
+            oW[r] = SW[PW_IJ(j6, r)];
             rL[r] = SL[72 - 36 + j6 * 6 + r];
             tS[r] = aD + (hasm ? bD : 0.0) + cD;
         });
@@ -479,7 +481,7 @@ __global__ __launch_bounds__(64, 1) void k_lm_step_quad(StepArgs a) {
             sfor<0, 15>([&](auto R) {           // (all LDS reads first: one round trip, not fifteen)
                 constexpr int r = KI(R);
                 cd[r] = SI[l15 ? PI_G + r : PI_II + tri_rc<r>(jc, cj)];
-                if constexpr (r < 6) cr[r] = SW[l15 ? r * 13 + 12 : r * 13 + j6];
+                if constexpr (r < 6) cr[r] = SW[l15 ? PW_G(r) : PW_II(r, j6)];
             });
             __builtin_amdgcn_sched_barrier(0);
             sfor<0, 15>([&](auto R) {

@@ -22,7 +22,8 @@ struct DevParams {
 // Partial-sum slots written by k_linearize, per buffer (doubles):
 //   PL[B][n][LP]   laser group (window, owning frame): Haa(36) Hbb(36) Hab(36) ga(6) gb(6) sum r^2 (1), pad -> 128
 //   PI[B][n-1][PIS] IMU block k (frames k,k+1): G = Y^T Y, Y = [J(15x30) | r]: blocks ii, jj (packed upper triangles), ij (15x15), g(30), sum r^2 -> 496
-//   PW[B][n-1][PWS] wheel block k: G 13x13 (Y = [J(3x12) | r]), pad -> 172
+//   PW[B][n-1][PWS] wheel block k: G = Y^T Y, Y = [J(3x12) | r]: blocks ii, ij, jj (6x6 each, row-major; the ji block is ij^T and not stored),
+//                   gradient (12), sum r^2 -> 121, pad -> 122   (a full 13x13 until round 3: 172)
 //   PG[B][n][PGS]   ground of frame i: n * G 7x7 (Y = [J(2x6) | r]), pad -> 52
 constexpr int LP = LIW_LASER_PARTIAL;
 constexpr int PIS = 496;
@@ -33,7 +34,13 @@ __host__ __device__ inline int pi_tri(int r, int c) {   // offset of entry (r, c
     const int lo = r < c ? r : c, hi = r < c ? c : r;
     return lo * 15 - (lo * (lo - 1)) / 2 + (hi - lo);
 }
-constexpr int PWS = 172;
+constexpr int PWS = 122;
+// entries of a wheel record: r, c < 6 index the pose entries of frame k (ii), of frame k+1 (jj), or one of each (ij: row = frame k)
+__host__ __device__ constexpr int PW_II(int r, int c) { return r * 6 + c; }
+__host__ __device__ constexpr int PW_IJ(int r, int c) { return 36 + r * 6 + c; }
+__host__ __device__ constexpr int PW_JJ(int r, int c) { return 72 + r * 6 + c; }
+__host__ __device__ constexpr int PW_G(int e) { return 108 + e; }   // e < 12: frame k's pose entries, then frame k+1's
+constexpr int PW_C = 120;
 constexpr int PGS = 52;
 constexpr int FTF = 32;   // frame transform record (k_frame_tf)
 
