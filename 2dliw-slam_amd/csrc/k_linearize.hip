@@ -714,39 +714,52 @@ __global__ __launch_bounds__(64, 2) void k_lin_all(LinArgs A, DevParams P, int G
 }
 
 // ids of the windows that are still iterating, in window order (deterministic): active[0] = count, active[1 ..] = ids; behind the list:
-// a ticket word and one flag byte per window.  Many SMALL work-groups: each pulls 256 `done` words (one cache line per window: LmState
-// is 15 kB) into the flag bytes, and the group that finishes last (ticket) scans the bytes and writes the list.  The first version was
-// ONE 1 024-thread group with 68 kB of LDS: behind the laser kernel (eight 17.5 kB waves per CU) it waited up to 0.9 ms for a CU to
-// drain, and the IMU / wheel / ground roles waited with it.
+// a ticket word and one 64-bit publication word per work-group.  Small work-groups (256 windows each: one cache line per window, LmState is
+// 15 kB): a group counts its live windows, PUBLISHES the count, adds up the counts of the groups in front of it as they appear (they were
+// dispatched earlier and are a few microseconds of work each) and writes its ids at that offset; the group that finishes last clears
+// the publication words for the next launch.  History: (1) ONE 1 024-thread group with 68 kB of LDS waited up to 0.9 ms for a CU to drain
+// behind the laser kernel; (2) small groups + a scan by the last group alone: 44 us per 24 576 windows (96 flag bytes per thread, serially).
 constexpr int COMPACT_MAX = 1 << 20;
-__host__ __device__ inline size_t compact_list_bytes(int B) { return sizeof(int) * ((size_t)B + 2) + (((size_t)B + 3) & ~(size_t)3); }
+__host__ __device__ inline size_t compact_pub_offset(int B) { return (sizeof(int) * ((size_t)B + 2) + 7) & ~(size_t)7; }
+__host__ __device__ inline size_t compact_list_bytes(int B) { return compact_pub_offset(B) + 8 * (((size_t)B + 255) / 256); }
 __global__ __launch_bounds__(256) void k_compact_active(int B, const LmState* lm, int* active) {
-    unsigned char* flags = reinterpret_cast<unsigned char*>(active + B + 2);
+    unsigned long long* pub = reinterpret_cast<unsigned long long*>(reinterpret_cast<char*>(active) + compact_pub_offset(B));
     int* ticket = active + B + 1;
-    __shared__ int cnt[256];
-    __shared__ int last;
-    const int t = threadIdx.x, b0 = (int)blockIdx.x * 256 + t;
-    if (b0 < B) flags[b0] = lm[b0].done ? 0 : 1;
-    __threadfence();                        // release (agent scope: the groups sit on different XCDs / L2s)
+    __shared__ int wcnt[4];
+    __shared__ int part[4];
+    const int t = threadIdx.x, lane = t & 63, wv = t >> 6, blk = (int)blockIdx.x, nblk = (int)gridDim.x;
+    const int b0 = blk * 256 + t;
+    const bool live = b0 < B && !lm[b0].done;
+    const unsigned long long m = __ballot(live);
+    const int before = __popcll(m & ((1ull << lane) - 1ull));       // live windows of this wave in front of this lane
+    if (lane == 0) wcnt[wv] = __popcll(m);
     __syncthreads();
-    if (t == 0) last = __hip_atomic_fetch_add(ticket, 1, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT) == (int)gridDim.x - 1;
-    __syncthreads();
-    if (!last) return;
-    __threadfence();                        // acquire
-    const int per = (B + 255) / 256, lo = t * per, hi = min(B, lo + per);
-    int c = 0;
-    for (int b = lo; b < hi; ++b) c += flags[b];
-    cnt[t] = c;
-    __syncthreads();
-    for (int o = 1; o < 256; o <<= 1) {     // inclusive scan
-        const int v = t >= o ? cnt[t - o] : 0;
-        __syncthreads();
-        cnt[t] += v;
-        __syncthreads();
+    const int bc = wcnt[0] + wcnt[1] + wcnt[2] + wcnt[3];
+    if (t == 0) __hip_atomic_store(pub + blk, ((unsigned long long)bc << 1) | 1ull, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+    // counts of the groups in front (bounded wait: a group that never shows up ends in a short list, not in a hung GPU)
+    int sum = 0;
+    for (int j = t; j < blk; j += 256) {
+        unsigned long long v = 0;
+        for (long polls = 0; polls < (1l << 24); ++polls) {
+            v = __hip_atomic_load(pub + j, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT);
+            if (v & 1ull) break;
+            __builtin_amdgcn_s_sleep(2);
+        }
+        sum += (int)(v >> 1);
     }
-    int pos = cnt[t] - c;
-    for (int b = lo; b < hi; ++b) if (flags[b]) active[1 + pos++] = b;
-    if (t == 255) { active[0] = cnt[255]; *ticket = 0; }
+    for (int o = 32; o > 0; o >>= 1) sum += __shfl_xor(sum, o, 64);
+    if (lane == 0) part[wv] = sum;
+    __syncthreads();
+    const int offset = part[0] + part[1] + part[2] + part[3];
+    int wbase = 0;
+    for (int q = 0; q < wv; ++q) wbase += wcnt[q];
+    if (live) active[1 + offset + wbase + before] = b0;
+    if (blk == nblk - 1 && t == 0) active[0] = offset + bc;
+    __syncthreads();
+    if (t == 0 && __hip_atomic_fetch_add(ticket, 1, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT) == nblk - 1) {
+        for (int j = 0; j < nblk; ++j) __hip_atomic_store(pub + j, 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(ticket, 0, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+    }
 }
 
 // laser block range of every (window, frame): first block of window b owned by a frame >= i

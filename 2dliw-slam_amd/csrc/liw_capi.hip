@@ -330,7 +330,7 @@ int liw_batch_lm_begin(liw_ctx* c, const liw_batch* b, int mode, int max_iters, 
     hipStream_t s = (hipStream_t)stream;
     launch_group_offsets(b->B, b->n, b->laser_off, b->laser_frame, v.group_off, s);
     launch_lm_begin(b->B, b->n, v.lm, c->last_iters, s);
-    (void)hipMemsetAsync(v.active + b->B + 1, 0, sizeof(int), s);   // ticket of k_compact_active
+    (void)hipMemsetAsync(v.active + b->B + 1, 0, compact_list_bytes_host(b->B) - sizeof(int) * ((size_t)b->B + 1), s);   // ticket + publication words of k_compact_active
     // IMU block records of this solve, packed once (the role kernel of large batches is HBM-bound; k_lin_all on a few windows reads the
     // caller's arrays); *imu_pk_bad != 0 (set here on the device) sends the role back to the full arrays
     if (b->n > 1 && b->eval_small) {
@@ -547,7 +547,7 @@ static int enqueue_solve(liw_ctx* c, const liw_batch* b, int mode, int K, void* 
     WsView v = make_view(ws, b->B, b->n, b->history_records);
     launch_group_offsets(b->B, b->n, b->laser_off, b->laser_frame, v.group_off, s);
     launch_lm_begin(b->B, b->n, v.lm, K, s);
-    (void)hipMemsetAsync(v.active + b->B + 1, 0, sizeof(int), s);   // ticket of k_compact_active
+    (void)hipMemsetAsync(v.active + b->B + 1, 0, compact_list_bytes_host(b->B) - sizeof(int) * ((size_t)b->B + 1), s);   // ticket + publication words of k_compact_active
     // (a few windows go through k_lin_all, whose IMU role reads the caller's arrays: nothing to pack)
     const bool pack = b->n > 1 && b->eval_small && !std::getenv("LIW_NO_IMU_PACK") && (long)b->B * (b->n - 1) >= 4096;
     if (pack) launch_imu_pack(b->B, b->n, b->imu_X, b->imu_J, b->imu_sqrtP, b->imu_Dt, v.imu_pk, v.imu_pk_bad, s);

@@ -78,7 +78,7 @@ struct WsView {
     double* history;      // [(records)][B][n][15] or null
     int history_records;
     int* active;          // [1 + B] compacted list of the windows still iterating (IMU / wheel / ground roles index their blocks over it);
-                          //    behind it the ticket word (zeroed by lm_begin) and flag bytes of k_compact_active
+                          //    behind it the ticket word and the per-group publication words of k_compact_active (zeroed by lm_begin)
     double* imu_pk;       // [B][n-1][IMU_PK] packed IMU block records of the solve in progress (launch_imu_pack, from liw_batch_lm_begin)
     int* imu_pk_bad;      // [0] != 0: some sqrt_inverse_P is not upper triangular -> the IMU role reads the caller's arrays;
                           // [1] != 0: some laser end point has a z component (launch_laser_z_scan)
@@ -253,7 +253,7 @@ void launch_lm_begin(int B, int n, LmState* lm, int max_iters, hipStream_t s);
 void launch_lm_step(const StepArgs& a, hipStream_t s);
 void launch_lm_step_quad(const StepArgs& a, hipStream_t s);   // k_lm_quad.hip: four windows per wave (INIT topology, large batches)
 bool lm_step_quad_fits(const StepArgs& a);
-size_t compact_list_bytes_host(int B);                // bytes of WsView::active (list + ticket + flag bytes)
+size_t compact_list_bytes_host(int B);                // bytes of WsView::active (list + ticket + publication words)
 bool lin_builds_active_list(int B, int eval_small);   // k_linearize.hip: does launch_linearize (with LM state) compact the active windows?
 void launch_lm_finish(const StepArgs& a, hipStream_t s);
 void launch_export_dense(const ExportArgs& a, hipStream_t s);
