@@ -324,7 +324,7 @@ def main():
     step_time_s = tm["step_ms"] * tm["step_launches"] * 1e-3
     step_bytes = (sm["read"] + sm["write"]) * step_window_launches
     step_roof = {"kernel": "k_lm_step_quad (normal-equation assembly + block-tridiagonal-arrow LM elimination + back substitution; four windows per wave)",
-                 "bound": "hbm: one wave per SIMD streams 30 KiB of partial records per frame through the CU's load path (first sweep, with the dependent pivot chains of the elimination exposed) and reads its back-substitution record back at ~4.8 TB/s chip-wide (second sweep); DESIGN 4",
+                 "bound": "one wave per SIMD (issuing in ~51 % of its cycles): the first sweep is the length of that wave's instruction stream with its latencies exposed, the second sweep reads the back-substitution record back at ~4.8 TB/s chip-wide (hbm); DESIGN 4",
                  "avg_launch_ms": round(tm["step_ms"], 5), "launches": tm["step_launches"],
                  "analytic_bytes_per_window_iteration": sm["read"] + sm["write"],
                  "achieved": round(step_bytes / step_time_s / 1e9, 2) if step_time_s > 0 else None, "peak": HBM_PEAK_GBS, "unit": "GB/s",
