@@ -144,7 +144,7 @@ __device__ __forceinline__ V3<double> mulc(const double* m, int ld, const V3<dou
 // PK: the block's inputs come from the packed records of the solve in progress (WsView::imu_pk, 1 536 B per block instead of the 3 728 B
 // of the caller's X / J / sqrt_inverse_P / Dt arrays: the role is HBM-bound, and those arrays are constant over the LM iterations).
 template <int ND, bool PK = false>
-__device__ __forceinline__ void imu_blocks(const LinArgs& A, const DevParams& P, int wave, double* lds) {
+__device__ __forceinline__ void imu_blocks(const LinArgs& A, const DevParams& P, int wave, double* lds, const int* const act) {
     constexpr int LPB = 9 / ND;
     constexpr int MAXB = 63 / LPB;
     typedef LJN<ND> JN;
@@ -152,13 +152,14 @@ __device__ __forceinline__ void imu_blocks(const LinArgs& A, const DevParams& P,
     const int f = g / (LPB / 3), e0 = ND == 3 ? 0 : g % 3;
     const int n = A.n, nb = n - 1, ipw = A.imu_per_wave;   // blocks per wave: IMU_PER_WAVE for throughput, fewer for latency
     // blocks are indexed over the windows that are still iterating (compacted list), so finished windows cost no lanes
-    const long total = (long)(A.active ? A.active[0] : A.B) * nb, gb0 = (long)wave * ipw;
+    // act: the compacted list of the windows still iterating, or null (index by window); the kernel checks that the list is complete
+    const long total = (long)(act ? act[0] : A.B) * nb, gb0 = (long)wave * ipw;
     if (gb0 >= total) return;
     const long gb = gb0 + blk;
     bool on = blk < ipw && gb < total;
     const int wi = on ? (int)(gb / nb) : 0, k = on ? (int)(gb % nb) : 0;
-    const int b = A.active ? A.active[1 + wi] : wi;
-    if (on && !A.active) on = window_live(A, b);
+    const int b = act ? act[1 + wi] : wi;
+    if (on && !act) on = window_live(A, b);
     double* rec = lds + (blk < MAXB ? blk : 0) * IMU_REC;
     const int sel_lane = (on && A.lm) ? (A.candidate ? 1 - A.lm[b].cur : A.lm[b].cur) : 0;   // partial buffer of this lane's block
     const int fk_lane = on ? b * nb + k : 0;                                                   // its record in the input / partial arrays
@@ -402,18 +403,18 @@ __device__ __forceinline__ void imu_blocks(const LinArgs& A, const DevParams& P,
 // run on LJN<3>.
 constexpr int WHEEL_PER_WAVE = 21;
 template <int ND>   // directions per lane: 3 (three lanes per block) or 1 (nine lanes per block, small batches), as in imu_blocks
-__device__ __forceinline__ void wheel_blocks(const LinArgs& A, const DevParams& P, int wave, double* lds) {
+__device__ __forceinline__ void wheel_blocks(const LinArgs& A, const DevParams& P, int wave, double* lds, const int* const act) {
     constexpr int LPB = 9 / ND;
     constexpr int MAXB = 63 / LPB;
     typedef LJN<ND> JN;
     const int lane = threadIdx.x & 63, blk = lane / LPB, g = lane % LPB;
     const int f = g / (LPB / 3), e0 = ND == 3 ? 0 : g % 3;   // f: 0 theta_i, 1 theta_j, 2 the relative translation; eg = e0 + e
     const int n = A.n, nb = n - 1;
-    const long total = (long)(A.active ? A.active[0] : A.B) * nb, gb = (long)wave * A.small_per_wave + blk;   // over the windows still iterating
+    const long total = (long)(act ? act[0] : A.B) * nb, gb = (long)wave * A.small_per_wave + blk;   // over the windows still iterating
     bool on = blk < A.small_per_wave && gb < total;
     const int wi = on ? (int)(gb / nb) : 0, k = on ? (int)(gb % nb) : 0;
-    const int b = A.active ? A.active[1 + wi] : wi;
-    if (on && !A.active) on = window_live(A, b);
+    const int b = act ? act[1 + wi] : wi;
+    if (on && !act) on = window_live(A, b);
     double* Y = lds + (blk < MAXB ? blk : 0) * 64;   // [3][13] then Dp [3][3] at 40, R_wi [3][3] at 49
     const size_t fk = on ? (size_t)b * nb + k : 0;
     if (on) {
@@ -571,14 +572,14 @@ __device__ __forceinline__ void wheel_blocks(const LinArgs& A, const DevParams& 
 // tf_w_o = make_tf(p, theta) * T_imu_to_wheel
 // 32 frames per wave, two lanes each: lane 0 the 3 directions of p, lane 1 of theta
 constexpr int GROUND_PER_WAVE = 32;
-__device__ __forceinline__ void ground_frames(const LinArgs& A, const DevParams& P, int wave, double* lds) {
+__device__ __forceinline__ void ground_frames(const LinArgs& A, const DevParams& P, int wave, double* lds, const int* const act) {
     const int lane = threadIdx.x & 63, sub = lane >> 1, g = lane & 1;
     const int n = A.n;
-    const long total = (long)(A.active ? A.active[0] : A.B) * n, gf = (long)wave * GROUND_PER_WAVE + sub;
+    const long total = (long)(act ? act[0] : A.B) * n, gf = (long)wave * GROUND_PER_WAVE + sub;
     bool on = gf < total;
     const int wi = on ? (int)(gf / n) : 0;
-    const int b = A.active ? A.active[1 + wi] : wi;
-    if (on && !A.active) on = window_live(A, b);
+    const int b = act ? act[1 + wi] : wi;
+    if (on && !act) on = window_live(A, b);
     double* Y = lds + sub * 16;   // [2][7]
     const size_t fi = on ? (size_t)b * n + (size_t)(gf % n) : 0;
     if (on) {
@@ -627,16 +628,17 @@ __host__ __device__ inline int imu_wave_count(int B, int n, int per_wave) { retu
 __host__ __device__ inline int wheel_wave_count(int B, int n, int per_wave) { return imu_wave_count(B, n, per_wave); }
 __host__ __device__ inline int ground_wave_count(int B, int n) { return (int)(((long)B * n + GROUND_PER_WAVE - 1) / GROUND_PER_WAVE); }
 template <int ND>
-__device__ __forceinline__ void small_role(const LinArgs& A, const DevParams& P, int vblock, double* lds) {
+__device__ __forceinline__ void small_role(const LinArgs& A, const DevParams& P, int vblock, double* lds, const int* const act) {
     const int nw = wheel_wave_count(A.B, A.n, A.small_per_wave);
-    if (vblock < nw) wheel_blocks<ND>(A, P, vblock, lds);
-    else ground_frames(A, P, vblock - nw, lds);
+    if (vblock < nw) wheel_blocks<ND>(A, P, vblock, lds, act);
+    else ground_frames(A, P, vblock - nw, lds, act);
 }
 constexpr int SMALL_LDS = WHEEL_PER_WAVE * 64 + 32;   // + 64 per-block meta words; >= GROUND_PER_WAVE * 16 + 32
 __global__ __launch_bounds__(64, 2) void k_lin_imu(LinArgs A, DevParams P) {
     __shared__ double lds[IMU_PER_WAVE * IMU_REC];
-    if (A.imu_pk && *A.imu_pk_bad == 0) imu_blocks<3, true>(A, P, (int)blockIdx.x, lds);   // (uniform)
-    else imu_blocks<3>(A, P, (int)blockIdx.x, lds);
+    const int* const act = usable_active_list(A.active, A.B);
+    if (A.imu_pk && *A.imu_pk_bad == 0) imu_blocks<3, true>(A, P, (int)blockIdx.x, lds, act);   // (uniform)
+    else imu_blocks<3>(A, P, (int)blockIdx.x, lds, act);
 }
 // Packed IMU block records of a solve (IMU_PK doubles per block, liw_kernels.hpp): one thread per entry; `bad` is raised when a
 // sqrt_inverse_P has a non-zero entry below its diagonal (not what imu_preintegraption.h:149 produces: the role then reads the full arrays).
@@ -682,7 +684,7 @@ void launch_imu_pack(int B, int n, const double* imu_X, const double* imu_J, con
 }
 __global__ __launch_bounds__(64, 2) void k_lin_small(LinArgs A, DevParams P) {
     __shared__ double lds[SMALL_LDS];
-    small_role<3>(A, P, (int)blockIdx.x, lds);
+    small_role<3>(A, P, (int)blockIdx.x, lds, usable_active_list(A.active, A.B));
 }
 __global__ void k_lm_reset(int B, LmState* lm, int max_iters) {
     const int b = blockIdx.x * blockDim.x + threadIdx.x;
@@ -703,9 +705,9 @@ __global__ __launch_bounds__(64, 2) void k_lin_all(LinArgs A, DevParams P, int G
 #endif
     if (v < n_laser) laser_wave_local<BOTH>(A, P, G, v);
     else if (A.small_nd == 1) {   // (uniform) one direction per lane: the short instruction stream a single window waits for
-        if (v < n_laser + n_imu) imu_blocks<1>(A, P, v - n_laser, lds); else small_role<1>(A, P, v - n_laser - n_imu, lds);
+        if (v < n_laser + n_imu) imu_blocks<1>(A, P, v - n_laser, lds, nullptr); else small_role<1>(A, P, v - n_laser - n_imu, lds, nullptr);
     } else {
-        if (v < n_laser + n_imu) imu_blocks<3>(A, P, v - n_laser, lds); else small_role<3>(A, P, v - n_laser - n_imu, lds);
+        if (v < n_laser + n_imu) imu_blocks<3>(A, P, v - n_laser, lds, nullptr); else small_role<3>(A, P, v - n_laser - n_imu, lds, nullptr);
     }
 #ifdef LIW_CLK
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
@@ -720,11 +722,12 @@ __global__ __launch_bounds__(64, 2) void k_lin_all(LinArgs A, DevParams P, int G
 // the publication words for the next launch.  History: (1) ONE 1 024-thread group with 68 kB of LDS waited up to 0.9 ms for a CU to drain
 // behind the laser kernel; (2) small groups + a scan by the last group alone: 44 us per 24 576 windows (96 flag bytes per thread, serially).
 constexpr int COMPACT_MAX = 1 << 20;
-__host__ __device__ inline size_t compact_pub_offset(int B) { return (sizeof(int) * ((size_t)B + 2) + 7) & ~(size_t)7; }
+__host__ __device__ inline size_t compact_pub_offset(int B) { return (sizeof(int) * ((size_t)B + 3) + 7) & ~(size_t)7; }   // list, ticket, status
 __host__ __device__ inline size_t compact_list_bytes(int B) { return compact_pub_offset(B) + 8 * (((size_t)B + 255) / 256); }
 __global__ __launch_bounds__(256) void k_compact_active(int B, const LmState* lm, int* active) {
     unsigned long long* pub = reinterpret_cast<unsigned long long*>(reinterpret_cast<char*>(active) + compact_pub_offset(B));
     int* ticket = active + B + 1;
+    int* status = active + B + 2;     // compact_status(): 1 = the list is complete, bit 1 = a group gave up waiting (consumers index by window)
     __shared__ int wcnt[4];
     __shared__ int part[4];
     const int t = threadIdx.x, lane = t & 63, wv = t >> 6, blk = (int)blockIdx.x, nblk = (int)gridDim.x;
@@ -745,6 +748,7 @@ __global__ __launch_bounds__(256) void k_compact_active(int B, const LmState* lm
             if (v & 1ull) break;
             __builtin_amdgcn_s_sleep(2);
         }
+        if (!(v & 1ull)) atomicOr(status, 2);   // this group's offset is wrong: the list is marked unusable, nobody reads it
         sum += (int)(v >> 1);
     }
     for (int o = 32; o > 0; o >>= 1) sum += __shfl_xor(sum, o, 64);
@@ -754,7 +758,7 @@ __global__ __launch_bounds__(256) void k_compact_active(int B, const LmState* lm
     int wbase = 0;
     for (int q = 0; q < wv; ++q) wbase += wcnt[q];
     if (live) active[1 + offset + wbase + before] = b0;
-    if (blk == nblk - 1 && t == 0) active[0] = offset + bc;
+    if (blk == nblk - 1 && t == 0) { active[0] = offset + bc; atomicOr(status, 1); }
     __syncthreads();
     if (t == 0 && __hip_atomic_fetch_add(ticket, 1, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT) == nblk - 1) {
         for (int j = 0; j < nblk; ++j) __hip_atomic_store(pub + j, 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);

@@ -1426,7 +1426,10 @@ __device__ __forceinline__ void pack_result_body(const PackArgs& a) {   // the w
     o += n * 12;
     if (a.marg) for (int e = t; e < 276; e += blockDim.x) o[e] = a.marg[e];
     // the sequence word goes LAST, behind a system-scope fence: a host that polls it in the page-locked record (liw_solve, zero-copy)
-    // sees the whole record — and what earlier kernels of the stream stored there — without waiting for the stream's completion signal
+    // sees the whole record — and what earlier kernels of the stream stored there — without waiting for the stream's completion signal.
+    // EVERY thread fences its own record stores before the barrier (the work-group-scope release of the barrier alone does not drain
+    // the other waves' stores, which travel through other L2 channels, to system scope)
+    __threadfence_system();
     __syncthreads();
     if (t == 0) { __threadfence_system(); __hip_atomic_store(hdr + 3, a.seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM); }
 }

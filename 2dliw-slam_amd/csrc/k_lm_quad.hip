@@ -7,7 +7,9 @@
 // in the same lanes — and lane 15 rides along in the O^T set with the gradient.  The broadcast of L[r][k] inside a row is the
 // DP-ALU's DPP operand (row_newbcast:r, the only DPP control 64-bit instructions take on gfx90a+):
 //     v_fmac_f64_dpp  a[r], -wk (row_newbcast:r), wk        ==   a[r] -= L[r][k] * wk     for 4 windows x 16 lanes in ONE instruction
-// at half the plain FMA rate (tools/ubench/dpp64.hip: 8.2 cycles), i.e. 2 cycles per window and row update instead of 12.  Rank-1
+// at the plain FMA's rate when consecutive instructions read different sources (tools/ubench/dpp64_rate.hip; the 8.2-cycle figure of
+// tools/ubench/dpp64.hip is the pattern where every instruction reads the same source register), i.e. one cycle per window and row
+// update instead of 12.  Rank-1
 // updates, the Schur products W^T W (next frame's tiles come out directly in the lane layout: no LDS, no MFMA operand tiles) and the
 // back-substitution operators L^-T W all take that form; nothing leaves the registers between assembly and the factor record.
 //
@@ -83,9 +85,11 @@ __global__ __launch_bounds__(64, 1) void k_lm_step_quad(StepArgs a) {
     // exactly the windows this step has to take), so that finished windows do not leave rows of a wave idle; else by index
     int b = (int)blockIdx.x * 4 + w;
     bool act;
-    if (a.use_active) {
-        act = b < a.w.active[0];
-        b = act ? a.w.active[1 + b] : 0;
+    const int* const alist = a.use_active ? usable_active_list(a.w.active, a.B) : nullptr;   // null: no complete list in this workspace
+    if (alist) {
+        act = b < alist[0];
+        b = act ? alist[1 + b] : 0;
+        if ((unsigned)b >= (unsigned)a.B) { act = false; b = 0; }
     } else {
         act = b < a.B;
         b = act ? b : a.B - 1;

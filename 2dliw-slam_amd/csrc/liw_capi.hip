@@ -338,7 +338,10 @@ int liw_batch_lm_begin(liw_ctx* c, const liw_batch* b, int mode, int max_iters, 
             launch_imu_pack(b->B, b->n, b->imu_X, b->imu_J, b->imu_sqrtP, b->imu_Dt, v.imu_pk, v.imu_pk_bad, s);
         else (void)hipMemsetAsync(v.imu_pk_bad, 0xff, sizeof(int), s);
     }
-    launch_laser_z_scan(b->Ltot, b->laser_pts, v.imu_pk_bad + 1, s);   // 2-D scans: the laser role skips the z planes
+    // 2-D scans: the laser role skips the z planes.  Only where that pays: the scan is a full pass over the 12 planes, a small or
+    // tracking-size batch saves less than that over its few linearisations (flag 1 = "has z": the role reads every plane)
+    if ((long)b->B * (b->n - 1) >= 4096) launch_laser_z_scan(b->Ltot, b->laser_pts, v.imu_pk_bad + 1, s);
+    else (void)hipMemsetAsync(v.imu_pk_bad + 1, 0xff, sizeof(int), s);
     HIPCHK(c, hipGetLastError());
     return LIW_OK;
 }
@@ -430,6 +433,13 @@ int liw_batch_solve_sharded(liw_ctx* c, const liw_batch* b, int mode, int max_it
         if (c->time_exchange) (void)hipEventRecord(next_event(c->ev_x, c->xev_used), s);
         return liw_batch_lm_join(c, stream);
     };
+    auto p2p_failed = [&]() -> int {   // blocking read of the peer-write error word (1 + rank whose flag never arrived)
+        int e = 0;
+        HIPCHK(c, hipMemcpyAsync(&e, c->p2p_err.p, sizeof(int), hipMemcpyDeviceToHost, s));
+        HIPCHK(c, hipStreamSynchronize(s));
+        if (e) return fail(c, LIW_EHIP, "peer-write exchange: a peer's flag never arrived (rank in p2p status)");
+        return LIW_OK;
+    };
     // windows still iterating at the last exchange: the trailer went through the same exchange, so every rank reads the same number and
     // takes the same decision without a second collective (blocking 8-byte read-backs, one per image)
     auto active = [&](long* out) -> int {
@@ -441,12 +451,7 @@ int liw_batch_solve_sharded(liw_ctx* c, const liw_batch* b, int mode, int max_it
             tot += v;
         }
         *out = (long)(tot + 0.5) / world;
-        if (p2p) {
-            int e = 0;
-            HIPCHK(c, hipMemcpyAsync(&e, c->p2p_err.p, sizeof(int), hipMemcpyDeviceToHost, s));
-            HIPCHK(c, hipStreamSynchronize(s));
-            if (e) return fail(c, LIW_EHIP, "peer-write exchange: a peer's flag never arrived (rank in p2p status)");
-        }
+        if (p2p) return p2p_failed();
         return LIW_OK;
     };
     if (int r = liw_batch_lm_begin(c, b, mode, K, ws, stream)) return r;
@@ -467,7 +472,11 @@ int liw_batch_solve_sharded(liw_ctx* c, const liw_batch* b, int mode, int max_it
         chunk *= 2;
     }
     if (int r = liw_batch_lm_step(c, b, mode, ws, stream)) return r;
-    return liw_batch_lm_finish(c, b, mode, ws, stream);
+    if (int r = liw_batch_lm_finish(c, b, mode, ws, stream)) return r;
+    // a flag that timed out in the LAST chunk (or in a solve short enough to have no read-back between chunks) is seen here: after the
+    // first timeout k_p2p_wait stops waiting, so the sums behind it may hold stale or partial peer images
+    if (p2p) return p2p_failed();
+    return LIW_OK;
 }
 /* native peer-write exchange: see include/liw_window.h */
 size_t liw_batch_p2p_area_doubles(int B, int n, int mode, int world) {
@@ -485,7 +494,14 @@ int liw_batch_p2p_setup(liw_ctx* c, int rank, int world, double* const* areas, u
     }
     if (c->p2p_err.ensure(sizeof(int))) return fail(c, LIW_ENOMEM, "hipMalloc");
     HIPCHK(c, hipMemset(c->p2p_err.p, 0, sizeof(int)));
-    c->p2p_rank = rank; c->p2p_world = world; c->p2p_epoch = 0;
+    // The exchange counter continues from what this rank's flag words already hold (all zero in a fresh area): a second setup on the
+    // same areas — or a new context on re-used ones — must not start again at 1 while the peers' words still carry the epochs of
+    // earlier exchanges, or the first waits would pass at once on stale images.  Exchanges are collective, so every rank reads the same
+    // maximum from its own words.
+    unsigned long long seen[P2P_MAX] = {0}, e0 = 0;
+    HIPCHK(c, hipMemcpy(seen, flags[rank], sizeof(unsigned long long) * (size_t)world, hipMemcpyDeviceToHost));
+    for (int r = 0; r < world; ++r) e0 = std::max(e0, seen[r]);
+    c->p2p_rank = rank; c->p2p_world = world; c->p2p_epoch = e0;
     return LIW_OK;
 }
 int liw_batch_p2p_status(liw_ctx* c, int* timed_out_rank_plus_1) {
@@ -750,6 +766,7 @@ int liw_set_window(liw_ctx* c, const liw_window* w) {
         const size_t ic = std::max(tot * 2, (size_t)65536), rc = std::max(readback * 2, (size_t)8192);
         if (hipHostMalloc(&c->pinned, 2 * ic + rc, hipHostMallocDefault) != hipSuccess) return fail(c, LIW_ENOMEM, "hipHostMalloc");
         c->img_cap = ic; c->readback_cap = rc; c->pinned_cap = 2 * ic + rc;
+        std::memset((char*)c->pinned + 2 * ic, 0, rc);   // the polled sequence word of a fresh read-back block must not hold a stale match
     }
     const int stage_id = c->img_valid ? 1 - c->img_cur : 0;
     char* stage = (char*)c->pinned + (size_t)stage_id * c->img_cap;

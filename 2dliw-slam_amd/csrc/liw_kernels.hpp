@@ -188,6 +188,16 @@ __device__ __forceinline__ double fast_rcp(double x) {     // v_rcp_f64 + two Ne
     return y;
 }
 
+// The compacted list of the windows still iterating (WsView::active) is usable when the status word behind it says so: 1 = complete;
+// 0 = no compaction has run in this workspace since liw_batch_lm_begin cleared it (a step driven by hand behind a stand-alone
+// linearisation, a fresh workspace); bit 1 = a group of k_compact_active gave up waiting for a predecessor (offsets wrong).  Consumers
+// then index by window — every launch is sized for that — so neither case reads an unfinished or uninitialised list.
+__device__ __forceinline__ const int* usable_active_list(const int* active, int B) {
+    if (!active) return nullptr;
+    const int st = __builtin_amdgcn_readfirstlane(active[B + 2]);
+    const int cnt = __builtin_amdgcn_readfirstlane(active[0]);
+    return (st == 1 && cnt >= 0 && cnt <= B) ? active : nullptr;
+}
 // is window b linearised by this launch?  (with a compacted `active` list the roles index live windows only and skip this test)
 __device__ __forceinline__ bool window_live(const LinArgs& A, int b) {
     if (A.gate) return A.gate[b].done != 0;

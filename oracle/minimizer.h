@@ -132,68 +132,100 @@ public:
     // non-constant block) is not finite: Ceres' ResidualBlock::Evaluate -> IsEvaluationValid rejects the evaluation then
     // (internal/ceres/residual_block.cc, array_utils.cc IsArrayValid).
     bool eval_ok = true;
+    // threads > 1 (oracle_set_threads; the all-cores CPU leg of bench.py): the residual blocks are evaluated by an OpenMP team — what
+    // Ceres does with Solver::Options::num_threads, which the reference leaves at 1 (src/factor/solver.cpp:798 is commented out) — and
+    // their contributions are then added to H, g and the cost by ONE thread in the same order as the serial path: identical bits.
+    int threads = 1;
+    struct BlockEval { std::vector<double> res, jbuf; bool ok = true; };
+    // one residual block at xv: residuals, (with_jac) Jacobian blocks in the tangent space of their parameter blocks, validity
+    void eval_block(int ri, const std::vector<double>& xv, bool with_jac, BlockEval& be) const {
+        const auto& rb = pr.rblocks[ri];
+        const int nb = int(rb.blocks.size());
+        const double* pp[16];
+        double* jp[16];
+        for (int b = 0; b < nb; ++b) pp[b] = &xv[pr.pblocks[rb.blocks[b]].amb_off];
+        be.ok = true;
+        be.res.assign(rb.n_res, 0.0);
+        if (!with_jac) {
+            rb.eval(pp, be.res.data(), nullptr);
+        } else {
+            int tot = 0;
+            for (int b = 0; b < nb; ++b) tot += pr.pblocks[rb.blocks[b]].size;
+            be.jbuf.assign(size_t(rb.n_res) * tot, 0.0);
+            int o = 0;
+            for (int b = 0; b < nb; ++b) { jp[b] = be.jbuf.data() + size_t(rb.n_res) * o; o += pr.pblocks[rb.blocks[b]].size; }
+            rb.eval(pp, be.res.data(), jp);
+            for (int b = 0; b < nb; ++b) {
+                const auto& pb = pr.pblocks[rb.blocks[b]];
+                if (pb.constant) continue;
+                for (int e = 0; e < rb.n_res * pb.size; ++e) if (!std::isfinite(jp[b][e])) be.ok = false;
+            }
+            // local parameterisation: J <- J * dPlus/ddelta
+            for (int b = 0; b < nb; ++b) {
+                const auto& pb = pr.pblocks[rb.blocks[b]];
+                if (pb.constant || !pb.so3) continue;
+                double P[9];
+                so3_plus_jacobian(pp[b], P);
+                for (int i = 0; i < rb.n_res; ++i) {
+                    double* row = jp[b] + i * 3;
+                    double t0 = row[0] * P[0] + row[1] * P[3] + row[2] * P[6];
+                    double t1 = row[0] * P[1] + row[1] * P[4] + row[2] * P[7];
+                    double t2 = row[0] * P[2] + row[1] * P[5] + row[2] * P[8];
+                    row[0] = t0; row[1] = t1; row[2] = t2;
+                }
+            }
+        }
+        for (int i = 0; i < rb.n_res; ++i) if (!std::isfinite(be.res[i])) be.ok = false;
+    }
+    // the block's share of H = J^T J, g = J^T r and sum r^2
+    void accumulate_block(int ri, bool with_jac, BlockEval& be, double& cost) {
+        const auto& rb = pr.rblocks[ri];
+        const int nb = int(rb.blocks.size());
+        if (with_jac) {
+            double* jp[16];
+            int o = 0;
+            for (int b = 0; b < nb; ++b) { jp[b] = be.jbuf.data() + size_t(rb.n_res) * o; o += pr.pblocks[rb.blocks[b]].size; }
+            for (int a = 0; a < nb; ++a) {
+                auto& pa = pr.pblocks[rb.blocks[a]];
+                if (pa.constant) continue;
+                for (int ka = 0; ka < pa.size; ++ka) {
+                    double gs = 0.0;
+                    for (int i = 0; i < rb.n_res; ++i) gs += jp[a][i * pa.size + ka] * be.res[i];
+                    g[pa.tan_off + ka] += gs;
+                }
+                for (int b = 0; b < nb; ++b) {
+                    auto& pb = pr.pblocks[rb.blocks[b]];
+                    if (pb.constant) continue;
+                    for (int ka = 0; ka < pa.size; ++ka)
+                        for (int kb = 0; kb < pb.size; ++kb) {
+                            double s = 0.0;
+                            for (int i = 0; i < rb.n_res; ++i) s += jp[a][i * pa.size + ka] * jp[b][i * pb.size + kb];
+                            H(pa.tan_off + ka, pb.tan_off + kb) += s;
+                        }
+                }
+            }
+        }
+        for (int i = 0; i < rb.n_res; ++i) cost += be.res[i] * be.res[i];
+        if (!be.ok) eval_ok = false;
+    }
     double evaluate(const std::vector<double>& xv, bool with_jac) {
         double cost = 0.0;
         eval_ok = true;
         if (with_jac) { H = DMat(n_tan, n_tan); g.assign(n_tan, 0.0); }
-        std::vector<double> res, jbuf;
-        std::vector<double> local(9 * 1);
-        for (int ri : active_r) {
-            auto& rb = pr.rblocks[ri];
-            const int nb = int(rb.blocks.size());
-            std::vector<const double*> pp(nb);
-            for (int b = 0; b < nb; ++b) pp[b] = &xv[pr.pblocks[rb.blocks[b]].amb_off];
-            res.assign(rb.n_res, 0.0);
-            if (!with_jac) {
-                rb.eval(pp.data(), res.data(), nullptr);
-            } else {
-                int tot = 0;
-                for (int b = 0; b < nb; ++b) tot += pr.pblocks[rb.blocks[b]].size;
-                jbuf.assign(size_t(rb.n_res) * tot, 0.0);
-                std::vector<double*> jp(nb);
-                int o = 0;
-                for (int b = 0; b < nb; ++b) { jp[b] = jbuf.data() + size_t(rb.n_res) * o; o += pr.pblocks[rb.blocks[b]].size; }
-                rb.eval(pp.data(), res.data(), jp.data());
-                for (int b = 0; b < nb; ++b) {
-                    auto& pb = pr.pblocks[rb.blocks[b]];
-                    if (pb.constant) continue;
-                    for (int e = 0; e < rb.n_res * pb.size; ++e) if (!std::isfinite(jp[b][e])) eval_ok = false;
-                }
-                // local parameterisation: J <- J * dPlus/ddelta
-                for (int b = 0; b < nb; ++b) {
-                    auto& pb = pr.pblocks[rb.blocks[b]];
-                    if (pb.constant || !pb.so3) continue;
-                    double P[9];
-                    so3_plus_jacobian(pp[b], P);
-                    for (int i = 0; i < rb.n_res; ++i) {
-                        double* row = jp[b] + i * 3;
-                        double t0 = row[0] * P[0] + row[1] * P[3] + row[2] * P[6];
-                        double t1 = row[0] * P[1] + row[1] * P[4] + row[2] * P[7];
-                        double t2 = row[0] * P[2] + row[1] * P[5] + row[2] * P[8];
-                        row[0] = t0; row[1] = t1; row[2] = t2;
-                    }
-                }
-                for (int a = 0; a < nb; ++a) {
-                    auto& pa = pr.pblocks[rb.blocks[a]];
-                    if (pa.constant) continue;
-                    for (int ka = 0; ka < pa.size; ++ka) {
-                        double gs = 0.0;
-                        for (int i = 0; i < rb.n_res; ++i) gs += jp[a][i * pa.size + ka] * res[i];
-                        g[pa.tan_off + ka] += gs;
-                    }
-                    for (int b = 0; b < nb; ++b) {
-                        auto& pb = pr.pblocks[rb.blocks[b]];
-                        if (pb.constant) continue;
-                        for (int ka = 0; ka < pa.size; ++ka)
-                            for (int kb = 0; kb < pb.size; ++kb) {
-                                double s = 0.0;
-                                for (int i = 0; i < rb.n_res; ++i) s += jp[a][i * pa.size + ka] * jp[b][i * pb.size + kb];
-                                H(pa.tan_off + ka, pb.tan_off + kb) += s;
-                            }
-                    }
-                }
+        const int nr = int(active_r.size());
+        if (threads > 1 && nr > 1) {
+            std::vector<BlockEval> all(nr);
+#if defined(_OPENMP)
+#pragma omp parallel for schedule(dynamic, 8) num_threads(threads)
+#endif
+            for (int k = 0; k < nr; ++k) eval_block(active_r[k], xv, with_jac, all[k]);
+            for (int k = 0; k < nr; ++k) accumulate_block(active_r[k], with_jac, all[k], cost);
+        } else {
+            BlockEval be;
+            for (int ri : active_r) {
+                eval_block(ri, xv, with_jac, be);
+                accumulate_block(ri, with_jac, be, cost);
             }
-            for (int i = 0; i < rb.n_res; ++i) { cost += res[i] * res[i]; if (!std::isfinite(res[i])) eval_ok = false; }
         }
         return 0.5 * cost;
     }
