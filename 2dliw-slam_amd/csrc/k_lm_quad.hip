@@ -18,6 +18,7 @@
 // windows of one batch: windows whose rotation vector left the |theta| <= pi ball (so3 Plus Jacobian != I, rare: Plus normalises) stay
 // on k_lm_step.  INIT and TRACK topologies.  Reference call sites: src/factor/solver.cpp:161-168 (init), :795-802 (tracking).
 #include <cstddef>
+#include <cstdlib>
 #include <type_traits>
 
 #include "liw_kernels.hpp"
@@ -62,9 +63,16 @@ __device__ __forceinline__ double row_max(double v) {
 // phase stamps (tools/clk_probe_quad.py): s_memtime of one wave at one frame of one LM iteration; dormant unless switched on
 __device__ long long g_qclk[64];
 __device__ int g_qclk_on[4];   // on, block, frame, iteration
+__device__ int g_qprobe;       // LIW_QUAD_PROBE (diagnosis only, results are wrong): bit 0 = every row reads window 0's partial records (cache-resident),
+                               // bit 1 = every row's back-substitution record is window 0's
 #define QSTAMP(id) do { if (clk_on && i == clk_frame) { if (lane == 0) g_qclk[(id)] = clock64(); } } while (0)
 
-constexpr int QTOT = 4 * (PIS + 86 + PWS + PGS);   // LDS doubles per wave: the prefetched partial records of its four rows (25.8 kB -> 6 waves per CU)
+#ifdef LIW_QUAD_TILE_ALIAS   // occupancy experiment only (WRONG results): the tile aliases the IMU record's ii block, LDS = the records alone
+constexpr int QTR = 0;
+#else
+constexpr int QTR = 4 * 15 * 6;                           // transposition tile of the carried arrow block (below)
+#endif
+constexpr int QTOT = 4 * (PIS + 86 + PWS + PGS) + QTR;   // LDS doubles per wave: the prefetched partial records of its four rows + the tile (27 072 B: six waves per CU)
 
 // offset of entry (r, j) inside a packed upper triangle of order 15, r a compile-time constant
 template <int R> __device__ __forceinline__ int tri_rc(int j, int cj) {   // cj = 14 j - j (j - 1) / 2
@@ -72,7 +80,10 @@ template <int R> __device__ __forceinline__ int tri_rc(int j, int cj) {   // cj 
     return R <= j ? cR + j : cj + R;
 }
 
-__global__ __launch_bounds__(64, 1) void k_lm_step_quad(StepArgs a) {
+#ifndef LIW_QUAD_OCC
+#define LIW_QUAD_OCC 1
+#endif
+__global__ __launch_bounds__(64, LIW_QUAD_OCC) void k_lm_step_quad(StepArgs a) {
     __shared__ double S[QTOT];
     const int lane = threadIdx.x & 63, j = lane & 15, w = lane >> 4;
     const int n = a.n;
@@ -234,11 +245,13 @@ __global__ __launch_bounds__(64, 1) void k_lm_step_quad(StepArgs a) {
     const double* const PI0 = a.w.PI[0];
     const double* const PW0 = a.w.PW[0];
     const double* const PG0 = a.w.PG[0];
-    const unsigned oPL = (unsigned)b * (unsigned)(n * LP) + (cur ? (unsigned)(a.w.PL[1] - a.w.PL[0]) : 0u);
-    const unsigned oPI = (unsigned)b * (unsigned)((n - 1) * PIS) + (cur ? (unsigned)(a.w.PI[1] - a.w.PI[0]) : 0u);
-    const unsigned oPW = (unsigned)b * (unsigned)((n - 1) * PWS) + (cur ? (unsigned)(a.w.PW[1] - a.w.PW[0]) : 0u);
-    const unsigned oPG = (unsigned)b * (unsigned)(n * PGS) + (cur ? (unsigned)(a.w.PG[1] - a.w.PG[0]) : 0u);
-    const unsigned oWS = (unsigned)b * (unsigned)(n * SOLVE_WS);
+    const unsigned bp = (g_qprobe & 1) ? 0u : (unsigned)b;
+    const unsigned oPL = bp * (unsigned)(n * LP) + (cur ? (unsigned)(a.w.PL[1] - a.w.PL[0]) : 0u);
+    const unsigned oPI = bp * (unsigned)((n - 1) * PIS) + (cur ? (unsigned)(a.w.PI[1] - a.w.PI[0]) : 0u);
+    const unsigned oPW = bp * (unsigned)((n - 1) * PWS) + (cur ? (unsigned)(a.w.PW[1] - a.w.PW[0]) : 0u);
+    const unsigned oPG = bp * (unsigned)(n * PGS) + (cur ? (unsigned)(a.w.PG[1] - a.w.PG[0]) : 0u);
+    const int qprobe = g_qprobe;
+    const unsigned oWS = (qprobe & 2) ? 0u : (unsigned)b * (unsigned)(n * SOLVE_WS);
     double* const WS = a.w.solve_ws;
     const unsigned oSC = oLM + LM_SCALE, oDG = oLM + LM_DIAG;
     const int jc = j < 15 ? j : 0;            // clamped column for addresses
@@ -276,9 +289,18 @@ __global__ __launch_bounds__(64, 1) void k_lm_step_quad(StepArgs a) {
     //   S_PL[w][86]    PL_f[36 .. 122): Hbb, Hab, ga, gb         1 piece per row (43 lanes)
     //   S_PW[w][122]   wheel partial of block (f-1, f)           1 piece per row (61 lanes; two until the record dropped its ji block)
     //   S_PG[w][52]    ground partial of frame f                 1 piece per two rows (26 lanes each)
+    // Round 4 measured what the staging costs and what does NOT change it (tools/quad_occ_probe2.sh, tools/quad_probe.py,
+    // tools/clk_probe_quad.py): issuing a frame's 26 pieces stalls the wave for ~4 k of its ~18.6 k cycles; with two waves per SIMD (a
+    // <= 256-register build, six waves per CU) the SAME phase takes 5 - 11 k per wave and the kernel is no faster — the other phases keep
+    // their length, so the ALUs are not what the waves share.  Plain global_load_dwordx4 into registers + ds_write_b128 (25 pieces, in three
+    // batches behind the elimination phases, or all at once held in AGPRs) stalls just as long at issue (~100 - 170 cycles per 1-KiB
+    // instruction): the CU's memory pipeline hands out ~8 B per clock — its share of what HBM delivers to this read / write mix
+    // (4.9 TB/s chip-wide during the sweep) — and whoever issues next waits for a slot.  Probes with the records aliased to one window
+    // (cache-resident) bound the memory share of the kernel at 21 %; the rest is the instruction stream.  The DMA form stays: it needs
+    // no registers.
     constexpr int QPIECES = 26;                     // IMU 16, wheel 4, laser 4, ground 2
-    constexpr int S_IMU = 0, S_PL = 4 * PIS, S_PW = S_PL + 4 * 86, S_PG = S_PW + 4 * PWS;
-    static_assert(S_PG + 4 * PGS <= QTOT, "LDS layout");
+    constexpr int S_IMU = 0, S_PL = 4 * PIS, S_PW = S_PL + 4 * 86, S_PG = S_PW + 4 * PWS, S_TR = S_PG + 4 * PGS;
+    static_assert(S_TR + QTR <= QTOT, "LDS layout");
     const unsigned rPL[4] = {(unsigned)__builtin_amdgcn_readlane(oPL, 0), (unsigned)__builtin_amdgcn_readlane(oPL, 16), (unsigned)__builtin_amdgcn_readlane(oPL, 32), (unsigned)__builtin_amdgcn_readlane(oPL, 48)};
     const unsigned rPI[4] = {(unsigned)__builtin_amdgcn_readlane(oPI, 0), (unsigned)__builtin_amdgcn_readlane(oPI, 16), (unsigned)__builtin_amdgcn_readlane(oPI, 32), (unsigned)__builtin_amdgcn_readlane(oPI, 48)};
     const unsigned rPW[4] = {(unsigned)__builtin_amdgcn_readlane(oPW, 0), (unsigned)__builtin_amdgcn_readlane(oPW, 16), (unsigned)__builtin_amdgcn_readlane(oPW, 32), (unsigned)__builtin_amdgcn_readlane(oPW, 48)};
@@ -332,12 +354,21 @@ __global__ __launch_bounds__(64, 1) void k_lm_step_quad(StepArgs a) {
     const double* SL = S + S_PL + w * 86;         // SL[e] = PL_f[36 + e]
     const double* SW = S + S_PW + w * PWS;
     const double* SG = S + S_PG + w * PGS;
+#ifdef LIW_QUAD_TILE_ALIAS
+    double* ST = S + S_IMU + w * PIS + PI_II;
+#else
+    double* ST = S + S_TR + w * 90;               // ST[c * 6 + q]: carried arrow block of the frame in front, row c (lane c), hub variable q
+#endif
 
-    double d[15], o[15], rr[15], cd[15], cr[15], D0[6];
-    double g0 = 0.0, gm = 0.0, ytg = 0.0, pdiag = 0.0, gsum = 0.0;
+    // The arrow block a frame hands to the frame in front of it (R' = -Wo^T Wr: 15 rows x 6 hub variables) is accumulated TRANSPOSED: lane c
+    // = its row c, register q = hub variable q — six registers and 90 DPP FMAs per frame instead of fifteen and 225 with the six busy
+    // lanes of the column layout — and turned into the column layout the elimination wants by one pass through LDS (6 writes, 15 reads).
+    // gsh (lane c < 15): the unscaled gradient share of block (i, i+1) that belongs to frame i (gradient max-norm, checksum).
+    double d[15], o[15], rr[15], cd[15], crt[6], D0[6];
+    double g0 = 0.0, gm = 0.0, ytg = 0.0, pdiag = 0.0, gsum = 0.0, gsh = 0.0;
     bool solved = true;
-    sfor<0, 15>([&](auto R) { constexpr int r = KI(R); cd[r] = 0.0; cr[r] = 0.0; });
-    sfor<0, 6>([&](auto R) { D0[KI(R)] = 0.0; });
+    sfor<0, 15>([&](auto R) { constexpr int r = KI(R); cd[r] = 0.0; });
+    sfor<0, 6>([&](auto R) { D0[KI(R)] = 0.0; crt[KI(R)] = 0.0; });
     const bool clk_on = g_qclk_on[0] && (int)blockIdx.x == g_qclk_on[1] && iteration == g_qclk_on[3];
     const int clk_frame = g_qclk_on[2];
     if (clk_k) g_qclk[13] = clock64();
@@ -410,27 +441,31 @@ __global__ __launch_bounds__(64, 1) void k_lm_step_quad(StepArgs a) {
             });
         }
         QSTAMP(2);
-        // ---- gradient max-norm of this frame, |x - Plus(x, -g)| (lane 15's registers hold the unscaled tangent gradient)
+        // ---- gradient max-norm of this frame, |x - Plus(x, -g)|, lane per entry: lane r takes entry r of the unscaled tangent gradient = the
+        //      share of block (i-1, i) + the pose blocks (lane 15's o registers, turned into a lane-per-entry vector through the LDS words of
+        //      the IMU record's ij block, which the assembly above has consumed) + the share of block (i, i+1) (gsh)
         QSTAMP(3);
         {
-            // (lane 15: o = the share of block (i-1, i) + the pose blocks, cr = the share of block (i, i+1) stashed by the previous step)
-            dpp_fence();
-            const double q0 = bc<3>(xq), q1 = bc<4>(xq), q2 = bc<5>(xq);
-            const double g3 = o[3] + cr[3], g4 = o[4] + cr[4], g5 = o[5] + cr[5];
-            const double a0 = q0 - g3, a1 = q1 - g4, a2 = q2 - g5;
-            double m3 = fabs(g3), m4 = fabs(g4), m5 = fabs(g5);     // |q - (q - g)| when Plus does not wrap
-            if (__any(proceed && l15 && !(a0 * a0 + a1 * a1 + a2 * a2 < 9.8))) {
-                const V3<double> nq = normalize_so3(V3<double>(a0, a1, a2));
-                m3 = fabs(q0 - nq.x); m4 = fabs(q1 - nq.y); m5 = fabs(q2 - nq.z);
+            double* GT = const_cast<double*>(SI) + PI_IJ;
+            if (l15) sfor<0, 15>([&](auto R) { constexpr int r = KI(R); GT[r] = o[r]; });
+            const double gt = gsh + (lm ? GT[jc] : 0.0);
+            double m = fabs(gt);                                   // |q - (q - g)| when Plus does not wrap (rotation entries), |g| elsewhere
+            {
+                const double av = xq - gt;
+                const double a2 = mul_nop(av, av);
+                const double s2 = bc<3>(a2) + bc<4>(a2) + bc<5>(a2);
+                if (__any(proceed && !(s2 < 9.8))) {
+                    dpp_fence();
+                    const V3<double> nq = normalize_so3(V3<double>(bc<3>(av), bc<4>(av), bc<5>(av)));
+                    if (j == 3) m = fabs(xq - nq.x);
+                    if (j == 4) m = fabs(xq - nq.y);
+                    if (j == 5) m = fabs(xq - nq.z);
+                }
             }
-            double m = fmax(fmax(fabs(o[0] + cr[0]), fabs(o[1] + cr[1])), fabs(o[2] + cr[2]));
-            m = fmax(m, fmax(fmax(m3, m4), m5));
-            if (is_const(i, 0)) m = 0.0;                                           // (constant pose: not a parameter of the problem)
-            sfor<6, 15>([&](auto R) { constexpr int r = KI(R); if (!is_const(i, r)) m = fmax(m, fabs(o[r] + cr[r])); });
+            if (!lm || is_const(i, j)) m = 0.0;                    // (constant blocks are not parameters of the problem)
             gm = fmax(gm, m);
-            // checksum of the assembled gradient (lane 15): a non-finite residual or Jacobian entry anywhere in the evaluation makes it non-finite
-            gsum += ((g3 + g4) + g5) + ((o[0] + cr[0]) + (o[1] + cr[1]) + (o[2] + cr[2]));
-            sfor<6, 15>([&](auto R) { constexpr int r = KI(R); gsum += o[r] + cr[r]; });
+            // checksum of the assembled gradient: a non-finite residual or Jacobian entry anywhere in the evaluation makes it non-finite
+            gsum += lm ? gt : 0.0;
         }
         // ---- LM diagonal (LevenbergMarquardtStrategy::ComputeStep): clamp(S H S, 1e-6, 1e32) at the last accepted point
         double dmp;
@@ -452,7 +487,7 @@ __global__ __launch_bounds__(64, 1) void k_lm_step_quad(StepArgs a) {
             const double rs = bc<r>(sci);
             d[r] = __builtin_fma(d[r], rs * sci, cd[r]) + ((j == r) ? dmp : 0.0);
             o[r] = __builtin_fma(o[r], rs * scm, l15 ? cd[r] : 0.0);
-            rr[r] = __builtin_fma(rr[r], rs * sc0, l15 ? 0.0 : cr[r]);
+            rr[r] = __builtin_fma(rr[r], rs * sc0, (l6 && i < n - 1) ? ST[r * 6 + j6] : 0.0);   // + the carried arrow block, column layout
         });
         if (i == 1) {   // frame 0 is both the chain neighbour and the arrow target: fold R^T into O^T
             sfor<0, 15>([&](auto R) { constexpr int r = KI(R); o[r] += rr[r]; rr[r] = 0.0; });
@@ -482,22 +517,26 @@ __global__ __launch_bounds__(64, 1) void k_lm_step_quad(StepArgs a) {
         QSTAMP(5);
         if (hasm) {
             dpp_fence();
+            double cw[6];
             sfor<0, 15>([&](auto R) {           // (all LDS reads first: one round trip, not fifteen)
                 constexpr int r = KI(R);
                 cd[r] = SI[l15 ? PI_G + r : PI_II + tri_rc<r>(jc, cj)];
-                if constexpr (r < 6) cr[r] = SW[l15 ? PW_G(r) : PW_II(r, j6)];
+                if constexpr (r < 6) cw[r] = SW[l15 ? PW_G(r) : PW_II(r, j6)];
             });
+            gsh = (lm ? SI[PI_G + jc] : 0.0) + (l6 ? SW[PW_G(j6)] : 0.0);   // frame i-1's unscaled gradient share, lane per entry
             __builtin_amdgcn_sched_barrier(0);
             sfor<0, 15>([&](auto R) {
                 constexpr int r = KI(R);
                 const double rs = bc<r>(scm);
                 double fi = cd[r];
-                if constexpr (r < 6) fi += (l6 || l15) ? cr[r] : 0.0;
+                if constexpr (r < 6) fi += (l6 || l15) ? cw[r] : 0.0;
                 cd[r] = fi * (rs * scm);
-                cr[r] = l15 ? fi : 0.0;            // lane 15 of the R^T set is idle: it carries frame i-1's unscaled gradient share (gradient max-norm)
-                pdiag = (j == r) ? cd[r] : pdiag;  // ... and this is its diagonal (LM diagonal of frame i-1)
+                pdiag = (j == r) ? cd[r] : pdiag;  // its diagonal (LM diagonal of frame i-1)
             });
+        } else {
+            gsh = 0.0;
         }
+        sfor<0, 6>([&](auto Q) { crt[KI(Q)] = 0.0; });
         // this frame is in registers: the next one streams in behind the elimination.  (Spreading the 30 pieces over the pivots of the
         // elimination was measured: each piece still costs ~130 ticks of issue there, no gain over the burst.)
         if (i >= 1) prefetch(i - 1);
@@ -535,11 +574,14 @@ __global__ __launch_bounds__(64, 1) void k_lm_step_quad(StepArgs a) {
             if (i >= 2) {
                 sfor<0, 15>([&](auto K) {
                     constexpr int k = KI(K);
-                    sfor<0, 15>([&](auto C) { constexpr int c = KI(C); fnma_bc<c>(cr[c], o[k], rr[k]); });
+                    sfor<0, 6>([&](auto Q) { constexpr int q = KI(Q); fnma_bc<q>(crt[q], rr[k], o[k]); });   // R'[c][q] -= Wr[k][q] Wo[k][c], lane c
                     sfor<0, 6>([&](auto C) { constexpr int c = KI(C); fnma_bc<c>(D0[c], rr[k], rr[k]); });
                     fnma_bc<15>(g0, o[k], rr[k]);
                 });
             }
+            // the arrow block for frame i-1 goes through LDS: lane c < 15 leaves its row, lanes q < 6 pick their column up at the next frame's
+            // scaling step (DS operations of a wave execute in order: no barrier)
+            if (lm) sfor<0, 6>([&](auto Q) { constexpr int q = KI(Q); ST[jc * 6 + q] = crt[q]; });
         }
         QSTAMP(8);
         // ---- back-substitution operators [Yo | yz] = L^-T [Wo | z], Yr = L^-T Wr in place (right-looking: once row r is final, every
@@ -568,11 +610,11 @@ __global__ __launch_bounds__(64, 1) void k_lm_step_quad(StepArgs a) {
     }
     if (clk_k) g_qclk[14] = clock64();
     dpp_fence();
-    const double gmax = bc<15>(gm);
+    const double gmax = row_max(gm);
     ytg = bc<15>(ytg);
     // ---- was the evaluation this linearisation came from valid?  (see k_lm_step: Ceres' IsEvaluationValid on the fused partial sums)
     {
-        const bool bad = !isfinite(bc<15>(gsum));
+        const bool bad = !isfinite(row_sum(gsum));
         if (proceed && bad) {   // IterationZero / HandleSuccessfulStep: evaluation failed -> FAILURE, the states the solve started from are handed back
             if (!fresh) for (int e = j; e < n * 15; e += 16) X[oX + (unsigned)e] = LMD[oLM + LM_X0 + (unsigned)e];
             if (j == 0) {
@@ -694,6 +736,8 @@ extern "C" void liw_debug_quad_clk(int on, int block, int frame, int iteration, 
     if (out) (void)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_qclk), sizeof(long long) * 64);
 }
 void launch_lm_step_quad(const StepArgs& a, hipStream_t s) {
+    static const int probe = [] { const char* e = getenv("LIW_QUAD_PROBE"); const int v = e ? atoi(e) : 0; if (v) (void)hipMemcpyToSymbol(HIP_SYMBOL(g_qprobe), &v, sizeof(v)); return v; }();
+    (void)probe;
     hipLaunchKernelGGL(k_lm_step_quad, dim3((a.B + 3) / 4), dim3(64), 0, s, a);
 }
 

@@ -24,6 +24,8 @@ struct DMat {
     const double* row(int i) const { return d.data() + size_t(i) * cols; }
 };
 
+inline int& dense_threads() { static int t = 1; return t; }   // OpenMP team of the dense kernels (oracle_set_threads; 1 = the reference's serial Eigen)
+
 // H = J^T J (all of it, like Eigen's general product — the reference does not exploit symmetry),
 // g = -J^T R.   J is rows x cols row-major.  Blocked over rows so that the update of a
 // (cols x cols) panel streams J once; inner loops are written for the auto-vectoriser.
@@ -61,6 +63,39 @@ inline void gemm_JtJ_dense(const DMat& J, DMat& H) {
     const int m = J.rows, n = J.cols;
     H = DMat(n, n);
     constexpr int RB = 8;
+    if (dense_threads() > 1) {   // every thread owns a band of rows of H and streams J once: same sums in the same order per entry
+        const int T = dense_threads();
+#if defined(_OPENMP)
+#pragma omp parallel for schedule(static) num_threads(T)
+#endif
+        for (int band = 0; band < T; ++band) {
+            const int a0 = int((long)n * band / T), a1 = int((long)n * (band + 1) / T);
+            int r = 0;
+            for (; r + RB <= m; r += RB) {
+                const double* j[RB];
+                for (int k = 0; k < RB; ++k) j[k] = J.row(r + k);
+                for (int a = a0; a < a1; ++a) {
+                    double* h = H.row(a);
+                    double c[RB];
+                    for (int k = 0; k < RB; ++k) c[k] = j[k][a];
+                    for (int b = 0; b < n; ++b) {
+                        double s = h[b];
+                        for (int k = 0; k < RB; ++k) s += c[k] * j[k][b];
+                        h[b] = s;
+                    }
+                }
+            }
+            for (; r < m; ++r) {
+                const double* j0 = J.row(r);
+                for (int a = a0; a < a1; ++a) {
+                    double* h = H.row(a);
+                    const double av = j0[a];
+                    for (int b = 0; b < n; ++b) h[b] += av * j0[b];
+                }
+            }
+        }
+        return;
+    }
     int r = 0;
     for (; r + RB <= m; r += RB) {
         const double* j[RB];
@@ -169,6 +204,10 @@ inline bool llt_lower(const DMat& A, DMat& L) {
         if (!(s > 0.0)) return false;
         const double d = std::sqrt(s);
         L(j, j) = d;
+        const int T = dense_threads();   // (rows below the pivot are independent dot products: same sums, same order, any team size)
+#if defined(_OPENMP)
+#pragma omp parallel for schedule(static) num_threads(T) if (T > 1 && n - j > 64)
+#endif
         for (int i = j + 1; i < n; ++i) {
             double t = A(i, j);
             const double* li = L.row(i);

@@ -45,6 +45,7 @@ struct Options {
     double parameter_tolerance = 1e-8;
     bool jacobi_scaling = true;
     int max_num_consecutive_invalid_steps = 5;
+    int num_threads = 1;   // Ceres Solver::Options::num_threads (Jacobian evaluation); the reference leaves it at 1 (solver.cpp:798 commented out)
 };
 
 struct IterationRecord {
@@ -118,7 +119,7 @@ public:
     std::vector<double> g;          // J^T r
     std::vector<double> scale;
 
-    Minimizer(Problem& p, const Options& o) : pr(p), opt(o) {}
+    Minimizer(Problem& p, const Options& o) : pr(p), opt(o) { threads = o.num_threads; }
 
     void plus(const std::vector<double>& xin, const std::vector<double>& delta, std::vector<double>& xout) const {
         xout = xin;

@@ -146,6 +146,9 @@ static void scatter_back(oracle_ctx* h) {
 
 void oracle_set_max_iterations(void* hv, int k) { ((oracle_ctx*)hv)->slv->options.max_num_iterations = k; }
 void oracle_set_dense_product(void* hv, int on) { ((oracle_ctx*)hv)->slv->dense_product = on != 0; }
+// OpenMP team for the residual-block evaluation of the LM loop (Ceres' num_threads) and the dense J^T J of the marginalisation:
+// bench.py's "one solve on all cores" CPU leg.  1 = the reference's configuration.
+void oracle_set_threads(void* hv, int t) { ((oracle_ctx*)hv)->slv->options.num_threads = t < 1 ? 1 : t; dense_threads() = t < 1 ? 1 : t; }
 
 // lvio_2d::solver::init_solve / solve / marginalization on a flat window; results scattered back in place
 void oracle_init_solve(void* hv, oracle_window_c* w) { oracle_ctx* h = (oracle_ctx*)hv; build_frames(h, w); h->slv->init_solve(h->frames); scatter_back(h); }

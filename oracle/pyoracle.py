@@ -185,6 +185,10 @@ class Oracle:
     def set_max_iterations(self, k):
         self.L.oracle_set_max_iterations(self.h, C.c_int(k))
 
+    def set_threads(self, t):
+        """OpenMP team for the residual-block evaluation (Ceres' num_threads) and the dense J^T J; 1 = the reference's configuration"""
+        self.L.oracle_set_threads(self.h, C.c_int(int(t)))
+
     def init_solve(self, w):
         self.L.oracle_init_solve(self.h, C.byref(w.c))
 
