@@ -390,7 +390,8 @@ class BatchSolver:
 
     def p2p_attach_ipc(self, mode):
         """one process per GPU: receive areas from hipMalloc, handles exchanged over torch.distributed, peers' areas mapped with hipIpc.
-        NOT exercised on the 1-GPU test box (hipIpcOpenMemHandle refuses a handle of the same process)."""
+        Exercised by two PROCESSES sharing the test box's one GPU (tests/test_gpu_p2p_ipc.py; hipIpcOpenMemHandle only refuses a handle
+        of its own process); across xGMI it has not run."""
         import torch.distributed as dist
         hip = C.CDLL("libamdhip64.so")
 
@@ -427,6 +428,7 @@ class BatchSolver:
                 ptrs.append(q.value)
             areas.append(ptrs[0]); flags.append(ptrs[1])
         dist.barrier(group=self.group)
+        self._p2p_ptrs = (areas, flags)
         self._p2p_set(mode, areas, flags, own)
 
     def exchange_timing(self):
@@ -454,6 +456,13 @@ class BatchSolver:
 
     def lm_finish(self, mode):
         self._chk(self.L.liw_batch_lm_finish(self.h, C.byref(self.b), C.c_int(mode), self._wsp(), self._stream()))
+
+    def time_kernels(self, mode, reps=3):
+        """liw_batch_time_kernels: ms of every kernel of one LM iteration launched alone over the whole batch (+ the marginalisation's)"""
+        out = (C.c_double * 6)()
+        self._chk(self.L.liw_batch_time_kernels(self.h, C.byref(self.b), C.c_int(mode), self._wsp(), self._stream(), C.c_int(reps), out))
+        self.torch.cuda.synchronize(self.dev)
+        return dict(zip(("k_lin_laser", "k_lin_imu", "k_lin_small", "k_lm_step", "k_marg_schur", "k_lin_laser_marg"), [float(v) for v in out]))
 
     def linearize(self, mode):
         self._chk(self.L.liw_batch_linearize(self.h, C.byref(self.b), C.c_int(mode), self._wsp(), self._stream()))

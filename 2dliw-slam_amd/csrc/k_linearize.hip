@@ -812,8 +812,9 @@ void launch_linearize(const LinArgs& A_, const DevParams& P, hipStream_t s, cons
     const int imu_waves = A.eval_small ? imu_wave_count(B, n, A.imu_per_wave) : 0;
     const int small_waves = A.eval_small ? wheel_wave_count(B, n, A.small_per_wave) + ground_wave_count(B, n) : 0;
     // large batches only: a single window gains nothing from the list and would pay one more launch per LM iteration
-    const bool compact = A.lm && A.active && lin_builds_active_list(B, A.eval_small);
-    if (!compact) A.active = nullptr;
+    const bool have_list = A.lm && A.active && lin_builds_active_list(B, A.eval_small);
+    const bool compact = have_list && (A.role_mask == 0 || (A.role_mask & 8));   // (a single timed role re-uses the list built in front of it)
+    if (!have_list) A.active = nullptr;
     // (also without the small roles — the older-frames laser evaluation of a marginalisation enqueued behind a tracking solve: the SAME
     // compiled body as the one-launch linearisation it must agree with bit for bit; the stand-alone k_lin_laser is a second compilation of
     // the body, whose FMA contraction may differ in the last bit)
@@ -836,10 +837,13 @@ void launch_linearize(const LinArgs& A_, const DevParams& P, hipStream_t s, cons
         hipStreamWaitEvent(fk->side[1], fk->ev_fork, 0);
     }
     hipStream_t s_imu = fork ? fk->side[0] : s, s_small = fork ? fk->side[1] : s;
-    if (A.mode == LIW_MODE_INIT) hipLaunchKernelGGL(k_lin_laser<true>, dim3((unsigned)laser_waves), dim3(64), 0, s, A, P, G);
-    else hipLaunchKernelGGL(k_lin_laser<false>, dim3((unsigned)laser_waves), dim3(64), 0, s, A, P, G);
-    if (imu_waves) hipLaunchKernelGGL(k_lin_imu, dim3((unsigned)imu_waves), dim3(64), 0, s_imu, A, P);
-    if (small_waves) hipLaunchKernelGGL(k_lin_small, dim3((unsigned)small_waves), dim3(64), 0, s_small, A, P);
+    const int rm = A.role_mask ? A.role_mask : 7;
+    if (rm & 1) {
+        if (A.mode == LIW_MODE_INIT) hipLaunchKernelGGL(k_lin_laser<true>, dim3((unsigned)laser_waves), dim3(64), 0, s, A, P, G);
+        else hipLaunchKernelGGL(k_lin_laser<false>, dim3((unsigned)laser_waves), dim3(64), 0, s, A, P, G);
+    }
+    if (imu_waves && (rm & 2)) hipLaunchKernelGGL(k_lin_imu, dim3((unsigned)imu_waves), dim3(64), 0, s_imu, A, P);
+    if (small_waves && (rm & 4)) hipLaunchKernelGGL(k_lin_small, dim3((unsigned)small_waves), dim3(64), 0, s_small, A, P);
     if (fork) {
         hipEventRecord(fk->ev_join[0], fk->side[0]);
         hipEventRecord(fk->ev_join[1], fk->side[1]);

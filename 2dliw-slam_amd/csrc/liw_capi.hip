@@ -672,6 +672,84 @@ int liw_batch_linearize(liw_ctx* c, const liw_batch* b, int mode, void* ws, void
     return LIW_OK;
 }
 
+/* profiling aid, see include/liw_window.h */
+int liw_batch_time_kernels(liw_ctx* c, const liw_batch* b, int mode, void* ws, void* stream, int reps, double* out_ms) {
+    NEEDDEV(c);
+    if (int r = check_batch(c, b, 2)) return r;
+    if (mode != LIW_MODE_INIT && mode != LIW_MODE_TRACK) return fail(c, LIW_EINVAL, "liw_batch_time_kernels: mode must be INIT or TRACK");
+    if (!out_ms || reps < 1) return fail(c, LIW_EINVAL, "liw_batch_time_kernels: out / reps");
+    hipStream_t s = (hipStream_t)stream;
+    WsView v = make_view(ws, b->B, b->n, b->history_records);
+    const int K = resolve_iters(c, mode, 0);
+    if (int r = liw_batch_lm_begin(c, b, mode, K, ws, stream)) return r;
+    const bool packed = true;
+    auto lin = [&](int cand, int mask) {
+        LinArgs A = lin_args(b, mode, cand ? v.x_cand : b->x, v, cand, true, packed);
+        A.role_mask = mask;
+        launch_linearize(A, c->dp, s, nullptr);          // (no fork: the kernel under the clock runs alone)
+    };
+    StepArgs st = step_args(c, b, mode, K, v);
+    lin(0, 0);
+    launch_lm_step(st, s);                                // the first step of a solve also builds the Jacobi scaling: not the one timed
+    lin(1, 0);
+    std::vector<hipEvent_t> ev((size_t)reps * 5 + 4);
+    for (auto& e : ev) HIPCHK(c, hipEventCreate(&e));
+    for (int r = 0; r < reps; ++r) {
+        hipEvent_t* e = &ev[(size_t)r * 5];
+        lin(1, 8);                                        // (the list of windows still iterating, as every linearisation of a solve builds it)
+        (void)hipEventRecord(e[0], s); lin(1, 1);
+        (void)hipEventRecord(e[1], s); lin(1, 2);
+        (void)hipEventRecord(e[2], s); lin(1, 4);
+        (void)hipEventRecord(e[3], s); launch_lm_step(st, s);
+        (void)hipEventRecord(e[4], s);
+    }
+    hipEvent_t* m = &ev[(size_t)reps * 5];
+    {   // marginalisation: its laser role (one pose free), then the chain Schur complement + eigen square root
+        launch_group_offsets(b->B, b->n, b->laser_off, b->laser_frame, v.group_off, s);
+        LinArgs A = lin_args(b, LIW_MODE_MARG, b->x, v, 0, false);
+        A.role_mask = 6;
+        launch_linearize(A, c->dp, s, nullptr);
+        (void)hipEventRecord(m[0], s);
+        A.role_mask = 1;
+        launch_linearize(A, c->dp, s, nullptr);
+        (void)hipEventRecord(m[1], s);
+    }
+    if (!c->prm.fast_mode) {
+        DevBuf tmp;
+        if (tmp.ensure(sizeof(double) * (size_t)b->B * (36 + 225 + 15))) return fail(c, LIW_ENOMEM, "hipMalloc");
+        // (a copy of the prior so that the measurement does not replace the caller's)
+        DevBuf pX, pJ, pR, pH;
+        if (pX.ensure(sizeof(double) * 15 * b->B) || pJ.ensure(sizeof(double) * 225 * b->B) || pR.ensure(sizeof(double) * 15 * b->B) || pH.ensure(sizeof(int) * b->B))
+            return fail(c, LIW_ENOMEM, "hipMalloc");
+        MargArgs a{};
+        a.B = b->B; a.n = b->n; a.x = b->x;
+        a.prior_X = b->prior_X; a.prior_J = b->prior_J; a.prior_R = b->prior_R; a.has_prior = b->has_prior;
+        a.out_X = pX.as<double>(); a.out_J = pJ.as<double>(); a.out_R = pR.as<double>(); a.out_has = pH.as<int>();
+        a.w = v; a.sqrt_H = tmp.as<double>(); a.Delta_H = a.sqrt_H + (size_t)36 * b->B; a.Delta_g = a.Delta_H + (size_t)225 * b->B; a.status = nullptr;
+        (void)hipEventRecord(m[2], s);
+        launch_marg_schur(a, s);
+        (void)hipEventRecord(m[3], s);
+        HIPCHK(c, hipStreamSynchronize(s));
+        tmp.release(); pX.release(); pJ.release(); pR.release(); pH.release();
+    } else {
+        (void)hipEventRecord(m[2], s); (void)hipEventRecord(m[3], s);
+    }
+    HIPCHK(c, hipStreamSynchronize(s));
+    for (int k = 0; k < 6; ++k) out_ms[k] = 0.0;
+    for (int r = 0; r < reps; ++r)
+        for (int k = 0; k < 4; ++k) {
+            float f = 0.f;
+            (void)hipEventElapsedTime(&f, ev[(size_t)r * 5 + k], ev[(size_t)r * 5 + k + 1]);
+            out_ms[k] += f / reps;
+        }
+    float f = 0.f;
+    (void)hipEventElapsedTime(&f, m[2], m[3]); out_ms[4] = f;
+    (void)hipEventElapsedTime(&f, m[0], m[1]); out_ms[5] = f;
+    for (auto e : ev) (void)hipEventDestroy(e);
+    HIPCHK(c, hipGetLastError());
+    return LIW_OK;
+}
+
 static PreintNoise preint_noise(const liw_params& prm) {
     PreintNoise N{};
     for (int k = 0; k < 3; ++k) {

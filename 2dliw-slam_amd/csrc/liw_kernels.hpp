@@ -116,6 +116,7 @@ struct LinArgs {
     const double* imu_pk;       // packed IMU block records (WsView::imu_pk) or null
     const int* imu_pk_bad;      //   ... usable iff *imu_pk_bad == 0
     const int* laser_hz;        // null, or -> 0 when no laser end point of the batch has a z component (2-D scans): the z planes are skipped
+    int role_mask;              // 0 = every role; else bit 0 laser, bit 1 IMU, bit 2 wheel + ground (liw_batch_time_kernels: one role kernel alone)
     // optional per-factor outputs (liw_eval_factors)
     double* dbg_laser_res; double* dbg_laser_jac; double* dbg_imu_res; double* dbg_imu_jac;
     double* dbg_wheel_res; double* dbg_wheel_jac; double* dbg_ground_res; double* dbg_ground_jac;

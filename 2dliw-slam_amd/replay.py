@@ -105,6 +105,28 @@ def write_log(path, msgs):
                 f.write(np.asarray(m["ranges"], dtype=np.float32).tobytes())
 
 
+def read_log(path):
+    """the messages of a flat log written by write_log / rosbag_reader.bag_to_flatlog, in file order"""
+    msgs = []
+    with open(path, "rb") as f:
+        raw = f.read()
+    o = 0
+    while o + 4 <= len(raw):
+        (ty,) = struct.unpack_from("<i", raw, o)
+        o += 4
+        if ty == 0:
+            v = struct.unpack_from("<7d", raw, o); o += 56
+            msgs.append(dict(type=0, time=v[0], acc=np.array(v[1:4]), gyro=np.array(v[4:7])))
+        elif ty == 1:
+            v = struct.unpack_from("<13d", raw, o); o += 104
+            msgs.append(dict(type=1, time=v[0], R=np.array(v[1:10]).reshape(3, 3), t=np.array(v[10:13])))
+        else:
+            t, amin, inc, tinc, nr = struct.unpack_from("<dfffi", raw, o); o += 24
+            rg = np.frombuffer(raw, dtype=np.float32, count=nr, offset=o).copy(); o += 4 * nr
+            msgs.append(dict(type=ty, time=t, angle_min=np.float32(amin), angle_increment=np.float32(inc), time_increment=np.float32(tinc), ranges=rg))
+    return msgs
+
+
 def read_tum(path):
     rows = [ln.split() for ln in open(path) if ln.strip() and not ln.startswith("#")]
     return np.array(rows, dtype=np.float64).reshape(-1, 8)

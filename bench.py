@@ -29,6 +29,7 @@ sys.path.insert(0, ROOT)
 
 # algorithmic bytes per residual block ("materialised-J" convention)
 BYTES_LASER_BOTH, BYTES_LASER_ONE, BYTES_IMU, BYTES_WHEEL, BYTES_GROUND, BYTES_STATE = 312, 216, 7448, 520, 60, 120
+PIS_BYTES, PWS_BYTES, LP_BYTES, PGS_BYTES = 496 * 8, 122 * 8, 128 * 8, 52 * 8   # partial-sum records (csrc/liw_kernels.hpp)
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8 TB/s
 
 
@@ -105,6 +106,100 @@ def make_batch(liw, synth, prm, B, n, L, seed0, n_base=64):
     return out
 
 
+def cpu_quota():
+    """CPUs this process may use: the cgroup CPU quota (v2 cpu.max, v1 cfs_quota_us / cfs_period_us) and the affinity mask — a box
+    can show 256 logical CPUs and grant 16"""
+    q = None
+    try:
+        with open("/sys/fs/cgroup/cpu.max") as f:
+            a, b = f.read().split()[:2]
+            q = None if a == "max" else float(a) / float(b)
+    except (OSError, ValueError):
+        try:
+            with open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us") as f, open("/sys/fs/cgroup/cpu/cpu.cfs_period_us") as g:
+                a, b = float(f.read()), float(g.read())
+                q = None if a <= 0 else a / b
+        except (OSError, ValueError):
+            q = None
+    try:
+        aff = len(os.sched_getaffinity(0))
+    except (AttributeError, OSError):
+        aff = os.cpu_count() or 1
+    return {"cgroup_cpu_quota": round(q, 2) if q else None, "affinity_cpus": aff, "logical_cpus": os.cpu_count()}
+
+
+def replay_leg(liw, synth, prm, path, seconds, keep, seed=11):
+    """BASELINE config C3 in one command: a flat sensor log (tools/replay_log's format; rosbag_reader.bag_to_flatlog
+    converts an OpenLORIS bag) through the C++ driver on the GPU and through the oracle's twin on the host, same run: frames / s side by
+    side, poses compared, the reference-shaped record table.  Default log: synthetic, corridor-rate sensors (IMU 200 Hz, odometry 20 Hz,
+    LaserScan 10 Hz).  keep = 1 is the reference's window policy (trajectory.cpp:590-617)."""
+    import struct
+    import subprocess
+    import tempfile
+    from oracle import pyoracle
+    replay = importlib.import_module("2dliw-slam_amd.replay")
+    tmp = tempfile.mkdtemp(prefix="liw_replay_")
+    if path:
+        msgs = replay.read_log(path)
+        src = "flat log %s" % os.path.basename(path)
+    else:
+        msgs, _ = replay.make_log(prm, duration=seconds, seed=seed)
+        path = os.path.join(tmp, "log.bin")
+        replay.write_log(path, msgs)
+        src = "synthetic corridor-rate log, %.0f s, seed %d (2dliw-slam_amd/replay.py)" % (seconds, seed)
+    exe = os.path.join(ROOT, "tools", "replay_log")
+    libdir = os.path.dirname(liw.LIB_PATH)
+    subprocess.check_call(["g++", "-O2", "-std=c++17", "-I", os.path.join(ROOT, "include"), os.path.join(ROOT, "tools", "replay_log.cpp"), "-o", exe,
+                           "-L", libdir, "-lliw_window", "-Wl,-rpath," + libdir, "-Wl,-rpath,/opt/rocm/lib"])
+    out = tmp + "/"
+    t0 = time.perf_counter()
+    r = subprocess.run([exe, path, out, "--keep", str(keep)] if keep != 1 else [exe, path, out], capture_output=True)
+    t_gpu = time.perf_counter() - t0
+    if r.returncode != 0:
+        return {"error": r.stderr.decode(errors="replace")[-300:]}
+    raw = open(out + "result.bin", "rb").read()
+    status, frames, tracked, inits, keyframes, sstat = struct.unpack("<6i", raw[:24])
+    lp = liw.laser.office_laser_params(prm)
+    orc = pyoracle.TrajectoryOracle(prm, lp, keep_window_size=keep)
+    t0 = time.perf_counter()
+    for m in msgs:
+        if m["type"] == 0:
+            orc.add_imu(m["time"], m["acc"], m["gyro"])
+        elif m["type"] == 1:
+            orc.add_wheel(m["time"], m["R"], m["t"])
+        else:
+            pts, ts = pyoracle.laser_to_points(m["ranges"], m["angle_min"], m["angle_increment"], m["time_increment"], m["time"])
+            orc.add_laser(m["time"], pts, ts)
+    t_cpu = time.perf_counter() - t0
+    c = orc.counters()
+    got = replay.read_tum(out + "fornt_end.txt")
+    ref = np.array([ln.split() for ln in orc.tum().splitlines()[1:]], dtype=np.float64).reshape(-1, 8)
+    m_ = min(len(got), len(ref))
+    err = np.abs(got[:m_, 1:] - ref[:m_, 1:]).max(axis=1) / max(1.0, np.abs(ref[:m_, 1:]).max()) if m_ else np.zeros(0)
+    beyond = np.nonzero(err > 1e-6)[0]
+    table = {}
+    try:
+        for ln in open(out + "traj.md"):
+            cells = [x.strip() for x in ln.strip().strip("|").split("|")]
+            if len(cells) >= 5 and cells[0] in ("solve", "marginalization", "spawn_scan", "match_line", "init_solve"):
+                table[cells[0]] = {"records": int(cells[1]), "max_us": float(cells[2]), "min_us": float(cells[3]), "aver_us": float(cells[4])}
+    except (OSError, ValueError):
+        pass
+    scans = sum(1 for m in msgs if m["type"] not in (0, 1))
+    return {"log": src, "messages": len(msgs), "laser_scans": scans, "keep_window_size": keep,
+            "gpu": {"seconds": round(t_gpu, 3), "scans_per_s": round(scans / t_gpu, 1), "frames": frames, "tracked": tracked, "initializations": inits,
+                    "note": "tools/replay_log: process start, log read, dispatch, pre-integration, laser front-end (host) and every solve / marginalisation (MI355X) included"},
+            "cpu_oracle": {"seconds": round(t_cpu, 3), "scans_per_s": round(scans / t_cpu, 1), "frames": c["frames"], "tracked": c["tracked"], "initializations": c["initializations"],
+                           "cores": 1},
+            "state_machine_identical": bool((frames, tracked, inits) == (c["frames"], c["tracked"], c["initializations"])),
+            "poses_compared": int(m_), "poses_within_1e-6_from_the_start": int(beyond[0]) if len(beyond) else int(m_),
+            "max_rel_pose_err": float("%.3e" % (float(err.max()) if m_ else 0.0)),
+            "max_position_difference_m": float("%.3e" % (float(np.abs(got[:m_, 1:4] - ref[:m_, 1:4]).max()) if m_ else 0.0)),
+            "note": "free-running replays are chaotic beyond their first frames — the oracle against itself with 1e-13 input noise departs the same way "
+                    "(tests/soak/sensitivity_replay.py, DESIGN 7); the 1e-6 statement on EVERY solve is teacher-forced in tests/test_gpu_replay.py",
+            "record_table_us": table}
+
+
 def _cpu_worker(job):
     """one host process = one oracle solving the same window `reps` times (window-parallel CPU throughput)"""
     prm, win, reps, iters = job
@@ -178,8 +273,13 @@ def main():
     ap.add_argument("--laser", type=int, default=2000)
     ap.add_argument("--iters", type=int, default=50, help="LM iteration cap (Ceres default 50)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-reps", type=int, default=30, help="timed solves of the 1-core CPU leg (after --cpu-warmup untimed ones)")
-    ap.add_argument("--cpu-warmup", type=int, default=3)
+    ap.add_argument("--cpu-reps", type=int, default=200, help="timed solves of the 1-core CPU leg (after --cpu-warmup untimed ones; SURVEY 8d: >= 200)")
+    ap.add_argument("--cpu-warmup", type=int, default=20, help="SURVEY 8d: >= 20")
+    ap.add_argument("--replay", nargs="?", const="", default=None, metavar="FLATLOG",
+                    help="C3 leg: replay a flat sensor log (default: a synthetic corridor-rate log of --replay-seconds) through the C++ driver on the "
+                         "GPU and the oracle twin on the host; runs by default at N = 1 unless --no-single")
+    ap.add_argument("--replay-seconds", type=float, default=60.0)
+    ap.add_argument("--replay-keep", type=int, default=1, help="frames kept after a tracking solve (1 = the reference's policy; 29 = the C3 30-KF window)")
     ap.add_argument("--distinct", type=int, default=64, help="fully generated windows with distinct seeds per rank (the rest of the batch tiles them with state jitter)")
     ap.add_argument("--gate-windows", type=int, default=4, help="windows of the timed batch whose results are checked against the oracle (parity gate)")
     ap.add_argument("--cpu-procs", type=int, default=64, help="processes of the all-cores CPU baseline leg (capped at the core count)")
@@ -391,6 +491,58 @@ def main():
                 "stopped_on_function_tolerance_pct": round(100.0 * float((tmc == 2).mean()), 1),
                 "note": "states = truth + scale x (C2 perturbation); same factors, same kernels; untimed-region side measurement (one pass)"}
 
+    # ---- every kernel of an LM iteration ALONE over the whole batch (all windows active), HIP events inside the library: the per-role
+    #      bounds the concurrent bracket above cannot show.  MFMA counts are static properties of the kernels
+    #      (20 v_mfma_f64_16x16x4 per IMU block: 8 whitening + 12 Gram; 4 per eliminated frame in the marginalisation chain), confirmed by
+    #      the SQ_INSTS_MFMA pass in profiles/ (tools/pmc_stall_passes.sh)
+    ktimes = None
+    if rank == 0 and world == 1 and not args.no_single:
+        bs.t["x"].copy_(x0); bs.t["match_pose"].copy_(mp0); bs.t["has_prior"].zero_()
+        kt = bs.time_kernels(liw.LIW_MODE_INIT, 3)
+        F64 = 78.6e12
+        mf = 2048.0                                    # flops of one v_mfma_f64_16x16x4_f64
+        lb, ib = B * L, B * (n - 1)
+        ris = pmcj.get("role_issue_stats", {}) if pmcj else {}
+
+        def issue(k):
+            return (ris.get(k) or {}).get("active_inst_frac")
+        t = {k: v * 1e-3 for k, v in kt.items()}
+        laser_flops = 500.0                            # essential fp64 flops of one laser_factor block (2-D scan, both poses free): 32 world points,
+        #                                                15 line direction, 81 its three rotation derivatives, 2 x 78 rows, 180 pair products, 28 lengths / weight
+        ktimes = {
+            "batch": B, "note": "each kernel launched alone, every window active (HIP events, 3 repeats); fractions are of the 78.6 TFLOP/s fp64 peak "
+                                "(vector = matrix on MI355X, and they share the pipe: tools/ubench/mfma_valu_f64)",
+            "k_lin_laser": {"ms": round(kt["k_lin_laser"], 4), "algorithmic_GBps": round(lb * BYTES_LASER_BOTH / t["k_lin_laser"] / 1e9, 1),
+                            "frac_laser_only": round(lb * BYTES_LASER_BOTH / t["k_lin_laser"] / 1e9 / HBM_PEAK_GBS, 4),
+                            "frac_laser_only_note": "SURVEY 8d's materialised-J bytes (312 B per block) over a kernel that never writes a Jacobian: a value above 1 says the CONVENTION, not the HBM, is what this figure measures",
+                            "read_GBps": round(lb * 72.0 / t["k_lin_laser"] / 1e9, 1), "essential_flops_per_block": laser_flops,
+                            "flops_frac": round(lb * laser_flops / t["k_lin_laser"] / F64, 4),
+                            "instructions_per_64_block_chunk": "~1000 issued for ~290 essential fp64 instructions: the rest is the per-group wave reduction (~260 per group end), the second masked round of pair products where a chunk straddles two groups (90), transform reads from LDS (~60), address / mask bookkeeping",
+                            "valu_issue_frac": issue("k_lin_laser"), "bound": "fp64 VALU issue (two waves per SIMD)"},
+            "k_lin_imu": {"ms": round(kt["k_lin_imu"], 4), "mfma_insts": int(ib * 20), "mfma_util": round(ib * 20 * mf / t["k_lin_imu"] / F64, 4),
+                          "flops_frac": round(ib * (20 * mf + 3 * 2600.0) / t["k_lin_imu"] / F64, 4), "valu_issue_frac": issue("k_lin_imu"),
+                          "bound": "fp64 pipe shared by MFMA and VALU (their times add), two waves per SIMD"},
+            "k_lin_small": {"ms": round(kt["k_lin_small"], 4), "valu_issue_frac": issue("k_lin_small"), "bound": "VALU issue / partial-sum writes"},
+            "k_lm_step": {"ms": round(kt["k_lm_step"], 4), "flops_frac": round(B * step_model(n)["flops"] / t["k_lm_step"] / F64, 4),
+                          "analytic_GBps": round(B * (step_model(n)["read"] + step_model(n)["write"]) / t["k_lm_step"] / 1e9, 1)},
+            "roofline_schur": {"kernel": "k_marg_schur (chain Schur complement of frames 0..n-2 onto the newest frame + 15x15 eigen square root)",
+                               "avg_launch_ms": round(kt["k_marg_schur"], 4), "mfma_insts": int(ib * 4),
+                               "mfma_util": round(ib * 4 * mf / t["k_marg_schur"] / F64, 5) if t["k_marg_schur"] > 0 else None,
+                               "bytes": int(B * ((n - 1) * (PIS_BYTES + PWS_BYTES) + n * (LP_BYTES + PGS_BYTES))),
+                               "GBps": round(B * ((n - 1) * (PIS_BYTES + PWS_BYTES) + n * (LP_BYTES + PGS_BYTES)) / t["k_marg_schur"] / 1e9, 1) if t["k_marg_schur"] > 0 else None,
+                               "note": "the reference's dense 6 337 x 450 J^T J (2.57 GFLOP) + 435^3 LU inverse is a 29-step chain of 15x15 eliminations here (~0.25 MFLOP per window): the Schur step is "
+                                       "latency-bound on one wave per window and its matrix-core share is small by construction"},
+            "k_lin_laser_marg": {"ms": round(kt["k_lin_laser_marg"], 4)},
+            "iteration_serial_ms": round(kt["k_lin_laser"] + kt["k_lin_imu"] + kt["k_lin_small"] + kt["k_lm_step"], 4)}
+
+    # ---- C3 leg: sensor-log replay, GPU and CPU oracle in the same run
+    replay_out = None
+    if rank == 0 and world == 1 and (args.replay is not None or not args.no_single):
+        try:
+            replay_out = replay_leg(liw, synth, prm, args.replay or None, args.replay_seconds, args.replay_keep)
+        except Exception as e:   # a side measurement must never take the headline line down
+            replay_out = {"error": repr(e)[:300]}
+
     # ---- CPU baseline: the oracle (port of the reference algorithm) on the host cores, rank 0, N = 1 only
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
@@ -409,7 +561,19 @@ def main():
                "sample": "%d warm-up + %d timed x (init_solve + marginalization) of window seed 20240 (n=%d, L=%d), %d LM iterations total, %.1f s; "
                          "value = 1 / median" % (args.cpu_warmup, args.cpu_reps, n, L, it, float(secs.sum())),
                "median_ms": round(1e3 * med, 2), "p95_ms": round(1e3 * p95, 2), "mean_ms": round(1e3 * float(secs.mean()), 2),
-               "host_cpu_count": os.cpu_count(), "host_cpu_model": cpu_model}
+               "host_cpu_count": os.cpu_count(), "host_cpu_model": cpu_model, "host_cpu_quota": cpu_quota()}
+        # ONE solve on many cores: the oracle with an OpenMP team over the residual blocks (what Ceres' num_threads does; the reference leaves
+        # it at 1, solver.cpp:798) and over the rows of its dense Cholesky / J^T J — bit-identical results for any team size
+        try:
+            q = cpu["host_cpu_quota"]
+            team = int(max(1, min(q["affinity_cpus"], q["cgroup_cpu_quota"] or q["affinity_cpus"], 64)))
+            orc.set_threads(team)
+            s2, it2 = orc.time_solves_each(pyoracle.Window(windows[0]), 2, 10, args.iters, dense_product=True)
+            orc.set_threads(1)
+            cpu["one_solve_all_cores"] = {"threads": team, "solves_per_s": round(1.0 / float(np.median(s2)), 3), "median_ms": round(1e3 * float(np.median(s2)), 2),
+                                          "sample": "2 warm-up + 10 timed solves, OpenMP team over residual blocks / Cholesky rows / dense J^T J bands (oracle_set_threads)"}
+        except Exception as e:
+            cpu["one_solve_all_cores"] = {"error": str(e)[:160]}
         # the same port on ALL host cores, one independent window stream per core (the CPU analogue of the batched GPU run),
         # so that the batched ratio is not inflated by the reference's single-threadedness
         try:
@@ -428,7 +592,7 @@ def main():
             cpu["all_cores"] = {"processes": ncpu, "solves_per_s": round(sum(2.0 / t for t in secs), 2), "wall_s": round(wall, 1),
                                 "effective_cores": round(busy / wall, 1),
                                 "sample": "2 solves per process, window-parallel; rate = sum over processes of their own solve rates; "
-                                          "effective_cores = children CPU time / wall (the box may cap the CPU quota below the core count)"}
+                                          "effective_cores = children CPU time / wall (the box may cap the CPU quota below the core count: host_cpu_quota)"}
         except Exception as e:
             cpu["all_cores"] = {"error": str(e)[:160]}
 
@@ -621,9 +785,27 @@ def main():
                     sharded["p2p_exchange"] = res
                 else:
                     sharded["oneshot_exchange"] = res
+                if world > 1:
+                    # DESIGN 5's arithmetic for this record on one node (xGMI: ~153 GB/s per link and direction, ~10 us per collective launch + ~2 us
+                    # per hop), printed beside the measurement so that the first multi-GPU run judges itself
+                    xb = float(res["exchange_bytes_per_rank"])
+                    link, launch, hop = 153e9, 10e-6, 2e-6
+                    model = {"allreduce": launch + 2.0 * (world - 1) / world * xb / link + 2 * (world - 1) * hop,
+                             "oneshot": launch + xb / link + hop + world * xb / 5e12, "p2p": xb / link + hop + world * xb / 5e12}[xch]
+                    res["exchange_model_ms_per_iteration"] = round(1e3 * model, 4)
+                    res["exchange_measured_over_model"] = round(res["exchange_ms_per_iteration"] / (1e3 * model), 2) if model > 0 else None
+                    if xi == 0:
+                        sharded["exchange_model_ms_per_iteration"] = res["exchange_model_ms_per_iteration"]
+                        sharded["exchange_measured_over_model"] = res["exchange_measured_over_model"]
                 if world > 1 and xi == 1:   # what exchange="auto" would keep on this machine at this record size (collective + sum, timed once)
                     sharded["auto_exchange_pick"] = {k: (round(v, 4) if isinstance(v, float) else v) for k, v in sb.pick_exchange(liw.LIW_MODE_INIT).items()}
                 sb.close()
+            if world > 1:
+                ok_ws = dist.get_world_size() == args.gpus
+                ok_id = bool(sharded.get("states_identical_across_ranks")) and all(
+                    sharded[k]["states_identical_across_ranks"] for k in ("oneshot_exchange", "p2p_exchange") if k in sharded)
+                sharded["self_check"] = {"process_group_world_size_equals_gpus": bool(ok_ws), "states_identical_across_ranks_every_exchange": bool(ok_id),
+                                         "passed": bool(ok_ws and ok_id)}
         except Exception as e:   # never lose the headline line because of the secondary measurement
             import traceback
             sharded = {"error": repr(e)[:300], "trace": traceback.format_exc()[-600:]}
@@ -665,9 +847,24 @@ def main():
             out["tracking_frame_latency"] = tracking
         if keepn:
             out["keep30_tracking_frame_latency"] = keepn
+            out["keep30_tracking_frame_latency"]["note"] = "keep-N is this repository's window policy for BASELINE C3 / C5, not a reference behaviour (the reference keeps 1 frame)"
+        if ktimes:
+            out["kernel_times"] = ktimes
+            out["roofline_schur"] = ktimes["roofline_schur"]
+            out["roofline"]["frac_laser_only"] = ktimes["k_lin_laser"]["frac_laser_only"]
+            out["roofline"]["mfma_util_k_lin_imu"] = ktimes["k_lin_imu"]["mfma_util"]
+        if replay_out:
+            out["c3_replay"] = replay_out
         if sharded:
             out["factor_sharded"] = sharded
         print(json.dumps(out))
+        if sharded and sharded.get("self_check") and not sharded["self_check"]["passed"]:
+            # the factor-sharded ranks must agree bit for bit and the process group must be the one asked for: a multi-GPU line that fails
+            # its own check is not a measurement
+            sys.stderr.write("bench.py: factor_sharded.self_check failed: %s\n" % json.dumps(sharded["self_check"]))
+            if world > 1:
+                dist.destroy_process_group()
+            sys.exit(5)
     if world > 1:
         dist.destroy_process_group()
 

@@ -194,6 +194,12 @@ int liw_batch_set_max_iters(liw_ctx* ctx, int mode, int max_iters); /* cap enfor
 /* stand-alone linearisation at b->x (partials "current", no LM state): what liw_linearize and the bench kernel
  * timing use */
 int liw_batch_linearize(liw_ctx* ctx, const liw_batch* b, int mode, void* ws, void* stream);
+/* Profiling aid (bench.py `kernel_times`; no reference counterpart): average device time in ms — HIP events on `stream`, `reps` repeats —
+ * of the kernels of ONE LM iteration of the batch as it stands (every window active), each launched ALONE back to back, and of the
+ * marginalisation: out_ms[0] laser role, [1] IMU role, [2] wheel + ground role, [3] the LM step (not the first of the solve, which also
+ * builds the Jacobi scaling), [4] chain Schur complement + eigen square root (k_marg_schur), [5] laser role of the marginalisation
+ * topology.  Opens a solve (liw_batch_lm_begin) and moves b->x along `reps` + 1 LM steps; the caller's prior is left alone. */
+int liw_batch_time_kernels(liw_ctx* ctx, const liw_batch* b, int mode, void* ws, void* stream, int reps, double* out_ms);
 int liw_batch_lm_begin(liw_ctx* ctx, const liw_batch* b, int mode, int max_iters, void* ws, void* stream);
 int liw_batch_lm_linearize(liw_ctx* ctx, const liw_batch* b, int mode, int candidate, void* ws, void* stream);
 int liw_batch_lm_step(liw_ctx* ctx, const liw_batch* b, int mode, void* ws, void* stream);
