@@ -6,7 +6,7 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libliw_window.so")
-SOURCES = ["k_linearize.hip", "k_lm.hip", "k_lm_quad.hip", "k_preint.hip", "k_posegraph.hip", "liw_capi.hip", "liw_preint.cpp", "liw_laser.cpp", "liw_io.cpp", "liw_lie.cpp"]
+SOURCES = ["k_linearize.hip", "k_laser_slab.hip", "k_lm.hip", "k_lm_quad.hip", "k_preint.hip", "k_posegraph.hip", "liw_capi.hip", "liw_preint.cpp", "liw_laser.cpp", "liw_io.cpp", "liw_lie.cpp"]
 HEADERS = ["liw_dual.hpp", "liw_kernels.hpp", "k_lm_common.hpp", "k_lin_laser_body.inc", os.path.join("..", "..", "include", "liw_window.h"), os.path.join("..", "..", "include", "liw_laser.h"), os.path.join("..", "..", "include", "liw_io.h"), os.path.join("..", "..", "include", "liw_posegraph.h")]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wno-unused-result"]
 if os.environ.get("LIW_QUAD_OCC"):   # A/B aid: waves per SIMD the quad step kernel is compiled for

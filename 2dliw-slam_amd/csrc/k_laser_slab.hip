@@ -1,0 +1,292 @@
+// k_laser_slab.hip — the laser role for LARGE batches of 2-D scans, init topology: a LANE is one (window, owning frame) group (gfx950, fp64).
+//
+// k_lin_laser (k_linearize.hip) makes a lane one laser_factor block and reduces every group's 45 pair totals across the wave: ~1 000 issued
+// instructions per 64 blocks, of which ~290 are the block's own arithmetic — the rest is the per-group wave reduction (~260 per group end),
+// the second masked round of pair products where a 64-block chunk straddles two groups, the transform records re-read from LDS, masks.
+// With thousands of windows in a batch there is a mapping without any of that: lane l of a wave is window 64 s + l of slab s, the wave is
+// one owning frame f of that slab, and every lane walks the blocks of ITS (window, frame) group one after the other — pair products
+// accumulate in the lane's own registers in block order (the order of the reference's sequential loop over residual blocks,
+// src/factor/solver.cpp:93-106), no cross-lane reduction, no group boundaries, the transform record of the lane's own pose in registers.
+// What that needs is block j of 64 DIFFERENT windows on consecutive addresses: liw_batch_lm_begin re-packs the caller's component-major
+// end-point planes once per solve (k_laser_slab_pack, the inputs are constant over the LM iterations) into rows
+//     row (s, f, j) = [8 planes: l1p1.x l1p1.y l1p2.x l1p2.y l2p1.x l2p1.y l2p2.x l2p2.y][64 lanes]          (4 KiB, lane-linear)
+// so that a row is eight coalesced 512-byte loads.  Rows of a (slab, frame) are padded to the slab's longest group.
+// Same per-block arithmetic as k_lin_laser_body.inc (reference src/factor/laser_factor.h:45-89, src/utilies/common.h:86-95 incl. the NaN
+// of a point exactly on the line); the sums differ from k_lin_laser's tree order by round-off only (tests/test_gpu_laser_slab.py).
+#include "liw_kernels.hpp"
+
+namespace liw {
+
+namespace {
+
+// compact frame transform record of a 2-D scan: rows 0,1 x columns 0,1 of make_tf(p, theta) * T_imu_to_laser and their three d/d theta_k
+//   [0..3] M[r][c]   [4..5] t[r]   [6 + 4k + 2r + c] dM_k[r][c]   [18 + 2k + r] dt_k[r]
+constexpr int TF2 = 24;
+__device__ __forceinline__ void frame_tf2(const DevParams& P, const double* pose6, double* o) {
+    typedef LJN<3> J3;
+    const V3<J3> p = cast_v3<J3>(pose6);
+    const V3<J3> th(seed<3>(pose6[3], 0, true), seed<3>(pose6[4], 1, true), seed<3>(pose6[5], 2, true));
+    const Iso<J3> Twl = mul(make_tf(p, th), cast_iso<J3>(P.Ril, P.til));
+    const J3 tt[2] = {Twl.t.x, Twl.t.y};
+#pragma unroll
+    for (int r = 0; r < 2; ++r) {
+#pragma unroll
+        for (int c = 0; c < 2; ++c) {
+            o[r * 2 + c] = Twl.R(r, c).v;
+#pragma unroll
+            for (int k = 0; k < 3; ++k) o[6 + 4 * k + 2 * r + c] = Twl.R(r, c).d[k];
+        }
+        o[4 + r] = tt[r].v;
+#pragma unroll
+        for (int k = 0; k < 3; ++k) o[18 + 2 * k + r] = tt[r].d[k];
+    }
+}
+
+// slot s of the 128-slot group record (liw_kernels.hpp) as (pair total | 64 if negated), -1 = structural zero; both poses free.
+// The constexpr twin of laser_slot_code<true>: a lane writes its own record, so the expansion is resolved at compile time.
+constexpr int slab_pairidx(int c1, int c2) { return c1 > c2 ? slab_pairidx(c2, c1) : c1 * 9 - c1 * (c1 - 1) / 2 + (c2 - c1); }
+constexpr int slab_col_a(int idx) { return idx < 2 ? idx : (idx == 2 ? -1 : idx - 1); }
+constexpr int slab_col_b(int idx) { return idx < 2 ? idx : (idx == 2 ? -1 : idx + 2); }
+constexpr int slab_slot_code(int s) {
+    if (s < 36) { const int ca = slab_col_a(s / 6), cb = slab_col_a(s % 6); return (ca >= 0 && cb >= 0) ? slab_pairidx(ca, cb) : -1; }
+    if (s < 72) {
+        const int ia = (s - 36) / 6, ib = (s - 36) % 6, ca = slab_col_b(ia), cb = slab_col_b(ib);
+        return (ca >= 0 && cb >= 0) ? (slab_pairidx(ca, cb) | (((ia < 2) != (ib < 2)) ? 64 : 0)) : -1;
+    }
+    if (s < 108) {
+        const int ia = (s - 72) / 6, ib = (s - 72) % 6, ca = slab_col_a(ia), cb = slab_col_b(ib);
+        return (ca >= 0 && cb >= 0) ? (slab_pairidx(ca, cb) | ((ib < 2) ? 64 : 0)) : -1;
+    }
+    if (s < 114) { const int ca = slab_col_a(s - 108); return ca >= 0 ? slab_pairidx(ca, 8) : -1; }
+    if (s < 120) { const int cb = slab_col_b(s - 114); return cb >= 0 ? (slab_pairidx(cb, 8) | ((s - 114 < 2) ? 64 : 0)) : -1; }
+    if (s == 120) return slab_pairidx(8, 8);
+    return -1;
+}
+template <int S_> __device__ __forceinline__ double slab_slot(const double* acc) {
+    constexpr int code = slab_slot_code(S_);
+    if constexpr (code < 0) return 0.0;
+    else if constexpr ((code & 64) != 0) return -acc[code & 63];
+    else return acc[code & 63];
+}
+template <int S_> __device__ __forceinline__ void slab_store(double* out, const double* acc) {
+    if constexpr (S_ < LP) {
+        typedef double __attribute__((ext_vector_type(2))) dbl2;
+        dbl2 v;
+        v.x = slab_slot<S_>(acc); v.y = slab_slot<S_ + 1>(acc);
+        *reinterpret_cast<dbl2*>(out + S_) = v;
+        slab_store<S_ + 2>(out, acc);
+    }
+}
+
+constexpr int SLAB = 64;
+constexpr int ROWD = 8 * SLAB;        // doubles per packed row
+
+}  // namespace
+
+// One wave per SIMD with the whole 512-entry register file: 45 accumulators, the two transform records and FIVE rows of end points in
+// flight (four rows = 16 KiB per wave ahead of the arithmetic: at four waves per CU that is what ~13 B per clock and CU of HBM share need
+// over ~2 us of latency); the block's arithmetic has the instruction-level parallelism (three rotation derivatives, two rows, 45
+// independent pair products) to keep the one wave issuing.  The <= 256-register build for two waves per SIMD spilled the rows in flight.
+__global__ __launch_bounds__(64, 1) void k_lin_laser_slab(LinArgs A, DevParams P) {
+    const int lane = threadIdx.x & 63, n = A.n;
+    const int s = (int)blockIdx.x / n, f = (int)blockIdx.x % n;
+    const int b = s * SLAB + lane;
+    bool in = b < A.B;
+    const int bb = in ? b : 0;
+    if (in) in = window_live(A, bb);
+    if (!__any(in)) return;
+    const int g0 = A.group_off[bb * (n + 1) + f], g1 = A.group_off[bb * (n + 1) + f + 1];
+    const bool fon = in && A.has_match[bb * n + f] != 0;
+    const int cnt = fon ? g1 - g0 : 0;
+    int maxc = cnt;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) maxc = max(maxc, __shfl_xor(maxc, o, 64));
+    maxc = __builtin_amdgcn_readfirstlane(maxc);
+    const int psel = (in && A.lm) ? (A.candidate ? 1 - A.lm[bb].cur : A.lm[bb].cur) : 0;
+    double ta[TF2], tb[TF2];    // transform records of pose a (frame 0 of the lane's window) and pose b (frame f)
+    if (in && maxc > 0) {
+        frame_tf2(P, A.x + (size_t)bb * n * 15, ta);
+        frame_tf2(P, A.x + ((size_t)bb * n + f) * 15, tb);
+    } else {
+#pragma unroll
+        for (int k = 0; k < TF2; ++k) { ta[k] = 0.0; tb[k] = 0.0; }
+    }
+    double acc[45];
+#pragma unroll
+    for (int e = 0; e < 45; ++e) acc[e] = 0.0;
+    const double* row0 = A.laser_pk + (size_t)A.laser_slab_off[(size_t)s * n + f] * ROWD + lane;
+    auto load_row = [&](double* q, int j) {
+        const double* r = row0 + (size_t)j * ROWD;
+#pragma unroll
+        for (int c = 0; c < 8; ++c) q[c] = r[c * SLAB];
+    };
+    const double w0 = P.laser_sqrt_info;
+#define TA(k) ta[(k)]
+#define TB(k) tb[(k)]
+    auto block = [&](const double* p) {     // one laser_factor block (k_lin_laser_body.inc, 2-D, both poses free): rows + pair products
+        const double d1x = p[0] - p[2], d1y = p[1] - p[3];
+        const double d2x = p[4] - p[6], d2y = p[5] - p[7];
+        const double l2 = fmin(d1x * d1x + d1y * d1y, d2x * d2x + d2y * d2y);
+        const double lmin25 = l2 > 0.0 ? 25.0 * (l2 * fast_rsqrt(l2)) : 0.0;
+        const double sum = lmin25 > 0.0 ? lmin25 * fast_rsqrt(lmin25) : 0.0;
+        double Ap[2], Bp[2], C[2][2];
+#pragma unroll
+        for (int r = 0; r < 2; ++r) {
+            Ap[r] = TA(4 + r) + TA(r * 2) * p[0] + TA(r * 2 + 1) * p[1];
+            Bp[r] = TA(4 + r) + TA(r * 2) * p[2] + TA(r * 2 + 1) * p[3];
+            C[0][r] = TB(4 + r) + TB(r * 2) * p[4] + TB(r * 2 + 1) * p[5];
+            C[1][r] = TB(4 + r) + TB(r * 2) * p[6] + TB(r * 2 + 1) * p[7];
+        }
+        const double ux = Bp[0] - Ap[0], uy = Bp[1] - Ap[1];
+        const double zz = ux * ux + uy * uy;
+        const bool regular = zz > 0.0;
+        const double rlen = regular ? fast_rsqrt(zz) : 1.0;
+        const double lx = ux * rlen, ly = uy * rlen;
+        double dBx[3], dBy[3], dlx[3], dly[3];
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            const double m0 = TA(6 + 4 * k), m1 = TA(6 + 4 * k + 1), m3 = TA(6 + 4 * k + 2), m4 = TA(6 + 4 * k + 3);
+            const double t0 = TA(18 + 2 * k), t1 = TA(18 + 2 * k + 1);
+            const double dAx = t0 + m0 * p[0] + m1 * p[1];
+            const double dAy = t1 + m3 * p[0] + m4 * p[1];
+            dBx[k] = t0 + m0 * p[2] + m1 * p[3];
+            dBy[k] = t1 + m3 * p[2] + m4 * p[3];
+            const double dux = dBx[k] - dAx, duy = dBy[k] - dAy;
+            const double pr = lx * dux + ly * duy;
+            dlx[k] = (dux - lx * pr) * rlen;
+            dly[k] = (duy - ly * pr) * rlen;
+        }
+        const double w = sum * w0;
+#pragma unroll
+        for (int k = 0; k < 2; ++k) {
+            const double pt0 = p[4 + 2 * k], pt1 = p[5 + 2 * k];
+            const double ex = C[k][0] - Bp[0], ey = C[k][1] - Bp[1];
+            double dCx[3], dCy[3];
+#pragma unroll
+            for (int m = 0; m < 3; ++m) {
+                dCx[m] = TB(18 + 2 * m) + TB(6 + 4 * m) * pt0 + TB(6 + 4 * m + 1) * pt1;
+                dCy[m] = TB(18 + 2 * m + 1) + TB(6 + 4 * m + 2) * pt0 + TB(6 + 4 * m + 3) * pt1;
+            }
+            double dist, jc[8], ws = w;
+            if (regular) {
+                const double sg = lx * ey - ly * ex;
+                ws = sg < 0.0 ? -w : w;
+                dist = fabs(sg);
+                {   // a point exactly on the line: norm() of a zero Jet in the reference (common.h:94) -> NaN derivative (k_lin_laser_body.inc)
+                    const double prj = lx * ex + ly * ey;
+                    const double vx = ex - prj * lx, vy = ey - prj * ly;
+                    if (vx * vx + vy * vy == 0.0) ws = __builtin_nan("");
+                }
+                jc[0] = ly; jc[1] = -lx;
+#pragma unroll
+                for (int m = 0; m < 3; ++m) {
+                    jc[2 + m] = dlx[m] * ey - dly[m] * ex - lx * dBy[m] + ly * dBx[m];
+                    jc[5 + m] = lx * dCy[m] - ly * dCx[m];
+                }
+            } else {   // zero-length reference segment: distance to the point B (Jet semantics of normalized(0))
+                dist = sqrt(ex * ex + ey * ey);
+                const double nx = ex / dist, ny = ey / dist;
+                jc[0] = -nx; jc[1] = -ny;
+#pragma unroll
+                for (int m = 0; m < 3; ++m) {
+                    jc[2 + m] = -(nx * dBx[m] + ny * dBy[m]);
+                    jc[5 + m] = nx * dCx[m] + ny * dCy[m];
+                }
+            }
+            double rw[9];
+#pragma unroll
+            for (int c = 0; c < 8; ++c) rw[c] = ws * jc[c];
+            rw[8] = sum * (w0 * dist);
+#pragma unroll
+            for (int c1 = 0; c1 < 9; ++c1)
+#pragma unroll
+                for (int c2 = c1; c2 < 9; ++c2) acc[c1 * 9 - c1 * (c1 - 1) / 2 + (c2 - c1)] += rw[c1] * rw[c2];
+        }
+    };
+    // rows four ahead in flight (five register sets in rotation).  The loads are UNCONDITIONAL (row index clamped to the slab's last row):
+    // behind a branch the compiler can no longer count them and waits for every outstanding load before each block
+    double q0[8], q1[8], q2[8], q3[8], q4[8];
+    const int last = maxc - 1;
+    if (maxc > 0) {
+        load_row(q0, 0); load_row(q1, min(1, last)); load_row(q2, min(2, last)); load_row(q3, min(3, last));
+        for (int j = 0; j < maxc; j += 5) {
+            load_row(q4, min(j + 4, last));
+            if (j < cnt) block(q0);
+            load_row(q0, min(j + 5, last));
+            if (j + 1 < cnt) block(q1);
+            load_row(q1, min(j + 6, last));
+            if (j + 2 < cnt) block(q2);
+            load_row(q2, min(j + 7, last));
+            if (j + 3 < cnt) block(q3);
+            load_row(q3, min(j + 8, last));
+            if (j + 4 < cnt) block(q4);
+        }
+    }
+#undef TA
+#undef TB
+    if (in) {
+        double* out = (psel ? A.PL[1] : A.PL[0]) + ((size_t)bb * n + f) * LP;
+        slab_store<0>(out, acc);
+    }
+}
+
+// longest group of every (slab, frame): mx[s * n + f] = max over the slab's windows of the block count of (window, f)
+__global__ void k_laser_slab_max(int B, int n, const int* group_off, int* mx) {
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    const int S = (B + SLAB - 1) / SLAB;
+    if (t >= S * n) return;
+    const int s = t / n, f = t % n;
+    int m = 0;
+    for (int l = 0; l < SLAB; ++l) {
+        const int b = s * SLAB + l;
+        if (b < B) m = max(m, group_off[b * (n + 1) + f + 1] - group_off[b * (n + 1) + f]);
+    }
+    mx[t] = m;
+}
+// exclusive prefix sum of mx (rows) by one work-group; off[N] = total rows, off[N + 1] = the z flag of k_laser_z_scan (one read-back for both)
+__global__ __launch_bounds__(1024) void k_laser_slab_scan(int N, const int* mx, long long* off, const int* hz) {
+    __shared__ long long part[1024];
+    const int t = threadIdx.x, per = (N + 1023) / 1024;
+    long long sum = 0;
+    for (int k = 0; k < per; ++k) { const int e = t * per + k; if (e < N) sum += mx[e]; }
+    part[t] = sum;
+    __syncthreads();
+    for (int d = 1; d < 1024; d <<= 1) {
+        const long long v = t >= d ? part[t - d] : 0;
+        __syncthreads();
+        part[t] += v;
+        __syncthreads();
+    }
+    long long base = part[t] - sum;
+    for (int k = 0; k < per; ++k) { const int e = t * per + k; if (e < N) { off[e] = base; base += mx[e]; } }
+    if (t == 1023) { off[N] = part[1023]; off[N + 1] = hz ? (long long)*hz : 0; }
+}
+// re-pack: thread (lane l, j-stripe) of work-group (s, f) copies block j of window 64 s + l; a wave writes 512 consecutive bytes per plane
+__global__ __launch_bounds__(256) void k_laser_slab_pack(int B, int n, long Ltot, const int* group_off, const double* pts, const long long* off, double* pk) {
+    const int s = (int)blockIdx.x / n, f = (int)blockIdx.x % n;
+    const int l = threadIdx.x & 63, stripe = threadIdx.x >> 6;
+    const int b = s * SLAB + l;
+    const int g0 = b < B ? group_off[b * (n + 1) + f] : 0, g1 = b < B ? group_off[b * (n + 1) + f + 1] : 0;
+    double* base = pk + (size_t)off[(size_t)s * n + f] * ROWD + l;
+    for (int j = stripe; j < g1 - g0; j += 4) {
+        const size_t src = (size_t)(g0 + j);
+        double* o = base + (size_t)j * ROWD;
+#pragma unroll
+        for (int c = 0; c < 8; ++c) o[c * SLAB] = pts[(size_t)(c + c / 2) * (size_t)Ltot + src];   // planes 0 1 3 4 6 7 9 10 (x, y of the four end points)
+    }
+}
+
+int laser_slab_count(int B) { return (B + SLAB - 1) / SLAB; }
+void launch_laser_slab_prepare(int B, int n, const int* group_off, int* mx, long long* off, const int* hz, hipStream_t s) {
+    const int N = laser_slab_count(B) * n;
+    hipLaunchKernelGGL(k_laser_slab_max, dim3((N + 255) / 256), dim3(256), 0, s, B, n, group_off, mx);
+    hipLaunchKernelGGL(k_laser_slab_scan, dim3(1), dim3(1024), 0, s, N, (const int*)mx, off, hz);
+}
+void launch_laser_slab_pack(int B, int n, long Ltot, const int* group_off, const double* pts, const long long* off, double* pk, hipStream_t s) {
+    hipLaunchKernelGGL(k_laser_slab_pack, dim3((unsigned)(laser_slab_count(B) * n)), dim3(256), 0, s, B, n, Ltot, group_off, pts, off, pk);
+}
+void launch_lin_laser_slab(const LinArgs& A, const DevParams& P, hipStream_t s) {
+    hipLaunchKernelGGL(k_lin_laser_slab, dim3((unsigned)(laser_slab_count(A.B) * A.n)), dim3(64), 0, s, A, P);
+}
+
+}  // namespace liw

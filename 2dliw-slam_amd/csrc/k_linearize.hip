@@ -839,7 +839,8 @@ void launch_linearize(const LinArgs& A_, const DevParams& P, hipStream_t s, cons
     hipStream_t s_imu = fork ? fk->side[0] : s, s_small = fork ? fk->side[1] : s;
     const int rm = A.role_mask ? A.role_mask : 7;
     if (rm & 1) {
-        if (A.mode == LIW_MODE_INIT) hipLaunchKernelGGL(k_lin_laser<true>, dim3((unsigned)laser_waves), dim3(64), 0, s, A, P, G);
+        if (A.mode == LIW_MODE_INIT && A.laser_pk) launch_lin_laser_slab(A, P, s);   // large 2-D batches: a lane per (window, frame) group
+        else if (A.mode == LIW_MODE_INIT) hipLaunchKernelGGL(k_lin_laser<true>, dim3((unsigned)laser_waves), dim3(64), 0, s, A, P, G);
         else hipLaunchKernelGGL(k_lin_laser<false>, dim3((unsigned)laser_waves), dim3(64), 0, s, A, P, G);
     }
     if (imu_waves && (rm & 2)) hipLaunchKernelGGL(k_lin_imu, dim3((unsigned)imu_waves), dim3(64), 0, s_imu, A, P);

@@ -78,6 +78,11 @@ struct liw_ctx {
     DevBuf p2p_err;
     LinFork fork{};
     bool have_fork = false;
+    // lane-per-group laser role of large 2-D batches (k_laser_slab.hip): the batch's laser blocks re-packed once per solve into ctx-owned
+    // memory (its size depends on the block counts, which liw_batch_ws_layout does not know), valid for the solve `lpk_key` names
+    DevBuf lpk, lpk_off, lpk_mx;
+    struct { const void* ws; const void* pts; const void* frame; int B, n; long Ltot; } lpk_key{};
+    bool lpk_on = false;
     // graph cache
     hipGraphExec_t gexec = nullptr;
     std::vector<unsigned char> gkey;
@@ -190,7 +195,7 @@ void liw_destroy(liw_ctx* c) {
     if (!c) return;
     if (c->have_device) {
         (void)hipSetDevice(c->prm.device);
-        DevBuf* bufs[] = {&c->arena, &c->prior_X, &c->prior_J, &c->prior_R, &c->has_prior, &c->ws, &c->scratch,
+        DevBuf* bufs[] = {&c->lpk, &c->lpk_off, &c->lpk_mx, &c->arena, &c->prior_X, &c->prior_J, &c->prior_R, &c->has_prior, &c->ws, &c->scratch,
                           &c->priorn_X, &c->priorn_J, &c->priorn_R, &c->has_priorn, &c->result, &c->marg_status};
         if (c->pinned) (void)hipHostFree(c->pinned);
         if (c->ev_upload) (void)hipEventDestroy(c->ev_upload);
@@ -290,7 +295,33 @@ static int check_batch(liw_ctx* c, const liw_batch* b, int min_n = 1) {
 }
 static int min_frames(int mode) { return mode == LIW_MODE_INIT ? 1 : 2; }
 // packed: the linearisation belongs to a solve opened by liw_batch_lm_begin (which packed the IMU block records into the workspace)
-static LinArgs lin_args(const liw_batch* b, int mode, const double* x, const WsView& v, int candidate, bool use_lm, bool packed = false) {
+static bool lpk_matches(const liw_ctx* c, const liw_batch* b, const void* ws) {
+    return c && c->lpk_on && c->lpk_key.ws == ws && c->lpk_key.pts == b->laser_pts && c->lpk_key.frame == b->laser_frame && c->lpk_key.B == b->B &&
+           c->lpk_key.n == b->n && c->lpk_key.Ltot == (long)b->Ltot;
+}
+// Re-pack the laser blocks of a large 2-D batch for the lane-per-group kernel.  Runs behind group_offsets and the z scan of the solve being
+// opened; ONE blocking 16-byte read-back (rows needed, z flag) sizes the ctx-owned buffer — only for batches that fill the chip that way
+// (>= 2 048 (slab, frame) waves), never under stream capture.  LIW_NO_LASER_SLAB=1: always the lane-per-block kernel.
+static int laser_slab_begin(liw_ctx* c, const liw_batch* b, int mode, const WsView& v, void* ws, hipStream_t s, bool may_sync) {
+    c->lpk_on = false;
+    if (mode != LIW_MODE_INIT || !may_sync || std::getenv("LIW_NO_LASER_SLAB")) return LIW_OK;
+    const int S = laser_slab_count(b->B), N = S * b->n;
+    if (N < 2048 || b->Ltot <= 0) return LIW_OK;
+    if (c->lpk_mx.ensure(sizeof(int) * (size_t)N) || c->lpk_off.ensure(sizeof(long long) * ((size_t)N + 2))) return fail(c, LIW_ENOMEM, "hipMalloc");
+    launch_laser_slab_prepare(b->B, b->n, v.group_off, c->lpk_mx.as<int>(), c->lpk_off.as<long long>(), v.imu_pk_bad + 1, s);
+    long long tail[2] = {0, 1};
+    HIPCHK(c, hipMemcpyAsync(tail, c->lpk_off.as<long long>() + N, sizeof(tail), hipMemcpyDeviceToHost, s));
+    HIPCHK(c, hipStreamSynchronize(s));
+    const long long rows = tail[0];
+    if (tail[1] != 0 || rows <= 0) return LIW_OK;                               // 3-D end points: the lane-per-block kernel handles them
+    if (rows * 64 > 4 * (long long)b->Ltot + 64ll * N) return LIW_OK;           // very ragged groups: padding would exceed 4x the data
+    if (c->lpk.ensure(sizeof(double) * 512 * (size_t)rows)) { c->lpk.release(); return LIW_OK; }   // (no memory for the copy: not an error)
+    launch_laser_slab_pack(b->B, b->n, (long)b->Ltot, v.group_off, b->laser_pts, c->lpk_off.as<long long>(), c->lpk.as<double>(), s);
+    c->lpk_key = {ws, b->laser_pts, b->laser_frame, b->B, b->n, (long)b->Ltot};
+    c->lpk_on = true;
+    return LIW_OK;
+}
+static LinArgs lin_args(const liw_batch* b, int mode, const double* x, const WsView& v, int candidate, bool use_lm, bool packed = false, const liw_ctx* c = nullptr, const void* ws = nullptr) {
     LinArgs A{};
     A.B = b->B; A.n = b->n; A.mode = mode; A.eval_small = b->eval_small;
     A.x = x; A.group_off = v.group_off; A.laser_off = b->laser_off; A.laser_pts = b->laser_pts; A.Ltot = b->Ltot;
@@ -303,6 +334,7 @@ static LinArgs lin_args(const liw_batch* b, int mode, const double* x, const WsV
     A.candidate = candidate;
     if (packed && b->n > 1 && b->eval_small) { A.imu_pk = v.imu_pk; A.imu_pk_bad = v.imu_pk_bad; }
     if (packed) A.laser_hz = v.imu_pk_bad + 1;
+    if (packed && mode == LIW_MODE_INIT && lpk_matches(c, b, ws)) { A.laser_pk = c->lpk.as<double>(); A.laser_slab_off = c->lpk_off.as<long long>(); }
     return A;
 }
 static StepArgs step_args(liw_ctx* c, const liw_batch* b, int mode, int max_iters, const WsView& v) {
@@ -340,8 +372,15 @@ int liw_batch_lm_begin(liw_ctx* c, const liw_batch* b, int mode, int max_iters, 
     }
     // 2-D scans: the laser role skips the z planes.  Only where that pays: the scan is a full pass over the 12 planes, a small or
     // tracking-size batch saves less than that over its few linearisations (flag 1 = "has z": the role reads every plane)
-    if ((long)b->B * (b->n - 1) >= 4096) launch_laser_z_scan(b->Ltot, b->laser_pts, v.imu_pk_bad + 1, s);
-    else (void)hipMemsetAsync(v.imu_pk_bad + 1, 0xff, sizeof(int), s);
+    if ((long)b->B * (b->n - 1) >= 4096) {
+        launch_laser_z_scan(b->Ltot, b->laser_pts, v.imu_pk_bad + 1, s);
+        hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+        (void)hipStreamIsCapturing(s, &cap);
+        if (int r = laser_slab_begin(c, b, mode, v, ws, s, cap == hipStreamCaptureStatusNone)) return r;
+    } else {
+        (void)hipMemsetAsync(v.imu_pk_bad + 1, 0xff, sizeof(int), s);
+        c->lpk_on = false;
+    }
     HIPCHK(c, hipGetLastError());
     return LIW_OK;
 }
@@ -349,7 +388,7 @@ int liw_batch_lm_linearize(liw_ctx* c, const liw_batch* b, int mode, int candida
     NEEDDEV(c);
     if (int r = check_batch(c, b, min_frames(mode))) return r;
     WsView v = make_view(ws, b->B, b->n, b->history_records);
-    LinArgs A = lin_args(b, mode, candidate ? v.x_cand : b->x, v, candidate != 0, true, true);
+    LinArgs A = lin_args(b, mode, candidate ? v.x_cand : b->x, v, candidate != 0, true, true, c, ws);
     launch_linearize(A, c->dp, (hipStream_t)stream, c->have_fork ? &c->fork : nullptr);
     HIPCHK(c, hipGetLastError());
     return LIW_OK;
@@ -359,7 +398,7 @@ int liw_batch_lm_linearize_async(liw_ctx* c, const liw_batch* b, int mode, int c
     NEEDDEV(c);
     if (int r = check_batch(c, b, min_frames(mode))) return r;
     WsView v = make_view(ws, b->B, b->n, b->history_records);
-    LinArgs A = lin_args(b, mode, candidate ? v.x_cand : b->x, v, candidate != 0, true, true);
+    LinArgs A = lin_args(b, mode, candidate ? v.x_cand : b->x, v, candidate != 0, true, true, c, ws);
     launch_linearize(A, c->dp, (hipStream_t)stream, c->have_fork ? &c->fork : nullptr, true);
     HIPCHK(c, hipGetLastError());
     return LIW_OK;
@@ -568,9 +607,15 @@ static int enqueue_solve(liw_ctx* c, const liw_batch* b, int mode, int K, void* 
     const bool pack = b->n > 1 && b->eval_small && !std::getenv("LIW_NO_IMU_PACK") && (long)b->B * (b->n - 1) >= 4096;
     if (pack) launch_imu_pack(b->B, b->n, b->imu_X, b->imu_J, b->imu_sqrtP, b->imu_Dt, v.imu_pk, v.imu_pk_bad, s);
     if (pack) launch_laser_z_scan(b->Ltot, b->laser_pts, v.imu_pk_bad + 1, s);
+    c->lpk_on = false;
+    if (pack) {
+        hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+        (void)hipStreamIsCapturing(s, &cap);
+        if (int r = laser_slab_begin(c, b, mode, v, ws, s, cap == hipStreamCaptureStatusNone)) return r;
+    }
     StepArgs st = step_args(c, b, mode, K, v);
     auto lin = [&](int cand) {
-        LinArgs A = lin_args(b, mode, cand ? v.x_cand : b->x, v, cand, true, pack);
+        LinArgs A = lin_args(b, mode, cand ? v.x_cand : b->x, v, cand, true, pack, c, ws);
         if (timed) (void)hipEventRecord(next_event(c->ev_lin, c->ev_lin_used), s);
         launch_linearize(A, c->dp, s, c->have_fork ? &c->fork : nullptr);
         if (timed) (void)hipEventRecord(next_event(c->ev_lin, c->ev_lin_used), s);
@@ -684,7 +729,7 @@ int liw_batch_time_kernels(liw_ctx* c, const liw_batch* b, int mode, void* ws, v
     if (int r = liw_batch_lm_begin(c, b, mode, K, ws, stream)) return r;
     const bool packed = true;
     auto lin = [&](int cand, int mask) {
-        LinArgs A = lin_args(b, mode, cand ? v.x_cand : b->x, v, cand, true, packed);
+        LinArgs A = lin_args(b, mode, cand ? v.x_cand : b->x, v, cand, true, packed, c, ws);
         A.role_mask = mask;
         launch_linearize(A, c->dp, s, nullptr);          // (no fork: the kernel under the clock runs alone)
     };

@@ -116,6 +116,8 @@ struct LinArgs {
     const double* imu_pk;       // packed IMU block records (WsView::imu_pk) or null
     const int* imu_pk_bad;      //   ... usable iff *imu_pk_bad == 0
     const int* laser_hz;        // null, or -> 0 when no laser end point of the batch has a z component (2-D scans): the z planes are skipped
+    const double* laser_pk;     // non-null: the batch's laser blocks re-packed per (slab of 64 windows, frame, block) rows (k_laser_slab.hip) ...
+    const long long* laser_slab_off;   // ... and the first row of every (slab, frame): the laser role of an INIT linearisation runs lane-per-group
     int role_mask;              // 0 = every role; else bit 0 laser, bit 1 IMU, bit 2 wheel + ground (liw_batch_time_kernels: one role kernel alone)
     // optional per-factor outputs (liw_eval_factors)
     double* dbg_laser_res; double* dbg_laser_jac; double* dbg_imu_res; double* dbg_imu_jac;
@@ -258,6 +260,11 @@ struct P2pPeers { double* area[P2P_MAX]; unsigned long long* flags[P2P_MAX]; }; 
 void launch_p2p_exchange(size_t nd, const double* buf, const P2pPeers& peers, int rank, int world, unsigned long long epoch, int* err, hipStream_t s);
 void launch_group_offsets(int B, int n, const int* laser_off, const int* laser_frame, int* group_off, hipStream_t s);
 void launch_laser_z_scan(long Ltot, const double* laser_pts, int* flag, hipStream_t s);
+// k_laser_slab.hip: lane-per-(window, frame) laser role of large 2-D batches
+int laser_slab_count(int B);
+void launch_laser_slab_prepare(int B, int n, const int* group_off, int* mx, long long* off, const int* hz, hipStream_t s);
+void launch_laser_slab_pack(int B, int n, long Ltot, const int* group_off, const double* pts, const long long* off, double* pk, hipStream_t s);
+void launch_lin_laser_slab(const LinArgs& A, const DevParams& P, hipStream_t s);
 void launch_imu_pack(int B, int n, const double* imu_X, const double* imu_J, const double* imu_sqrtP, const double* imu_Dt, double* pk, int* bad, hipStream_t s);
 void launch_pack_result(const PackArgs& a, hipStream_t s);
 void launch_lm_begin(int B, int n, LmState* lm, int max_iters, hipStream_t s);
