@@ -83,10 +83,13 @@ constexpr int ROWD = 8 * SLAB;        // doubles per packed row
 
 }  // namespace
 
-// One wave per SIMD with the whole 512-entry register file: 45 accumulators, the two transform records and FIVE rows of end points in
-// flight (four rows = 16 KiB per wave ahead of the arithmetic: at four waves per CU that is what ~13 B per clock and CU of HBM share need
-// over ~2 us of latency); the block's arithmetic has the instruction-level parallelism (three rotation derivatives, two rows, 45
-// independent pair products) to keep the one wave issuing.  The <= 256-register build for two waves per SIMD spilled the rows in flight.
+// One wave per SIMD with the whole 512-entry register file (256 + 74): 45 accumulators and FIVE rows of end points in flight (four rows
+// = 16 KiB per wave ahead of the arithmetic); the two transform records live in LDS, [entry][lane], and are re-read per block (in registers
+// they sat in the accumulation half of the file at one v_accvgpr_read per use).  Measured on 24 576 C2 windows (tools/ktimes.py,
+// tools/slab_pmc.sh): 1.16 ms against 1.68 ms for k_lin_laser; a wave issues ~350 VALU instructions per row of 64 blocks where k_lin_laser issues ~1 000
+// per 64-block chunk, and the one wave of a SIMD issues VALU work in 52 % of its cycles.
+// What did not help (each built and timed): a <= 256-register build for two waves per SIMD (it spills the rows in flight: 1.56 ms), blocks
+// taken in pairs or as branch-free straight-line code for more instruction-level parallelism (register pressure: 1.23 ms / spills).
 __global__ __launch_bounds__(64, 1) void k_lin_laser_slab(LinArgs A, DevParams P) {
     const int lane = threadIdx.x & 63, n = A.n;
     const int s = (int)blockIdx.x / n, f = (int)blockIdx.x % n;
@@ -103,14 +106,23 @@ __global__ __launch_bounds__(64, 1) void k_lin_laser_slab(LinArgs A, DevParams P
     for (int o = 32; o > 0; o >>= 1) maxc = max(maxc, __shfl_xor(maxc, o, 64));
     maxc = __builtin_amdgcn_readfirstlane(maxc);
     const int psel = (in && A.lm) ? (A.candidate ? 1 - A.lm[bb].cur : A.lm[bb].cur) : 0;
-    double ta[TF2], tb[TF2];    // transform records of pose a (frame 0 of the lane's window) and pose b (frame f)
-    if (in && maxc > 0) {
-        frame_tf2(P, A.x + (size_t)bb * n * 15, ta);
-        frame_tf2(P, A.x + ((size_t)bb * n + f) * 15, tb);
-    } else {
+    // transform records of pose a (frame 0 of the lane's window) and pose b (frame f): [entry][lane] in LDS, re-read per block — in
+    // registers they ended up in the accumulation half of the file and cost a v_accvgpr_read per use (96 of a block's ~670 instructions)
+    __shared__ double lta[TF2 * SLAB], ltb[TF2 * SLAB];
+    {
+        double t2[TF2];
+        if (in && maxc > 0) frame_tf2(P, A.x + (size_t)bb * n * 15, t2);
+        else {
 #pragma unroll
-        for (int k = 0; k < TF2; ++k) { ta[k] = 0.0; tb[k] = 0.0; }
+            for (int k = 0; k < TF2; ++k) t2[k] = 0.0;
+        }
+#pragma unroll
+        for (int k = 0; k < TF2; ++k) lta[k * SLAB + lane] = t2[k];
+        if (in && maxc > 0) frame_tf2(P, A.x + ((size_t)bb * n + f) * 15, t2);
+#pragma unroll
+        for (int k = 0; k < TF2; ++k) ltb[k * SLAB + lane] = t2[k];
     }
+    lds_sync();
     double acc[45];
 #pragma unroll
     for (int e = 0; e < 45; ++e) acc[e] = 0.0;
@@ -121,8 +133,8 @@ __global__ __launch_bounds__(64, 1) void k_lin_laser_slab(LinArgs A, DevParams P
         for (int c = 0; c < 8; ++c) q[c] = r[c * SLAB];
     };
     const double w0 = P.laser_sqrt_info;
-#define TA(k) ta[(k)]
-#define TB(k) tb[(k)]
+#define TA(k) lta[(k) * SLAB + lane]
+#define TB(k) ltb[(k) * SLAB + lane]
     auto block = [&](const double* p) {     // one laser_factor block (k_lin_laser_body.inc, 2-D, both poses free): rows + pair products
         const double d1x = p[0] - p[2], d1y = p[1] - p[3];
         const double d2x = p[4] - p[6], d2y = p[5] - p[7];
@@ -210,6 +222,7 @@ __global__ __launch_bounds__(64, 1) void k_lin_laser_slab(LinArgs A, DevParams P
     if (maxc > 0) {
         load_row(q0, 0); load_row(q1, min(1, last)); load_row(q2, min(2, last)); load_row(q3, min(3, last));
         for (int j = 0; j < maxc; j += 5) {
+            asm volatile("" ::: "memory");
             load_row(q4, min(j + 4, last));
             if (j < cnt) block(q0);
             load_row(q0, min(j + 5, last));
