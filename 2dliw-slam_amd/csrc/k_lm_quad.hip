@@ -72,7 +72,7 @@ constexpr int QTR = 0;
 #else
 constexpr int QTR = 4 * 15 * 6;                           // transposition tile of the carried arrow block (below)
 #endif
-constexpr int QTOT = 4 * (PIS + 86 + PWS + PGS) + QTR;   // LDS doubles per wave: the prefetched partial records of its four rows + the tile (27 072 B: six waves per CU)
+constexpr int QTOT = 4 * (PIS + 86 + PWS + PGS) + 24 + QTR;   // LDS doubles per wave: the prefetched partial records of its four rows + the tile (27 072 B: six waves per CU)
 
 // offset of entry (r, j) inside a packed upper triangle of order 15, r a compile-time constant
 template <int R> __device__ __forceinline__ int tri_rc(int j, int cj) {   // cj = 14 j - j (j - 1) / 2
@@ -298,8 +298,7 @@ __global__ __launch_bounds__(64, LIW_QUAD_OCC) void k_lm_step_quad(StepArgs a) {
     // (4.9 TB/s chip-wide during the sweep) — and whoever issues next waits for a slot.  Probes with the records aliased to one window
     // (cache-resident) bound the memory share of the kernel at 21 %; the rest is the instruction stream.  The DMA form stays: it needs
     // no registers.
-    constexpr int QPIECES = 26;                     // IMU 16, wheel 4, laser 4, ground 2
-    constexpr int S_IMU = 0, S_PL = 4 * PIS, S_PW = S_PL + 4 * 86, S_PG = S_PW + 4 * PWS, S_TR = S_PG + 4 * PGS;
+    constexpr int S_IMU = 0, S_PL = 4 * PIS, S_PW = S_PL + 4 * 86, S_PG = S_PW + 4 * PWS, S_TR = S_PG + 4 * PGS + 24;   // (24 doubles of pad: the over-read of the last ground piece)
     static_assert(S_TR + QTR <= QTOT, "LDS layout");
     const unsigned rPL[4] = {(unsigned)__builtin_amdgcn_readlane(oPL, 0), (unsigned)__builtin_amdgcn_readlane(oPL, 16), (unsigned)__builtin_amdgcn_readlane(oPL, 32), (unsigned)__builtin_amdgcn_readlane(oPL, 48)};
     const unsigned rPI[4] = {(unsigned)__builtin_amdgcn_readlane(oPI, 0), (unsigned)__builtin_amdgcn_readlane(oPI, 16), (unsigned)__builtin_amdgcn_readlane(oPI, 32), (unsigned)__builtin_amdgcn_readlane(oPI, 48)};
@@ -308,46 +307,51 @@ __global__ __launch_bounds__(64, LIW_QUAD_OCC) void k_lm_step_quad(StepArgs a) {
     typedef __attribute__((address_space(3))) void* lds_t;
     const int j_ = j;
     double scm_n = 1.0, dg_n = 0.0, xq_n = 0.0;     // prefetched: scale of frame f-1, LM diagonal and state entry of frame f (lane j)
-    // one piece of frame f's prefetch, P = 0 .. QPIECES-1 (compile-time: row, part and LDS destination are immediates)
-    auto piece = [&](auto PP, int f) {
-        constexpr int P = KI(PP);
-        const int k = f - 1;                        // frame f's block towards the frame before
-        // the lane's 16-byte slot of a piece, in doubles: the ONLY lane-dependent part of an address.  Laundered, so that the per-lane
-        // pointers are formed right here (one 64-bit add each) and never kept across the frame loop — as hoisted loop invariants they
-        // spilled, and every reload inside a burst waited (vmcnt) for the pieces already in flight
-        int lane2 = lane * 2;
-        asm volatile("" : "+v"(lane2));
-        if constexpr (P < 16) {                     // IMU partial: 4 pieces per row (the immediate offset moves the global AND the LDS address)
-            constexpr int ws = P >> 2, part = P & 3;
-            if (k >= 0 && (part < 3 || lane < (PIS - 3 * 128) / 2))
-                __builtin_amdgcn_global_load_lds(PI0 + rPI[ws] + (unsigned)(k * PIS) + lane2, (lds_t)(S + S_IMU + ws * PIS), 16, part * 1024, 0);
-        } else if constexpr (P < 20) {              // wheel partial: 1 piece per row
-            constexpr int ws = P - 16;
-            static_assert(PWS % 2 == 0 && PWS <= 128, "one piece");
-            if (k >= 0 && lane < PWS / 2)
-                __builtin_amdgcn_global_load_lds(PW0 + rPW[ws] + (unsigned)(k * PWS) + lane2, (lds_t)(S + S_PW + ws * PWS), 16, 0, 0);
-        } else if constexpr (P < 24) {              // laser group record, slots 36 .. 122
-            constexpr int ws = P - 20;
-            if (lane < 43)
-                __builtin_amdgcn_global_load_lds(PL0 + rPL[ws] + (unsigned)(f * LP + 36) + lane2, (lds_t)(S + S_PL + ws * 86), 16, 0, 0);
-        } else {                                    // ground partial, two rows per piece: lanes 0..25 row 2h, 26..51 row 2h+1
-            constexpr int h = P - 24;
-            // (signed lane part: row 2h+1's lanes start 52 doubles into the piece, and its window's offset may be 0)
-            const unsigned ob = lane < 26 ? rPG[2 * h] : rPG[2 * h + 1];
-            const long lo = (long)(f * PGS) + (lane < 26 ? lane2 : lane2 - 52);
-            if (lane < 52) __builtin_amdgcn_global_load_lds(PG0 + ob + lo, (lds_t)(S + S_PG + h * 2 * PGS), 16, 0, 0);
-        }
-        asm volatile("" ::: "memory");              // keeps the piece where it was written
-    };
     auto prefetch_regs = [&](int f) {
         const int jq = j_ < 15 ? j_ : 0;
         scm_n = (j_ < 15 && f >= 1) ? LMD[oSC + (unsigned)((f - 1) * 15 + jq)] : 1.0;
         dg_n = LMD[oDG + (unsigned)(f * 15 + jq)];
         xq_n = X[oX + (unsigned)(f * 15 + jq)];
     };
-    auto prefetch = [&](int f) {                    // the whole frame at once (the first frame of the sweep)
+    // The 26 pieces of a frame as STRAIGHT-LINE code.  Round 3 issued each piece under its own lane mask (the last piece of a record does
+    // not fill 64 lanes) and its own `block exists` test: 26 basic blocks of ~22 instructions each — a branch, the 64-bit scalar address
+    // rebuilt from spilled SGPRs (v_readlane / v_writelane), m0 — ~580 instructions and ~4 k of a frame's ~18.6 k cycles with every record
+    // cache-resident (tools/clk_probe_quad.py under LIW_QUAD_PROBE=3: the phase is instruction-bound, not memory-bound).  Now every piece
+    // runs with all 64 lanes: lanes past the end of a record read on into whatever follows it in the workspace (always inside it) and their
+    // 16 bytes land in the LDS words right behind the record's area — the start of the NEXT area in the layout, whose own piece is issued
+    // later and overwrites them (loads of a wave return in order); behind the last area (ground) sits a 24-double pad.  The only test
+    // left is the uniform `this frame has a block towards the frame before` around the IMU and wheel pieces.
+    auto prefetch = [&](int f) {
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        sfor<0, QPIECES>([&](auto PP) { piece(PP, f); });
+        const int k = f - 1;                        // frame f's block towards the frame before
+        int lane2 = lane * 2;                       // the lane's 16-byte slot of a piece, in doubles: the ONLY lane-dependent part of an address
+        asm volatile("" : "+v"(lane2));             // (laundered: per-lane pointers are formed here, never hoisted out of the frame loop)
+        if (k >= 0) {
+            sfor<0, 4>([&](auto W) {                // IMU partial: 4 pieces per row (the immediate offset moves the global AND the LDS address)
+                constexpr int ws = KI(W);
+                const double* g = PI0 + rPI[ws] + (unsigned)(k * PIS) + lane2;
+                sfor<0, 4>([&](auto Q) { __builtin_amdgcn_global_load_lds(g, (lds_t)(S + S_IMU + ws * PIS), 16, KI(Q) * 1024, 0); });
+            });
+        }
+        sfor<0, 4>([&](auto W) {                    // laser group record, slots 36 .. 122 (+ 42 doubles of over-read)
+            constexpr int ws = KI(W);
+            __builtin_amdgcn_global_load_lds(PL0 + rPL[ws] + (unsigned)(f * LP + 36) + lane2, (lds_t)(S + S_PL + ws * 86), 16, 0, 0);
+        });
+        if (k >= 0) {
+            sfor<0, 4>([&](auto W) {                // wheel partial: 1 piece per row
+                constexpr int ws = KI(W);
+                static_assert(PWS % 2 == 0 && PWS <= 128, "one piece");
+                __builtin_amdgcn_global_load_lds(PW0 + rPW[ws] + (unsigned)(k * PWS) + lane2, (lds_t)(S + S_PW + ws * PWS), 16, 0, 0);
+            });
+        }
+        sfor<0, 2>([&](auto H) {                    // ground partial, two rows per piece: lanes 0..25 row 2h, 26..63 row 2h+1 (52 doubles + over-read)
+            constexpr int h = KI(H);
+            // (signed lane part: row 2h+1's lanes start 52 doubles into the piece, and its window's offset may be 0)
+            const unsigned ob = lane < 26 ? rPG[2 * h] : rPG[2 * h + 1];
+            const long lo = (long)(f * PGS) + (lane < 26 ? lane2 : lane2 - 52);
+            __builtin_amdgcn_global_load_lds(PG0 + ob + lo, (lds_t)(S + S_PG + h * 2 * PGS), 16, 0, 0);
+        });
+        asm volatile("" ::: "memory");
         prefetch_regs(f);
     };
     const double* SI = S + S_IMU + w * PIS;
