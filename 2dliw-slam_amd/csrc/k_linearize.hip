@@ -549,19 +549,25 @@ __device__ __forceinline__ void wheel_blocks(const LinArgs& A, const DevParams& 
         meta[blk] = on ? (A.lm ? (A.candidate ? 1 - A.lm[b].cur : A.lm[b].cur) : 0) : -1;
         meta[32 + blk] = (int)fk;
     }
+    // record entry e -> columns (r, c) of Y: ii | ij | jj | gradient | cost (liw_kernels.hpp), as a table built once per wave (the divisions
+    // and selects it replaces were ~20 of the ~45 instructions of every output element: 40 elements per lane and wave)
+    int* rc_tab = meta + 64;
+    for (int e = lane; e < PWS; e += 64) {
+        const int blk6 = e / 36, w6 = e % 36;
+        const int r = e < 108 ? (blk6 == 2 ? 6 : 0) + w6 / 6 : (e < 120 ? e - 108 : 12);
+        const int c = e < 108 ? (blk6 == 0 ? 0 : 6) + w6 % 6 : 12;
+        rc_tab[e] = e <= PW_C ? (r << 8) | c : -1;
+    }
     lds_sync();
     {
         const long gb0 = (long)wave * A.small_per_wave;
         const int nblk = (int)min((long)A.small_per_wave, total - gb0);
         for (int idx = lane; idx < nblk * PWS; idx += 64) {
-            const int q = idx / PWS, e = idx % PWS, sel = meta[q];
+            const int q = idx / PWS, e = idx - q * PWS, sel = meta[q];
             if (sel < 0) continue;
             const double* Yq = lds + q * 64;
-            // record entry e -> columns (r, c) of Y: ii | ij | jj | gradient | cost (liw_kernels.hpp)
-            const int blk6 = e / 36, w6 = e % 36;
-            const int r = e < 108 ? (blk6 == 2 ? 6 : 0) + w6 / 6 : (e < 120 ? e - 108 : 12);
-            const int c = e < 108 ? (blk6 == 0 ? 0 : 6) + w6 % 6 : 12;
-            const double v = e <= PW_C ? Yq[r] * Yq[c] + Yq[13 + r] * Yq[13 + c] + Yq[26 + r] * Yq[26 + c] : 0.0;
+            const int rc = rc_tab[e], r = rc >> 8, c = rc & 255;
+            const double v = rc >= 0 ? Yq[r] * Yq[c] + Yq[13 + r] * Yq[13 + c] + Yq[26 + r] * Yq[26 + c] : 0.0;
             (sel ? A.PW[1] : A.PW[0])[(size_t)meta[32 + q] * PWS + e] = v;
         }
     }
@@ -633,7 +639,7 @@ __device__ __forceinline__ void small_role(const LinArgs& A, const DevParams& P,
     if (vblock < nw) wheel_blocks<ND>(A, P, vblock, lds, act);
     else ground_frames(A, P, vblock - nw, lds, act);
 }
-constexpr int SMALL_LDS = WHEEL_PER_WAVE * 64 + 32;   // + 64 per-block meta words; >= GROUND_PER_WAVE * 16 + 32
+constexpr int SMALL_LDS = WHEEL_PER_WAVE * 64 + 32 + 64;   // + 64 per-block meta words + the 122-entry (r, c) table of the wheel record; >= GROUND_PER_WAVE * 16 + 32
 __global__ __launch_bounds__(64, 2) void k_lin_imu(LinArgs A, DevParams P) {
     __shared__ double lds[IMU_PER_WAVE * IMU_REC];
     const int* const act = usable_active_list(A.active, A.B);

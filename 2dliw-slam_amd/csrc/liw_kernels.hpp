@@ -263,7 +263,7 @@ void launch_laser_z_scan(long Ltot, const double* laser_pts, int* flag, hipStrea
 // k_laser_slab.hip: lane-per-(window, frame) laser role of large 2-D batches
 int laser_slab_count(int B);
 void launch_laser_slab_prepare(int B, int n, const int* group_off, int* mx, long long* off, const int* hz, hipStream_t s);
-void launch_laser_slab_pack(int B, int n, long Ltot, const int* group_off, const double* pts, const long long* off, double* pk, hipStream_t s);
+void launch_laser_slab_pack(int B, int n, long Ltot, const int* group_off, const double* pts, const long long* off, const int* mx, double* pk, hipStream_t s);
 void launch_lin_laser_slab(const LinArgs& A, const DevParams& P, hipStream_t s);
 void launch_imu_pack(int B, int n, const double* imu_X, const double* imu_J, const double* imu_sqrtP, const double* imu_Dt, double* pk, int* bad, hipStream_t s);
 void launch_pack_result(const PackArgs& a, hipStream_t s);

@@ -31,7 +31,8 @@ def main():
     a, na = sums(st)
     b, nb = sums(st2)
     res = {}
-    for key, name in (("k_lin_laser<true>", "k_lin_laser"), ("k_lin_imu", "k_lin_imu"), ("k_lin_small", "k_lin_small"), ("k_lm_step_quad", "k_lm_step_quad")):
+    laser_key = "k_lin_laser_slab" if pick(a, "k_lin_laser_slab") else "k_lin_laser<true>"   # (large 2-D batches run the lane-per-group kernel)
+    for key, name in ((laser_key, "k_lin_laser"), ("k_lin_imu", "k_lin_imu"), ("k_lin_small", "k_lin_small"), ("k_lm_step_quad", "k_lm_step_quad")):
         s, s2 = pick(a, key), pick(b, key)
         launches = max(pick(na, key).values()) if pick(na, key) else 0
         wc = s.get("SQ_WAVE_CYCLES", 0.0)

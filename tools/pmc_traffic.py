@@ -54,11 +54,14 @@ def main():
     # factor depends on the access pattern, so it is fixed per kernel on a read volume that is known exactly:
     #   k_lin_laser<true>: 8 B x planes of end points per block + 512 B of frame states per group (8-byte-per-lane SoA loads)
     #   k_lm_step_quad:    step_known_read() (LDS-DMA dwordx4 pieces + 128-bit record rows), on its launch with every window active
-    known_laser_read = B * L * 8.0 * planes + B * n * 512.0
-    cal_laser = known_laser_read / pick(fx, "k_lin_laser<true>") if pick(fx, "k_lin_laser<true>") else None
+    #   k_lin_laser_slab (round 4, large 2-D batches): the packed rows (64 B per block for groups of equal length, as in bench.py's windows) +
+    #                      two poses, the group range and the has_match byte per (window, frame)
+    laser_name = "k_lin_laser_slab" if pick(fx, "k_lin_laser_slab") else "k_lin_laser<true>"
+    known_laser_read = B * L * 8.0 * planes + B * n * (112.0 if laser_name == "k_lin_laser_slab" else 512.0)
+    cal_laser = known_laser_read / pick(fx, laser_name) if pick(fx, laser_name) else None
     step_name = "k_lm_step_quad" if pick(fx, "k_lm_step_quad") else "k_lm_step"
     cal_step = step_known_read(B, n) / pick(fx, step_name) if step_name == "k_lm_step_quad" else cal_laser
-    names = ["k_frame_tf", "k_lin_laser<true>", "k_lin_imu", "k_lin_small"]
+    names = ["k_frame_tf", laser_name, "k_lin_imu", "k_lin_small"]
     kern = {}
     for k in names + [step_name, "k_marg_schur"]:
         cal = cal_step if k == step_name else cal_laser
@@ -70,7 +73,7 @@ def main():
     step_read_full = pick(fx, step_name) * cal_step
     ok = step_read_full <= 1.10 * produced
     res = {"windows": B, "frames": n, "laser_blocks": L, "laser_planes_read": planes, "fetch_calibration_factor": cal_laser, "fetch_calibration_factor_step": cal_step,
-           "step_kernel": step_name,
+           "step_kernel": step_name, "laser_kernel": laser_name,
            "k_linearize_hbm_bytes_per_launch": sum(kern[k]["fetch_calibrated"] + kern[k]["write"] for k in names),
            "k_lm_step_hbm_bytes_per_launch": kern[step_name]["fetch_calibrated"] + kern[step_name]["write"], "kernels": kern,
            "step_read_vs_produced": {"step_read_full_launch": step_read_full, "producers_wrote_plus_own": produced, "consistent": ok},

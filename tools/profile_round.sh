@@ -24,5 +24,5 @@ cp profiles/pmc_traffic.json gpurun_out/${TAG}_pmc_traffic.json
 rm -rf gpurun_out/prof_a gpurun_out/prof_s gpurun_out/prof_f gpurun_out/prof_w
 # the default bench line LAST, with the traffic file of this very build in place
 cp gpurun_out/${TAG}_pmc_traffic.json profiles/pmc_traffic.json
-python bench.py --batch $B > gpurun_out/${TAG}_bench_default.json 2> gpurun_out/${TAG}_bench_default.err < /dev/null
+[ -z "$SKIP_BENCH" ] && python bench.py --batch $B > gpurun_out/${TAG}_bench_default.json 2> gpurun_out/${TAG}_bench_default.err < /dev/null
 ls -la gpurun_out | grep ${TAG}
