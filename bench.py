@@ -265,10 +265,10 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--batch", type=int, default=int(os.environ.get("LIW_BENCH_BATCH", 24576)),
-                    help="windows per GPU per step (24 576 = six full rounds of the quad step kernel, 3 072 waves on 1 024 SIMDs each pair; "
-                         "end of round 3 on one box: 8 192 -> 91.7 k, 12 288 -> 93.4 k, 16 384 -> 95.3 k, 24 576 -> 96.5 k solves/s: the rounding of "
-                         "the late, partly finished launches to whole rounds weighs less; ~0.85 MB of HBM per window)")
+    ap.add_argument("--batch", type=int, default=int(os.environ.get("LIW_BENCH_BATCH", 49152)),
+                    help="windows per GPU per step (49 152 = twelve full rounds of the quad step kernel, 12 288 waves on 1 024 SIMDs; round 4 on one "
+                         "box: 24 576 -> 106.0 k, 32 768 -> 107.2 k, 49 152 -> 108.7 - 110.3 k, 65 536 -> 109.0 k solves/s: the late, partly finished "
+                         "launches and the whole-round quantisation of the one-wave-per-SIMD kernels weigh less; ~1 MB of HBM per window)")
     ap.add_argument("--frames", type=int, default=30)
     ap.add_argument("--laser", type=int, default=2000)
     ap.add_argument("--iters", type=int, default=50, help="LM iteration cap (Ceres default 50)")
