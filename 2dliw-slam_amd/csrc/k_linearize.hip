@@ -143,7 +143,13 @@ __device__ __forceinline__ V3<double> mulc(const double* m, int ld, const V3<dou
 // differentiates (0: theta_i, 1: theta_j, 2: bw_i through gamma), eg = e0 + e its global direction.
 // PK: the block's inputs come from the packed records of the solve in progress (WsView::imu_pk, 1 536 B per block instead of the 3 728 B
 // of the caller's X / J / sqrt_inverse_P / Dt arrays: the role is HBM-bound, and those arrays are constant over the LM iterations).
-template <int ND, bool PK = false>
+// CHAIN (large batches, per-frame records PIF_*, liw_kernels.hpp): a wave walks CONSECUTIVE blocks of ONE window; the jj tile of block k
+// stays in the accumulator registers and enters block k+1's ii product as its MFMA C operand, so every frame's COMPLETE diagonal tile
+// is written once and the consumers no longer add a neighbour block's share.  A window of more than IMU_PER_WAVE blocks is split over
+// several waves; a wave that starts in the middle of a window evaluates the block in front of its first one once more, for that block's
+// jj tile only (a "ghost": nothing of it is stored) — one block in 15 for the 29 blocks of a 30-frame window.
+__host__ __device__ inline int imu_chain_parts(int nb) { return nb <= IMU_PER_WAVE ? 1 : (nb + IMU_PER_WAVE - 2) / (IMU_PER_WAVE - 1); }
+template <int ND, bool PK = false, bool CHAIN = false>
 __device__ __forceinline__ void imu_blocks(const LinArgs& A, const DevParams& P, int wave, double* lds, const int* const act) {
     constexpr int LPB = 9 / ND;
     constexpr int MAXB = 63 / LPB;
@@ -153,13 +159,28 @@ __device__ __forceinline__ void imu_blocks(const LinArgs& A, const DevParams& P,
     const int n = A.n, nb = n - 1, ipw = A.imu_per_wave;   // blocks per wave: IMU_PER_WAVE for throughput, fewer for latency
     // blocks are indexed over the windows that are still iterating (compacted list), so finished windows cost no lanes
     // act: the compacted list of the windows still iterating, or null (index by window); the kernel checks that the list is complete
-    const long total = (long)(act ? act[0] : A.B) * nb, gb0 = (long)wave * ipw;
-    if (gb0 >= total) return;
+    const long total = (long)(act ? act[0] : A.B) * nb, gb0 = CHAIN ? 0 : (long)wave * ipw;
+    int chain_b = 0, chain_k0 = 0, chain_nblk = 0, ghost = 0;
+    if constexpr (CHAIN) {
+        if (nb < 1) return;
+        const int npw = imu_chain_parts(nb), bpw = (nb + npw - 1) / npw;
+        const int wiw = wave / npw, part = wave % npw;
+        if (wiw >= (act ? act[0] : A.B)) return;
+        chain_b = act ? act[1 + wiw] : wiw;
+        if (!act && !window_live(A, chain_b)) return;
+        const int kfirst = part * bpw, kend = min(nb, kfirst + bpw);
+        if (kfirst >= kend) return;
+        ghost = part > 0 ? 1 : 0;
+        chain_k0 = kfirst - ghost;
+        chain_nblk = kend - chain_k0;
+    } else {
+        if (gb0 >= total) return;
+    }
     const long gb = gb0 + blk;
-    bool on = blk < ipw && gb < total;
-    const int wi = on ? (int)(gb / nb) : 0, k = on ? (int)(gb % nb) : 0;
-    const int b = act ? act[1 + wi] : wi;
-    if (on && !act) on = window_live(A, b);
+    bool on = CHAIN ? blk < chain_nblk : (blk < ipw && gb < total);
+    const int wi = (!CHAIN && on) ? (int)(gb / nb) : 0, k = CHAIN ? (on ? chain_k0 + blk : 0) : (on ? (int)(gb % nb) : 0);
+    const int b = CHAIN ? chain_b : (act ? act[1 + wi] : wi);
+    if (!CHAIN && on && !act) on = window_live(A, b);
     double* rec = lds + (blk < MAXB ? blk : 0) * IMU_REC;
     const int sel_lane = (on && A.lm) ? (A.candidate ? 1 - A.lm[b].cur : A.lm[b].cur) : 0;   // partial buffer of this lane's block
     const int fk_lane = on ? b * nb + k : 0;                                                   // its record in the input / partial arrays
@@ -167,7 +188,7 @@ __device__ __forceinline__ void imu_blocks(const LinArgs& A, const DevParams& P,
     // group's fetch in flight while this group runs on the matrix cores: three memory round trips per wave instead of one per block.
     // The one-direction instantiation (a wave per block: latency) issues its fetch HERE, ahead of the dual-number part.
     const int ml = lane & 15, mk = lane >> 4;
-    const int nblk = (int)min((long)ipw, total - gb0);
+    const int nblk = CHAIN ? chain_nblk : (int)min((long)ipw, total - gb0);
     constexpr int GRP = ND == 3 ? 7 : 1;
     auto load_sop = [&](int gq, double* o) {
         const int fq = __shfl(fk_lane, gq < nblk ? LPB * gq : 0, 64);
@@ -324,6 +345,7 @@ __device__ __forceinline__ void imu_blocks(const LinArgs& A, const DevParams& P,
         code1[c] = imu_entry_code(mk + 4 * c, ml < 15 ? 16 + ml : 31, &cst1[c]);
     }
     const unsigned long long onmask = __ballot(on);           // lane LPB q = block q is live (in range, window still iterating)
+    d4 chain11 = {0.0, 0.0, 0.0, 0.0};                         // CHAIN: the jj tile of the block before (zero in front of a window's first block)
     if constexpr (ND == 3) {
 #pragma unroll
         for (int q = 0; q < GRP; ++q) load_sop(q, sop[q]);
@@ -352,6 +374,7 @@ __device__ __forceinline__ void imu_blocks(const LinArgs& A, const DevParams& P,
             }
             // y_t[r] = Y[mk + 4r][ml + 16t]  ==  operand chunk r of Y^T Y
             d4 g00 = {0.0, 0.0, 0.0, 0.0}, g01 = g00, g11 = g00;
+            if constexpr (CHAIN) g00 = chain11;   // + jj of the block before: frame k's diagonal tile is complete when this product is
 #pragma unroll
             for (int c = 0; c < 4; ++c) {
                 g00 = __builtin_amdgcn_mfma_f64_16x16x4f64(y0[c], y0[c], g00, 0, 0, 0);
@@ -360,6 +383,33 @@ __device__ __forceinline__ void imu_blocks(const LinArgs& A, const DevParams& P,
             }
             const size_t fg = (size_t)__shfl(fk_lane, LPB * gq, 64);
             const int sel = __shfl(sel_lane, LPB * gq, 64);
+            if constexpr (CHAIN) {
+                chain11 = g11;
+                if (ghost && gq == 0) continue;   // evaluated for its jj tile only
+                // frame kq's record: diagonal tile (upper triangle), gradient part of block (kq, kq+1); frame kq+1's: coupling, gradient
+                // part and cost of the block; behind a window's last block the jj tile is frame n-1's diagonal
+                const int kq = chain_k0 + gq;
+                double* rf = (sel ? A.PI[1] : A.PI[0]) + ((size_t)b * n + kq) * PIFS;
+                const bool lastb = kq == nb - 1;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int row = mk + 4 * r;
+                    if (row < 15 && ml < 15) {
+                        rf[PIFS + PIF_IJ + row * 15 + ml] = g01[r];
+                        if (ml >= row) {
+                            const int tq = row * 15 - (row * (row - 1)) / 2 + (ml - row);
+                            rf[PIF_D + tq] = g00[r];
+                            if (lastb) rf[PIFS + PIF_D + tq] = g11[r];
+                        }
+                    }
+                    if (row < 15 && ml == 15) { rf[PIF_GI + row] = g00[r]; if (lastb) rf[PIFS + PIF_GI + row] = 0.0; }
+                    if (r == 3) {
+                        if (row == 15 && ml < 15) rf[PIFS + PIF_GJ + ml] = g01[r];
+                        if (row == 15 && ml == 15) rf[PIFS + PIF_C] = g00[r];
+                    }
+                }
+                continue;
+            }
             double* out = (sel ? A.PI[1] : A.PI[0]) + fg * PIS;   // (a select, not an indexed load: an indexed kernel argument sends the whole struct through scratch)
             // tile (0,0) = [ii | gradient_i ; . | cost], tile (0,1) = [ij ; gradient_j], tile (1,1) = jj: one masked store per tile row group
 #pragma unroll
@@ -646,6 +696,12 @@ __global__ __launch_bounds__(64, 2) void k_lin_imu(LinArgs A, DevParams P) {
     if (A.imu_pk && *A.imu_pk_bad == 0) imu_blocks<3, true>(A, P, (int)blockIdx.x, lds, act);   // (uniform)
     else imu_blocks<3>(A, P, (int)blockIdx.x, lds, act);
 }
+__global__ __launch_bounds__(64, 2) void k_lin_imu_chain(LinArgs A, DevParams P) {   // consecutive blocks of one window per wave: per-frame IMU records
+    __shared__ double lds[IMU_PER_WAVE * IMU_REC];
+    const int* const act = usable_active_list(A.active, A.B);
+    if (A.imu_pk && *A.imu_pk_bad == 0) imu_blocks<3, true, true>(A, P, (int)blockIdx.x, lds, act);   // (uniform)
+    else imu_blocks<3, false, true>(A, P, (int)blockIdx.x, lds, act);
+}
 // Packed IMU block records of a solve (IMU_PK doubles per block, liw_kernels.hpp): one thread per entry; `bad` is raised when a
 // sqrt_inverse_P has a non-zero entry below its diagonal (not what imu_preintegraption.h:149 produces: the role then reads the full arrays).
 __global__ void k_imu_pack(long blocks, const double* X, const double* J, const double* S, const double* Dt, double* pk, int* bad) {
@@ -807,7 +863,7 @@ void launch_linearize(const LinArgs& A_, const DevParams& P, hipStream_t s, cons
         int pw = WHEEL_PER_WAVE;
         while (pw > 3 && (blocks + pw - 1) / pw < 512) pw = (pw + 1) / 2;   // 21 -> 11 -> 6 -> 3
         const bool nd3 = getenv("LIW_SMALL_ND3") != nullptr;                 // profiling / test aid (read per launch): three directions per lane everywhere
-        if (A.eval_small && !nd3 && (long)B * n + 2 * blocks + ground_wave_count(B, n) <= 256) { pw = 1; A.small_nd = 1; }
+        if (A.eval_small && !nd3 && !A.pi_frame && (long)B * n + 2 * blocks + ground_wave_count(B, n) <= 256) { pw = 1; A.small_nd = 1; }
         A.small_per_wave = pw;
         A.imu_per_wave = pw < IMU_PER_WAVE ? pw : IMU_PER_WAVE;
     }
@@ -824,7 +880,7 @@ void launch_linearize(const LinArgs& A_, const DevParams& P, hipStream_t s, cons
     // (also without the small roles — the older-frames laser evaluation of a marginalisation enqueued behind a tracking solve: the SAME
     // compiled body as the one-launch linearisation it must agree with bit for bit; the stand-alone k_lin_laser is a second compilation of
     // the body, whose FMA contraction may differ in the last bit)
-    if (laser_waves + imu_waves + small_waves <= 256) {
+    if (!A.pi_frame && laser_waves + imu_waves + small_waves <= 256) {   // (per-frame IMU records come from k_lin_imu_chain only)
         const int roles = laser_waves + imu_waves + small_waves;
         const unsigned tot = (unsigned)(roles + (A.reset_lm ? 1 : 0));
         if (A.mode == LIW_MODE_INIT) hipLaunchKernelGGL(k_lin_all<true>, dim3(tot), dim3(64), 0, s, A, P, G, laser_waves, imu_waves, roles);
@@ -849,7 +905,8 @@ void launch_linearize(const LinArgs& A_, const DevParams& P, hipStream_t s, cons
         else if (A.mode == LIW_MODE_INIT) hipLaunchKernelGGL(k_lin_laser<true>, dim3((unsigned)laser_waves), dim3(64), 0, s, A, P, G);
         else hipLaunchKernelGGL(k_lin_laser<false>, dim3((unsigned)laser_waves), dim3(64), 0, s, A, P, G);
     }
-    if (imu_waves && (rm & 2)) hipLaunchKernelGGL(k_lin_imu, dim3((unsigned)imu_waves), dim3(64), 0, s_imu, A, P);
+    if (imu_waves && (rm & 2) && A.pi_frame) hipLaunchKernelGGL(k_lin_imu_chain, dim3((unsigned)(B * imu_chain_parts(n - 1))), dim3(64), 0, s_imu, A, P);
+    else if (imu_waves && (rm & 2)) hipLaunchKernelGGL(k_lin_imu, dim3((unsigned)imu_waves), dim3(64), 0, s_imu, A, P);
     if (small_waves && (rm & 4)) hipLaunchKernelGGL(k_lin_small, dim3((unsigned)small_waves), dim3(64), 0, s_small, A, P);
     if (fork) {
         hipEventRecord(fk->ev_join[0], fk->side[0]);

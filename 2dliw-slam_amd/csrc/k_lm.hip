@@ -42,6 +42,7 @@ __device__ long long g_span[3 * 16384];   // per window: start, end (s_memtime),
 
 struct AsmCtx {
     int n, mode, fast, b, buf;
+    int pif;                  // 1: PI holds per-frame IMU records (PIF_*, liw_kernels.hpp), 0: per-block records (PI_*)
     const double* PL; const double* PI; const double* PW; const double* PG;   // of window b already offset? no: batch base
     const double* x;          // states the partials were evaluated at, window base [n][15]
     const double* pJ; const double* pX; bool prior_on;
@@ -105,12 +106,16 @@ __device__ __forceinline__ AsmRegs asm_issue(const AsmCtx& c, int i, const doubl
     const int n = c.n;
     const bool up = dir > 0;
     const double* PLb = c.PL + (size_t)c.b * n * LP;
-    const double* PIb = c.PI + (size_t)c.b * (n - 1) * PIS;
+    const bool pif = c.pif != 0;
+    const bool hasm = i >= 1, hasp = i <= n - 2;
+    // per-block records: PIm = block (i-1, i), PIp = block (i, i+1).  Per-frame records: PIm = frame i's record (diagonal tile complete,
+    // coupling to frame i-1, both gradient parts), PIp = frame i+1's (coupling of block (i, i+1), for the upward sweep)
+    const double* PIb = c.PI + (size_t)c.b * (pif ? (size_t)n * PIFS : (size_t)(n - 1) * PIS);
     const double* PWb = c.PW + (size_t)c.b * (n - 1) * PWS;
     const double* PGb = c.PG + (size_t)c.b * n * PGS;
-    const bool hasm = i >= 1, hasp = i <= n - 2;
-    const double* PIm = PIb + (size_t)(hasm ? i - 1 : 0) * PIS;   // IMU block (i-1, i)
-    const double* PIp = PIb + (size_t)(hasp ? i : 0) * PIS;       // IMU block (i, i+1)
+    const double* PIm = pif ? PIb + (size_t)i * PIFS : PIb + (size_t)(hasm ? i - 1 : 0) * PIS;
+    const double* PIp = pif ? PIb + (size_t)(hasp ? i + 1 : i) * PIFS : PIb + (size_t)(hasp ? i : 0) * PIS;
+    const int oJJ = pif ? PIF_D : PI_JJ, oIJ = pif ? PIF_IJ : PI_IJ;
     const double* PWm = PWb + (size_t)(hasm ? i - 1 : 0) * PWS;
     const double* PWp = PWb + (size_t)(hasp ? i : 0) * PWS;
     // frame-level bases are wave-uniform (SGPR pairs), the lane-dependent part of every address is an unsigned 32-bit element offset:
@@ -125,9 +130,9 @@ __device__ __forceinline__ AsmRegs asm_issue(const AsmCtx& c, int i, const doubl
         const bool valid = r < 15 && cc < 15;
         const int rs = valid ? r : 0, cs = valid ? cc : 0;
         const int tq = pi_tri(rs, cs);
-        R.v5[q] = PIm[(unsigned)(PI_JJ + tq)];
-        R.v6[q] = PIp[(unsigned)(PI_II + tq)];
-        R.v7[q] = up ? PIp[(unsigned)(PI_IJ + cs * 15 + rs)] : PIm[(unsigned)(PI_IJ + rs * 15 + cs)];   // (row r = neighbour's entry, column cc = frame i's)
+        R.v5[q] = PIm[(unsigned)(oJJ + tq)];
+        R.v6[q] = pif ? 0.0 : PIp[(unsigned)(PI_II + tq)];
+        R.v7[q] = up ? PIp[(unsigned)(oIJ + cs * 15 + rs)] : PIm[(unsigned)(oIJ + rs * 15 + cs)];   // (row r = neighbour's entry, column cc = frame i's)
     }
     {   // the 6x6 pose block terms: one element per lane (lanes 0..35)
         const bool pl = lane < 36;
@@ -147,8 +152,8 @@ __device__ __forceinline__ AsmRegs asm_issue(const AsmCtx& c, int i, const doubl
         R.g2 = PWm[(unsigned)PW_G(6 + r6)];
         R.g3 = PWp[(unsigned)PW_G(r6)];
         R.g4 = PGi[(unsigned)(r6 * 7 + 6)];
-        R.g5 = PIm[(unsigned)(PI_G + 15 + r)];
-        R.g6 = PIp[(unsigned)(PI_G + r)];
+        R.g5 = PIm[(unsigned)((pif ? PIF_GJ : PI_G + 15) + r)];
+        R.g6 = pif ? PIm[(unsigned)(PIF_GI + r)] : PIp[(unsigned)(PI_G + r)];
     }
     const int nbf = up ? (hasp ? i + 1 : i) : (hasm ? i - 1 : i);   // the sweep neighbour (or i itself at the end of the chain)
     {   // states (rotation vectors of frames i, its neighbour, 0 for the so3 Plus Jacobian test) and the LM scales
@@ -164,7 +169,7 @@ __device__ __forceinline__ AsmRegs asm_issue(const AsmCtx& c, int i, const doubl
 #pragma unroll
     for (int q = 0; q < 2; ++q) {   // rows 0..5 (pose of frame i-1) of the IMU block (i-1, i): element e = r * 15 + c < 90
         const int e = lane + 64 * q;
-        R.e1[q] = up ? PIm[(unsigned)(PI_IJ + (e < 90 ? e : 0))] : 0.0;
+        R.e1[q] = up ? PIm[(unsigned)(oIJ + (e < 90 ? e : 0))] : 0.0;
     }
     return R;
 }
@@ -213,7 +218,7 @@ __device__ void asm_commit(const AsmCtx& c, int i, const AsmRegs& R, const Tiles
     for (int q = 0; q < 4; ++q) {
         const int e = lane + 64 * q, r = e >> 4, cc = e & 15;
         const bool valid = r < 15 && cc < 15;
-        dI[q] = ((valid && hasm) ? R.v5[q] : 0.0) + ((valid && hasp) ? R.v6[q] : 0.0);
+        dI[q] = ((valid && (hasm || c.pif)) ? R.v5[q] : 0.0) + ((valid && hasp && !c.pif) ? R.v6[q] : 0.0);   // (per-frame records: v5 is the whole tile)
         oI[q] = (valid && hasnb) ? R.v7[q] : 0.0;
     }
     double dP = 0.0, oP = 0.0, rP = 0.0;
@@ -359,7 +364,8 @@ __device__ double window_cost(const AsmCtx& c, double* gchk = nullptr) {
     const int lane = threadIdx.x & 63;
     const int n = c.n;
     const double* PLb = c.PL + (size_t)c.b * n * LP;
-    const double* PIb = c.PI + (size_t)c.b * (n - 1) * PIS;
+    const bool pif = c.pif != 0;
+    const double* PIb = c.PI + (size_t)c.b * (pif ? (size_t)n * PIFS : (size_t)(n - 1) * PIS);
     const double* PWb = c.PW + (size_t)c.b * (n - 1) * PWS;
     const double* PGb = c.PG + (size_t)c.b * n * PGS;
     const bool track = c.mode == LIW_MODE_TRACK;
@@ -378,12 +384,13 @@ __device__ double window_cost(const AsmCtx& c, double* gchk = nullptr) {
         }
     }
     for (int k = lane; k < n - 1; k += 64) {
-        s += PIb[(size_t)k * PIS + PI_C];
+        s += pif ? PIb[(size_t)(k + 1) * PIFS + PIF_C] : PIb[(size_t)k * PIS + PI_C];   // (per-frame records: block (k, k+1)'s cost sits in frame k+1's)
         const bool won = !(track && k < n - 2);
         if (won) s += PWb[(size_t)k * PWS + PW_C];
         if (gchk) {
 #pragma unroll
-            for (int e = 0; e < 30; ++e) gs += PIb[(size_t)k * PIS + PI_G + e];
+            for (int e = 0; e < 30; ++e)   // g_i of block (k, k+1) | g_j of block (k, k+1)
+                gs += pif ? (e < 15 ? PIb[(size_t)k * PIFS + PIF_GI + e] : PIb[(size_t)(k + 1) * PIFS + PIF_GJ + e - 15]) : PIb[(size_t)k * PIS + PI_G + e];
             if (won) {
 #pragma unroll
                 for (int e = 0; e < 12; ++e) gs += PWb[(size_t)k * PWS + PW_G(e)];
@@ -477,7 +484,7 @@ __device__ double frame_diag(const AsmCtx& c, int i, LdsStep& T) {
     if (lane >= 15) return 0.0;
     const int r = lane;
     const double* PLb = c.PL + (size_t)c.b * n * LP;
-    const double* PIb = c.PI + (size_t)c.b * (n - 1) * PIS;
+    const double* PIb = c.PI + (size_t)c.b * (c.pif ? (size_t)n * PIFS : (size_t)(n - 1) * PIS);
     const double* PWb = c.PW + (size_t)c.b * (n - 1) * PWS;
     const double* PGb = c.PG + (size_t)c.b * n * PGS;
     double d = 0.0;
@@ -488,8 +495,11 @@ __device__ double frame_diag(const AsmCtx& c, int i, LdsStep& T) {
         if (i <= n - 2) d += PWb[(size_t)i * PWS + PW_II(r, r)];
         d += PGb[(size_t)i * PGS + r * 8];
     }
-    if (i >= 1) d += PIb[(size_t)(i - 1) * PIS + PI_JJ + pi_tri(r, r)];
-    if (i <= n - 2) d += PIb[(size_t)i * PIS + PI_II + pi_tri(r, r)];
+    if (c.pif) d += PIb[(size_t)i * PIFS + PIF_D + pi_tri(r, r)];
+    else {
+        if (i >= 1) d += PIb[(size_t)(i - 1) * PIS + PI_JJ + pi_tri(r, r)];
+        if (i <= n - 2) d += PIb[(size_t)i * PIS + PI_II + pi_tri(r, r)];
+    }
     if (c.prior_on && i == n - 2) { double s = 0.0; for (int k = 0; k < 15; ++k) s += c.pJ[k * 15 + r] * c.pJ[k * 15 + r]; d += s; }
     return d;
 }
@@ -513,6 +523,7 @@ __device__ __forceinline__ void lm_step_body(const StepArgs& a, const int b, Lds
     double* xc = a.w.x_cand + (size_t)b * n * 15;
 
     AsmCtx c;
+    c.pif = a.w.pi_frame;
     c.n = n; c.mode = a.mode; c.fast = a.fast_mode; c.b = b;
     c.pJ = a.prior_J + (size_t)b * 225; c.pX = a.prior_X + (size_t)b * 15;
     c.prior_on = a.mode == LIW_MODE_TRACK && a.has_prior[b] && !a.fast_mode;
@@ -964,6 +975,7 @@ __global__ __launch_bounds__(256, 1) void k_lm_step_tw(StepArgs a) {
     LdsStep& T = SS.T;
 
     AsmCtx c;
+    c.pif = a.w.pi_frame;
     c.n = n; c.mode = a.mode; c.fast = a.fast_mode; c.b = b;
     c.pJ = a.prior_J + (size_t)b * 225; c.pX = a.prior_X + (size_t)b * 15;
     c.prior_on = a.mode == LIW_MODE_TRACK && a.has_prior[b] && !a.fast_mode;
@@ -1462,6 +1474,7 @@ __global__ __launch_bounds__(64) void k_export_dense(ExportArgs a) {
     __shared__ LdsTiles T;
     const int b = blockIdx.x, lane = threadIdx.x & 63, n = a.n, N = 15 * n;
     AsmCtx c;
+    c.pif = a.w.pi_frame;
     c.n = n; c.mode = a.mode; c.fast = a.fast_mode; c.b = b; c.buf = a.buf;
     c.PL = a.w.PL[0]; c.PI = a.w.PI[0]; c.PW = a.w.PW[0]; c.PG = a.w.PG[0];   // standalone linearise writes buffer 0
     c.x = a.x + (size_t)b * n * 15;
@@ -1496,6 +1509,7 @@ __global__ __launch_bounds__(64) void k_export_dense(ExportArgs a) {
 __device__ __forceinline__ bool marg_chain(const MargArgs& a, const int b, LdsTiles& T) {
     const int lane = threadIdx.x & 63, n = a.n;
     AsmCtx c;
+    c.pif = a.w.pi_frame;
     const int sel = a.use_cur ? __builtin_amdgcn_readfirstlane(a.w.lm[b].cur) : 0;
     c.n = n; c.mode = LIW_MODE_MARG; c.fast = 0; c.b = b; c.buf = sel;
     c.PL = sel ? a.w.PL[1] : a.w.PL[0]; c.PI = sel ? a.w.PI[1] : a.w.PI[0]; c.PW = sel ? a.w.PW[1] : a.w.PW[0]; c.PG = sel ? a.w.PG[1] : a.w.PG[0];

@@ -72,7 +72,7 @@ constexpr int QTR = 0;
 #else
 constexpr int QTR = 4 * 15 * 6;                           // transposition tile of the carried arrow block (below)
 #endif
-constexpr int QTOT = 4 * (PIS + 86 + PWS + PGS) + 24 + QTR;   // LDS doubles per wave: the prefetched partial records of its four rows + the tile (27 072 B: six waves per CU)
+constexpr int QTOT = 4 * (PIFS + 86 + PWS + PGS) + 24 + QTR;   // LDS doubles per wave: the prefetched partial records of its four rows + the tile (27 072 B: six waves per CU)
 
 // offset of entry (r, j) inside a packed upper triangle of order 15, r a compile-time constant
 template <int R> __device__ __forceinline__ int tri_rc(int j, int cj) {   // cj = 14 j - j (j - 1) / 2
@@ -144,7 +144,7 @@ __global__ __launch_bounds__(64, LIW_QUAD_OCC) void k_lm_step_quad(StepArgs a) {
         double cost;
         {
             const double* PLb = (cb ? a.w.PL[1] : a.w.PL[0]) + (size_t)b * n * LP;
-            const double* PIb = (cb ? a.w.PI[1] : a.w.PI[0]) + (size_t)b * (n - 1) * PIS;
+            const double* PIb = (cb ? a.w.PI[1] : a.w.PI[0]) + (size_t)b * n * PIFS;   // per-frame IMU records (liw_kernels.hpp)
             const double* PWb = (cb ? a.w.PW[1] : a.w.PW[0]) + (size_t)b * (n - 1) * PWS;
             const double* PGb = (cb ? a.w.PG[1] : a.w.PG[0]) + (size_t)b * n * PGS;
             double s = 0.0;
@@ -153,7 +153,7 @@ __global__ __launch_bounds__(64, LIW_QUAD_OCC) void k_lm_step_quad(StepArgs a) {
                 if (!(track && i < n - 1)) s += PGb[(size_t)i * PGS + 48];
             }
             for (int k = j; k < n - 1; k += 16) {
-                s += PIb[(size_t)k * PIS + PI_C];
+                s += PIb[(size_t)(k + 1) * PIFS + PIF_C];   // (block (k, k+1)'s cost sits in frame k+1's record)
                 if (!(track && k < n - 2)) s += PWb[(size_t)k * PWS + PW_C];
             }
             if (track && !fast && a.has_prior[b] && j < 15) {   // marginalization_factor: r = linearized_J (x_{n-2} - linearized_X)  (:22-53)
@@ -247,7 +247,7 @@ __global__ __launch_bounds__(64, LIW_QUAD_OCC) void k_lm_step_quad(StepArgs a) {
     const double* const PG0 = a.w.PG[0];
     const unsigned bp = (g_qprobe & 1) ? 0u : (unsigned)b;
     const unsigned oPL = bp * (unsigned)(n * LP) + (cur ? (unsigned)(a.w.PL[1] - a.w.PL[0]) : 0u);
-    const unsigned oPI = bp * (unsigned)((n - 1) * PIS) + (cur ? (unsigned)(a.w.PI[1] - a.w.PI[0]) : 0u);
+    const unsigned oPI = bp * (unsigned)(n * PIFS) + (cur ? (unsigned)(a.w.PI[1] - a.w.PI[0]) : 0u);
     const unsigned oPW = bp * (unsigned)((n - 1) * PWS) + (cur ? (unsigned)(a.w.PW[1] - a.w.PW[0]) : 0u);
     const unsigned oPG = bp * (unsigned)(n * PGS) + (cur ? (unsigned)(a.w.PG[1] - a.w.PG[0]) : 0u);
     const int qprobe = g_qprobe;
@@ -270,8 +270,7 @@ __global__ __launch_bounds__(64, LIW_QUAD_OCC) void k_lm_step_quad(StepArgs a) {
                 if (i <= n - 2) dd += PW0[oPW + (unsigned)(i * PWS + PW_II(jc, jc))];
                 dd += PG0[oPG + (unsigned)(i * PGS + jc * 8)];
             }
-            if (i >= 1) dd += PI0[oPI + (unsigned)((i - 1) * PIS + PI_JJ + pi_tri(jc, jc))];
-            if (i <= n - 2) dd += PI0[oPI + (unsigned)(i * PIS + PI_II + pi_tri(jc, jc))];
+            if (n > 1) dd += PI0[oPI + (unsigned)(i * PIFS + PIF_D + pi_tri(jc, jc))];   // (the frame's complete IMU diagonal)
             if (prior_row && i == n - 2) {
                 double sp = 0.0;
                 for (int k = 0; k < 15; ++k) { const double v = a.prior_J[(size_t)b * 225 + k * 15 + jc]; sp += v * v; }
@@ -298,7 +297,7 @@ __global__ __launch_bounds__(64, LIW_QUAD_OCC) void k_lm_step_quad(StepArgs a) {
     // (4.9 TB/s chip-wide during the sweep) — and whoever issues next waits for a slot.  Probes with the records aliased to one window
     // (cache-resident) bound the memory share of the kernel at 21 %; the rest is the instruction stream.  The DMA form stays: it needs
     // no registers.
-    constexpr int S_IMU = 0, S_PL = 4 * PIS, S_PW = S_PL + 4 * 86, S_PG = S_PW + 4 * PWS, S_TR = S_PG + 4 * PGS + 24;   // (24 doubles of pad: the over-read of the last ground piece)
+    constexpr int S_IMU = 0, S_PL = 4 * PIFS, S_PW = S_PL + 4 * 86, S_PG = S_PW + 4 * PWS, S_TR = S_PG + 4 * PGS + 24;   // (24 doubles of pad: the over-read of the last ground piece)
     static_assert(S_TR + QTR <= QTOT, "LDS layout");
     const unsigned rPL[4] = {(unsigned)__builtin_amdgcn_readlane(oPL, 0), (unsigned)__builtin_amdgcn_readlane(oPL, 16), (unsigned)__builtin_amdgcn_readlane(oPL, 32), (unsigned)__builtin_amdgcn_readlane(oPL, 48)};
     const unsigned rPI[4] = {(unsigned)__builtin_amdgcn_readlane(oPI, 0), (unsigned)__builtin_amdgcn_readlane(oPI, 16), (unsigned)__builtin_amdgcn_readlane(oPI, 32), (unsigned)__builtin_amdgcn_readlane(oPI, 48)};
@@ -326,11 +325,11 @@ __global__ __launch_bounds__(64, LIW_QUAD_OCC) void k_lm_step_quad(StepArgs a) {
         const int k = f - 1;                        // frame f's block towards the frame before
         int lane2 = lane * 2;                       // the lane's 16-byte slot of a piece, in doubles: the ONLY lane-dependent part of an address
         asm volatile("" : "+v"(lane2));             // (laundered: per-lane pointers are formed here, never hoisted out of the frame loop)
-        if (k >= 0) {
-            sfor<0, 4>([&](auto W) {                // IMU partial: 4 pieces per row (the immediate offset moves the global AND the LDS address)
+        if (n > 1) {
+            sfor<0, 4>([&](auto W) {                // per-frame IMU record: 3 pieces per row (the immediate offset moves the global AND the LDS address)
                 constexpr int ws = KI(W);
-                const double* g = PI0 + rPI[ws] + (unsigned)(k * PIS) + lane2;
-                sfor<0, 4>([&](auto Q) { __builtin_amdgcn_global_load_lds(g, (lds_t)(S + S_IMU + ws * PIS), 16, KI(Q) * 1024, 0); });
+                const double* g = PI0 + rPI[ws] + (unsigned)(f * PIFS) + lane2;
+                sfor<0, 3>([&](auto Q) { __builtin_amdgcn_global_load_lds(g, (lds_t)(S + S_IMU + ws * PIFS), 16, KI(Q) * 1024, 0); });
             });
         }
         sfor<0, 4>([&](auto W) {                    // laser group record, slots 36 .. 122 (+ 42 doubles of over-read)
@@ -354,12 +353,12 @@ __global__ __launch_bounds__(64, LIW_QUAD_OCC) void k_lm_step_quad(StepArgs a) {
         asm volatile("" ::: "memory");
         prefetch_regs(f);
     };
-    const double* SI = S + S_IMU + w * PIS;
+    const double* SI = S + S_IMU + w * PIFS;
     const double* SL = S + S_PL + w * 86;         // SL[e] = PL_f[36 + e]
     const double* SW = S + S_PW + w * PWS;
     const double* SG = S + S_PG + w * PGS;
 #ifdef LIW_QUAD_TILE_ALIAS
-    double* ST = S + S_IMU + w * PIS + PI_II;
+    double* ST = S + S_IMU + w * PIFS + PIF_IJ + 100;
 #else
     double* ST = S + S_TR + w * 90;               // ST[c * 6 + q]: carried arrow block of the frame in front, row c (lane c), hub variable q
 #endif
@@ -411,12 +410,14 @@ __global__ __launch_bounds__(64, LIW_QUAD_OCC) void k_lm_step_quad(StepArgs a) {
             }
             sfor<0, 6>([&](auto R) { tS[KI(R)] += hA[KI(R)]; });
         }
-        // ---- IMU block (i-1, i): jj -> D, ij -> O^T, g_j -> gradient (lane 15); ii / g_i are frame i-1's share (-> cd below)
-        if (hasm) {
+        // ---- IMU record of frame i: the complete diagonal tile -> D, ij of block (i-1, i) -> O^T, both gradient parts -> lane 15
+        if (n > 1) {
             sfor<0, 15>([&](auto R) {
                 constexpr int r = KI(R);
-                d[r] = SI[PI_JJ + tri_rc<r>(jc, cj)];
-                o[r] = SI[l15 ? PI_G + 15 + r : PI_IJ + jc * 15 + r];
+                d[r] = SI[PIF_D + tri_rc<r>(jc, cj)];
+                const double ov = SI[l15 ? PIF_GJ + r : PIF_IJ + jc * 15 + r];      // (frame 0's record has no block in front of it)
+                const double gi = SI[PIF_GI + r];                                  // (zero in frame n-1's record)
+                o[r] = (hasm ? ov : 0.0) + (l15 ? gi : 0.0);
             });
         } else {
             sfor<0, 15>([&](auto R) { constexpr int r = KI(R); d[r] = 0.0; o[r] = 0.0; });
@@ -450,7 +451,7 @@ __global__ __launch_bounds__(64, LIW_QUAD_OCC) void k_lm_step_quad(StepArgs a) {
         //      the IMU record's ij block, which the assembly above has consumed) + the share of block (i, i+1) (gsh)
         QSTAMP(3);
         {
-            double* GT = const_cast<double*>(SI) + PI_IJ;
+            double* GT = const_cast<double*>(SI) + PIF_IJ;
             if (l15) sfor<0, 15>([&](auto R) { constexpr int r = KI(R); GT[r] = o[r]; });
             const double gt = gsh + (lm ? GT[jc] : 0.0);
             double m = fabs(gt);                                   // |q - (q - g)| when Plus does not wrap (rotation entries), |g| elsewhere
@@ -521,20 +522,19 @@ __global__ __launch_bounds__(64, LIW_QUAD_OCC) void k_lm_step_quad(StepArgs a) {
         QSTAMP(5);
         if (hasm) {
             dpp_fence();
+            // (the IMU share of frame i-1 arrives with that frame's own record: only the wheel block's pose share is folded here)
             double cw[6];
-            sfor<0, 15>([&](auto R) {           // (all LDS reads first: one round trip, not fifteen)
-                constexpr int r = KI(R);
-                cd[r] = SI[l15 ? PI_G + r : PI_II + tri_rc<r>(jc, cj)];
-                if constexpr (r < 6) cw[r] = SW[l15 ? PW_G(r) : PW_II(r, j6)];
-            });
-            gsh = (lm ? SI[PI_G + jc] : 0.0) + (l6 ? SW[PW_G(j6)] : 0.0);   // frame i-1's unscaled gradient share, lane per entry
+            sfor<0, 6>([&](auto R) { constexpr int r = KI(R); cw[r] = SW[l15 ? PW_G(r) : PW_II(r, j6)]; });
+            gsh = l6 ? SW[PW_G(j6)] : 0.0;                  // frame i-1's unscaled wheel gradient share, lane per entry
             __builtin_amdgcn_sched_barrier(0);
             sfor<0, 15>([&](auto R) {
                 constexpr int r = KI(R);
-                const double rs = bc<r>(scm);
-                double fi = cd[r];
-                if constexpr (r < 6) fi += (l6 || l15) ? cw[r] : 0.0;
-                cd[r] = fi * (rs * scm);
+                double fi = 0.0;
+                if constexpr (r < 6) {
+                    const double rs = bc<r>(scm);
+                    fi = ((l6 || l15) ? cw[r] : 0.0) * (rs * scm);
+                }
+                cd[r] = fi;
                 pdiag = (j == r) ? cd[r] : pdiag;  // its diagonal (LM diagonal of frame i-1)
             });
         } else {
@@ -730,7 +730,7 @@ bool lm_step_quad_fits(const StepArgs& a) {
         return d <= lim && d + (unsigned long long)a.B * per <= lim;
     };
     const int nm = a.n > 1 ? a.n - 1 : 1;
-    return a.n >= 1 && (a.mode == LIW_MODE_INIT || (a.mode == LIW_MODE_TRACK && a.n >= 2)) && span(a.w.PL[0], a.w.PL[1], (unsigned long long)a.n * LP) && span(a.w.PI[0], a.w.PI[1], (unsigned long long)nm * PIS) &&
+    return a.n >= 1 && (a.mode == LIW_MODE_INIT || (a.mode == LIW_MODE_TRACK && a.n >= 2)) && span(a.w.PL[0], a.w.PL[1], (unsigned long long)a.n * LP) && a.w.pi_frame && span(a.w.PI[0], a.w.PI[1], (unsigned long long)a.n * PIFS) &&
            span(a.w.PW[0], a.w.PW[1], (unsigned long long)nm * PWS) && span(a.w.PG[0], a.w.PG[1], (unsigned long long)a.n * PGS) &&
            (unsigned long long)a.B * (sizeof(LmState) / 8) <= lim && (unsigned long long)a.B * a.n * SOLVE_WS <= lim;
 }

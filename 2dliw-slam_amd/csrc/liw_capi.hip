@@ -236,7 +236,7 @@ static FullLayout full_layout(int B, int n, int hist) {
     size_t o = 0;
     const int nm = n > 1 ? n - 1 : 1;
     for (int k = 0; k < 2; ++k) { f.PL[k] = o; o = al256(o + sizeof(double) * (size_t)B * n * LP); }
-    for (int k = 0; k < 2; ++k) { f.PI[k] = o; o = al256(o + sizeof(double) * (size_t)B * nm * PIS); }
+    for (int k = 0; k < 2; ++k) { f.PI[k] = o; o = al256(o + sizeof(double) * (size_t)B * pi_doubles_per_window(n)); }
     for (int k = 0; k < 2; ++k) { f.PW[k] = o; o = al256(o + sizeof(double) * (size_t)B * nm * PWS); }
     for (int k = 0; k < 2; ++k) { f.PG[k] = o; o = al256(o + sizeof(double) * (size_t)B * n * PGS); }
     f.x_cand = o; o = al256(o + sizeof(double) * (size_t)B * n * 15);
@@ -268,6 +268,7 @@ static WsView make_view(void* ws, int B, int n, int hist) {
     v.history = hist > 0 ? (double*)(base + f.history) : nullptr;
     v.history_records = hist;
     v.active = (int*)(base + f.active);
+    v.pi_frame = pi_frame_format(B) ? 1 : 0;
     v.imu_pk = (double*)(base + f.imu_pk);
     v.imu_pk_bad = (int*)(base + f.imu_pk_bad);
     return v;
@@ -332,6 +333,7 @@ static LinArgs lin_args(const liw_batch* b, int mode, const double* x, const WsV
     A.lm = use_lm ? v.lm : nullptr;
     A.active = use_lm ? v.active : nullptr;
     A.candidate = candidate;
+    A.pi_frame = v.pi_frame;
     if (packed && b->n > 1 && b->eval_small) { A.imu_pk = v.imu_pk; A.imu_pk_bad = v.imu_pk_bad; }
     if (packed) A.laser_hz = v.imu_pk_bad + 1;
     if (packed && mode == LIW_MODE_INIT && lpk_matches(c, b, ws)) { A.laser_pk = c->lpk.as<double>(); A.laser_slab_off = c->lpk_off.as<long long>(); }

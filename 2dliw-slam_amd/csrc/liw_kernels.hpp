@@ -1,5 +1,6 @@
 // liw_kernels.hpp — shared device-side declarations of libliw_window.so (gfx950 only).
 #pragma once
+#include <cstdlib>
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
@@ -33,6 +34,20 @@ constexpr int PI_II = 0, PI_IJ = 120, PI_JJ = 345, PI_G = 465, PI_C = 495;   // 
 __host__ __device__ inline int pi_tri(int r, int c) {   // offset of entry (r, c) = (c, r) inside a packed upper triangle of order 15
     const int lo = r < c ? r : c, hi = r < c ? c : r;
     return lo * 15 - (lo * (lo - 1)) / 2 + (hi - lo);
+}
+// Large batches (pi_frame_format): the IMU partial PER FRAME instead of per block — PI[B][n][PIFS]: frame f's record holds the complete IMU
+// diagonal tile of the frame, ii of block (f, f+1) + jj of block (f-1, f) (the same 15x15 index space; the role chains the jj accumulator
+// of a block into the next block's ii product as its MFMA C operand), the coupling ij of block (f-1, f), both gradient parts and the
+// cost of block (f-1, f): 376 instead of 496 doubles per frame, and no consumer has to add a neighbour block's share to its diagonal.
+constexpr int PIF_D = 0, PIF_IJ = 120, PIF_GJ = 345, PIF_GI = 360, PIF_C = 375, PIFS = 376;
+// the regime of k_lm_step_quad (which reads per-frame records only): batches above 2 048 windows, or the kernel forced by LIW_STEP_VARIANT=3
+inline bool pi_frame_format(int B) {
+    const char* env = getenv("LIW_STEP_VARIANT");
+    return env ? env[0] == '3' : B > 2048;
+}
+__host__ __device__ inline size_t pi_doubles_per_window(int n) {               // room for either format
+    const size_t a = (size_t)(n > 1 ? n - 1 : 1) * PIS, b = (size_t)n * PIFS;
+    return a > b ? a : b;
 }
 constexpr int PWS = 122;
 // entries of a wheel record: r, c < 6 index the pose entries of frame k (ii), of frame k+1 (jj), or one of each (ij: row = frame k)
@@ -79,6 +94,7 @@ struct WsView {
     int history_records;
     int* active;          // [1 + B] compacted list of the windows still iterating (IMU / wheel / ground roles index their blocks over it);
                           //    behind it the ticket word and the per-group publication words of k_compact_active (zeroed by lm_begin)
+    int pi_frame;         // 1: PI holds per-frame records (PIF_*, pi_frame_format(B)), 0: per-block records (PI_*)
     double* imu_pk;       // [B][n-1][IMU_PK] packed IMU block records of the solve in progress (launch_imu_pack, from liw_batch_lm_begin)
     int* imu_pk_bad;      // [0] != 0: some sqrt_inverse_P is not upper triangular -> the IMU role reads the caller's arrays;
                           // [1] != 0: some laser end point has a z component (launch_laser_z_scan)
@@ -113,6 +129,7 @@ struct LinArgs {
     int imu_per_wave;           // IMU blocks per wave (set by launch_linearize)
     int small_nd;               // derivative directions per lane of the IMU / wheel roles: 3 (batches) or 1 (k_lin_all on a few windows)
     int* active;                // [1 + B]: number of windows still iterating, then their ids (built per linearisation when lm != null)
+    int pi_frame;               // 1: write per-frame IMU records (WsView::pi_frame)
     const double* imu_pk;       // packed IMU block records (WsView::imu_pk) or null
     const int* imu_pk_bad;      //   ... usable iff *imu_pk_bad == 0
     const int* laser_hz;        // null, or -> 0 when no laser end point of the batch has a z component (2-D scans): the z planes are skipped

@@ -39,14 +39,14 @@ def algorithmic_bytes(n, L, both_free):
 
 def step_model(n, arrow=True):
     """HBM bytes and essential flops of ONE LM step of one window in k_lm_step_quad (csrc/k_lm_quad.hip), init topology.
-    Reads (LDS-DMA pieces, as issued): per frame the IMU partial of its block (3 968 B), the wheel partial (976), 688 B of the laser
+    Reads (LDS-DMA pieces): per frame its IMU record (3 008 B: the per-frame format of large batches, round 4), the wheel partial of its block (976), 688 B of the laser
     group record, the ground partial (416); Jacobi scale / LM diagonal / state entries (3 x 120 B per frame, twice: both sweeps) and the
     current + candidate states; the cost slots of the prologue (four 128-byte lines per frame).  Writes: the 22-column back-substitution
     record (2 640 B per frame, read again by the second sweep), LM diagonal, candidate states.
     Flops: Cholesky 15^3/3, 22 forward and 22 backward substitutions 2 x 22 x 15^2, Schur products (16x16 + 6x16 + 6x6/2) x 15 x 2, second
     sweep 21 x 15 x 2 — per frame."""
     nb = max(n - 1, 0)
-    rd = nb * (3968 + 976) + n * (688 + 416) + 2 * n * 3 * 120 + 2 * n * 120 + n * 4 * 128 + n * 2640
+    rd = (n * 3008 if nb else 0) + nb * 976 + n * (688 + 416) + 2 * n * 3 * 120 + 2 * n * 120 + n * 4 * 128 + n * 2640
     wr = n * 2640 + n * 120 + n * 120
     fl = n * (15 ** 3 / 3.0 + 2 * 22 * 15 * 15 + (16 * 16 + (6 * 16 + 18 if arrow else 0)) * 15 * 2 + 21 * 15 * 2)
     return {"read": int(rd), "write": int(wr), "flops": float(fl)}
