@@ -517,8 +517,9 @@ def main():
                             "frac_laser_only_note": "SURVEY 8d's materialised-J bytes (312 B per block) over a kernel that never writes a Jacobian: a value above 1 says the CONVENTION, not the HBM, is what this figure measures",
                             "read_GBps": round(lb * 72.0 / t["k_lin_laser"] / 1e9, 1), "essential_flops_per_block": laser_flops,
                             "flops_frac": round(lb * laser_flops / t["k_lin_laser"] / F64, 4),
-                            "instructions_per_64_block_chunk": "~1000 issued for ~290 essential fp64 instructions: the rest is the per-group wave reduction (~260 per group end), the second masked round of pair products where a chunk straddles two groups (90), transform reads from LDS (~60), address / mask bookkeeping",
-                            "valu_issue_frac": issue("k_lin_laser"), "bound": "fp64 VALU issue (two waves per SIMD)"},
+                            "kernel": "k_lin_laser_slab (a lane per (window, frame) group over per-solve packed rows: batches of >= 2 048 (slab, frame) waves of 2-D scans)" if (B + 63) // 64 * n >= 2048 and not os.environ.get("LIW_NO_LASER_SLAB") else "k_lin_laser<true> (a lane per block, wave reduction per group)",
+                            "instructions": "lane-per-group kernel: ~350 VALU instructions per row of 64 blocks (~290 of them the blocks' own fp64 arithmetic), no cross-lane reduction; lane-per-block kernel: ~1000 per 64-block chunk (per-group wave reduction ~260 per group end, second masked round of pair products where a chunk straddles two groups, transform reads from LDS, masks)",
+                            "valu_issue_frac": issue("k_lin_laser"), "bound": "fp64 VALU issue (lane-per-group kernel: one wave per SIMD, 52 % VALU-busy; lane-per-block kernel: two waves per SIMD)"},
             "k_lin_imu": {"ms": round(kt["k_lin_imu"], 4), "mfma_insts": int(ib * 20), "mfma_util": round(ib * 20 * mf / t["k_lin_imu"] / F64, 4),
                           "flops_frac": round(ib * (20 * mf + 3 * 2600.0) / t["k_lin_imu"] / F64, 4), "valu_issue_frac": issue("k_lin_imu"),
                           "bound": "fp64 pipe shared by MFMA and VALU (their times add), two waves per SIMD"},
