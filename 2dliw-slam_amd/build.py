@@ -11,6 +11,8 @@ HEADERS = ["liw_dual.hpp", "liw_kernels.hpp", "k_lm_common.hpp", "k_lin_laser_bo
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wno-unused-result"]
 if os.environ.get("LIW_QUAD_OCC"):   # A/B aid: waves per SIMD the quad step kernel is compiled for
     FLAGS.append("-DLIW_QUAD_OCC=" + os.environ["LIW_QUAD_OCC"])
+if os.environ.get("LIW_SMALL_OCC"):   # A/B aid: waves per SIMD k_lin_small is compiled for (3: <= 168 registers, co-resident with the lane-per-group laser kernel)
+    FLAGS.append("-DLIW_SMALL_OCC=" + os.environ["LIW_SMALL_OCC"])
 if os.environ.get("LIW_QUAD_TILE_ALIAS"):
     FLAGS.append("-DLIW_QUAD_TILE_ALIAS")
 if os.environ.get("LIW_CLK"):   # phase-timing build for tools/clk_probe.py

@@ -240,6 +240,7 @@ __global__ __launch_bounds__(64, 1) void k_lin_laser_slab(LinArgs A, DevParams P
     if (in) {
         double* out = (psel ? A.PL[1] : A.PL[0]) + ((size_t)bb * n + f) * LP;
         slab_store<0>(out, acc);
+        if (A.CS[0]) (psel ? A.CS[1] : A.CS[0])[cs_index(n, bb, CS_LASER, f)] = acc[slab_pairidx(8, 8)];
     }
 }
 

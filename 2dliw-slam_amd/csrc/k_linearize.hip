@@ -72,11 +72,13 @@ constexpr int LASER_GMAX = 8;   // (window, frame) groups one wave may own
 // registers over all passes; one butterfly per group reduces them across the wave.
 template <bool BOTH>
 __device__ __forceinline__ void laser_wave_local(const LinArgs& A, const DevParams& P, int G, int vblock) {
+    constexpr bool kCostCopy = false;   // (k_lin_all: a few windows, never the per-frame format the compact cost array belongs to)
 #include "k_lin_laser_body.inc"
 }
 template <bool BOTH>
 __global__ __launch_bounds__(64, 2) void k_lin_laser(LinArgs A, DevParams P, int G) {
     const int vblock = (int)blockIdx.x;
+    constexpr bool kCostCopy = true;
 #include "k_lin_laser_body.inc"
 }
 
@@ -405,7 +407,7 @@ __device__ __forceinline__ void imu_blocks(const LinArgs& A, const DevParams& P,
                     if (row < 15 && ml == 15) { rf[PIF_GI + row] = g00[r]; if (lastb) rf[PIFS + PIF_GI + row] = 0.0; }
                     if (r == 3) {
                         if (row == 15 && ml < 15) rf[PIFS + PIF_GJ + ml] = g01[r];
-                        if (row == 15 && ml == 15) rf[PIFS + PIF_C] = g00[r];
+                        if (row == 15 && ml == 15) { rf[PIFS + PIF_C] = g00[r]; if (A.CS[0]) (sel ? A.CS[1] : A.CS[0])[cs_index(n, b, CS_IMU, kq)] = g00[r]; }
                     }
                 }
                 continue;
@@ -452,7 +454,7 @@ __device__ __forceinline__ void imu_blocks(const LinArgs& A, const DevParams& P,
 // gets its derivative parts as  L * dM_e * R  with lane-selected double matrices; only log_SO3 and the scalar tail of the residual
 // run on LJN<3>.
 constexpr int WHEEL_PER_WAVE = 21;
-template <int ND>   // directions per lane: 3 (three lanes per block) or 1 (nine lanes per block, small batches), as in imu_blocks
+template <int ND, bool COSTCOPY>   // directions per lane: 3 (three lanes per block) or 1 (nine lanes per block, small batches), as in imu_blocks; COSTCOPY: see CS in LinArgs
 __device__ __forceinline__ void wheel_blocks(const LinArgs& A, const DevParams& P, int wave, double* lds, const int* const act) {
     constexpr int LPB = 9 / ND;
     constexpr int MAXB = 63 / LPB;
@@ -598,14 +600,21 @@ __device__ __forceinline__ void wheel_blocks(const LinArgs& A, const DevParams& 
     if (g == 0 && blk < MAXB) {
         meta[blk] = on ? (A.lm ? (A.candidate ? 1 - A.lm[b].cur : A.lm[b].cur) : 0) : -1;
         meta[32 + blk] = (int)fk;
+        meta[64 + blk] = (int)cs_index(n, b, CS_WHEEL, k);   // its slot of the compact cost array
     }
     // record entry e -> columns (r, c) of Y: ii | ij | jj | gradient | cost (liw_kernels.hpp), as a table built once per wave (the divisions
     // and selects it replaces were ~20 of the ~45 instructions of every output element: 40 elements per lane and wave)
-    int* rc_tab = meta + 64;
+    int* rc_tab = meta + 96;
     for (int e = lane; e < PWS; e += 64) {
-        const int blk6 = e / 36, w6 = e % 36;
-        const int r = e < 108 ? (blk6 == 2 ? 6 : 0) + w6 / 6 : (e < 120 ? e - 108 : 12);
-        const int c = e < 108 ? (blk6 == 0 ? 0 : 6) + w6 % 6 : 12;
+        int r = 12, c = 12;                                   // e == PW_C: sum r^2
+        if (e < PW_IJ(0, 0) || (e >= PW_JJ(0, 0) && e < PW_G(0))) {   // packed upper triangles of ii / jj: row r has 6 - r entries
+            const int jj = e >= PW_JJ(0, 0);
+            int t = e - (jj ? PW_JJ(0, 0) : 0);
+            r = 0;
+            while (t >= 6 - r) { t -= 6 - r; ++r; }
+            c = r + t + (jj ? 6 : 0); r += jj ? 6 : 0;
+        } else if (e < PW_JJ(0, 0)) { r = (e - PW_IJ(0, 0)) / 6; c = 6 + (e - PW_IJ(0, 0)) % 6; }
+        else if (e < PW_C) { r = e - PW_G(0); c = 12; }
         rc_tab[e] = e <= PW_C ? (r << 8) | c : -1;
     }
     lds_sync();
@@ -619,6 +628,7 @@ __device__ __forceinline__ void wheel_blocks(const LinArgs& A, const DevParams& 
             const int rc = rc_tab[e], r = rc >> 8, c = rc & 255;
             const double v = rc >= 0 ? Yq[r] * Yq[c] + Yq[13 + r] * Yq[13 + c] + Yq[26 + r] * Yq[26 + c] : 0.0;
             (sel ? A.PW[1] : A.PW[0])[(size_t)meta[32 + q] * PWS + e] = v;
+            if (COSTCOPY && e == PW_C && A.CS[0]) (sel ? A.CS[1] : A.CS[0])[meta[64 + q]] = v;
         }
     }
 }
@@ -628,6 +638,7 @@ __device__ __forceinline__ void wheel_blocks(const LinArgs& A, const DevParams& 
 // tf_w_o = make_tf(p, theta) * T_imu_to_wheel
 // 32 frames per wave, two lanes each: lane 0 the 3 directions of p, lane 1 of theta
 constexpr int GROUND_PER_WAVE = 32;
+template <bool COSTCOPY>
 __device__ __forceinline__ void ground_frames(const LinArgs& A, const DevParams& P, int wave, double* lds, const int* const act) {
     const int lane = threadIdx.x & 63, sub = lane >> 1, g = lane & 1;
     const int n = A.n;
@@ -660,7 +671,13 @@ __device__ __forceinline__ void ground_frames(const LinArgs& A, const DevParams&
             for (int e = 0; e < 3; ++e) { A.dbg_ground_jac[(fi * 2) * 6 + 3 * g + e] = res[0].d[e]; A.dbg_ground_jac[(fi * 2 + 1) * 6 + 3 * g + e] = res[1].d[e]; }
     }
     int* meta = reinterpret_cast<int*>(lds + GROUND_PER_WAVE * 16);
-    if (g == 0) { meta[sub] = on ? (A.lm ? (A.candidate ? 1 - A.lm[b].cur : A.lm[b].cur) : 0) : -1; meta[32 + sub] = (int)fi; }
+    if (g == 0) { meta[sub] = on ? (A.lm ? (A.candidate ? 1 - A.lm[b].cur : A.lm[b].cur) : 0) : -1; meta[32 + sub] = (int)fi; meta[64 + sub] = (int)cs_index(n, b, CS_GROUND, (int)(gf % n)); }
+    int* rc_tab = meta + 96;                                   // record entry e -> (r, c) of the packed upper triangle of the 7x7 G (PG_H / PG_G / PG_C)
+    if (lane < PGS) {
+        int r = 0, c = lane;
+        while (c >= 7 - r) { c -= 7 - r; ++r; }               // row r has 7 - r entries
+        rc_tab[lane] = (r << 8) | (c + r);
+    }
     lds_sync();
     {   // n * Y^T Y (7 x 7 per frame; the block set is added once per outer frame index, solver.cpp:142-159), coalesced as in the wheel role
         const long gf0 = (long)wave * GROUND_PER_WAVE;
@@ -670,9 +687,10 @@ __device__ __forceinline__ void ground_frames(const LinArgs& A, const DevParams&
             const int q = idx / PGS, e = idx % PGS, sel = meta[q];
             if (sel < 0) continue;
             const double* Yq = lds + q * 16;
-            const int r = e / 7, c = e % 7;
-            const double v = e < 49 ? mult * (Yq[r] * Yq[c] + Yq[7 + r] * Yq[7 + c]) : 0.0;
+            const int rc = rc_tab[e], r = rc >> 8, c = rc & 255;
+            const double v = mult * (Yq[r] * Yq[c] + Yq[7 + r] * Yq[7 + c]);
             (sel ? A.PG[1] : A.PG[0])[(size_t)meta[32 + q] * PGS + e] = v;
+            if (COSTCOPY && e == PG_C && A.CS[0]) (sel ? A.CS[1] : A.CS[0])[meta[64 + q]] = v;
         }
     }
 }
@@ -683,13 +701,13 @@ __device__ __forceinline__ void ground_frames(const LinArgs& A, const DevParams&
 __host__ __device__ inline int imu_wave_count(int B, int n, int per_wave) { return n > 1 ? (int)(((long)B * (n - 1) + per_wave - 1) / per_wave) : 0; }
 __host__ __device__ inline int wheel_wave_count(int B, int n, int per_wave) { return imu_wave_count(B, n, per_wave); }
 __host__ __device__ inline int ground_wave_count(int B, int n) { return (int)(((long)B * n + GROUND_PER_WAVE - 1) / GROUND_PER_WAVE); }
-template <int ND>
+template <int ND, bool COSTCOPY>
 __device__ __forceinline__ void small_role(const LinArgs& A, const DevParams& P, int vblock, double* lds, const int* const act) {
     const int nw = wheel_wave_count(A.B, A.n, A.small_per_wave);
-    if (vblock < nw) wheel_blocks<ND>(A, P, vblock, lds, act);
-    else ground_frames(A, P, vblock - nw, lds, act);
+    if (vblock < nw) wheel_blocks<ND, COSTCOPY>(A, P, vblock, lds, act);
+    else ground_frames<COSTCOPY>(A, P, vblock - nw, lds, act);
 }
-constexpr int SMALL_LDS = WHEEL_PER_WAVE * 64 + 32 + 64;   // + 64 per-block meta words + the 122-entry (r, c) table of the wheel record; >= GROUND_PER_WAVE * 16 + 32
+constexpr int SMALL_LDS = WHEEL_PER_WAVE * 64 + 32 + 16 + 64;   // + 64 per-block meta words + the (r, c) table of the wheel / ground record; >= GROUND_PER_WAVE * 16 + 32
 __global__ __launch_bounds__(64, 2) void k_lin_imu(LinArgs A, DevParams P) {
     __shared__ double lds[IMU_PER_WAVE * IMU_REC];
     const int* const act = usable_active_list(A.active, A.B);
@@ -744,9 +762,12 @@ void launch_imu_pack(int B, int n, const double* imu_X, const double* imu_J, con
     if (blocks <= 0) return;
     hipLaunchKernelGGL(k_imu_pack, dim3((unsigned)blocks), dim3(256), 0, s, blocks, imu_X, imu_J, imu_sqrtP, imu_Dt, pk, bad);
 }
-__global__ __launch_bounds__(64, 2) void k_lin_small(LinArgs A, DevParams P) {
+#ifndef LIW_SMALL_OCC
+#define LIW_SMALL_OCC 3
+#endif
+__global__ __launch_bounds__(64, LIW_SMALL_OCC) void k_lin_small(LinArgs A, DevParams P) {
     __shared__ double lds[SMALL_LDS];
-    small_role<3>(A, P, (int)blockIdx.x, lds, usable_active_list(A.active, A.B));
+    small_role<3, true>(A, P, (int)blockIdx.x, lds, usable_active_list(A.active, A.B));
 }
 __global__ void k_lm_reset(int B, LmState* lm, int max_iters) {
     const int b = blockIdx.x * blockDim.x + threadIdx.x;
@@ -767,9 +788,9 @@ __global__ __launch_bounds__(64, 2) void k_lin_all(LinArgs A, DevParams P, int G
 #endif
     if (v < n_laser) laser_wave_local<BOTH>(A, P, G, v);
     else if (A.small_nd == 1) {   // (uniform) one direction per lane: the short instruction stream a single window waits for
-        if (v < n_laser + n_imu) imu_blocks<1>(A, P, v - n_laser, lds, nullptr); else small_role<1>(A, P, v - n_laser - n_imu, lds, nullptr);
+        if (v < n_laser + n_imu) imu_blocks<1>(A, P, v - n_laser, lds, nullptr); else small_role<1, false>(A, P, v - n_laser - n_imu, lds, nullptr);
     } else {
-        if (v < n_laser + n_imu) imu_blocks<3>(A, P, v - n_laser, lds, nullptr); else small_role<3>(A, P, v - n_laser - n_imu, lds, nullptr);
+        if (v < n_laser + n_imu) imu_blocks<3>(A, P, v - n_laser, lds, nullptr); else small_role<3, false>(A, P, v - n_laser - n_imu, lds, nullptr);
     }
 #ifdef LIW_CLK
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");

@@ -140,7 +140,7 @@ __device__ __forceinline__ AsmRegs asm_issue(const AsmCtx& c, int i, const doubl
         R.t1 = PLi[(unsigned)(36 + r * 6 + cc)];
         R.t2 = PWm[(unsigned)PW_JJ(r, cc)];
         R.t3 = PWp[(unsigned)PW_II(r, cc)];
-        R.t4 = PGi[(unsigned)(r * 7 + cc)];
+        R.t4 = PGi[(unsigned)PG_H(r, cc)];
         R.t8 = up ? PWp[(unsigned)PW_IJ(cc, r)] : PWm[(unsigned)PW_IJ(r, cc)];
         R.e2 = up ? PWm[(unsigned)PW_IJ(r, cc)] : 0.0;
         R.t9 = PL1[(unsigned)(72 + r * 6 + cc)];
@@ -151,7 +151,7 @@ __device__ __forceinline__ AsmRegs asm_issue(const AsmCtx& c, int i, const doubl
         R.g1 = PLi[(unsigned)(114 + r6)];
         R.g2 = PWm[(unsigned)PW_G(6 + r6)];
         R.g3 = PWp[(unsigned)PW_G(r6)];
-        R.g4 = PGi[(unsigned)(r6 * 7 + 6)];
+        R.g4 = PGi[(unsigned)PG_G(r6)];
         R.g5 = PIm[(unsigned)((pif ? PIF_GJ : PI_G + 15) + r)];
         R.g6 = pif ? PIm[(unsigned)(PIF_GI + r)] : PIp[(unsigned)(PI_G + r)];
     }
@@ -373,13 +373,13 @@ __device__ double window_cost(const AsmCtx& c, double* gchk = nullptr) {
     for (int i = lane; i < n; i += 64) {
         s += PLb[(size_t)i * LP + 120];
         const bool gon = !(track && i < n - 1);
-        if (gon) s += PGb[(size_t)i * PGS + 48];
+        if (gon) s += PGb[(size_t)i * PGS + PG_C];
         if (gchk) {
 #pragma unroll
             for (int k = 0; k < 12; ++k) gs += PLb[(size_t)i * LP + 108 + k];
             if (gon) {
 #pragma unroll
-                for (int k = 0; k < 6; ++k) gs += PGb[(size_t)i * PGS + k * 7 + 6];
+                for (int k = 0; k < 6; ++k) gs += PGb[(size_t)i * PGS + PG_G(k)];
             }
         }
     }
@@ -493,7 +493,7 @@ __device__ double frame_diag(const AsmCtx& c, int i, LdsStep& T) {
         if (i == 0) for (int j = 0; j < n; ++j) d += PLb[(size_t)j * LP + r * 7];
         if (i >= 1) d += PWb[(size_t)(i - 1) * PWS + PW_JJ(r, r)];
         if (i <= n - 2) d += PWb[(size_t)i * PWS + PW_II(r, r)];
-        d += PGb[(size_t)i * PGS + r * 8];
+        d += PGb[(size_t)i * PGS + PG_H(r, r)];
     }
     if (c.pif) d += PIb[(size_t)i * PIFS + PIF_D + pi_tri(r, r)];
     else {

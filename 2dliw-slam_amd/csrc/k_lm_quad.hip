@@ -72,7 +72,7 @@ constexpr int QTR = 0;
 #else
 constexpr int QTR = 4 * 15 * 6;                           // transposition tile of the carried arrow block (below)
 #endif
-constexpr int QTOT = 4 * (PIFS + 86 + PWS + PGS) + 24 + QTR;   // LDS doubles per wave: the prefetched partial records of its four rows + the tile (27 072 B: six waves per CU)
+constexpr int QTOT = 4 * (PIFS + LP + PWS + PGS) + 24 + QTR;   // LDS doubles per wave: the prefetched partial records of its four rows + the tile (27 072 B: six waves per CU)
 
 // offset of entry (r, j) inside a packed upper triangle of order 15, r a compile-time constant
 template <int R> __device__ __forceinline__ int tri_rc(int j, int cj) {   // cj = 14 j - j (j - 1) / 2
@@ -143,18 +143,16 @@ __global__ __launch_bounds__(64, LIW_QUAD_OCC) void k_lm_step_quad(StepArgs a) {
         const int cb = (fresh || !have_cand) ? cur : 1 - cur;
         double cost;
         {
-            const double* PLb = (cb ? a.w.PL[1] : a.w.PL[0]) + (size_t)b * n * LP;
-            const double* PIb = (cb ? a.w.PI[1] : a.w.PI[0]) + (size_t)b * n * PIFS;   // per-frame IMU records (liw_kernels.hpp)
-            const double* PWb = (cb ? a.w.PW[1] : a.w.PW[0]) + (size_t)b * (n - 1) * PWS;
-            const double* PGb = (cb ? a.w.PG[1] : a.w.PG[0]) + (size_t)b * n * PGS;
+            // the records' cost slots, from the compact copy the roles keep (liw_kernels.hpp, cs_index): 8 lines per window instead of 4 n - 2
+            const double* CSb = (cb ? a.w.CS[1] : a.w.CS[0]) + cs_index(n, b, 0, 0);
             double s = 0.0;
             for (int i = j; i < n; i += 16) {   // (blocks whose parameters are all constant are not in Ceres' problem)
-                s += PLb[(size_t)i * LP + 120];
-                if (!(track && i < n - 1)) s += PGb[(size_t)i * PGS + 48];
+                s += CSb[CS_LASER * n + i];
+                if (!(track && i < n - 1)) s += CSb[CS_GROUND * n + i];
             }
             for (int k = j; k < n - 1; k += 16) {
-                s += PIb[(size_t)(k + 1) * PIFS + PIF_C];   // (block (k, k+1)'s cost sits in frame k+1's record)
-                if (!(track && k < n - 2)) s += PWb[(size_t)k * PWS + PW_C];
+                s += CSb[CS_IMU * n + k];
+                if (!(track && k < n - 2)) s += CSb[CS_WHEEL * n + k];
             }
             if (track && !fast && a.has_prior[b] && j < 15) {   // marginalization_factor: r = linearized_J (x_{n-2} - linearized_X)  (:22-53)
                 const double* xs = ((fresh || !have_cand) ? X : XC) + oX + (unsigned)((n - 2) * 15);
@@ -268,7 +266,7 @@ __global__ __launch_bounds__(64, LIW_QUAD_OCC) void k_lm_step_quad(StepArgs a) {
                 if (i == 0) for (int f = 0; f < n; ++f) dd += PL0[oPL + (unsigned)(f * LP + jc * 7)];
                 if (i >= 1) dd += PW0[oPW + (unsigned)((i - 1) * PWS + PW_JJ(jc, jc))];
                 if (i <= n - 2) dd += PW0[oPW + (unsigned)(i * PWS + PW_II(jc, jc))];
-                dd += PG0[oPG + (unsigned)(i * PGS + jc * 8)];
+                dd += PG0[oPG + (unsigned)(i * PGS + PG_H(jc, jc))];
             }
             if (n > 1) dd += PI0[oPI + (unsigned)(i * PIFS + PIF_D + pi_tri(jc, jc))];   // (the frame's complete IMU diagonal)
             if (prior_row && i == n - 2) {
@@ -284,12 +282,12 @@ __global__ __launch_bounds__(64, LIW_QUAD_OCC) void k_lm_step_quad(StepArgs a) {
     // Everything frame f needs from HBM is fetched ONE FRAME AHEAD, behind the elimination of frame f+1: the partial records by LDS-DMA
     // (global_load_lds: no VGPRs, no waits; LDS destination = uniform base + lane * 16 bytes, so every instruction fills a lane-linear
     // piece of one row's area), the Jacobi scale / LM diagonal / state entry of this lane in three registers.
-    //   S_IMU[w][496]  IMU partial of block (f-1, f)            4 pieces per row
-    //   S_PL[w][86]    PL_f[36 .. 122): Hbb, Hab, ga, gb         1 piece per row (43 lanes)
-    //   S_PW[w][122]   wheel partial of block (f-1, f)           1 piece per row (61 lanes; two until the record dropped its ji block)
-    //   S_PG[w][52]    ground partial of frame f                 1 piece per two rows (26 lanes each)
+    //   S_IMU[w][376]  per-frame IMU record of frame f           3 pieces per row
+    //   S_PL[w][128]   laser group record of frame f             1 piece per row (the whole record: Haa / ga feed the hub accumulators)
+    //   S_PW[w][92]    wheel partial of block (f-1, f)           1 piece per row (46 lanes)
+    //   S_PG[w][28]    ground partial of frame f                 1 piece for the four rows (14 lanes each)
     // Round 4 measured what the staging costs and what does NOT change it (tools/quad_occ_probe2.sh, tools/quad_probe.py,
-    // tools/clk_probe_quad.py): issuing a frame's 26 pieces stalls the wave for ~4 k of its ~18.6 k cycles; with two waves per SIMD (a
+    // tools/clk_probe_quad.py): issuing a frame's 26 pieces (21 since the packed wheel / ground records) stalls the wave for ~4 k of its ~18.6 k cycles; with two waves per SIMD (a
     // <= 256-register build, six waves per CU) the SAME phase takes 5 - 11 k per wave and the kernel is no faster — the other phases keep
     // their length, so the ALUs are not what the waves share.  Plain global_load_dwordx4 into registers + ds_write_b128 (25 pieces, in three
     // batches behind the elimination phases, or all at once held in AGPRs) stalls just as long at issue (~100 - 170 cycles per 1-KiB
@@ -297,7 +295,7 @@ __global__ __launch_bounds__(64, LIW_QUAD_OCC) void k_lm_step_quad(StepArgs a) {
     // (4.9 TB/s chip-wide during the sweep) — and whoever issues next waits for a slot.  Probes with the records aliased to one window
     // (cache-resident) bound the memory share of the kernel at 21 %; the rest is the instruction stream.  The DMA form stays: it needs
     // no registers.
-    constexpr int S_IMU = 0, S_PL = 4 * PIFS, S_PW = S_PL + 4 * 86, S_PG = S_PW + 4 * PWS, S_TR = S_PG + 4 * PGS + 24;   // (24 doubles of pad: the over-read of the last ground piece)
+    constexpr int S_IMU = 0, S_PL = 4 * PIFS, S_PW = S_PL + 4 * LP, S_PG = S_PW + 4 * PWS, S_TR = S_PG + 4 * PGS + 24;   // (24 doubles of pad: the over-read of the last ground piece)
     static_assert(S_TR + QTR <= QTOT, "LDS layout");
     const unsigned rPL[4] = {(unsigned)__builtin_amdgcn_readlane(oPL, 0), (unsigned)__builtin_amdgcn_readlane(oPL, 16), (unsigned)__builtin_amdgcn_readlane(oPL, 32), (unsigned)__builtin_amdgcn_readlane(oPL, 48)};
     const unsigned rPI[4] = {(unsigned)__builtin_amdgcn_readlane(oPI, 0), (unsigned)__builtin_amdgcn_readlane(oPI, 16), (unsigned)__builtin_amdgcn_readlane(oPI, 32), (unsigned)__builtin_amdgcn_readlane(oPI, 48)};
@@ -332,29 +330,30 @@ __global__ __launch_bounds__(64, LIW_QUAD_OCC) void k_lm_step_quad(StepArgs a) {
                 sfor<0, 3>([&](auto Q) { __builtin_amdgcn_global_load_lds(g, (lds_t)(S + S_IMU + ws * PIFS), 16, KI(Q) * 1024, 0); });
             });
         }
-        sfor<0, 4>([&](auto W) {                    // laser group record, slots 36 .. 122 (+ 42 doubles of over-read)
+        sfor<0, 4>([&](auto W) {                    // laser group record: exactly one piece
             constexpr int ws = KI(W);
-            __builtin_amdgcn_global_load_lds(PL0 + rPL[ws] + (unsigned)(f * LP + 36) + lane2, (lds_t)(S + S_PL + ws * 86), 16, 0, 0);
+            static_assert(LP == 128, "one piece");
+            __builtin_amdgcn_global_load_lds(PL0 + rPL[ws] + (unsigned)(f * LP) + lane2, (lds_t)(S + S_PL + ws * LP), 16, 0, 0);
         });
         if (k >= 0) {
             sfor<0, 4>([&](auto W) {                // wheel partial: 1 piece per row
                 constexpr int ws = KI(W);
-                static_assert(PWS % 2 == 0 && PWS <= 128, "one piece");
+                static_assert(PWS % 2 == 0 && PWS <= 128 && PGS % 2 == 0 && 4 * PGS <= 128, "one piece");
                 __builtin_amdgcn_global_load_lds(PW0 + rPW[ws] + (unsigned)(k * PWS) + lane2, (lds_t)(S + S_PW + ws * PWS), 16, 0, 0);
             });
         }
-        sfor<0, 2>([&](auto H) {                    // ground partial, two rows per piece: lanes 0..25 row 2h, 26..63 row 2h+1 (52 doubles + over-read)
-            constexpr int h = KI(H);
-            // (signed lane part: row 2h+1's lanes start 52 doubles into the piece, and its window's offset may be 0)
-            const unsigned ob = lane < 26 ? rPG[2 * h] : rPG[2 * h + 1];
-            const long lo = (long)(f * PGS) + (lane < 26 ? lane2 : lane2 - 52);
-            __builtin_amdgcn_global_load_lds(PG0 + ob + lo, (lds_t)(S + S_PG + h * 2 * PGS), 16, 0, 0);
-        });
+        {                                           // ground partials of the four rows in ONE piece: 14 lanes per row (28 doubles), lanes 56 .. 63 read on (16 doubles of over-read)
+            const int pr = lane < 14 ? 0 : (lane < 28 ? 1 : (lane < 42 ? 2 : 3));
+            const unsigned ob = pr == 0 ? rPG[0] : (pr == 1 ? rPG[1] : (pr == 2 ? rPG[2] : rPG[3]));
+            // (signed lane part: a row's lanes start 28 * row doubles into the piece, and its window's offset may be 0)
+            const long lo = (long)(f * PGS) + (long)(lane2 - PGS * pr);
+            __builtin_amdgcn_global_load_lds(PG0 + ob + lo, (lds_t)(S + S_PG), 16, 0, 0);
+        }
         asm volatile("" ::: "memory");
         prefetch_regs(f);
     };
     const double* SI = S + S_IMU + w * PIFS;
-    const double* SL = S + S_PL + w * 86;         // SL[e] = PL_f[36 + e]
+    const double* SL = S + S_PL + w * LP;         // SL[e] = PL_f[e]
     const double* SW = S + S_PW + w * PWS;
     const double* SG = S + S_PG + w * PGS;
 #ifdef LIW_QUAD_TILE_ALIAS
@@ -367,11 +366,11 @@ __global__ __launch_bounds__(64, LIW_QUAD_OCC) void k_lm_step_quad(StepArgs a) {
     // = its row c, register q = hub variable q — six registers and 90 DPP FMAs per frame instead of fifteen and 225 with the six busy
     // lanes of the column layout — and turned into the column layout the elimination wants by one pass through LDS (6 writes, 15 reads).
     // gsh (lane c < 15): the unscaled gradient share of block (i, i+1) that belongs to frame i (gradient max-norm, checksum).
-    double d[15], o[15], rr[15], cd[15], crt[6], D0[6];
+    double d[15], o[15], rr[15], cd[15], crt[6], D0[6], hA[6];
     double g0 = 0.0, gm = 0.0, ytg = 0.0, pdiag = 0.0, gsum = 0.0, gsh = 0.0;
     bool solved = true;
     sfor<0, 15>([&](auto R) { constexpr int r = KI(R); cd[r] = 0.0; });
-    sfor<0, 6>([&](auto R) { D0[KI(R)] = 0.0; crt[KI(R)] = 0.0; });
+    sfor<0, 6>([&](auto R) { D0[KI(R)] = 0.0; crt[KI(R)] = 0.0; hA[KI(R)] = 0.0; });
     const bool clk_on = g_qclk_on[0] && (int)blockIdx.x == g_qclk_on[1] && iteration == g_qclk_on[3];
     const int clk_frame = g_qclk_on[2];
     if (clk_k) g_qclk[13] = clock64();
@@ -394,21 +393,17 @@ __global__ __launch_bounds__(64, LIW_QUAD_OCC) void k_lm_step_quad(StepArgs a) {
         double tS[6], oW[6], rL[6];
         sfor<0, 6>([&](auto R) {
             constexpr int r = KI(R);
-            const double aD = SL[l15 ? 114 - 36 + r : r * 6 + j6];
-            const double cD = SG[l15 ? r * 7 + 6 : r * 7 + j6];
+            const double aD = SL[l15 ? 114 + r : 36 + r * 6 + j6];
+            const double cD = SG[l15 ? PG_G(r) : PG_H(r, j6)];
             const double bD = SW[l15 ? PW_G(6 + r) : PW_JJ(r, j6)];
             oW[r] = SW[PW_IJ(j6, r)];
-            rL[r] = SL[72 - 36 + j6 * 6 + r];
+            rL[r] = SL[72 + j6 * 6 + r];
             tS[r] = aD + (hasm ? bD : 0.0) + cD;
         });
-        if (i == 0 && !track) {   // every laser frame's Haa / ga lands on frame 0's pose (init topology)
-            double hA[6];
-            sfor<0, 6>([&](auto R) { hA[KI(R)] = 0.0; });
-            for (int f = 0; f < n; ++f) {
-                const unsigned oLf = oPL + (unsigned)(f * LP);
-                sfor<0, 6>([&](auto R) { constexpr int r = KI(R); hA[r] += PL0[oLf + (unsigned)(l15 ? 108 + r : r * 6 + j6)]; });
-            }
-            sfor<0, 6>([&](auto R) { tS[KI(R)] += hA[KI(R)]; });
+        if (!track) {   // every laser frame's Haa / ga lands on frame 0's pose (init topology): summed as the frames stream by (until round 4
+                        // frame 0 re-read the n records: 4 lines per frame a second time from HBM)
+            sfor<0, 6>([&](auto R) { constexpr int r = KI(R); hA[r] += SL[l15 ? 108 + r : r * 6 + j6]; });
+            if (i == 0) sfor<0, 6>([&](auto R) { tS[KI(R)] += hA[KI(R)]; });
         }
         // ---- IMU record of frame i: the complete diagonal tile -> D, ij of block (i-1, i) -> O^T, both gradient parts -> lane 15
         if (n > 1) {
@@ -730,7 +725,7 @@ bool lm_step_quad_fits(const StepArgs& a) {
         return d <= lim && d + (unsigned long long)a.B * per <= lim;
     };
     const int nm = a.n > 1 ? a.n - 1 : 1;
-    return a.n >= 1 && (a.mode == LIW_MODE_INIT || (a.mode == LIW_MODE_TRACK && a.n >= 2)) && span(a.w.PL[0], a.w.PL[1], (unsigned long long)a.n * LP) && a.w.pi_frame && span(a.w.PI[0], a.w.PI[1], (unsigned long long)a.n * PIFS) &&
+    return a.n >= 1 && (a.mode == LIW_MODE_INIT || (a.mode == LIW_MODE_TRACK && a.n >= 2)) && span(a.w.PL[0], a.w.PL[1], (unsigned long long)a.n * LP) && a.w.pi_frame && a.w.CS[0] && a.w.CS[1] && span(a.w.PI[0], a.w.PI[1], (unsigned long long)a.n * PIFS) &&
            span(a.w.PW[0], a.w.PW[1], (unsigned long long)nm * PWS) && span(a.w.PG[0], a.w.PG[1], (unsigned long long)a.n * PGS) &&
            (unsigned long long)a.B * (sizeof(LmState) / 8) <= lim && (unsigned long long)a.B * a.n * SOLVE_WS <= lim;
 }

@@ -229,7 +229,7 @@ int liw_get_extrinsics(const liw_ctx* c, double* A, double* Bm) {
 // ------------------------------------------------------------------------------------------ workspace
 static size_t al256(size_t v) { return (v + 255) & ~(size_t)255; }
 struct FullLayout {
-    size_t PL[2], PI[2], PW[2], PG[2], x_cand, group_off, lm, solve_ws, info, history, active, imu_pk, imu_pk_bad, bytes;
+    size_t PL[2], PI[2], PW[2], PG[2], CS[2], x_cand, group_off, lm, solve_ws, info, history, active, imu_pk, imu_pk_bad, bytes;
 };
 static FullLayout full_layout(int B, int n, int hist) {
     FullLayout f{};
@@ -249,6 +249,7 @@ static FullLayout full_layout(int B, int n, int hist) {
     if (hist > 0) o = al256(o + sizeof(double) * (size_t)hist * B * n * 15);
     f.imu_pk_bad = o; o = al256(o + 2 * sizeof(int));
     f.imu_pk = o; o = al256(o + sizeof(double) * (size_t)B * nm * IMU_PK);
+    for (int k = 0; k < 2; ++k) { f.CS[k] = o; o = al256(o + sizeof(double) * (size_t)B * 4 * n); }
     f.bytes = o;
     return f;
 }
@@ -269,6 +270,7 @@ static WsView make_view(void* ws, int B, int n, int hist) {
     v.history_records = hist;
     v.active = (int*)(base + f.active);
     v.pi_frame = pi_frame_format(B) ? 1 : 0;
+    for (int k = 0; k < 2; ++k) v.CS[k] = (double*)(base + f.CS[k]);
     v.imu_pk = (double*)(base + f.imu_pk);
     v.imu_pk_bad = (int*)(base + f.imu_pk_bad);
     return v;
@@ -334,6 +336,7 @@ static LinArgs lin_args(const liw_batch* b, int mode, const double* x, const WsV
     A.active = use_lm ? v.active : nullptr;
     A.candidate = candidate;
     A.pi_frame = v.pi_frame;
+    for (int k = 0; k < 2; ++k) A.CS[k] = v.pi_frame ? v.CS[k] : nullptr;
     if (packed && b->n > 1 && b->eval_small) { A.imu_pk = v.imu_pk; A.imu_pk_bad = v.imu_pk_bad; }
     if (packed) A.laser_hz = v.imu_pk_bad + 1;
     if (packed && mode == LIW_MODE_INIT && lpk_matches(c, b, ws)) { A.laser_pk = c->lpk.as<double>(); A.laser_slab_off = c->lpk_off.as<long long>(); }

@@ -23,9 +23,9 @@ struct DevParams {
 // Partial-sum slots written by k_linearize, per buffer (doubles):
 //   PL[B][n][LP]   laser group (window, owning frame): Haa(36) Hbb(36) Hab(36) ga(6) gb(6) sum r^2 (1), pad -> 128
 //   PI[B][n-1][PIS] IMU block k (frames k,k+1): G = Y^T Y, Y = [J(15x30) | r]: blocks ii, jj (packed upper triangles), ij (15x15), g(30), sum r^2 -> 496
-//   PW[B][n-1][PWS] wheel block k: G = Y^T Y, Y = [J(3x12) | r]: blocks ii, ij, jj (6x6 each, row-major; the ji block is ij^T and not stored),
-//                   gradient (12), sum r^2 -> 121, pad -> 122   (a full 13x13 until round 3: 172)
-//   PG[B][n][PGS]   ground of frame i: n * G 7x7 (Y = [J(2x6) | r]), pad -> 52
+//   PW[B][n-1][PWS] wheel block k: G = Y^T Y, Y = [J(3x12) | r]: blocks ii, jj as packed upper triangles (21 each), ij (6x6 row-major; the ji
+//                   block is ij^T and not stored), gradient (12), sum r^2 -> 91, pad -> 92   (a full 13x13 = 172 until round 3, square ii / jj = 122 until round 4)
+//   PG[B][n][PGS]   ground of frame i: n * G 7x7 (Y = [J(2x6) | r]) as its packed upper triangle: 28   (the full 7x7 padded to 52 until round 4)
 constexpr int LP = LIW_LASER_PARTIAL;
 constexpr int PIS = 496;
 // compact IMU partial: G = Y^T Y restricted to what the assembly reads; the symmetric blocks ii and jj as packed upper triangles
@@ -49,14 +49,29 @@ __host__ __device__ inline size_t pi_doubles_per_window(int n) {               /
     const size_t a = (size_t)(n > 1 ? n - 1 : 1) * PIS, b = (size_t)n * PIFS;
     return a > b ? a : b;
 }
-constexpr int PWS = 122;
-// entries of a wheel record: r, c < 6 index the pose entries of frame k (ii), of frame k+1 (jj), or one of each (ij: row = frame k)
-__host__ __device__ constexpr int PW_II(int r, int c) { return r * 6 + c; }
-__host__ __device__ constexpr int PW_IJ(int r, int c) { return 36 + r * 6 + c; }
-__host__ __device__ constexpr int PW_JJ(int r, int c) { return 72 + r * 6 + c; }
-__host__ __device__ constexpr int PW_G(int e) { return 108 + e; }   // e < 12: frame k's pose entries, then frame k+1's
-constexpr int PW_C = 120;
-constexpr int PGS = 52;
+// offset of entry (r, c) = (c, r) inside a packed upper triangle of order N (row-major over r <= c)
+template <int N> __host__ __device__ constexpr int tri_sym(int r, int c) {
+    return r <= c ? r * N - (r * (r - 1)) / 2 + (c - r) : c * N - (c * (c - 1)) / 2 + (r - c);
+}
+// Compact cost array of the large-batch format, CS[B][4][n] per partial buffer: the sum r^2 of (window b, role, record) — laser group /
+// ground record of frame f, IMU / wheel record of block k — stored a second time by the role that writes the record.  The prologue of
+// k_lm_step_quad needs nothing but these 4 n - 2 numbers of a window's candidate linearisation; in the records they sit in 4 n - 2
+// different 128-byte lines (15 kB of HBM traffic per window and LM iteration for 1 kB of values).
+constexpr int CS_LASER = 0, CS_GROUND = 1, CS_IMU = 2, CS_WHEEL = 3;
+__host__ __device__ inline size_t cs_index(int n, int b, int role, int rec) { return ((size_t)b * 4 + role) * n + rec; }
+constexpr int PWS = 92;
+// entries of a wheel record: r, c < 6 index the pose entries of frame k (ii), of frame k+1 (jj), or one of each (ij: row = frame k).
+// The step kernels stream these records once per LM iteration and are HBM-bound: the symmetric blocks are stored once (122 -> 92 doubles).
+__host__ __device__ constexpr int PW_II(int r, int c) { return tri_sym<6>(r, c); }
+__host__ __device__ constexpr int PW_IJ(int r, int c) { return 21 + r * 6 + c; }
+__host__ __device__ constexpr int PW_JJ(int r, int c) { return 57 + tri_sym<6>(r, c); }
+__host__ __device__ constexpr int PW_G(int e) { return 78 + e; }   // e < 12: frame k's pose entries, then frame k+1's
+constexpr int PW_C = 90;
+// entries of a ground record: H (6x6, symmetric), gradient (6), sum r^2 = the packed upper triangle of the 7x7 G (52 -> 28 doubles)
+constexpr int PGS = 28;
+__host__ __device__ constexpr int PG_H(int r, int c) { return tri_sym<7>(r, c); }
+__host__ __device__ constexpr int PG_G(int r) { return tri_sym<7>(r, 6); }
+constexpr int PG_C = 27;
 constexpr int FTF = 32;   // frame transform record (k_frame_tf)
 
 // per-window LM state kept on the device across the launches of one solve
@@ -95,6 +110,7 @@ struct WsView {
     int* active;          // [1 + B] compacted list of the windows still iterating (IMU / wheel / ground roles index their blocks over it);
                           //    behind it the ticket word and the per-group publication words of k_compact_active (zeroed by lm_begin)
     int pi_frame;         // 1: PI holds per-frame records (PIF_*, pi_frame_format(B)), 0: per-block records (PI_*)
+    double* CS[2];        // [B][4][n] per buffer: the cost slot (sum r^2) of every record once more, compact (cs_index; written in the per-frame format only)
     double* imu_pk;       // [B][n-1][IMU_PK] packed IMU block records of the solve in progress (launch_imu_pack, from liw_batch_lm_begin)
     int* imu_pk_bad;      // [0] != 0: some sqrt_inverse_P is not upper triangular -> the IMU role reads the caller's arrays;
                           // [1] != 0: some laser end point has a z component (launch_laser_z_scan)
@@ -130,6 +146,7 @@ struct LinArgs {
     int small_nd;               // derivative directions per lane of the IMU / wheel roles: 3 (batches) or 1 (k_lin_all on a few windows)
     int* active;                // [1 + B]: number of windows still iterating, then their ids (built per linearisation when lm != null)
     int pi_frame;               // 1: write per-frame IMU records (WsView::pi_frame)
+    double* CS[2];              // non-null (per-frame format): every role also stores its record's cost into the compact cost array (cs_index)
     const double* imu_pk;       // packed IMU block records (WsView::imu_pk) or null
     const int* imu_pk_bad;      //   ... usable iff *imu_pk_bad == 0
     const int* laser_hz;        // null, or -> 0 when no laser end point of the batch has a z component (2-D scans): the z planes are skipped

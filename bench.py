@@ -29,7 +29,7 @@ sys.path.insert(0, ROOT)
 
 # algorithmic bytes per residual block ("materialised-J" convention)
 BYTES_LASER_BOTH, BYTES_LASER_ONE, BYTES_IMU, BYTES_WHEEL, BYTES_GROUND, BYTES_STATE = 312, 216, 7448, 520, 60, 120
-PIS_BYTES, PWS_BYTES, LP_BYTES, PGS_BYTES = 496 * 8, 122 * 8, 128 * 8, 52 * 8   # partial-sum records (csrc/liw_kernels.hpp)
+PIS_BYTES, PWS_BYTES, LP_BYTES, PGS_BYTES = 496 * 8, 92 * 8, 128 * 8, 28 * 8   # partial-sum records (csrc/liw_kernels.hpp)
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8 TB/s
 
 
@@ -39,14 +39,14 @@ def algorithmic_bytes(n, L, both_free):
 
 def step_model(n, arrow=True):
     """HBM bytes and essential flops of ONE LM step of one window in k_lm_step_quad (csrc/k_lm_quad.hip), init topology.
-    Reads (LDS-DMA pieces): per frame its IMU record (3 008 B: the per-frame format of large batches, round 4), the wheel partial of its block (976), 688 B of the laser
-    group record, the ground partial (416); Jacobi scale / LM diagonal / state entries (3 x 120 B per frame, twice: both sweeps) and the
-    current + candidate states; the cost slots of the prologue (four 128-byte lines per frame).  Writes: the 22-column back-substitution
+    Reads (LDS-DMA pieces): per frame its IMU record (3 008 B: the per-frame format of large batches, round 4), the wheel partial of its block (736: packed triangles since round 4), the laser
+    group record (1 024; until round 4 688 B of it, and frame 0 read the Haa / ga slots of all n records a second time), the ground partial (224); Jacobi scale / LM diagonal / state entries (3 x 120 B per frame, twice: both sweeps) and the
+    current + candidate states; the compact cost array of the prologue (eight 128-byte lines per window; four lines per FRAME until round 4).  Writes: the 22-column back-substitution
     record (2 640 B per frame, read again by the second sweep), LM diagonal, candidate states.
     Flops: Cholesky 15^3/3, 22 forward and 22 backward substitutions 2 x 22 x 15^2, Schur products (16x16 + 6x16 + 6x6/2) x 15 x 2, second
     sweep 21 x 15 x 2 — per frame."""
     nb = max(n - 1, 0)
-    rd = (n * 3008 if nb else 0) + nb * 976 + n * (688 + 416) + 2 * n * 3 * 120 + 2 * n * 120 + n * 4 * 128 + n * 2640
+    rd = (n * 3008 if nb else 0) + nb * 736 + n * (1024 + 224) + 2 * n * 3 * 120 + 2 * n * 120 + 8 * 128 + n * 2640
     wr = n * 2640 + n * 120 + n * 120
     fl = n * (15 ** 3 / 3.0 + 2 * 22 * 15 * 15 + (16 * 16 + (6 * 16 + 18 if arrow else 0)) * 15 * 2 + 21 * 15 * 2)
     return {"read": int(rd), "write": int(wr), "flops": float(fl)}

@@ -42,7 +42,7 @@ def step_known_read(B, n):
     """bytes ONE full launch of k_lm_step_quad reads (bench.py step_model; every piece is an explicit 16-byte-per-lane LDS-DMA or a
     128-bit row load, so the volume is known exactly)"""
     nb = n - 1
-    return B * (n * 3008 + nb * 976 + n * (688 + 416) + 2 * n * 3 * 120 + 2 * n * 120 + n * 4 * 128 + n * 2640)   # (per-frame IMU records since round 4)
+    return B * (n * 3008 + nb * 736 + n * (1024 + 224) + 2 * n * 3 * 120 + 2 * n * 120 + 8 * 128 + n * 2640)   # (per-frame IMU records since round 4)
 
 
 def main():
