@@ -30,6 +30,8 @@ template <int B_, int E_, class F> __device__ __forceinline__ void sfor(F&& f) {
     if constexpr (B_ < E_) { f(std::integral_constant<int, B_>{}); sfor<B_ + 1, E_>(f); }
 }
 #define KI(K) (std::remove_reference_t<decltype(K)>::value)
+template <int V> using KC = std::integral_constant<int, V>;
+__device__ __forceinline__ double bits_and(double x, unsigned long long m) { return __longlong_as_double((long long)((unsigned long long)__double_as_longlong(x) & m)); }
 
 // ---- DP-ALU DPP primitives.  volatile: they must execute with all 64 lanes enabled (a DPP read of a disabled lane is not a read), so
 // the compiler may neither sink them into divergent code nor reorder them against each other; program order below is written for ILP
@@ -72,7 +74,13 @@ constexpr int QTR = 0;
 #else
 constexpr int QTR = 4 * 15 * 6;                           // transposition tile of the carried arrow block (below)
 #endif
-constexpr int QTOT = 4 * (PIFS + LP + PWS + PGS) + 24 + QTR;   // LDS doubles per wave: the prefetched partial records of its four rows + the tile (27 072 B: six waves per CU)
+// Gather table of the assembly phase: one 16-bit LDS byte offset per (read, lane) — see the kernel.  Reads: K_A laser Hbb | gb, K_B wheel
+// jj | g_j, K_C ground H | g, K_OW wheel ij, K_RL laser Hab, K_HA laser Haa | ga, K_CW wheel ii | g_i, K_GSH wheel g_i lane per entry,
+// K_D IMU diagonal tile, K_OV IMU coupling | g_j, K_GI IMU g_i.
+constexpr int K_A = 0, K_B = 6, K_C = 12, K_OW = 18, K_RL = 24, K_HA = 30, K_CW = 36, K_GSH = 42, K_D = 43, K_OV = 58, K_GI = 73, NRD = 88;
+constexpr int QTAB = NRD * 16;                            // doubles: NRD x 64 unsigned shorts
+constexpr int QZB = 16;                                  // a block of zeros: lanes that take no part in a strided read
+constexpr int QTOT = 4 * (PIFS + LP + PWS + PGS) + 32 + QTR + QZB + QTAB;   // LDS doubles per wave: the prefetched partial records of its four rows, the tile, a zero word, the gather table (35.6 kB: four waves per CU)
 
 // offset of entry (r, j) inside a packed upper triangle of order 15, r a compile-time constant
 template <int R> __device__ __forceinline__ int tri_rc(int j, int cj) {   // cj = 14 j - j (j - 1) / 2
@@ -295,12 +303,14 @@ __global__ __launch_bounds__(64, LIW_QUAD_OCC) void k_lm_step_quad(StepArgs a) {
     // (4.9 TB/s chip-wide during the sweep) — and whoever issues next waits for a slot.  Probes with the records aliased to one window
     // (cache-resident) bound the memory share of the kernel at 21 %; the rest is the instruction stream.  The DMA form stays: it needs
     // no registers.
-    constexpr int S_IMU = 0, S_PL = 4 * PIFS, S_PW = S_PL + 4 * LP, S_PG = S_PW + 4 * PWS, S_TR = S_PG + 4 * PGS + 24;   // (24 doubles of pad: the over-read of the last ground piece)
-    static_assert(S_TR + QTR <= QTOT, "LDS layout");
+    constexpr int S_IMU = 0, S_PL = 4 * PIFS, S_PW = S_PL + 4 * LP, S_PG = S_PW + 4 * PWS, S_TR = S_PG + 4 * PGS + 32;   // (32 doubles of pad: the over-read of the last piece)
+    constexpr int S_ZERO = S_TR + QTR, S_TAB = S_ZERO + QZB;
+    static_assert(S_TAB + QTAB <= QTOT && 8 * QTOT < 65536, "LDS layout");
     const unsigned rPL[4] = {(unsigned)__builtin_amdgcn_readlane(oPL, 0), (unsigned)__builtin_amdgcn_readlane(oPL, 16), (unsigned)__builtin_amdgcn_readlane(oPL, 32), (unsigned)__builtin_amdgcn_readlane(oPL, 48)};
     const unsigned rPI[4] = {(unsigned)__builtin_amdgcn_readlane(oPI, 0), (unsigned)__builtin_amdgcn_readlane(oPI, 16), (unsigned)__builtin_amdgcn_readlane(oPI, 32), (unsigned)__builtin_amdgcn_readlane(oPI, 48)};
     const unsigned rPW[4] = {(unsigned)__builtin_amdgcn_readlane(oPW, 0), (unsigned)__builtin_amdgcn_readlane(oPW, 16), (unsigned)__builtin_amdgcn_readlane(oPW, 32), (unsigned)__builtin_amdgcn_readlane(oPW, 48)};
-    const unsigned rPG[4] = {(unsigned)__builtin_amdgcn_readlane(oPG, 0), (unsigned)__builtin_amdgcn_readlane(oPG, 16), (unsigned)__builtin_amdgcn_readlane(oPG, 32), (unsigned)__builtin_amdgcn_readlane(oPG, 48)};
+    const unsigned oPGw = oPG + (unsigned)(PG0 - PW0);   // ground records relative to the wheel buffer (launch_lm_step_quad checks the span): one base pointer per piece
+    const unsigned rPGw[4] = {(unsigned)__builtin_amdgcn_readlane(oPGw, 0), (unsigned)__builtin_amdgcn_readlane(oPGw, 16), (unsigned)__builtin_amdgcn_readlane(oPGw, 32), (unsigned)__builtin_amdgcn_readlane(oPGw, 48)};
     typedef __attribute__((address_space(3))) void* lds_t;
     const int j_ = j;
     double scm_n = 1.0, dg_n = 0.0, xq_n = 0.0;     // prefetched: scale of frame f-1, LM diagonal and state entry of frame f (lane j)
@@ -333,21 +343,29 @@ __global__ __launch_bounds__(64, LIW_QUAD_OCC) void k_lm_step_quad(StepArgs a) {
         sfor<0, 4>([&](auto W) {                    // laser group record: exactly one piece
             constexpr int ws = KI(W);
             static_assert(LP == 128, "one piece");
+#ifndef LIW_QUAD_NOPL   // (timing probe: no laser pieces, the area zeroed once)
             __builtin_amdgcn_global_load_lds(PL0 + rPL[ws] + (unsigned)(f * LP) + lane2, (lds_t)(S + S_PL + ws * LP), 16, 0, 0);
+#endif
         });
-        if (k >= 0) {
-            sfor<0, 4>([&](auto W) {                // wheel partial: 1 piece per row
-                constexpr int ws = KI(W);
-                static_assert(PWS % 2 == 0 && PWS <= 128 && PGS % 2 == 0 && 4 * PGS <= 128, "one piece");
-                __builtin_amdgcn_global_load_lds(PW0 + rPW[ws] + (unsigned)(k * PWS) + lane2, (lds_t)(S + S_PW + ws * PWS), 16, 0, 0);
+        // wheel partials (block f-1; frame 0 re-reads block 0, unused) and ground partials of the four rows: the 4 x 92 + 4 x 28 doubles that lie
+        // back to back in LDS are cut into 128-double pieces wherever the cuts fall (4 pieces; a piece per wheel record + one for the ground
+        // records was 5): a lane's global address = the base of the record its 16 bytes belong to + its offset inside it; the lanes behind
+        // the last record read on (over-read into the pad)
+        {
+            const unsigned fw = (unsigned)((k >= 0 ? k : 0) * PWS), fg = (unsigned)(f * PGS);
+            sfor<0, 4>([&](auto P) {
+                constexpr int q0 = KI(P) * 128;                     // first stream double of this piece (stream = the S_PW .. S_PG areas)
+                unsigned off = 0;
+                sfor<0, 8>([&](auto G) {
+                    constexpr int g = KI(G);
+                    constexpr int st = g < 4 ? g * PWS : 4 * PWS + (g - 4) * PGS, en = g == 7 ? (1 << 20) : st + (g < 4 ? PWS : PGS);
+                    if constexpr (st < q0 + 128 && en > q0) {
+                        const unsigned v = (g < 4 ? rPW[g & 3] + fw : rPGw[g & 3] + fg) + (unsigned)(lane2 - (st - q0));
+                        if constexpr (st <= q0) off = v; else off = lane2 >= st - q0 ? v : off;
+                    }
+                });
+                __builtin_amdgcn_global_load_lds(PW0 + off, (lds_t)(S + S_PW + q0), 16, 0, 0);
             });
-        }
-        {                                           // ground partials of the four rows in ONE piece: 14 lanes per row (28 doubles), lanes 56 .. 63 read on (16 doubles of over-read)
-            const int pr = lane < 14 ? 0 : (lane < 28 ? 1 : (lane < 42 ? 2 : 3));
-            const unsigned ob = pr == 0 ? rPG[0] : (pr == 1 ? rPG[1] : (pr == 2 ? rPG[2] : rPG[3]));
-            // (signed lane part: a row's lanes start 28 * row doubles into the piece, and its window's offset may be 0)
-            const long lo = (long)(f * PGS) + (long)(lane2 - PGS * pr);
-            __builtin_amdgcn_global_load_lds(PG0 + ob + lo, (lds_t)(S + S_PG), 16, 0, 0);
         }
         asm volatile("" ::: "memory");
         prefetch_regs(f);
@@ -356,6 +374,54 @@ __global__ __launch_bounds__(64, LIW_QUAD_OCC) void k_lm_step_quad(StepArgs a) {
     const double* SL = S + S_PL + w * LP;         // SL[e] = PL_f[e]
     const double* SW = S + S_PW + w * PWS;
     const double* SG = S + S_PG + w * PGS;
+    // Gather table.  The assembly of a frame reads 88 values per lane out of the staged records, at addresses that depend on the lane's role
+    // (its column j of the 6x6 pose blocks / of the 15x15 IMU tiles, lane 15 = the gradient column, lanes that take no part) — packed
+    // triangles, row strides that differ between a block and its gradient.  Computed per frame those addresses were ~900 issued
+    // instructions (integer selects and multiplies, the nested lane tests as divergent branches): 5.0 k of a frame's 18.9 k cycles
+    // (tools/clk_probe_quad.py).  They do not depend on the frame: every lane's byte offset for read k sits in LDS, TAB[k][lane], built
+    // once per launch, and a read is ds_read_u16 + ds_read_b64 — no vector ALU.  A lane that takes no part in a read is pointed at a
+    // word that holds 0.0, so most lane masks of the assembly vanish as well.
+    unsigned short* const TAB = reinterpret_cast<unsigned short*>(S + S_TAB);
+    {
+        const int jt = j < 15 ? j : 0, cjt = 14 * jt - (jt * (jt - 1)) / 2, j6t = j < 6 ? j : 0;
+        const bool t6 = j < 6, t15 = j == 15, tm = j < 15;
+        const int oL = S_PL + w * LP, oW_ = S_PW + w * PWS, oG = S_PG + w * PGS, oI = S_IMU + w * PIFS;
+        auto put = [&](int k, bool on, int idx) { TAB[k * 64 + lane] = (unsigned short)(8 * (on ? idx : S_ZERO)); };
+        if (lane < QZB) S[S_ZERO + lane] = 0.0;
+        sfor<0, 6>([&](auto R) {
+            constexpr int r = KI(R);
+            put(K_A + r, t6 || t15, oL + (t15 ? 114 + r : 36 + r * 6 + j6t));
+            put(K_B + r, t6 || t15, oW_ + (t15 ? PW_G(6 + r) : PW_JJ(r, j6t)));
+            put(K_C + r, t6 || t15, oG + (t15 ? PG_G(r) : PG_H(r, j6t)));
+            put(K_OW + r, t6, oW_ + PW_IJ(j6t, r));
+            put(K_RL + r, t6, oL + 72 + j6t * 6 + r);
+            put(K_HA + r, t6 || t15, oL + (t15 ? 108 + r : r * 6 + j6t));
+            put(K_CW + r, t6 || t15, oW_ + (t15 ? PW_G(r) : PW_II(r, j6t)));
+        });
+        put(K_GSH, t6, oW_ + PW_G(j6t));
+        sfor<0, 15>([&](auto R) {
+            constexpr int r = KI(R);
+            put(K_D + r, tm, oI + PIF_D + tri_rc<r>(jt, cjt));
+            put(K_OV + r, true, oI + (t15 ? PIF_GJ + r : PIF_IJ + jt * 15 + r));
+            put(K_GI + r, t15, oI + PIF_GI + r);
+        });
+    }
+    const int lane_tab = lane * 2;                  // byte offset of the lane's entry inside a table row
+    // N reads K0 .. K0 + N - 1 as ONE batch: all offsets first, then all values — two LDS round trips for the batch (the compiler, left
+    // alone, waits for every handful of offsets before it issues their value reads: ~35 dependent round trips per frame)
+    auto RDB = [&](auto K0, auto N_, double* out) {
+        constexpr int k0 = KI(K0), N = KI(N_);
+        unsigned of[N];
+        sfor<0, N>([&](auto Q) { constexpr int q = KI(Q); of[q] = *reinterpret_cast<const unsigned short*>(reinterpret_cast<const char*>(TAB) + (k0 + q) * 128 + lane_tab); });
+        asm volatile("" ::: "memory");
+        sfor<0, N>([&](auto Q) { constexpr int q = KI(Q); out[q] = *reinterpret_cast<const double*>(reinterpret_cast<const char*>(S) + of[q]); });
+        asm volatile("" ::: "memory");
+    };
+    auto RD = [&](auto K) -> double {               // read K of the gather table
+        constexpr int k = KI(K);
+        const unsigned off = *reinterpret_cast<const unsigned short*>(reinterpret_cast<const char*>(TAB) + k * 128 + lane_tab);
+        return *reinterpret_cast<const double*>(reinterpret_cast<const char*>(S) + off);
+    };
 #ifdef LIW_QUAD_TILE_ALIAS
     double* ST = S + S_IMU + w * PIFS + PIF_IJ + 100;
 #else
@@ -373,6 +439,9 @@ __global__ __launch_bounds__(64, LIW_QUAD_OCC) void k_lm_step_quad(StepArgs a) {
     sfor<0, 6>([&](auto R) { D0[KI(R)] = 0.0; crt[KI(R)] = 0.0; hA[KI(R)] = 0.0; });
     const bool clk_on = g_qclk_on[0] && (int)blockIdx.x == g_qclk_on[1] && iteration == g_qclk_on[3];
     const int clk_frame = g_qclk_on[2];
+#ifdef LIW_QUAD_NOPL
+    for (int e = lane; e < 4 * LP; e += 64) S[S_PL + e] = 0.0;
+#endif
     if (clk_k) g_qclk[13] = clock64();
     prefetch(n - 1);
     double sci_carry = (j_ < 15) ? LMD[oSC + (unsigned)((n - 1) * 15 + (j_ < 15 ? j_ : 0))] : 1.0;   // scale of frame n-1; later frames reuse scm
@@ -389,40 +458,55 @@ __global__ __launch_bounds__(64, LIW_QUAD_OCC) void k_lm_step_quad(StepArgs a) {
         QSTAMP(1);
         const double sci = sci_carry, scm = scm_n, dg_old = dg_n, xq = xq_n;
         sci_carry = scm;
-        // ---- pose-block partials: lanes j < 6 the 6x6 blocks, lane 15 the gradient slots
+        // ---- the frame's blocks out of the staged records, in TWO LDS round trips: (1) the table offsets of the reads whose addresses are not
+        //      affine in the lane (packed triangles, block | gradient with different strides) together with the values of those that are
+        //      (lane base + compile-time offset: the IMU coupling ij | g_j, g_i, the wheel ij and laser Hab blocks), (2) the values behind the offsets.
+        //      Pose blocks: lanes j < 6 the 6x6 blocks, lane 15 the gradient slots, zero in the lanes between; IMU: lane j < 15 column j of
+        //      the complete diagonal tile -> D, row j of ij of block (i-1, i) -> O^T, both gradient parts -> lane 15.
+        // (lane and frame conditions as bit masks: written as selects, `x + (c ? y : 0.0)` came back from the compiler as nests of divergent
+        // branches around the additions — ~40 instructions per entry)
+        const unsigned long long m15 = l15 ? ~0ull : 0ull, mh = hasm ? ~0ull : 0ull;
         double tS[6], oW[6], rL[6];
-        sfor<0, 6>([&](auto R) {
-            constexpr int r = KI(R);
-            const double aD = SL[l15 ? 114 + r : 36 + r * 6 + j6];
-            const double cD = SG[l15 ? PG_G(r) : PG_H(r, j6)];
-            const double bD = SW[l15 ? PW_G(6 + r) : PW_JJ(r, j6)];
-            oW[r] = SW[PW_IJ(j6, r)];
-            rL[r] = SL[72 + j6 * 6 + r];
-            tS[r] = aD + (hasm ? bD : 0.0) + cD;
-        });
-        if (!track) {   // every laser frame's Haa / ga lands on frame 0's pose (init topology): summed as the frames stream by (until round 4
-                        // frame 0 re-read the n records: 4 lines per frame a second time from HBM)
-            sfor<0, 6>([&](auto R) { constexpr int r = KI(R); hA[r] += SL[l15 ? 108 + r : r * 6 + j6]; });
-            if (i == 0) sfor<0, 6>([&](auto R) { tS[KI(R)] += hA[KI(R)]; });
-        }
-        // ---- IMU record of frame i: the complete diagonal tile -> D, ij of block (i-1, i) -> O^T, both gradient parts -> lane 15
-        if (n > 1) {
-            sfor<0, 15>([&](auto R) {
-                constexpr int r = KI(R);
-                d[r] = SI[PIF_D + tri_rc<r>(jc, cj)];
-                const double ov = SI[l15 ? PIF_GJ + r : PIF_IJ + jc * 15 + r];      // (frame 0's record has no block in front of it)
-                const double gi = SI[PIF_GI + r];                                  // (zero in frame n-1's record)
-                o[r] = (hasm ? ov : 0.0) + (l15 ? gi : 0.0);
-            });
-        } else {
-            sfor<0, 15>([&](auto R) { constexpr int r = KI(R); d[r] = 0.0; o[r] = 0.0; });
+        {
+            constexpr int NT = K_OW - K_A;               // K_A, K_B, K_C: table reads; K_HA and K_D behind them
+            unsigned of[NT + 6 + 15];
+            auto tab_at = [&](int k) { return (unsigned)*reinterpret_cast<const unsigned short*>(reinterpret_cast<const char*>(TAB) + k * 128 + lane_tab); };
+            sfor<0, NT>([&](auto Q) { constexpr int q = KI(Q); of[q] = tab_at(K_A + q); });
+            sfor<0, 6>([&](auto Q) { constexpr int q = KI(Q); of[NT + q] = tab_at(K_HA + q); });
+            if (n > 1) sfor<0, 15>([&](auto Q) { constexpr int q = KI(Q); of[NT + 6 + q] = tab_at(K_D + q); });
+            const char* const Sb = reinterpret_cast<const char*>(S);
+            const int w8 = (lane >> 4) * 8;
+            const char* const bOV = Sb + (l15 ? 8 * (S_IMU + PIF_GJ) : 8 * (S_IMU + PIF_IJ) + jc * 120) + w8 * PIFS;
+            const char* const bGI = Sb + (l15 ? 8 * (S_IMU + PIF_GI) + w8 * PIFS : 8 * S_ZERO);
+            const char* const bRL = Sb + (l6 ? 8 * (S_PL + 72) + w8 * LP + j6 * 48 : 8 * S_ZERO);
+            const char* const bOW = Sb + (l6 ? 8 * (S_PW + PW_IJ(0, 0)) + w8 * PWS + j6 * 48 : 8 * S_ZERO);
+            double gi[15];
+            if (n > 1) {
+                sfor<0, 15>([&](auto R) { constexpr int r = KI(R); o[r] = *reinterpret_cast<const double*>(bOV + 8 * r); gi[r] = *reinterpret_cast<const double*>(bGI + 8 * r); });
+            } else {
+                sfor<0, 15>([&](auto R) { constexpr int r = KI(R); d[r] = 0.0; o[r] = 0.0; gi[r] = 0.0; });
+            }
+            sfor<0, 6>([&](auto R) { constexpr int r = KI(R); rL[r] = *reinterpret_cast<const double*>(bRL + 8 * r); oW[r] = *reinterpret_cast<const double*>(bOW + 8 * r); });
+            asm volatile("" ::: "memory");
+            double pb[NT], hb[6];
+            sfor<0, NT>([&](auto Q) { constexpr int q = KI(Q); pb[q] = *reinterpret_cast<const double*>(Sb + of[q]); });
+            sfor<0, 6>([&](auto Q) { constexpr int q = KI(Q); hb[q] = *reinterpret_cast<const double*>(Sb + of[NT + q]); });
+            if (n > 1) sfor<0, 15>([&](auto Q) { constexpr int q = KI(Q); d[q] = *reinterpret_cast<const double*>(Sb + of[NT + 6 + q]); });
+            asm volatile("" ::: "memory");
+            sfor<0, 6>([&](auto R) { constexpr int r = KI(R); tS[r] = pb[K_A + r] + bits_and(pb[K_B + r], mh) + pb[K_C + r]; });
+            if (!track) {   // every laser frame's Haa / ga lands on frame 0's pose (init topology): summed as the frames stream by (until round 4
+                            // frame 0 re-read the n records from HBM)
+                sfor<0, 6>([&](auto R) { constexpr int r = KI(R); hA[r] += hb[r]; });
+                if (i == 0) sfor<0, 6>([&](auto R) { tS[KI(R)] += hA[KI(R)]; });
+            }
+            sfor<0, 15>([&](auto R) { constexpr int r = KI(R); o[r] = bits_and(o[r], mh) + gi[r]; });   // (frame 0's record has no block in front of it)
         }
         sfor<0, 15>([&](auto R) { rr[KI(R)] = 0.0; });
         sfor<0, 6>([&](auto R) {
             constexpr int r = KI(R);
-            d[r] += l6 ? tS[r] : 0.0;
-            o[r] += l15 ? tS[r] : ((l6 && hasm) ? oW[r] : 0.0);
-            rr[r] = (l6 && hasm) ? rL[r] : 0.0;
+            d[r] += bits_and(tS[r], ~m15);
+            o[r] += bits_and(tS[r], m15) + bits_and(oW[r], mh);   // (oW, rL: zero outside lanes 0 .. 5)
+            rr[r] = bits_and(rL[r], mh);
         });
         if (track && i == n - 2 && __any(prior_row)) {
             // marginalization_factor (marginalization_factor.h:22-53, linearized_R omitted there): r = J (x - X), H += J^T J, g += J^T r.
@@ -519,15 +603,15 @@ __global__ __launch_bounds__(64, LIW_QUAD_OCC) void k_lm_step_quad(StepArgs a) {
             dpp_fence();
             // (the IMU share of frame i-1 arrives with that frame's own record: only the wheel block's pose share is folded here)
             double cw[6];
-            sfor<0, 6>([&](auto R) { constexpr int r = KI(R); cw[r] = SW[l15 ? PW_G(r) : PW_II(r, j6)]; });
-            gsh = l6 ? SW[PW_G(j6)] : 0.0;                  // frame i-1's unscaled wheel gradient share, lane per entry
+            sfor<0, 6>([&](auto R) { constexpr int r = KI(R); cw[r] = RD(KC<K_CW + r>{}); });   // (zero outside lanes 0..5, 15)
+            gsh = RD(KC<K_GSH>{});                          // frame i-1's unscaled wheel gradient share, lane per entry
             __builtin_amdgcn_sched_barrier(0);
             sfor<0, 15>([&](auto R) {
                 constexpr int r = KI(R);
                 double fi = 0.0;
                 if constexpr (r < 6) {
                     const double rs = bc<r>(scm);
-                    fi = ((l6 || l15) ? cw[r] : 0.0) * (rs * scm);
+                    fi = cw[r] * (rs * scm);
                 }
                 cd[r] = fi;
                 pdiag = (j == r) ? cd[r] : pdiag;  // its diagonal (LM diagonal of frame i-1)
@@ -727,6 +811,7 @@ bool lm_step_quad_fits(const StepArgs& a) {
     const int nm = a.n > 1 ? a.n - 1 : 1;
     return a.n >= 1 && (a.mode == LIW_MODE_INIT || (a.mode == LIW_MODE_TRACK && a.n >= 2)) && span(a.w.PL[0], a.w.PL[1], (unsigned long long)a.n * LP) && a.w.pi_frame && a.w.CS[0] && a.w.CS[1] && span(a.w.PI[0], a.w.PI[1], (unsigned long long)a.n * PIFS) &&
            span(a.w.PW[0], a.w.PW[1], (unsigned long long)nm * PWS) && span(a.w.PG[0], a.w.PG[1], (unsigned long long)a.n * PGS) &&
+           a.w.PG[0] >= a.w.PW[0] && span(a.w.PW[0], a.w.PG[1], (unsigned long long)a.n * PGS) &&   // (ground records are addressed from the wheel buffer)
            (unsigned long long)a.B * (sizeof(LmState) / 8) <= lim && (unsigned long long)a.B * a.n * SOLVE_WS <= lim;
 }
 extern "C" void liw_debug_quad_clk(int on, int block, int frame, int iteration, long long* out) {
