@@ -79,8 +79,10 @@ constexpr int QTR = 4 * 15 * 6;                           // transposition tile 
 // K_D IMU diagonal tile, K_OV IMU coupling | g_j, K_GI IMU g_i.
 constexpr int K_A = 0, K_B = 6, K_C = 12, K_OW = 18, K_RL = 24, K_HA = 30, K_CW = 36, K_GSH = 42, K_D = 43, K_OV = 58, K_GI = 73, NRD = 88;
 constexpr int QTAB = NRD * 16;                            // doubles: NRD x 64 unsigned shorts
-constexpr int QZB = 16;                                  // a block of zeros: lanes that take no part in a strided read
-constexpr int QTOT = 4 * (PIFS + LP + PWS + PGS) + 32 + QTR + QZB + QTAB;   // LDS doubles per wave: the prefetched partial records of its four rows, the tile, a zero word, the gather table (35.6 kB: four waves per CU)
+constexpr int QZB = 86;                                  // a block of zeros: lanes that take no part in a strided read
+constexpr int QTOT_1 = 4 * (PIFS + LP + PWS + PGS) + 32 + QTR + QZB + QTAB;   // first sweep
+constexpr int QTOT_2 = 3 * (((4 * REC_GS + 127) / 128) * 128 + 6 * 32);             // second sweep: three frames of records + state / scale / diagonal entries
+constexpr int QTOT = QTOT_1 > QTOT_2 ? QTOT_1 : QTOT_2;   // LDS doubles per wave: the prefetched partial records of its four rows, the tile, a zero word, the gather table (35.6 kB: four waves per CU)
 
 // offset of entry (r, j) inside a packed upper triangle of order 15, r a compile-time constant
 template <int R> __device__ __forceinline__ int tri_rc(int j, int cj) {   // cj = 14 j - j (j - 1) / 2
@@ -387,7 +389,7 @@ __global__ __launch_bounds__(64, LIW_QUAD_OCC) void k_lm_step_quad(StepArgs a) {
         const bool t6 = j < 6, t15 = j == 15, tm = j < 15;
         const int oL = S_PL + w * LP, oW_ = S_PW + w * PWS, oG = S_PG + w * PGS, oI = S_IMU + w * PIFS;
         auto put = [&](int k, bool on, int idx) { TAB[k * 64 + lane] = (unsigned short)(8 * (on ? idx : S_ZERO)); };
-        if (lane < QZB) S[S_ZERO + lane] = 0.0;
+        for (int e = lane; e < QZB; e += 64) S[S_ZERO + e] = 0.0;
         sfor<0, 6>([&](auto R) {
             constexpr int r = KI(R);
             put(K_A + r, t6 || t15, oL + (t15 ? 114 + r : 36 + r * 6 + j6t));
@@ -566,12 +568,13 @@ __global__ __launch_bounds__(64, LIW_QUAD_OCC) void k_lm_step_quad(StepArgs a) {
         // ---- Jacobi scaling, carried Schur terms, damping
         QSTAMP(4);
         dpp_fence();
+        const double* const stp = (l6 && i < n - 1) ? ST + j6 : S + S_ZERO;   // (a zero block needs 14 * 6 + 1 doubles behind it: QZB)
         sfor<0, 15>([&](auto R) {
             constexpr int r = KI(R);
             const double rs = bc<r>(sci);
             d[r] = __builtin_fma(d[r], rs * sci, cd[r]) + ((j == r) ? dmp : 0.0);
-            o[r] = __builtin_fma(o[r], rs * scm, l15 ? cd[r] : 0.0);
-            rr[r] = __builtin_fma(rr[r], rs * sc0, (l6 && i < n - 1) ? ST[r * 6 + j6] : 0.0);   // + the carried arrow block, column layout
+            o[r] = __builtin_fma(o[r], rs * scm, bits_and(cd[r], m15));
+            rr[r] = __builtin_fma(rr[r], rs * sc0, stp[r * 6]);   // + the carried arrow block, column layout (zeros outside lanes 0 .. 5 and at frame n-1)
         });
         if (i == 1) {   // frame 0 is both the chain neighbour and the arrow target: fold R^T into O^T
             sfor<0, 15>([&](auto R) { constexpr int r = KI(R); o[r] += rr[r]; rr[r] = 0.0; });
@@ -723,27 +726,83 @@ __global__ __launch_bounds__(64, LIW_QUAD_OCC) void k_lm_step_quad(StepArgs a) {
     // ---------------------------------------------------------------- back substitution, frame 0 first; lane r owns unknown r
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the records written above are read by other lanes of the row
     double sn2 = 0.0, dsum = 0.0, yprev = 0.0, y0v = 0.0;
-    // the sweep is a chain of small matrix-vector products (21 DPP FMAs per frame) fed by 2.6 kB of record per frame and window: BSD
-    // frames of loads are kept in flight (a set is refilled as soon as it has been consumed)
-    struct BsRow { double row[22], xold, scv, dgv; };
-    auto fetch = [&](int i) {
-        BsRow R;
-        const double2* f2 = reinterpret_cast<const double2*>(WS + oWS + (unsigned)(i * SOLVE_WS + jc * REC_LD));
-#pragma unroll
-        for (int k = 0; k < 11; ++k) { const double2 v = f2[k]; R.row[2 * k] = v.x; R.row[2 * k + 1] = v.y; }
-        R.xold = X[oX + (unsigned)(i * 15 + jc)]; R.scv = LMD[oSC + (unsigned)(i * 15 + jc)]; R.dgv = LMD[oDG + (unsigned)(i * 15 + jc)];
-        return R;
+    // The sweep is a chain of small matrix-vector products (21 DPP FMAs per frame) fed by 2.6 kB of record per frame and window.  Until round 4
+    // every lane loaded its own 176-byte record row with eleven 16-byte loads — 64 separate lines per instruction, ~700 line requests per
+    // frame and wave, and the XC stores of the sweep in the same counter (loads and stores may complete out of order, so every use of a loaded
+    // value waited for ALL outstanding operations): 7 k cycles per frame, 30 % of the kernel.  Now the records of a frame's four rows are
+    // staged like the partial records of the first sweep: 11 lane-linear LDS-DMA pieces (the 4 x 330 doubles cut every 128, a lane's
+    // address = its record's base + its offset inside it), the state / Jacobi scale / LM diagonal entries as 6 four-byte pieces, three
+    // frames deep into the (now free) LDS of the wave; no register loads are left, so the only waits are the explicit ones below —
+    // s_waitcnt vmcnt(N) with N = the LOADS issued behind the frame's own (loads return in order; a store that completes early only
+    // makes the wait stricter).
+    constexpr int RECP = (4 * REC_GS + 127) / 128, XP = (4 * 30 + 63) / 64, LP_ = (8 * 30 + 63) / 64;   // 16-byte pieces of the records; 4-byte pieces of X; of scale + diagonal
+    constexpr int NLD = RECP + XP + LP_, BUFD = RECP * 128 + (XP + LP_) * 32;
+    static_assert(3 * BUFD <= QTOT && 2 * NLD <= 63, "second-sweep staging");
+    const unsigned rWS[4] = {(unsigned)__builtin_amdgcn_readlane(oWS, 0), (unsigned)__builtin_amdgcn_readlane(oWS, 16), (unsigned)__builtin_amdgcn_readlane(oWS, 32), (unsigned)__builtin_amdgcn_readlane(oWS, 48)};
+    const unsigned rX[4] = {(unsigned)__builtin_amdgcn_readlane(oX, 0), (unsigned)__builtin_amdgcn_readlane(oX, 16), (unsigned)__builtin_amdgcn_readlane(oX, 32), (unsigned)__builtin_amdgcn_readlane(oX, 48)};
+    const unsigned rLM[4] = {(unsigned)__builtin_amdgcn_readlane(oLM, 0), (unsigned)__builtin_amdgcn_readlane(oLM, 16), (unsigned)__builtin_amdgcn_readlane(oLM, 32), (unsigned)__builtin_amdgcn_readlane(oLM, 48)};
+    auto stage2 = [&](int f, int buf) {
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // the buffer's previous contents have been read
+        int ln = lane;
+        asm volatile("" : "+v"(ln));
+        const int lane2 = ln * 2;
+        double* const dst = S + buf * BUFD;
+        const unsigned fo = (unsigned)(f * SOLVE_WS), fx = (unsigned)(f * 15);
+        sfor<0, RECP>([&](auto P) {
+            constexpr int q0 = KI(P) * 128;
+            unsigned off = 0;
+            sfor<0, 4>([&](auto G) {
+                constexpr int g = KI(G), st = g * REC_GS, en = g == 3 ? (1 << 20) : st + REC_GS;
+                if constexpr (st < q0 + 128 && en > q0) {
+                    const unsigned v = rWS[g] + fo + (unsigned)(lane2 - (st - q0));
+                    if constexpr (st <= q0) off = v; else off = lane2 >= st - q0 ? v : off;
+                }
+            });
+            __builtin_amdgcn_global_load_lds(WS + off, (lds_t)(dst + q0), 16, 0, 0);
+        });
+        const unsigned* const X32 = reinterpret_cast<const unsigned*>(X);
+        const unsigned* const L32 = reinterpret_cast<const unsigned*>(LMD);
+        sfor<0, XP>([&](auto P) {                                // states: 30 dwords per row
+            constexpr int q0 = KI(P) * 64;
+            unsigned off = 0;
+            sfor<0, 4>([&](auto G) {
+                constexpr int g = KI(G), st = g * 30, en = g == 3 ? (1 << 20) : st + 30;
+                if constexpr (st < q0 + 64 && en > q0) {
+                    const unsigned v = 2u * (rX[g] + fx) + (unsigned)(ln - (st - q0));
+                    if constexpr (st <= q0) off = v; else off = ln >= st - q0 ? v : off;
+                }
+            });
+            __builtin_amdgcn_global_load_lds(X32 + off, (lds_t)(dst + RECP * 128 + KI(P) * 32), 4, 0, 0);
+        });
+        sfor<0, LP_>([&](auto P) {                               // Jacobi scale (rows 0 .. 3), then LM diagonal (rows 0 .. 3)
+            constexpr int q0 = KI(P) * 64;
+            unsigned off = 0;
+            sfor<0, 8>([&](auto G) {
+                constexpr int g = KI(G), st = g * 30, en = g == 7 ? (1 << 20) : st + 30;
+                if constexpr (st < q0 + 64 && en > q0) {
+                    const unsigned v = 2u * (rLM[g & 3] + (g < 4 ? LM_SCALE : LM_DIAG) + fx) + (unsigned)(ln - (st - q0));
+                    if constexpr (st <= q0) off = v; else off = ln >= st - q0 ? v : off;
+                }
+            });
+            __builtin_amdgcn_global_load_lds(L32 + off, (lds_t)(dst + RECP * 128 + XP * 32 + KI(P) * 32), 4, 0, 0);
+        });
+        asm volatile("" ::: "memory");
     };
-    auto solve_frame = [&](const BsRow& R, int i) {
-        double t = R.row[21];
+    auto solve_frame = [&](int buf, int i) {
+        const double* const B_ = S + buf * BUFD;
+        const double* const rowp = B_ + w * REC_GS + jc * REC_LD;
+        double row[22];
+        sfor<0, 11>([&](auto K) { constexpr int k = KI(K); const double2 v = reinterpret_cast<const double2*>(rowp)[k]; row[2 * k] = v.x; row[2 * k + 1] = v.y; });
+        const double xold = B_[RECP * 128 + w * 15 + jc], scv = B_[RECP * 128 + XP * 32 + w * 15 + jc], dgv = B_[RECP * 128 + XP * 32 + 60 + w * 15 + jc];
+        double t = row[21];
         dpp_fence();
-        if (i >= 1) sfor<0, 15>([&](auto K) { constexpr int k = KI(K); fnma_bc<k>(t, yprev, R.row[k]); });
-        if (i >= 2) sfor<0, 6>([&](auto K) { constexpr int k = KI(K); fnma_bc<k>(t, y0v, R.row[15 + k]); });
+        if (i >= 1) sfor<0, 15>([&](auto K) { constexpr int k = KI(K); fnma_bc<k>(t, yprev, row[k]); });
+        if (i >= 2) sfor<0, 6>([&](auto K) { constexpr int k = KI(K); fnma_bc<k>(t, y0v, row[15 + k]); });
         yprev = t;
         if (i == 0) y0v = t;
         const bool cst = is_const(i, j);
-        const double del = (lm && !cst) ? -t * R.scv : 0.0;
-        double xnew = R.xold + del;
+        const double del = (lm && !cst) ? -t * scv : 0.0;
+        double xnew = xold + del;
         {
             dpp_fence();
             const double a0 = bc<3>(xnew), a1 = bc<4>(xnew), a2 = bc<5>(xnew);
@@ -757,21 +816,24 @@ __global__ __launch_bounds__(64, LIW_QUAD_OCC) void k_lm_step_quad(StepArgs a) {
         if (lm) {
             if (proceed) XC[oX + (unsigned)(i * 15 + j)] = xnew;
             if (!cst) {
-                sn2 += (R.xold - xnew) * (R.xold - xnew);
-                dsum += R.dgv * inv_radius * t * t;
+                sn2 += (xold - xnew) * (xold - xnew);
+                dsum += dgv * inv_radius * t * t;
             }
         }
     };
-    constexpr int BSD = 4;      // frames of record loads in flight (14 loads each: the 6-bit vmcnt cannot tell more than 63 apart, 8 measured no better)
-    BsRow RB[BSD];
-    sfor<0, BSD>([&](auto Q) { constexpr int q = KI(Q); RB[q] = fetch(q < n ? q : 0); });
-    for (int i0 = 0; i0 < n; i0 += BSD) {
-        sfor<0, BSD>([&](auto Q) {
+    sfor<0, 3>([&](auto Q) { constexpr int q = KI(Q); if (q < n) stage2(q, q); });
+    for (int i0 = 0; i0 < n; i0 += 3) {
+        sfor<0, 3>([&](auto Q) {
             constexpr int q = KI(Q);
             __builtin_amdgcn_sched_barrier(0);
-            if (i0 + q < n) {
-                solve_frame(RB[q], i0 + q);
-                if (i0 + q + BSD < n) RB[q] = fetch(i0 + q + BSD);
+            const int i = i0 + q;
+            if (i < n) {
+                const int later = n - 1 - i;                     // frames staged behind frame i at this point (at most two)
+                if (later >= 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * NLD) : "memory");
+                else if (later == 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NLD) : "memory");
+                else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                solve_frame(q, i);
+                if (i + 3 < n) stage2(i + 3, q);
             }
         });
     }
