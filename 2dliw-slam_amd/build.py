@@ -13,8 +13,6 @@ if os.environ.get("LIW_QUAD_OCC"):   # A/B aid: waves per SIMD the quad step ker
     FLAGS.append("-DLIW_QUAD_OCC=" + os.environ["LIW_QUAD_OCC"])
 if os.environ.get("LIW_SMALL_OCC"):   # A/B aid: waves per SIMD k_lin_small is compiled for (3: <= 168 registers, co-resident with the lane-per-group laser kernel)
     FLAGS.append("-DLIW_SMALL_OCC=" + os.environ["LIW_SMALL_OCC"])
-if os.environ.get("LIW_QUAD_NOPL"):   # timing probe only (wrong results): the step kernel without its laser pieces
-    FLAGS.append("-DLIW_QUAD_NOPL")
 if os.environ.get("LIW_QUAD_TILE_ALIAS"):
     FLAGS.append("-DLIW_QUAD_TILE_ALIAS")
 if os.environ.get("LIW_CLK"):   # phase-timing build for tools/clk_probe.py

@@ -168,7 +168,7 @@ __device__ __forceinline__ void imu_blocks(const LinArgs& A, const DevParams& P,
         const int npw = imu_chain_parts(nb), bpw = (nb + npw - 1) / npw;
         const int wiw = wave / npw, part = wave % npw;
         if (wiw >= (act ? act[0] : A.B)) return;
-        chain_b = act ? act[1 + wiw] : wiw;
+        chain_b = __builtin_amdgcn_readfirstlane(act ? act[1 + wiw] : wiw);
         if (!act && !window_live(A, chain_b)) return;
         const int kfirst = part * bpw, kend = min(nb, kfirst + bpw);
         if (kfirst >= kend) return;
@@ -383,8 +383,11 @@ __device__ __forceinline__ void imu_blocks(const LinArgs& A, const DevParams& P,
                 g01 = __builtin_amdgcn_mfma_f64_16x16x4f64(y0[c], y1[c], g01, 0, 0, 0);
                 g11 = __builtin_amdgcn_mfma_f64_16x16x4f64(y1[c], y1[c], g11, 0, 0, 0);
             }
-            const size_t fg = (size_t)__shfl(fk_lane, LPB * gq, 64);
-            const int sel = __shfl(sel_lane, LPB * gq, 64);
+            // (the block's record index and partial buffer are the same in every lane: as SCALARS, so that the output addresses below are a
+            // scalar base + a 32-bit lane offset — as lane values every store paid a 64-bit select between the two buffers and a 64-bit
+            // shift-and-add: ~1 400 of the kernel's 11 600 instructions)
+            const size_t fg = (size_t)__builtin_amdgcn_readfirstlane(__shfl(fk_lane, LPB * gq, 64));
+            const int sel = __builtin_amdgcn_readfirstlane(__shfl(sel_lane, LPB * gq, 64));
             if constexpr (CHAIN) {
                 chain11 = g11;
                 if (ghost && gq == 0) continue;   // evaluated for its jj tile only

@@ -75,9 +75,8 @@ constexpr int QTR = 0;
 constexpr int QTR = 4 * 15 * 6;                           // transposition tile of the carried arrow block (below)
 #endif
 // Gather table of the assembly phase: one 16-bit LDS byte offset per (read, lane) — see the kernel.  Reads: K_A laser Hbb | gb, K_B wheel
-// jj | g_j, K_C ground H | g, K_OW wheel ij, K_RL laser Hab, K_HA laser Haa | ga, K_CW wheel ii | g_i, K_GSH wheel g_i lane per entry,
-// K_D IMU diagonal tile, K_OV IMU coupling | g_j, K_GI IMU g_i.
-constexpr int K_A = 0, K_B = 6, K_C = 12, K_OW = 18, K_RL = 24, K_HA = 30, K_CW = 36, K_GSH = 42, K_D = 43, K_OV = 58, K_GI = 73, NRD = 88;
+// jj | g_j, K_C ground H | g, K_HA laser Haa | ga, K_D IMU diagonal tile, K_CW wheel ii | g_i, K_GSH wheel g_i lane per entry.
+constexpr int K_A = 0, K_B = 6, K_C = 12, K_HA = 18, K_D = 24, K_CW = 39, K_GSH = 45, NRD = 46;
 constexpr int QTAB = NRD * 16;                            // doubles: NRD x 64 unsigned shorts
 constexpr int QZB = 86;                                  // a block of zeros: lanes that take no part in a strided read
 constexpr int QTOT_1 = 4 * (PIFS + LP + PWS + PGS) + 32 + QTR + QZB + QTAB;   // first sweep
@@ -345,9 +344,7 @@ __global__ __launch_bounds__(64, LIW_QUAD_OCC) void k_lm_step_quad(StepArgs a) {
         sfor<0, 4>([&](auto W) {                    // laser group record: exactly one piece
             constexpr int ws = KI(W);
             static_assert(LP == 128, "one piece");
-#ifndef LIW_QUAD_NOPL   // (timing probe: no laser pieces, the area zeroed once)
             __builtin_amdgcn_global_load_lds(PL0 + rPL[ws] + (unsigned)(f * LP) + lane2, (lds_t)(S + S_PL + ws * LP), 16, 0, 0);
-#endif
         });
         // wheel partials (block f-1; frame 0 re-reads block 0, unused) and ground partials of the four rows: the 4 x 92 + 4 x 28 doubles that lie
         // back to back in LDS are cut into 128-double pieces wherever the cuts fall (4 pieces; a piece per wheel record + one for the ground
@@ -377,12 +374,12 @@ __global__ __launch_bounds__(64, LIW_QUAD_OCC) void k_lm_step_quad(StepArgs a) {
     const double* SW = S + S_PW + w * PWS;
     const double* SG = S + S_PG + w * PGS;
     // Gather table.  The assembly of a frame reads 88 values per lane out of the staged records, at addresses that depend on the lane's role
-    // (its column j of the 6x6 pose blocks / of the 15x15 IMU tiles, lane 15 = the gradient column, lanes that take no part) — packed
-    // triangles, row strides that differ between a block and its gradient.  Computed per frame those addresses were ~900 issued
-    // instructions (integer selects and multiplies, the nested lane tests as divergent branches): 5.0 k of a frame's 18.9 k cycles
-    // (tools/clk_probe_quad.py).  They do not depend on the frame: every lane's byte offset for read k sits in LDS, TAB[k][lane], built
-    // once per launch, and a read is ds_read_u16 + ds_read_b64 — no vector ALU.  A lane that takes no part in a read is pointed at a
-    // word that holds 0.0, so most lane masks of the assembly vanish as well.
+    // (its column j of the 6x6 pose blocks / of the 15x15 IMU tiles, lane 15 = the gradient column, lanes that take no part).  Computed per
+    // frame those addresses were ~900 issued instructions (integer selects and multiplies, the nested lane tests as divergent branches):
+    // 5.0 k of a frame's 18.9 k cycles (tools/clk_probe_quad.py).  They do not depend on the frame.  42 of the reads are lane base +
+    // compile-time offset (the assembly forms four bases per frame); the other 46 — packed triangles, a block and its gradient with
+    // different strides — take their byte offset from LDS, TAB[k][lane], built here once per launch: ds_read_u16 + ds_read_b64, no
+    // vector ALU.  A lane that takes no part in a read is pointed at a block of zeros, so most lane masks of the assembly vanish as well.
     unsigned short* const TAB = reinterpret_cast<unsigned short*>(S + S_TAB);
     {
         const int jt = j < 15 ? j : 0, cjt = 14 * jt - (jt * (jt - 1)) / 2, j6t = j < 6 ? j : 0;
@@ -395,8 +392,6 @@ __global__ __launch_bounds__(64, LIW_QUAD_OCC) void k_lm_step_quad(StepArgs a) {
             put(K_A + r, t6 || t15, oL + (t15 ? 114 + r : 36 + r * 6 + j6t));
             put(K_B + r, t6 || t15, oW_ + (t15 ? PW_G(6 + r) : PW_JJ(r, j6t)));
             put(K_C + r, t6 || t15, oG + (t15 ? PG_G(r) : PG_H(r, j6t)));
-            put(K_OW + r, t6, oW_ + PW_IJ(j6t, r));
-            put(K_RL + r, t6, oL + 72 + j6t * 6 + r);
             put(K_HA + r, t6 || t15, oL + (t15 ? 108 + r : r * 6 + j6t));
             put(K_CW + r, t6 || t15, oW_ + (t15 ? PW_G(r) : PW_II(r, j6t)));
         });
@@ -404,21 +399,9 @@ __global__ __launch_bounds__(64, LIW_QUAD_OCC) void k_lm_step_quad(StepArgs a) {
         sfor<0, 15>([&](auto R) {
             constexpr int r = KI(R);
             put(K_D + r, tm, oI + PIF_D + tri_rc<r>(jt, cjt));
-            put(K_OV + r, true, oI + (t15 ? PIF_GJ + r : PIF_IJ + jt * 15 + r));
-            put(K_GI + r, t15, oI + PIF_GI + r);
         });
     }
     const int lane_tab = lane * 2;                  // byte offset of the lane's entry inside a table row
-    // N reads K0 .. K0 + N - 1 as ONE batch: all offsets first, then all values — two LDS round trips for the batch (the compiler, left
-    // alone, waits for every handful of offsets before it issues their value reads: ~35 dependent round trips per frame)
-    auto RDB = [&](auto K0, auto N_, double* out) {
-        constexpr int k0 = KI(K0), N = KI(N_);
-        unsigned of[N];
-        sfor<0, N>([&](auto Q) { constexpr int q = KI(Q); of[q] = *reinterpret_cast<const unsigned short*>(reinterpret_cast<const char*>(TAB) + (k0 + q) * 128 + lane_tab); });
-        asm volatile("" ::: "memory");
-        sfor<0, N>([&](auto Q) { constexpr int q = KI(Q); out[q] = *reinterpret_cast<const double*>(reinterpret_cast<const char*>(S) + of[q]); });
-        asm volatile("" ::: "memory");
-    };
     auto RD = [&](auto K) -> double {               // read K of the gather table
         constexpr int k = KI(K);
         const unsigned off = *reinterpret_cast<const unsigned short*>(reinterpret_cast<const char*>(TAB) + k * 128 + lane_tab);
@@ -441,9 +424,6 @@ __global__ __launch_bounds__(64, LIW_QUAD_OCC) void k_lm_step_quad(StepArgs a) {
     sfor<0, 6>([&](auto R) { D0[KI(R)] = 0.0; crt[KI(R)] = 0.0; hA[KI(R)] = 0.0; });
     const bool clk_on = g_qclk_on[0] && (int)blockIdx.x == g_qclk_on[1] && iteration == g_qclk_on[3];
     const int clk_frame = g_qclk_on[2];
-#ifdef LIW_QUAD_NOPL
-    for (int e = lane; e < 4 * LP; e += 64) S[S_PL + e] = 0.0;
-#endif
     if (clk_k) g_qclk[13] = clock64();
     prefetch(n - 1);
     double sci_carry = (j_ < 15) ? LMD[oSC + (unsigned)((n - 1) * 15 + (j_ < 15 ? j_ : 0))] : 1.0;   // scale of frame n-1; later frames reuse scm
@@ -470,12 +450,11 @@ __global__ __launch_bounds__(64, LIW_QUAD_OCC) void k_lm_step_quad(StepArgs a) {
         const unsigned long long m15 = l15 ? ~0ull : 0ull, mh = hasm ? ~0ull : 0ull;
         double tS[6], oW[6], rL[6];
         {
-            constexpr int NT = K_OW - K_A;               // K_A, K_B, K_C: table reads; K_HA and K_D behind them
-            unsigned of[NT + 6 + 15];
+            constexpr int NT = K_D - K_A;                // K_A, K_B, K_C, K_HA; K_D behind them
+            unsigned of[NT + 15];
             auto tab_at = [&](int k) { return (unsigned)*reinterpret_cast<const unsigned short*>(reinterpret_cast<const char*>(TAB) + k * 128 + lane_tab); };
             sfor<0, NT>([&](auto Q) { constexpr int q = KI(Q); of[q] = tab_at(K_A + q); });
-            sfor<0, 6>([&](auto Q) { constexpr int q = KI(Q); of[NT + q] = tab_at(K_HA + q); });
-            if (n > 1) sfor<0, 15>([&](auto Q) { constexpr int q = KI(Q); of[NT + 6 + q] = tab_at(K_D + q); });
+            if (n > 1) sfor<0, 15>([&](auto Q) { constexpr int q = KI(Q); of[NT + q] = tab_at(K_D + q); });
             const char* const Sb = reinterpret_cast<const char*>(S);
             const int w8 = (lane >> 4) * 8;
             const char* const bOV = Sb + (l15 ? 8 * (S_IMU + PIF_GJ) : 8 * (S_IMU + PIF_IJ) + jc * 120) + w8 * PIFS;
@@ -490,15 +469,14 @@ __global__ __launch_bounds__(64, LIW_QUAD_OCC) void k_lm_step_quad(StepArgs a) {
             }
             sfor<0, 6>([&](auto R) { constexpr int r = KI(R); rL[r] = *reinterpret_cast<const double*>(bRL + 8 * r); oW[r] = *reinterpret_cast<const double*>(bOW + 8 * r); });
             asm volatile("" ::: "memory");
-            double pb[NT], hb[6];
+            double pb[NT];
             sfor<0, NT>([&](auto Q) { constexpr int q = KI(Q); pb[q] = *reinterpret_cast<const double*>(Sb + of[q]); });
-            sfor<0, 6>([&](auto Q) { constexpr int q = KI(Q); hb[q] = *reinterpret_cast<const double*>(Sb + of[NT + q]); });
-            if (n > 1) sfor<0, 15>([&](auto Q) { constexpr int q = KI(Q); d[q] = *reinterpret_cast<const double*>(Sb + of[NT + 6 + q]); });
+            if (n > 1) sfor<0, 15>([&](auto Q) { constexpr int q = KI(Q); d[q] = *reinterpret_cast<const double*>(Sb + of[NT + q]); });
             asm volatile("" ::: "memory");
             sfor<0, 6>([&](auto R) { constexpr int r = KI(R); tS[r] = pb[K_A + r] + bits_and(pb[K_B + r], mh) + pb[K_C + r]; });
             if (!track) {   // every laser frame's Haa / ga lands on frame 0's pose (init topology): summed as the frames stream by (until round 4
                             // frame 0 re-read the n records from HBM)
-                sfor<0, 6>([&](auto R) { constexpr int r = KI(R); hA[r] += hb[r]; });
+                sfor<0, 6>([&](auto R) { constexpr int r = KI(R); hA[r] += pb[K_HA + r]; });
                 if (i == 0) sfor<0, 6>([&](auto R) { tS[KI(R)] += hA[KI(R)]; });
             }
             sfor<0, 15>([&](auto R) { constexpr int r = KI(R); o[r] = bits_and(o[r], mh) + gi[r]; });   // (frame 0's record has no block in front of it)
