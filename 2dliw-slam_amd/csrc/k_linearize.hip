@@ -95,11 +95,12 @@ typedef LJN<3> J3;
 // and the pre-integration Jacobian; they are never materialised: the MFMA operand of the whitening  Y = sqrt_info [J_raw | r_raw]
 // (imu_factor.h:85-86) is composed per lane from the compact block record below, and  G = Y^T Y  follows on the matrix cores
 // (8 + 12 v_mfma_f64_16x16x4_f64 per block, the accumulator layout of Y being the operand layout of Y^T Y).
-// Blocks per wave: 18 (54 of the 64 lanes in the dual-number part) x 132 doubles of LDS each = 19 kB per wave, so that EIGHT waves fit a
-// CU (two per SIMD, the register limit).  The role is bound by the latency of one wave's instruction stream (a block's 20 dependent
-// fp64 MFMAs + operand reads + stores: 3.1 k ticks, tools/clk_probe_imu.py), not by HBM: with 21 blocks x 188 doubles (31.6 kB, five
-// waves per CU) the kernel took 563 us per 12 288 C2 windows, with the packed inputs alone 3 % less.
-constexpr int IMU_PER_WAVE = 18;
+// Blocks per wave: 16 (48 of the 64 lanes in the dual-number part) x 132 doubles of LDS each (+ the chain kernel's output staging area)
+// = 19 kB per wave, so that EIGHT waves fit a CU (two per SIMD, the register limit).  The role is bound by the fp64 pipe its matrix-core and
+// vector instructions share (~80 % busy with two waves per SIMD, tools/clk_probe_imu.py), not by HBM: with 21 blocks x 188 doubles
+// (31.6 kB, five waves per CU) the kernel took 563 us per 12 288 C2 windows, with the packed inputs alone 3 % less.
+constexpr int IMU_PER_WAVE = 16;    // (18 until the chain kernel's output staging area took the room of two blocks)
+constexpr int IMU_STAGE = 244;      // k_lin_imu_chain: one frame record's larger part (ij | g_j: 240 doubles) on its way out
 // compact block record in LDS (doubles): Xc[9][10] = rows alpha, beta, gamma: the 9 derivative columns (theta_i 0-2, theta_j 3-5,
 // bw_i 6-8) + r_raw (9); Rb[6] = r_raw of the bias rows (their derivative columns are constants); Rt[9] = R_i^T; RtDt[9];
 // Jb[18] = alpha_J_ba (9), beta_J_ba (9)
@@ -396,23 +397,40 @@ __device__ __forceinline__ void imu_blocks(const LinArgs& A, const DevParams& P,
                 const int kq = chain_k0 + gq;
                 double* rf = (sel ? A.PI[1] : A.PI[0]) + ((size_t)b * n + kq) * PIFS;
                 const bool lastb = kq == nb - 1;
+                // The tiles leave through LDS: in the accumulator layout a store instruction covers four 15-double row segments of a tile
+                // (~8 lines, ~20 masked instructions and ~160 line writes per block for a 3-kB record: 0.22 of the kernel's 1.10 ms per
+                // 24 576 windows went into them); staged, the same doubles go out as 16 bytes per lane on consecutive addresses — ij | g_j
+                // (240 doubles, slots 120 .. 359 of frame kq+1's record) in two instructions, the diagonal triangle (120) in one, g_i in one.
+                double* const img = lds + IMU_PER_WAVE * IMU_REC;
+                typedef double __attribute__((ext_vector_type(2))) dbl2;
+                auto flush = [&](double* dst, int nd) {          // nd doubles (even) from img to dst, 16 bytes per lane
+                    lds_sync();
+                    for (int e = 2 * lane; e < nd; e += 128) *reinterpret_cast<dbl2*>(dst + e) = *reinterpret_cast<const dbl2*>(img + e);
+                    lds_sync();
+                };
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
                     const int row = mk + 4 * r;
-                    if (row < 15 && ml < 15) {
-                        rf[PIFS + PIF_IJ + row * 15 + ml] = g01[r];
-                        if (ml >= row) {
-                            const int tq = row * 15 - (row * (row - 1)) / 2 + (ml - row);
-                            rf[PIF_D + tq] = g00[r];
-                            if (lastb) rf[PIFS + PIF_D + tq] = g11[r];
-                        }
-                    }
-                    if (row < 15 && ml == 15) { rf[PIF_GI + row] = g00[r]; if (lastb) rf[PIFS + PIF_GI + row] = 0.0; }
-                    if (r == 3) {
-                        if (row == 15 && ml < 15) rf[PIFS + PIF_GJ + ml] = g01[r];
-                        if (row == 15 && ml == 15) { rf[PIFS + PIF_C] = g00[r]; if (A.CS[0]) (sel ? A.CS[1] : A.CS[0])[cs_index(n, b, CS_IMU, kq)] = g00[r]; }
-                    }
+                    if (row < 15 && ml < 15) img[row * 15 + ml] = g01[r];
+                    if (r == 3 && row == 15 && ml < 15) img[225 + ml] = g01[r];
                 }
+                flush(rf + PIFS + PIF_IJ, 240);
+                static_assert(PIF_GJ == PIF_IJ + 225 && PIF_IJ % 2 == 0 && PIFS % 2 == 0 && PIF_GI % 2 == 0, "staged ranges");
+                auto diag_out = [&](const d4& gd, double* rec, bool with_gi) {   // upper triangle of a diagonal tile -> slots 0 .. 119, its column 15 -> g_i
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const int row = mk + 4 * r;
+                        if (row < 15 && ml < 15 && ml >= row) img[row * 15 - (row * (row - 1)) / 2 + (ml - row)] = gd[r];
+                        if (row < 15 && ml == 15) img[120 + row] = with_gi ? gd[r] : 0.0;
+                    }
+                    lds_sync();
+                    if (lane < 60) *reinterpret_cast<dbl2*>(rec + PIF_D + 2 * lane) = *reinterpret_cast<const dbl2*>(img + 2 * lane);
+                    if (lane < 15) rec[PIF_GI + lane] = img[120 + lane];
+                    lds_sync();
+                };
+                diag_out(g00, rf, true);
+                if (lastb) diag_out(g11, rf + PIFS, false);
+                if (mk == 3 && ml == 15) { rf[PIFS + PIF_C] = g00[3]; if (A.CS[0]) (sel ? A.CS[1] : A.CS[0])[cs_index(n, b, CS_IMU, kq)] = g00[3]; }
                 continue;
             }
             double* out = (sel ? A.PI[1] : A.PI[0]) + fg * PIS;   // (a select, not an indexed load: an indexed kernel argument sends the whole struct through scratch)
@@ -718,7 +736,7 @@ __global__ __launch_bounds__(64, 2) void k_lin_imu(LinArgs A, DevParams P) {
     else imu_blocks<3>(A, P, (int)blockIdx.x, lds, act);
 }
 __global__ __launch_bounds__(64, 2) void k_lin_imu_chain(LinArgs A, DevParams P) {   // consecutive blocks of one window per wave: per-frame IMU records
-    __shared__ double lds[IMU_PER_WAVE * IMU_REC];
+    __shared__ __attribute__((aligned(16))) double lds[IMU_PER_WAVE * IMU_REC + IMU_STAGE];
     const int* const act = usable_active_list(A.active, A.B);
     if (A.imu_pk && *A.imu_pk_bad == 0) imu_blocks<3, true, true>(A, P, (int)blockIdx.x, lds, act);   // (uniform)
     else imu_blocks<3, false, true>(A, P, (int)blockIdx.x, lds, act);

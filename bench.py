@@ -38,15 +38,18 @@ def algorithmic_bytes(n, L, both_free):
 
 
 def step_model(n, arrow=True):
-    """HBM bytes and essential flops of ONE LM step of one window in k_lm_step_quad (csrc/k_lm_quad.hip), init topology.
-    Reads (LDS-DMA pieces): per frame its IMU record (3 008 B: the per-frame format of large batches, round 4), the wheel partial of its block (736: packed triangles since round 4), the laser
-    group record (1 024; until round 4 688 B of it, and frame 0 read the Haa / ga slots of all n records a second time), the ground partial (224); Jacobi scale / LM diagonal / state entries (3 x 120 B per frame, twice: both sweeps) and the
-    current + candidate states; the compact cost array of the prologue (eight 128-byte lines per window; four lines per FRAME until round 4).  Writes: the 22-column back-substitution
-    record (2 640 B per frame, read again by the second sweep), LM diagonal, candidate states.
+    """HBM bytes and essential flops of ONE LM step of one window in k_lm_step_quad (csrc/k_lm_quad.hip), init topology.  Every read of
+    the two sweeps is an LDS-DMA piece of 64 lanes (a wave = four windows), so the volume is known exactly.
+    First sweep, per frame and wave: 12 pieces of 1 KiB for the four per-frame IMU records (3 008 B each), 4 for the laser group records
+    (1 024 B each), 4 for the four wheel (736 B) + four ground (224 B) records, gathered; per window 3 x 120 B of Jacobi scale / LM diagonal /
+    state entries.  Second sweep: 11 pieces for the four back-substitution records (2 640 B each), 6 four-byte pieces (256 B) for state / scale /
+    diagonal.  Prologue: the compact cost array (eight 128-byte lines per window) and the current + candidate states.  Writes: the 22-column
+    back-substitution record (2 640 B per frame, read again by the second sweep), LM diagonal, candidate states.
     Flops: Cholesky 15^3/3, 22 forward and 22 backward substitutions 2 x 22 x 15^2, Schur products (16x16 + 6x16 + 6x6/2) x 15 x 2, second
     sweep 21 x 15 x 2 — per frame."""
-    nb = max(n - 1, 0)
-    rd = (n * 3008 if nb else 0) + nb * 736 + n * (1024 + 224) + 2 * n * 3 * 120 + 2 * n * 120 + 8 * 128 + n * 2640
+    sweep1 = n * ((12 + 4 + 4) * 1024 // 4 + 3 * 120)
+    sweep2 = n * ((11 * 1024 + 6 * 256) // 4)
+    rd = sweep1 + sweep2 + 8 * 128 + 2 * n * 120
     wr = n * 2640 + n * 120 + n * 120
     fl = n * (15 ** 3 / 3.0 + 2 * 22 * 15 * 15 + (16 * 16 + (6 * 16 + 18 if arrow else 0)) * 15 * 2 + 21 * 15 * 2)
     return {"read": int(rd), "write": int(wr), "flops": float(fl)}

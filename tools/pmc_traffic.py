@@ -41,8 +41,7 @@ def per_kernel_max(path, counter):
 def step_known_read(B, n):
     """bytes ONE full launch of k_lm_step_quad reads (bench.py step_model; every piece is an explicit 16-byte-per-lane LDS-DMA or a
     128-bit row load, so the volume is known exactly)"""
-    nb = n - 1
-    return B * (n * 3008 + nb * 736 + n * (1024 + 224) + 2 * n * 3 * 120 + 2 * n * 120 + 8 * 128 + n * 2640)   # (per-frame IMU records since round 4)
+    return B * (n * ((12 + 4 + 4) * 1024 // 4 + 3 * 120) + n * ((11 * 1024 + 6 * 256) // 4) + 8 * 128 + 2 * n * 120)   # (bench.py step_model)
 
 
 def main():

@@ -13,9 +13,8 @@ cp gpurun_out/${TAG}_pmc_traffic.json profiles/pmc_traffic.json
 python tools/ktimes.py > gpurun_out/${TAG}_ktimes.log 2>&1
 LIW_NO_LASER_SLAB=1 python tools/ktimes.py >> gpurun_out/${TAG}_ktimes.log 2>&1
 python tools/two_stream_probe.py $B > gpurun_out/${TAG}_two_stream.log 2>&1
-bash tools/quad_occ_probe2.sh > gpurun_out/${TAG}_quad_occupancy.log 2>&1
-unset LIW_QUAD_OCC LIW_QUAD_TILE_ALIAS
-python -c "import __graft_entry__ as g; g.build()"
+# (tools/quad_occ_probe2.sh belongs to the kernel of r04_v1 / v2: since the gather table and the staged second sweep a wave holds 38 kB of LDS,
+#  four waves fill a CU and a two-waves-per-SIMD build no longer exists)
 python tools/clk_probe_quad.py $B 100 15 3 > gpurun_out/${TAG}_quad_phases.log 2>&1
 # the default bench line once more with the issue statistics of this build in place
 python bench.py --batch $B > gpurun_out/${TAG}_bench_default.json 2> gpurun_out/${TAG}_bench_default.err < /dev/null
