@@ -427,7 +427,7 @@ def main():
     step_time_s = tm["step_ms"] * tm["step_launches"] * 1e-3
     step_bytes = (sm["read"] + sm["write"]) * step_window_launches
     step_roof = {"kernel": "k_lm_step_quad (normal-equation assembly + block-tridiagonal-arrow LM elimination + back substitution; four windows per wave)",
-                 "bound": "one wave per SIMD (issuing in ~51 % of its cycles): the first sweep is the length of that wave's instruction stream with its latencies exposed, the second sweep reads the back-substitution record back at ~4.8 TB/s chip-wide (hbm); DESIGN 4",
+                 "bound": "hbm: both sweeps stage their records by LDS-DMA and move ~8 B per clock and CU (4.6 - 4.9 TB/s chip-wide, the practical rate of this read / write mix); one wave per SIMD, four per CU (38 kB of LDS each); DESIGN 4",
                  "avg_launch_ms": round(tm["step_ms"], 5), "launches": tm["step_launches"],
                  "analytic_bytes_per_window_iteration": sm["read"] + sm["write"],
                  "achieved": round(step_bytes / step_time_s / 1e9, 2) if step_time_s > 0 else None, "peak": HBM_PEAK_GBS, "unit": "GB/s",
