@@ -83,7 +83,7 @@ def test_posegraph_ground_gates_and_iteration_cap(liw, synth, pyoracle):
 
 
 def test_posegraph_cost_vs_cpu_restatement(liw, synth, pyoracle):
-    """Measurement row of f2: 200 key frames, GPU solve against the oracle's dense CPU minimizer, same graph."""
+    """Measurement row of f2 (docs/WIDENING.md): 200 key frames, GPU solve against the oracle's dense CPU minimizer, same graph."""
     import time
     prm = synth.office_params()
     pg = dict(liw.posegraph.office_pg_params(), use_ground_q_factor=False)

@@ -212,7 +212,7 @@ def test_reference_quirk_ref_n_accumulation_2(liw, synth, env, pyoracle):
 
 
 def test_spawn_scan_cost_vs_restatement(liw, synth, env):
-    """Measurement row of the front-end: the sparse-grid / moment-matrix implementation against the oracle's
+    """Measurement row of the front-end (docs/WIDENING.md): the sparse-grid / moment-matrix implementation against the oracle's
     literal restatement (std::map grid, shared_ptr lines, one-sided Jacobi SVD) on the same scan; both through ctypes."""
     import time
     prm, lp, orc = env
