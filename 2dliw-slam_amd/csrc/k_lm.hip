@@ -1588,6 +1588,18 @@ __device__ __forceinline__ bool marg_chain(const MargArgs& a, const int b, LdsTi
     return true;
 }
 
+// The plane rotation that annihilates a_pq, from d = a_qq - a_pp and h = 2 a_pq (h != 0): t = sgn(d) h / (|d| + r), r = sqrt(d^2 + h^2),
+// cs = 1 / sqrt(1 + t^2), sn = t cs.  With u = |d| + r:  1 + t^2 = (u^2 + h^2) / u^2 = 2 r u / u^2, so  cs = u / sqrt(2 r u),
+// sn = sgn(d) h / sqrt(2 r u): two reciprocal square roots on the dependent chain (until round 4: rsqrt, reciprocal, rsqrt — a round of
+// the four-wave Jacobi is ~660 cycles of mostly this chain).  cs^2 + sn^2 = (u^2 + h^2) / (2 r u) = 1 up to the rounding of the products.
+__device__ __forceinline__ void jacobi_rotation(double d, double h, double& cs, double& sn) {
+    const double qq = d * d + h * h;
+    const double r = qq * fast_rsqrt(qq);
+    const double u = fabs(d) + r;
+    const double winv = fast_rsqrt(2.0 * r * u);
+    cs = u * winv;
+    sn = (d >= 0.0 ? h : -h) * winv;
+}
 // cyclic Jacobi by ONE wave (large batches: a wave per window): T.D -> eigenvalues on the diagonal of Am, eigenvectors in the columns of V
 __device__ __forceinline__ void jacobi15_wave(LdsTiles& T, double* V, double* Am, double* rot) {
     const int lane = threadIdx.x & 63;
@@ -1632,9 +1644,7 @@ __device__ __forceinline__ void jacobi15_wave(LdsTiles& T, double* V, double* Am
                     // square root, reciprocal and reciprocal square root from the hardware estimates + Newton steps (the rotation only
                     // has to be orthogonal to working precision: cs^2 + sn^2 = 1 holds by construction)
                     const double d = Am[q * 16 + q] - Am[p * 16 + p], h = 2.0 * apq;
-                    const double qq = d * d + h * h;
-                    const double t = (d >= 0.0 ? h : -h) * fast_rcp(fabs(d) + qq * fast_rsqrt(qq));
-                    cs = fast_rsqrt(1.0 + t * t); sn = t * cs;
+                    jacobi_rotation(d, h, cs, sn);
                 }
                 rot[lane * 2] = cs; rot[lane * 2 + 1] = sn;
             }
@@ -1730,9 +1740,8 @@ __device__ __forceinline__ int jacobi15_block(const double* D, double* A2, doubl
         partner = pr;
         if (apq == 0.0) return;
         const double d = A[Q * 16 + Q] - A[P * 16 + P], h = 2.0 * apq;
-        const double qq = d * d + h * h;
-        const double tt = (d >= 0.0 ? h : -h) * fast_rcp(fabs(d) + qq * fast_rsqrt(qq));
-        const double cs = fast_rsqrt(1.0 + tt * tt), sn = tt * cs;
+        double cs, sn;
+        jacobi_rotation(d, h, cs, sn);
         g = cs; sg = i == P ? -sn : sn;
     };
     for (int sweep = 0; sweep < 60; ++sweep) {

@@ -25,7 +25,7 @@ def oracle_history(pyoracle, orc, d, iters):
 
 # (a window without laser blocks crawls along the ground_factor_q cone and is round-off chaotic beyond ~35 iterations — DESIGN 6,
 #  tools/quad_diag.py shows both step kernels leaving the oracle there — so those appear with the 20-iteration cap only)
-@pytest.mark.parametrize("n,B,iters", [(1, 5, 20), (2, 6, 50), (3, 7, 20), (7, 9, 20), (7, 10, 50), (30, 5, 50)])
+@pytest.mark.parametrize("n,B,iters", [(1, 5, 20), (2, 6, 50), (3, 7, 20), (5, 6, 20), (7, 9, 20), (7, 10, 50), (8, 5, 20), (30, 5, 50)])
 def test_quad_step_follows_the_oracle_iteration_by_iteration(liw, synth, pyoracle, monkeypatch, n, B, iters):
     prm = synth.office_params()
     orc = pyoracle.Oracle(prm)
