@@ -1809,7 +1809,7 @@ void launch_lm_step(const StepArgs& a, hipStream_t s) {
     const bool tw = (env ? env[0] == '2' : a.B <= 512) && a.n >= 6;   // (tools/step_variant_sweep.py: 97 k vs 67 k solves/s at 256 windows, 120 k vs 116 k at 512)
     // four windows per wave (k_lm_quad.hip) once the batch is large enough to fill the chip that way; the windows it leaves out
     // (a rotation vector outside the |theta| <= pi ball) are stepped by the one-wave kernel right behind it
-    const bool quad = (env ? env[0] == '3' : a.B > 2048) && lm_step_quad_fits(a);
+    const bool quad = (env ? env[0] == '3' : a.B >= QUAD_MIN_BATCH) && lm_step_quad_fits(a);
     if (quad) {
         launch_lm_step_quad(a, s);
         StepArgs a2 = a;

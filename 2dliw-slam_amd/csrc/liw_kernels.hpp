@@ -40,10 +40,13 @@ __host__ __device__ inline int pi_tri(int r, int c) {   // offset of entry (r, c
 // of a block into the next block's ii product as its MFMA C operand), the coupling ij of block (f-1, f), both gradient parts and the
 // cost of block (f-1, f): 376 instead of 496 doubles per frame, and no consumer has to add a neighbour block's share to its diagonal.
 constexpr int PIF_D = 0, PIF_IJ = 120, PIF_GJ = 345, PIF_GI = 360, PIF_C = 375, PIFS = 376;
-// the regime of k_lm_step_quad (which reads per-frame records only): batches above 2 048 windows, or the kernel forced by LIW_STEP_VARIANT=3
+// the regime of k_lm_step_quad (which reads per-frame records only): batches of QUAD_MIN_BATCH windows and more, or the kernel forced by LIW_STEP_VARIANT=3
+// (tools/step_variant_sweep.py, end of round 4, C2 windows, 12 iterations: 1 024 windows 185 k solves/s with the quad kernel against 173 k with
+//  the one-wave kernels, 2 048: 280 k against 255 k; 512: 111 k against 122 k for the four-wave kernel.  The threshold was 2 049 until then.)
+constexpr int QUAD_MIN_BATCH = 1024;
 inline bool pi_frame_format(int B) {
     const char* env = getenv("LIW_STEP_VARIANT");
-    return env ? env[0] == '3' : B > 2048;
+    return env ? env[0] == '3' : B >= QUAD_MIN_BATCH;
 }
 __host__ __device__ inline size_t pi_doubles_per_window(int n) {               // room for either format
     const size_t a = (size_t)(n > 1 ? n - 1 : 1) * PIS, b = (size_t)n * PIFS;

@@ -1,7 +1,7 @@
 """Parity at the shapes bench.py measures: the benchmarked configuration itself goes through the oracle.
 
-  * B > 2 048 windows of C2 (n = 30, L = 2 000) — the k_lm_step<THROUGHPUT> instantiation, G = 8 laser groups per wave, forked role
-    streams — per-iteration states, iteration counts and terminations of sampled windows against the oracle;
+  * B > 2 048 windows of C2 (n = 30, L = 2 000) — k_lm_step_quad (k_lm_step<THROUGHPUT> until round 3), G = 8 laser groups per wave, forked
+    role streams — per-iteration states, iteration counts and terminations of sampled windows against the oracle;
   * C2- and C5-size batched marginalisation (Delta_H, Delta_g, prior J^T J) against the oracle at the same linearisation point;
   * n = 50 / L = 5 000 LM history;
   * a C4-size (n = 30, L = 20 000) 10-iteration factor-sharded solve: two rank objects on this one GPU driven in lock-step

@@ -144,7 +144,7 @@ def test_zero_norm_sites_in_a_batch_fail_only_their_own_window(liw, synth, pyora
     neighbours solve exactly as they do alone."""
     prm = synth.office_params()
     orc = pyoracle.Oracle(prm)
-    n, L, B = 6, 60, 2304          # > 2 048 windows: k_lm_step_quad
+    n, L, B = 6, 60, 2304          # >= 1 024 windows: k_lm_step_quad
     base = [synth.make_window(orc, prm, seed=40 + k, n=n, L=L) for k in range(4)]
     bad = dict(base[1])
     bad = {k: (np.array(v, copy=True) if isinstance(v, np.ndarray) else v) for k, v in bad.items()}
