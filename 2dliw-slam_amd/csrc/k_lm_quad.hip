@@ -750,6 +750,9 @@ __global__ __launch_bounds__(64, LIW_QUAD_OCC) void k_lm_step_quad(StepArgs a) {
                     if constexpr (st <= q0) off = v; else off = ln >= st - q0 ? v : off;
                 }
             });
+            // (X is the CALLER's array: the lanes behind the last row's 30 dwords re-read its first ones instead of reading on past the
+            // end of the allocation; everything else staged here lies inside the workspace, where reading on is harmless)
+            if constexpr (q0 + 64 > 120) off = ln >= 120 - q0 ? 2u * (rX[3] + fx) + (unsigned)(ln - (120 - q0)) : off;
             __builtin_amdgcn_global_load_lds(X32 + off, (lds_t)(dst + RECP * 128 + KI(P) * 32), 4, 0, 0);
         });
         sfor<0, LP_>([&](auto P) {                               // Jacobi scale (rows 0 .. 3), then LM diagonal (rows 0 .. 3)
