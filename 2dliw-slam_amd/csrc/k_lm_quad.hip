@@ -262,9 +262,7 @@ __global__ __launch_bounds__(64, LIW_QUAD_OCC) void k_lm_step_quad(StepArgs a) {
     double* const WS = a.w.solve_ws;
     const unsigned oSC = oLM + LM_SCALE, oDG = oLM + LM_DIAG;
     const int jc = j < 15 ? j : 0;            // clamped column for addresses
-    const int cj = 14 * jc - (jc * (jc - 1)) / 2;
-    const bool l6 = j < 6, l15 = j == 15, lm = j < 15;
-    const int j6 = l6 ? j : 0;
+    const bool l6 = j < 6, lm = j < 15;
 
     const bool prior_row = track && !fast && a.has_prior[b] != 0;   // this row's window carries the prior block (frame n-2)
     if (__any(proceed && fresh)) {   // Jacobi scaling 1 / (1 + sqrt(H_jj)), once per solve (same sums, same order as k_lm_step's frame_diag)
@@ -370,9 +368,6 @@ __global__ __launch_bounds__(64, LIW_QUAD_OCC) void k_lm_step_quad(StepArgs a) {
         prefetch_regs(f);
     };
     const double* SI = S + S_IMU + w * PIFS;
-    const double* SL = S + S_PL + w * LP;         // SL[e] = PL_f[e]
-    const double* SW = S + S_PW + w * PWS;
-    const double* SG = S + S_PG + w * PGS;
     // Gather table.  The assembly of a frame reads 88 values per lane out of the staged records, at addresses that depend on the lane's role
     // (its column j of the 6x6 pose blocks / of the 15x15 IMU tiles, lane 15 = the gradient column, lanes that take no part).  Computed per
     // frame those addresses were ~900 issued instructions (integer selects and multiplies, the nested lane tests as divergent branches):
@@ -433,7 +428,7 @@ __global__ __launch_bounds__(64, LIW_QUAD_OCC) void k_lm_step_quad(StepArgs a) {
         // hoisted out of the loop into registers that then spill (the same trick as in k_lm_step)
         int j = j_;
         asm volatile("" : "+v"(j));
-        const int jc = j < 15 ? j : 0, cj = 14 * jc - (jc * (jc - 1)) / 2, j6 = j < 6 ? j : 0;
+        const int jc = j < 15 ? j : 0, j6 = j < 6 ? j : 0;
         const bool l6 = j < 6, l15 = j == 15, lm = j < 15;
         const bool hasm = i >= 1;
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this frame's records have landed in LDS (and the row's earlier stores are done)
