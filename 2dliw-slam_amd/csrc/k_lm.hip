@@ -923,7 +923,9 @@ __device__ __forceinline__ void lm_step_body(const StepArgs& a, const int b, Lds
     STAMP(4006);
 }
 template <bool THROUGHPUT>
-__global__ __launch_bounds__(64, THROUGHPUT ? 3 : 2) void k_lm_step(StepArgs a) {
+// (THROUGHPUT was built for three waves per SIMD — 168 registers, 60 B of scratch — while it carried the large batches; those run
+//  k_lm_step_quad now, the instantiation only takes the windows that kernel hands over: two waves, 208 registers, no scratch)
+__global__ __launch_bounds__(64, 2) void k_lm_step(StepArgs a) {
     __shared__ LdsStep T;
     if ((int)blockIdx.x >= a.B) return;
     lm_step_body<THROUGHPUT>(a, (int)blockIdx.x, T);

@@ -66,7 +66,7 @@ def test_large_batch_solve_matches_oracle_on_sampled_windows(liw, synth, pyoracl
 
 
 def test_throughput_step_kernel_variant_matches_latency_variant_and_oracle(liw, synth, pyoracle):
-    """Batches of 1 024 windows and more run k_lm_step_quad (four windows per wave; k_lm_step<true> — 3 waves per SIMD, no look-ahead in
+    """Batches of 1 024 windows and more run k_lm_step_quad (four windows per wave; k_lm_step<true> — no look-ahead in
     the elimination sweep — right behind it for the windows it leaves out), smaller ones k_lm_step<false> / k_lm_step_tw.  Same arithmetic, different load schedule: states must agree window by window — init topology
     (arrow) and, after the on-device marginalisation, tracking topology with the stored prior — and follow the oracle."""
     prm = synth.office_params()
