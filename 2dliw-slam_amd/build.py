@@ -13,6 +13,8 @@ if os.environ.get("LIW_QUAD_OCC"):   # A/B aid: waves per SIMD the quad step ker
     FLAGS.append("-DLIW_QUAD_OCC=" + os.environ["LIW_QUAD_OCC"])
 if os.environ.get("LIW_SMALL_OCC"):   # A/B aid: waves per SIMD k_lin_small is compiled for (3: <= 168 registers, co-resident with the lane-per-group laser kernel)
     FLAGS.append("-DLIW_SMALL_OCC=" + os.environ["LIW_SMALL_OCC"])
+if os.environ.get("LIW_QUAD_BSD"):   # second-sweep staging depth of the quad step kernel (2 / 3)
+    FLAGS.append("-DLIW_QUAD_BSD=" + os.environ["LIW_QUAD_BSD"])
 if os.environ.get("LIW_QUAD_TILE_ALIAS"):
     FLAGS.append("-DLIW_QUAD_TILE_ALIAS")
 if os.environ.get("LIW_CLK"):   # phase-timing build for tools/clk_probe.py

@@ -80,7 +80,11 @@ constexpr int K_A = 0, K_B = 6, K_C = 12, K_HA = 18, K_D = 24, K_CW = 39, K_GSH 
 constexpr int QTAB = NRD * 16;                            // doubles: NRD x 64 unsigned shorts
 constexpr int QZB = 86;                                  // a block of zeros: lanes that take no part in a strided read
 constexpr int QTOT_1 = 4 * (PIFS + LP + PWS + PGS) + 32 + QTR + QZB + QTAB;   // first sweep
-constexpr int QTOT_2 = 3 * (((4 * REC_GS + 127) / 128) * 128 + 6 * 32);             // second sweep: three frames of records + state / scale / diagonal entries
+#ifndef LIW_QUAD_BSD
+#define LIW_QUAD_BSD 3   // frames of second-sweep records in flight (2: 30 kB of LDS per wave instead of 38 — co-residency experiments)
+#endif
+constexpr int BSD2 = LIW_QUAD_BSD;
+constexpr int QTOT_2 = BSD2 * (((4 * REC_GS + 127) / 128) * 128 + 6 * 32);             // second sweep: three frames of records + state / scale / diagonal entries
 constexpr int QTOT = QTOT_1 > QTOT_2 ? QTOT_1 : QTOT_2;   // LDS doubles per wave: the prefetched partial records of its four rows, the tile, a zero word, the gather table (35.6 kB: four waves per CU)
 
 // offset of entry (r, j) inside a packed upper triangle of order 15, r a compile-time constant
@@ -710,7 +714,7 @@ __global__ __launch_bounds__(64, LIW_QUAD_OCC) void k_lm_step_quad(StepArgs a) {
     // makes the wait stricter).
     constexpr int RECP = (4 * REC_GS + 127) / 128, XP = (4 * 30 + 63) / 64, LP_ = (8 * 30 + 63) / 64;   // 16-byte pieces of the records; 4-byte pieces of X; of scale + diagonal
     constexpr int NLD = RECP + XP + LP_, BUFD = RECP * 128 + (XP + LP_) * 32;
-    static_assert(3 * BUFD <= QTOT && 2 * NLD <= 63, "second-sweep staging");
+    static_assert(BSD2 * BUFD <= QTOT && 2 * NLD <= 63 && (BSD2 == 2 || BSD2 == 3), "second-sweep staging");
     const unsigned rWS[4] = {(unsigned)__builtin_amdgcn_readlane(oWS, 0), (unsigned)__builtin_amdgcn_readlane(oWS, 16), (unsigned)__builtin_amdgcn_readlane(oWS, 32), (unsigned)__builtin_amdgcn_readlane(oWS, 48)};
     const unsigned rX[4] = {(unsigned)__builtin_amdgcn_readlane(oX, 0), (unsigned)__builtin_amdgcn_readlane(oX, 16), (unsigned)__builtin_amdgcn_readlane(oX, 32), (unsigned)__builtin_amdgcn_readlane(oX, 48)};
     const unsigned rLM[4] = {(unsigned)__builtin_amdgcn_readlane(oLM, 0), (unsigned)__builtin_amdgcn_readlane(oLM, 16), (unsigned)__builtin_amdgcn_readlane(oLM, 32), (unsigned)__builtin_amdgcn_readlane(oLM, 48)};
@@ -797,19 +801,19 @@ __global__ __launch_bounds__(64, LIW_QUAD_OCC) void k_lm_step_quad(StepArgs a) {
             }
         }
     };
-    sfor<0, 3>([&](auto Q) { constexpr int q = KI(Q); if (q < n) stage2(q, q); });
-    for (int i0 = 0; i0 < n; i0 += 3) {
-        sfor<0, 3>([&](auto Q) {
+    sfor<0, BSD2>([&](auto Q) { constexpr int q = KI(Q); if (q < n) stage2(q, q); });
+    for (int i0 = 0; i0 < n; i0 += BSD2) {
+        sfor<0, BSD2>([&](auto Q) {
             constexpr int q = KI(Q);
             __builtin_amdgcn_sched_barrier(0);
             const int i = i0 + q;
             if (i < n) {
-                const int later = n - 1 - i;                     // frames staged behind frame i at this point (at most two)
+                const int later = min(n - 1 - i, BSD2 - 1);      // frames staged behind frame i at this point
                 if (later >= 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * NLD) : "memory");
                 else if (later == 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NLD) : "memory");
                 else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
                 solve_frame(q, i);
-                if (i + 3 < n) stage2(i + 3, q);
+                if (i + BSD2 < n) stage2(i + BSD2, q);
             }
         });
     }
