@@ -126,14 +126,82 @@ class LockstepComm:
         return torch.maximum(a, b)
 
 
+def host_arrays(windows):
+    """concatenated host image of `windows` (the caller-side arrays of include/liw_window.h's liw_batch)"""
+    B = len(windows)
+    Ls = [int(np.asarray(w["laser_frame"]).shape[0]) for w in windows]
+    Ltot = int(sum(Ls))
+    off = np.zeros(B + 1, dtype=np.int32)
+    off[1:] = np.cumsum(Ls)
+    cat = lambda k, dt: np.ascontiguousarray(np.concatenate([np.asarray(w[k], dtype=dt).reshape(-1) for w in windows]))
+    pts = np.concatenate([np.asarray(w["laser_pts"], dtype=np.float64).reshape(-1, 12) for w in windows], axis=0) if Ltot else np.zeros((1, 12))
+    return dict(
+        x=cat("states", np.float64), laser_off=off, laser_frame=cat("laser_frame", np.int32) if Ltot else np.zeros(1, np.int32),
+        laser_pts=np.ascontiguousarray(pts.T).reshape(-1),   # component-major [12][Ltot]
+        match_pose=cat("match_pose", np.float64), has_match=cat("has_match", np.uint8),
+        imu_X=cat("imu_X", np.float64), imu_J=cat("imu_J", np.float64), imu_sqrtP=cat("imu_sqrtP", np.float64), imu_Dt=cat("imu_Dt", np.float64),
+        wheel_T=cat("wheel_T", np.float64), wheel_sqrtP=cat("wheel_sqrtP", np.float64),
+        prior_X=np.zeros(B * 15), prior_J=np.zeros(B * 225), prior_R=np.zeros(B * 15), has_prior=np.zeros(B, dtype=np.int32), _Ltot=Ltot)
+
+
+def tiled_tensors(base, tile, device):
+    """the batch of tile["B"] windows cycling through `base`, built in HBM from the uploaded distinct windows"""
+    import torch
+    B, nb, n = int(tile["B"]), len(base), int(base[0]["n"])
+    dev = torch.device(device)
+    assert B >= 1 and nb >= 1
+    reps, rem = divmod(B, nb)
+    host = host_arrays(base)
+    Lb = int(host.pop("_Ltot"))
+    Lrem = int(host["laser_off"][rem])
+    Ltot = reps * Lb + Lrem
+    assert Ltot < 2 ** 31, "laser_off is int32"
+    d = {k: torch.from_numpy(a if a.size else np.zeros(1, dtype=a.dtype)).to(dev) for k, a in host.items()}
+
+    t_ = {}
+
+    def cyc(t, per):   # per-window records of `per` elements: base pattern `reps` times, then its first `rem` windows
+        if per == 0 or t.numel() < nb * per:           # (empty role: n == 1 has no IMU / wheel blocks — a one-element placeholder)
+            return t.clone()
+        return torch.cat([t.repeat(reps), t[:rem * per]]) if rem else t.repeat(reps)
+    for k, per in (("has_match", n), ("imu_X", (n - 1) * 15), ("imu_J", (n - 1) * 225), ("imu_sqrtP", (n - 1) * 225), ("imu_Dt", n - 1),
+                   ("wheel_T", (n - 1) * 12), ("wheel_sqrtP", (n - 1) * 9)):
+        t_[k] = cyc(d[k], per)
+    if Lb:
+        pb = d["laser_pts"].view(12, Lb)                     # component-major planes of the distinct windows
+        t_["laser_pts"] = (torch.cat([pb.repeat(1, reps), pb[:, :Lrem]], dim=1) if Lrem else pb.repeat(1, reps)).contiguous().view(-1)
+        fb = d["laser_frame"]
+        t_["laser_frame"] = torch.cat([fb.repeat(reps), fb[:Lrem]]) if Lrem else fb.repeat(reps)
+    else:
+        t_["laser_pts"], t_["laser_frame"] = d["laser_pts"], d["laser_frame"]
+    ob = d["laser_off"][:nb].to(torch.int64)
+    off = (torch.arange(reps, device=dev, dtype=torch.int64)[:, None] * Lb + ob[None, :]).reshape(-1)
+    tail = reps * Lb + d["laser_off"][:rem + 1].to(torch.int64)
+    t_["laser_off"] = torch.cat([off, tail]).to(torch.int32)
+    assert t_["laser_off"].numel() == B + 1
+    st = np.ascontiguousarray(np.asarray(tile["states"], dtype=np.float64).reshape(-1))
+    mp = np.ascontiguousarray(np.asarray(tile["match_pose"], dtype=np.float64).reshape(-1))
+    assert st.size == B * n * 15 and mp.size == B * n * 12
+    t_["x"] = torch.from_numpy(st).to(dev)
+    t_["match_pose"] = torch.from_numpy(mp).to(dev)
+    z = lambda m, dt=torch.float64: torch.zeros(m, dtype=dt, device=dev)
+    t_.update(prior_X=z(B * 15), prior_J=z(B * 225), prior_R=z(B * 15), has_prior=z(B, torch.int32))
+    return t_, B, Ltot
+
+
 class BatchSolver:
     """B independent windows (uniform n) resident on one GPU.
 
     windows: list of window dicts (synth.make_window layout).  With `world > 1` each window's laser blocks are
     sharded across ranks (`shard_laser`), the small factors are evaluated on every rank, and `solve` all-reduces
-    the laser partial sums after every linearisation (one exchange per LM iteration)."""
+    the laser partial sums after every linearisation (one exchange per LM iteration).
 
-    def __init__(self, prm, windows, device="cuda:0", history_records=0, rank=0, world=1, group=None, exchange="allreduce", force_exchange=False, comm=None):
+    tile = dict(B=, states=[B, n, 15], match_pose=[B, n, 12]) (host arrays): `windows` are the DISTINCT windows of a batch of B that
+    cycles through them (window b = windows[b % len(windows)] with its own states / laser_match poses).  Only the distinct windows and
+    the two small per-window arrays cross PCIe; the batch is laid out in HBM by device-side repeats, so the host never holds the
+    B-fold concatenation (25 GB per rank at bench.py's 49 152 C2 windows: eight ranks of that did not fit a node's RAM)."""
+
+    def __init__(self, prm, windows, device="cuda:0", history_records=0, rank=0, world=1, group=None, exchange="allreduce", force_exchange=False, comm=None, tile=None):
         import torch
         from . import BatchC, WsLayoutC, lib, params_struct, LiwError
         self.torch = torch
@@ -159,29 +227,22 @@ class BatchSolver:
         self.time_exchange = False
         if world > 1:
             windows = [shard_laser(w, rank, world) for w in windows]
-        self.B = len(windows)
         self.n = int(windows[0]["n"])
-        n, B = self.n, self.B
+        n = self.n
         for w in windows:
             assert int(w["n"]) == n, "uniform n per batch"
-        Ls = [int(np.asarray(w["laser_frame"]).shape[0]) for w in windows]
-        self.Ltot = int(sum(Ls))
-        off = np.zeros(B + 1, dtype=np.int32)
-        off[1:] = np.cumsum(Ls)
-        cat = lambda k, dt: np.ascontiguousarray(np.concatenate([np.asarray(w[k], dtype=dt).reshape(-1) for w in windows]))
-        pts = np.concatenate([np.asarray(w["laser_pts"], dtype=np.float64).reshape(-1, 12) for w in windows], axis=0) if self.Ltot else np.zeros((1, 12))
-        host = dict(
-            x=cat("states", np.float64), laser_off=off, laser_frame=cat("laser_frame", np.int32) if self.Ltot else np.zeros(1, np.int32),
-            laser_pts=np.ascontiguousarray(pts.T).reshape(-1),   # component-major [12][Ltot]
-            match_pose=cat("match_pose", np.float64), has_match=cat("has_match", np.uint8),
-            imu_X=cat("imu_X", np.float64), imu_J=cat("imu_J", np.float64), imu_sqrtP=cat("imu_sqrtP", np.float64), imu_Dt=cat("imu_Dt", np.float64),
-            wheel_T=cat("wheel_T", np.float64), wheel_sqrtP=cat("wheel_sqrtP", np.float64),
-            prior_X=np.zeros(B * 15), prior_J=np.zeros(B * 225), prior_R=np.zeros(B * 15), has_prior=np.zeros(B, dtype=np.int32))
-        self.t = {}
-        for k, a in host.items():
-            if a.size == 0:
-                a = np.zeros(1, dtype=a.dtype)
-            self.t[k] = torch.from_numpy(a).to(self.dev)
+        if tile is None:
+            self.B = len(windows)
+            host = host_arrays(windows)
+            self.Ltot = int(host.pop("_Ltot"))
+            self.t = {}
+            for k, a in host.items():
+                if a.size == 0:
+                    a = np.zeros(1, dtype=a.dtype)
+                self.t[k] = torch.from_numpy(a).to(self.dev)
+        else:
+            self.t, self.B, self.Ltot = tiled_tensors(windows, tile, self.dev)
+        B = self.B
         self.history_records = int(history_records)
         lay = WsLayoutC()
         r = self.L.liw_batch_ws_layout(C.c_int(B), C.c_int(n), C.c_int(self.history_records), C.byref(lay))

@@ -905,7 +905,7 @@ void launch_linearize(const LinArgs& A_, const DevParams& P, hipStream_t s, cons
         int pw = WHEEL_PER_WAVE;
         while (pw > 3 && (blocks + pw - 1) / pw < 512) pw = (pw + 1) / 2;   // 21 -> 11 -> 6 -> 3
         const bool nd3 = getenv("LIW_SMALL_ND3") != nullptr;                 // profiling / test aid (read per launch): three directions per lane everywhere
-        if (A.eval_small && !nd3 && !A.pi_frame && (long)B * n + 2 * blocks + ground_wave_count(B, n) <= 256) { pw = 1; A.small_nd = 1; }
+        if (A.eval_small && !nd3 && !A.pi_frame && A.role_mask == 0 && (long)B * n + 2 * blocks + ground_wave_count(B, n) <= 256) { pw = 1; A.small_nd = 1; }
         A.small_per_wave = pw;
         A.imu_per_wave = pw < IMU_PER_WAVE ? pw : IMU_PER_WAVE;
     }
@@ -922,7 +922,8 @@ void launch_linearize(const LinArgs& A_, const DevParams& P, hipStream_t s, cons
     // (also without the small roles — the older-frames laser evaluation of a marginalisation enqueued behind a tracking solve: the SAME
     // compiled body as the one-launch linearisation it must agree with bit for bit; the stand-alone k_lin_laser is a second compilation of
     // the body, whose FMA contraction may differ in the last bit)
-    if (!A.pi_frame && laser_waves + imu_waves + small_waves <= 256) {   // (per-frame IMU records come from k_lin_imu_chain only)
+    // (a single timed role, role_mask != 0, always takes the stand-alone kernels: the one-launch form cannot run a role alone)
+    if (!A.pi_frame && A.role_mask == 0 && laser_waves + imu_waves + small_waves <= 256) {   // (per-frame IMU records come from k_lin_imu_chain only)
         const int roles = laser_waves + imu_waves + small_waves;
         const unsigned tot = (unsigned)(roles + (A.reset_lm ? 1 : 0));
         if (A.mode == LIW_MODE_INIT) hipLaunchKernelGGL(k_lin_all<true>, dim3(tot), dim3(64), 0, s, A, P, G, laser_waves, imu_waves, roles);
@@ -979,7 +980,7 @@ __global__ void k_exchange_pack(int groups, int n, int np, LaserPackTable tb, co
     buf[t] = dead ? 0.0 : (tb.neg[p] ? -v : v);
 }
 template <bool BOTH>
-__global__ void k_exchange_unpack(int groups, int n, int np, int world, size_t stride, const double* buf, double* PL0, double* PL1, int candidate, const LmState* lm, int sysload) {
+__global__ void k_exchange_unpack(int groups, int n, int np, int world, size_t stride, const double* buf, double* PL0, double* PL1, double* CS0, double* CS1, int candidate, const LmState* lm, int sysload) {
     const int t = blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= groups * LP) return;
     const int grp = t / LP, s = t % LP;
@@ -996,6 +997,10 @@ __global__ void k_exchange_unpack(int groups, int n, int np, int world, size_t s
         if (code & 64) v = -v;
     }
     PL[t] = v;
+    // the compact cost array of the large-batch format (liw_kernels.hpp, cs_index) holds the record's sum r^2 a second time: the prologue of
+    // k_lm_step_quad reads ONLY that copy, so it has to carry the cross-rank total like the record does (else every rank would accept or
+    // reject on its own shard's laser cost and the ranks would part ways)
+    if (s == 120 && CS0) (sel ? CS1 : CS0)[cs_index(n, grp / n, CS_LASER, grp % n)] = v;
 }
 __global__ void k_count_active(int B, const LmState* lm, double* out) {
     __shared__ int cnt;
@@ -1018,10 +1023,10 @@ void launch_exchange_pack(int B, int n, bool both, const double* PL0, const doub
     hipLaunchKernelGGL(k_exchange_pack, dim3((groups * np + 255) / 256), dim3(256), 0, s, groups, n, np, tb, PL0, PL1, candidate, lm, buf);
     if (lm) hipLaunchKernelGGL(k_count_active, dim3(1), dim3(256), 0, s, B, lm, buf + (size_t)groups * np);
 }
-void launch_exchange_unpack(int B, int n, bool both, int world, size_t stride, const double* buf, double* PL0, double* PL1, int candidate, const LmState* lm, hipStream_t s, bool sysload) {
+void launch_exchange_unpack(int B, int n, bool both, int world, size_t stride, const double* buf, double* PL0, double* PL1, double* CS0, double* CS1, int candidate, const LmState* lm, hipStream_t s, bool sysload) {
     const int np = both ? 45 : 21, groups = B * n;
-    if (both) hipLaunchKernelGGL(k_exchange_unpack<true>, dim3((groups * LP + 255) / 256), dim3(256), 0, s, groups, n, np, world, stride, buf, PL0, PL1, candidate, lm, sysload ? 1 : 0);
-    else hipLaunchKernelGGL(k_exchange_unpack<false>, dim3((groups * LP + 255) / 256), dim3(256), 0, s, groups, n, np, world, stride, buf, PL0, PL1, candidate, lm, sysload ? 1 : 0);
+    if (both) hipLaunchKernelGGL(k_exchange_unpack<true>, dim3((groups * LP + 255) / 256), dim3(256), 0, s, groups, n, np, world, stride, buf, PL0, PL1, CS0, CS1, candidate, lm, sysload ? 1 : 0);
+    else hipLaunchKernelGGL(k_exchange_unpack<false>, dim3((groups * LP + 255) / 256), dim3(256), 0, s, groups, n, np, world, stride, buf, PL0, PL1, CS0, CS1, candidate, lm, sysload ? 1 : 0);
 }
 
 // ---- native one-shot exchange: instead of an all-gather collective every rank WRITES its packed record

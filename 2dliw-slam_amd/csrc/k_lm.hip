@@ -218,7 +218,7 @@ __device__ void asm_commit(const AsmCtx& c, int i, const AsmRegs& R, const Tiles
     for (int q = 0; q < 4; ++q) {
         const int e = lane + 64 * q, r = e >> 4, cc = e & 15;
         const bool valid = r < 15 && cc < 15;
-        dI[q] = ((valid && (hasm || c.pif)) ? R.v5[q] : 0.0) + ((valid && hasp && !c.pif) ? R.v6[q] : 0.0);   // (per-frame records: v5 is the whole tile)
+        dI[q] = ((valid && (c.pif ? n > 1 : hasm)) ? R.v5[q] : 0.0) + ((valid && hasp && !c.pif) ? R.v6[q] : 0.0);   // (per-frame records: v5 is the whole tile; a 1-frame window has no IMU block and nobody wrote its record)
         oI[q] = (valid && hasnb) ? R.v7[q] : 0.0;
     }
     double dP = 0.0, oP = 0.0, rP = 0.0;
@@ -495,7 +495,7 @@ __device__ double frame_diag(const AsmCtx& c, int i, LdsStep& T) {
         if (i <= n - 2) d += PWb[(size_t)i * PWS + PW_II(r, r)];
         d += PGb[(size_t)i * PGS + PG_H(r, r)];
     }
-    if (c.pif) d += PIb[(size_t)i * PIFS + PIF_D + pi_tri(r, r)];
+    if (c.pif) { if (n > 1) d += PIb[(size_t)i * PIFS + PIF_D + pi_tri(r, r)]; }
     else {
         if (i >= 1) d += PIb[(size_t)(i - 1) * PIS + PI_JJ + pi_tri(r, r)];
         if (i <= n - 2) d += PIb[(size_t)i * PIS + PI_II + pi_tri(r, r)];

@@ -389,6 +389,13 @@ int liw_batch_lm_begin(liw_ctx* c, const liw_batch* b, int mode, int max_iters, 
     HIPCHK(c, hipGetLastError());
     return LIW_OK;
 }
+int liw_batch_launch_paths(liw_ctx* c, const liw_batch* b, const void* ws, int* flags) {
+    if (!c) return LIW_EINVAL;
+    if (int r = check_batch(c, b)) return r;
+    if (!flags) return fail(c, LIW_EINVAL, "liw_batch_launch_paths: null flags");
+    *flags = (pi_frame_format(b->B) ? 1 : 0) | (lpk_matches(c, b, ws) ? 2 : 0);
+    return LIW_OK;
+}
 int liw_batch_lm_linearize(liw_ctx* c, const liw_batch* b, int mode, int candidate, void* ws, void* stream) {
     NEEDDEV(c);
     if (int r = check_batch(c, b, min_frames(mode))) return r;
@@ -433,7 +440,7 @@ int liw_batch_exchange_unpack(liw_ctx* c, const liw_batch* b, int mode, int cand
     if (!buf || copies < 1) return fail(c, LIW_EINVAL, "liw_batch_exchange_unpack: null buffer / copies < 1");
     WsView v = make_view(ws, b->B, b->n, b->history_records);
     const size_t stride = (size_t)liw_batch_exchange_doubles(b->B, b->n, mode);
-    launch_exchange_unpack(b->B, b->n, mode == LIW_MODE_INIT, copies, stride, buf, v.PL[0], v.PL[1], candidate, mode == LIW_MODE_MARG ? nullptr : v.lm, (hipStream_t)stream);
+    launch_exchange_unpack(b->B, b->n, mode == LIW_MODE_INIT, copies, stride, buf, v.PL[0], v.PL[1], v.pi_frame ? v.CS[0] : nullptr, v.pi_frame ? v.CS[1] : nullptr, candidate, mode == LIW_MODE_MARG ? nullptr : v.lm, (hipStream_t)stream);
     HIPCHK(c, hipGetLastError());
     return LIW_OK;
 }
@@ -462,7 +469,7 @@ int liw_batch_solve_sharded(liw_ctx* c, const liw_batch* b, int mode, int max_it
             c->last_x = c->p2p.area[c->p2p_rank] + (size_t)(e & 1ull) * world * nd;
             c->last_x_copies = world;
             WsView v = make_view(ws, b->B, b->n, b->history_records);
-            launch_exchange_unpack(b->B, b->n, mode == LIW_MODE_INIT, world, nd, c->last_x, v.PL[0], v.PL[1], cand, v.lm, s, true);
+            launch_exchange_unpack(b->B, b->n, mode == LIW_MODE_INIT, world, nd, c->last_x, v.PL[0], v.PL[1], v.pi_frame ? v.CS[0] : nullptr, v.pi_frame ? v.CS[1] : nullptr, cand, v.lm, s, true);
             HIPCHK(c, hipGetLastError());
             if (c->time_exchange) (void)hipEventRecord(next_event(c->ev_x, c->xev_used), s);
             return liw_batch_lm_join(c, stream);
@@ -742,8 +749,13 @@ int liw_batch_time_kernels(liw_ctx* c, const liw_batch* b, int mode, void* ws, v
     lin(0, 0);
     launch_lm_step(st, s);                                // the first step of a solve also builds the Jacobi scaling: not the one timed
     lin(1, 0);
-    std::vector<hipEvent_t> ev((size_t)reps * 5 + 4);
-    for (auto& e : ev) HIPCHK(c, hipEventCreate(&e));
+    struct EventPool {   // destroyed on every return path (HIPCHK / ENOMEM below)
+        std::vector<hipEvent_t> v;
+        ~EventPool() { for (auto e : v) if (e) (void)hipEventDestroy(e); }
+        hipEvent_t& operator[](size_t i) { return v[i]; }
+    } ev;
+    ev.v.assign((size_t)reps * 5 + 4, nullptr);
+    for (auto& e : ev.v) HIPCHK(c, hipEventCreate(&e));
     for (int r = 0; r < reps; ++r) {
         hipEvent_t* e = &ev[(size_t)r * 5];
         lin(1, 8);                                        // (the list of windows still iterating, as every linearisation of a solve builds it)
@@ -795,7 +807,6 @@ int liw_batch_time_kernels(liw_ctx* c, const liw_batch* b, int mode, void* ws, v
     float f = 0.f;
     (void)hipEventElapsedTime(&f, m[2], m[3]); out_ms[4] = f;
     (void)hipEventElapsedTime(&f, m[0], m[1]); out_ms[5] = f;
-    for (auto e : ev) (void)hipEventDestroy(e);
     HIPCHK(c, hipGetLastError());
     return LIW_OK;
 }

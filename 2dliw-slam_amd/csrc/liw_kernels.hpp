@@ -291,7 +291,7 @@ struct PackArgs {
 void launch_linearize(const LinArgs& A, const DevParams& P, hipStream_t s, const LinFork* fk, bool defer_join = false);
 void launch_linearize_join(hipStream_t s, const LinFork* fk);
 void launch_exchange_pack(int B, int n, bool both, const double* PL0, const double* PL1, int candidate, const LmState* lm, double* buf, hipStream_t s);
-void launch_exchange_unpack(int B, int n, bool both, int world, size_t stride, const double* buf, double* PL0, double* PL1, int candidate, const LmState* lm, hipStream_t s, bool sysload = false);
+void launch_exchange_unpack(int B, int n, bool both, int world, size_t stride, const double* buf, double* PL0, double* PL1, double* CS0, double* CS1, int candidate, const LmState* lm, hipStream_t s, bool sysload = false);   // CS0 / CS1: the compact cost arrays of the large-batch format (or null)
 constexpr int P2P_MAX = 16;
 struct P2pPeers { double* area[P2P_MAX]; unsigned long long* flags[P2P_MAX]; };   // device pointers to every rank's receive area / flags, as mapped here
 void launch_p2p_exchange(size_t nd, const double* buf, const P2pPeers& peers, int rank, int world, unsigned long long epoch, int* err, hipStream_t s);

@@ -200,7 +200,17 @@ int liw_batch_linearize(liw_ctx* ctx, const liw_batch* b, int mode, void* ws, vo
  * builds the Jacobi scaling), [4] chain Schur complement + eigen square root (k_marg_schur), [5] laser role of the marginalisation
  * topology.  Opens a solve (liw_batch_lm_begin) and moves b->x along `reps` + 1 LM steps; the caller's prior is left alone. */
 int liw_batch_time_kernels(liw_ctx* ctx, const liw_batch* b, int mode, void* ws, void* stream, int reps, double* out_ms);
+/* NOT purely stream-asynchronous for large batches: when the batch qualifies for the lane-per-group laser kernel (INIT topology, 2-D
+ * scans, >= 2 048 (slab of 64 windows, frame) pairs) liw_batch_lm_begin BLOCKS once on `stream` — a 16-byte read-back sizes the
+ * ctx-owned re-packed copy of the laser end points, which may be (re)allocated with hipMalloc / hipFree.  Consequences: two solves
+ * on different streams of one process serialise at this point, and it must not run while ANOTHER stream of the process is being
+ * captured in global capture mode (capture on `stream` itself is detected: the re-pack is skipped and the lane-per-block kernel
+ * used).  LIW_NO_LASER_SLAB=1 removes the blocking step (and the kernel).  liw_batch_solve / _solve_sharded inherit this. */
 int liw_batch_lm_begin(liw_ctx* ctx, const liw_batch* b, int mode, int max_iters, void* ws, void* stream);
+/* Which kernels the solve opened by the last liw_batch_lm_begin(ctx, b, ..., ws, ...) runs (tests pin the benchmarked launch shape with
+ * it; no reference counterpart): *flags bit 0 = large-batch record format (per-frame IMU records + compact cost array: k_lin_imu_chain,
+ * k_lm_step_quad), bit 1 = the lane-per-group laser kernel is armed for this (batch, workspace) (k_lin_laser_slab; INIT topology). */
+int liw_batch_launch_paths(liw_ctx* ctx, const liw_batch* b, const void* ws, int* flags);
 int liw_batch_lm_linearize(liw_ctx* ctx, const liw_batch* b, int mode, int candidate, void* ws, void* stream);
 int liw_batch_lm_step(liw_ctx* ctx, const liw_batch* b, int mode, void* ws, void* stream);
 int liw_batch_lm_finish(liw_ctx* ctx, const liw_batch* b, int mode, void* ws, void* stream);

@@ -1,7 +1,11 @@
-"""Parity at the shapes bench.py measures (VERDICT r1 item 2): the benchmarked configuration itself goes through the oracle.
+"""Parity at the shapes bench.py measures (VERDICT r1 item 2, r4 item 2): the benchmarked configuration itself goes through the oracle.
 
-  * B > 2 048 windows of C2 (n = 30, L = 2 000) — k_lm_step_quad (k_lm_step<THROUGHPUT> until round 3), G = 8 laser groups per wave, forked
-    role streams — per-iteration states, iteration counts and terminations of sampled windows against the oracle;
+  * 4 421 windows of C2 (n = 30, L = 2 000; not a multiple of 64 or of 4) — bench.py's OWN launch shape since round 4: the lane-per-group
+    laser kernel k_lin_laser_slab (needs >= 2 048 (slab, frame) pairs: >= 4 353 windows at n = 30), k_lin_imu_chain, k_lm_step_quad, forked
+    role streams, the batch tiled on the device — per-iteration states, iteration counts and terminations of the first / last windows of the
+    first and last slab and of jittered copies against the oracle;
+  * 2 304 windows of C2 — the same step kernels behind the lane-per-BLOCK laser kernel k_lin_laser<true> (G = 8 groups per wave), which
+    medium batches and 3-D scans still take;
   * C2- and C5-size batched marginalisation (Delta_H, Delta_g, prior J^T J) against the oracle at the same linearisation point;
   * n = 50 / L = 5 000 LM history;
   * a C4-size (n = 30, L = 20 000) 10-iteration factor-sharded solve: two rank objects on this one GPU driven in lock-step
@@ -24,8 +28,49 @@ def env(liw, synth, pyoracle):
     return prm, pyoracle.Oracle(prm)
 
 
+def test_bench_launch_shape_slab_chain_quad_per_iteration_parity(liw, synth, pyoracle, env):
+    """The kernels behind bench.py's `value`: k_lin_laser_slab + k_lin_imu_chain + k_lm_step_quad at L = 2 000, on a batch whose last slab
+    holds 5 windows and whose last quad wave holds one.  Windows {0, 63, 64, B-65, B-1} (first / last lane of slab 0, first lane of slab 1,
+    last full slab, tail) + two more jittered copies: every LM iteration within 1e-6 of the oracle, equal iteration counts and
+    terminations (solver.cpp:50-169, north_star's per-iteration bar)."""
+    import ctypes as C
+    import importlib
+    import sys
+    import os
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    bench = importlib.import_module("bench")
+    prm, orc = env
+    B, n, L, K, nd = 4421, 30, 2000, 50, 8
+    tw = bench.make_tiled(liw, synth, prm, B, n, L, seed0=20240, n_base=nd)
+    bs = liw.BatchSolver(prm, tw.base, tile=tw.tile(), history_records=K + 1)
+    bs.solve(liw.LIW_MODE_INIT, K)
+    flags = C.c_int(0)
+    assert bs.L.liw_batch_launch_paths(bs.h, C.byref(bs.b), bs._wsp(), C.byref(flags)) == 0
+    assert flags.value == 3, flags.value          # large-batch format (chain + quad kernels) AND the lane-per-group laser kernel armed
+    hist, summ, xg = bs.history(), bs.summaries(), bs.states()
+    orc.set_max_iterations(K)
+    sample = [0, 63, 64, B - 65, B - 1, nd + 3, B // 2 + 1]
+    worst = 0.0
+    for b in sample:
+        w = pyoracle.Window(tw[b])
+        orc.set_prior(None)
+        orc.init_solve(w)
+        so, its = orc.summary(), orc.iterations()
+        assert summ[b]["iterations"] == so["iterations"] and summ[b]["termination"] == so["termination"], (b, summ[b], so)
+        for it in range(so["iterations"] + 1):
+            e = rel_inf(hist[it, b], its[it]["x"].reshape(n, 15))
+            worst = max(worst, e)
+            assert e <= 1e-6, (b, it, e)
+        assert rel_inf(xg[b], w["states"].reshape(n, 15)) <= 1e-6
+        assert abs(summ[b]["final_cost"] - so["final_cost"]) <= 1e-9 * so["final_cost"]
+    orc.set_max_iterations(50)
+    assert len({(s["iterations"], s["termination"], round(s["final_cost"], 6)) for s in summ[:nd]}) > 1
+    print("bench launch shape (slab / chain / quad) per-iteration state error (max over %d windows): %.2e" % (len(sample), worst))
+
+
 def test_bench_configuration_per_iteration_parity(liw, synth, pyoracle, env):
-    """bench.py's own launch shape: 2 304 C2 windows (8 distinct seeds + jittered copies)."""
+    """2 304 C2 windows (8 distinct seeds + jittered copies): the lane-per-block laser kernel k_lin_laser<true> (below the slab kernel's
+    4 353-window threshold at n = 30) in front of k_lin_imu_chain / k_lm_step_quad."""
     import importlib
     import sys
     import os

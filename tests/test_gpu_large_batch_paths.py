@@ -191,3 +191,65 @@ def test_laser_end_points_with_z_take_the_full_path(liw, synth, pyoracle):
     for k in range(4):                                                   # z = 0 windows: skipping the planes is exact up to the order of the sums
         assert rel(x_mixed[k], x_flat[k]) <= 1e-9, k
     orc.set_max_iterations(50)
+
+
+def _lockstep_solve(liw, prm, windows, exchange, mode, K):
+    """two rank objects of this process through the real sharded loop (LockstepComm stands in for RCCL only)"""
+    import threading
+    import torch
+    comms = liw.batch.LockstepComm.make(2)
+    ranks = [liw.BatchSolver(prm, windows, rank=r, world=2, exchange=exchange, comm=comms[r]) for r in range(2)]
+    errs = []
+
+    def drive(rk):
+        try:
+            rk.solve(mode, K)
+        except Exception as e:   # noqa: BLE001
+            errs.append(e)
+            comms[0].sh["bar"].abort()
+    th = [threading.Thread(target=drive, args=(rk,)) for rk in ranks]
+    for t in th:
+        t.start()
+    for t in th:
+        t.join(timeout=300)
+    assert not errs, errs
+    torch.cuda.synchronize()
+    return ranks
+
+
+@pytest.mark.parametrize("B,variant", [(1088, None), (3, "3")])
+def test_factor_sharded_solve_in_the_large_batch_format(liw, synth, pyoracle, monkeypatch, B, variant):
+    """in the large-batch format (>= 1 024 windows, or LIW_STEP_VARIANT=3) the prologue of k_lm_step_quad takes a
+    candidate's laser cost from the compact cost array CS, which only the LOCAL laser role wrote — the exchange refreshed the group
+    records and not CS, so every rank accepted / rejected on its own shard's cost.  Two ranks over a batch that takes that path:
+    ranks bit-identical, same iteration counts / terminations as the un-sharded solve and the oracle (solver.cpp:93-106, :161-168)."""
+    if variant:
+        monkeypatch.setenv("LIW_STEP_VARIANT", variant)
+    prm = synth.office_params()
+    orc = pyoracle.Oracle(prm)
+    n, K, nb = 6, 12, 4
+    base = [synth.make_window(orc, prm, seed=5100 + k, n=n, L=40 + 23 * k) for k in range(nb)]
+    windows = [base[b % nb] for b in range(B)]
+    ref = liw.BatchSolver(prm, windows)
+    ref.solve(liw.LIW_MODE_INIT, K)
+    rs, rsum = ref.states(), ref.summaries()
+    orc.set_max_iterations(K)
+    want = []
+    for k in range(nb):
+        wo = pyoracle.Window(base[k])
+        orc.set_prior(None)
+        orc.init_solve(wo)
+        want.append((orc.summary(), wo["states"].reshape(n, 15).copy()))
+    orc.set_max_iterations(50)
+    for xch in ("allreduce", "oneshot"):
+        ranks = _lockstep_solve(liw, prm, windows, xch, liw.LIW_MODE_INIT, K)
+        a, b = ranks[0].states(), ranks[1].states()
+        assert np.array_equal(a, b), xch                                          # same sums -> same decisions -> same bits
+        sa, sb = ranks[0].summaries(), ranks[1].summaries()
+        assert [(s["iterations"], s["termination"]) for s in sa] == [(s["iterations"], s["termination"]) for s in sb]
+        assert [(s["iterations"], s["termination"]) for s in sa] == [(s["iterations"], s["termination"]) for s in rsum], xch
+        assert rel(a, rs) <= 1e-9, xch
+        for k in range(min(nb, B)):
+            for bb in {k, B - nb + k if B > nb else k}:
+                assert sa[bb]["iterations"] == want[k][0]["iterations"] and sa[bb]["termination"] == want[k][0]["termination"], (xch, bb)
+                assert rel(a[bb], want[k][1]) <= 1e-6, (xch, bb)
