@@ -78,3 +78,23 @@ def test_gpus_flag_must_match_the_launcher():
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--batch", "8", "--steps", "1", "--warmup", "0"],
                        capture_output=True, cwd=ROOT, env=env, timeout=300)
     assert r.returncode != 0 and b"--gpus 2" in r.stderr
+
+
+def test_eight_rank_control_flow_on_one_gpu():
+    """`bench.py --gpus 8` the way the driver's 8-GPU node will run it, eight processes sharing this box's GPU over gloo: the batch is tiled
+    on the device (eight host-side concatenations of the default batch did not fit a node's RAM), every rank's peak RSS is
+    in the line, the factor-sharded C4 section runs with world 8 and checks itself."""
+    env = dict(os.environ, LIW_BENCH_SHARE_GPU="1")
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "8", "--batch", "512", "--steps", "1", "--warmup", "0", "--distinct", "4"],
+                       capture_output=True, cwd=ROOT, env=env, timeout=1500)
+    assert r.returncode == 0, r.stderr.decode()[-2000:]
+    d = last_json(r.stdout)
+    assert d["n_gpus"] == 8 and d["value"] > 0 and d["parity_gate"]["passed"]
+    rss = d["host_peak_rss_mb_per_rank"]["end_of_run"]
+    assert len(rss) == 8 and all(0 < v < 6000 for v in rss), rss
+    fs = d["factor_sharded"]
+    assert "error" not in fs, fs
+    assert fs["ranks"] == 8 and fs["process_group"]["world_size"] == 8 and fs["states_identical_across_ranks"]
+    assert fs["oneshot_exchange"]["states_identical_across_ranks"] and fs["self_check"]["passed"]
