@@ -1508,7 +1508,8 @@ __global__ __launch_bounds__(64) void k_export_dense(ExportArgs a) {
 // marginalisation: chain Schur complement of frames 0..n-2 onto frame n-1 (marginalization_matrix,
 // solver.cpp:4-40, on the block tri-diagonal H), eigen square root (solver.cpp:390-402), prior update (:407-441)
 // chain Schur complement of one window by ONE wave: Delta_H -> T.D (ld 16), Delta_g(+J^T R convention) -> T.g, outputs, status; false = a pivot failed
-__device__ __forceinline__ bool marg_chain(const MargArgs& a, const int b, LdsTiles& T) {
+template <class TILES>
+__device__ __forceinline__ bool marg_chain(const MargArgs& a, const int b, TILES& T) {
     const int lane = threadIdx.x & 63, n = a.n;
     AsmCtx c;
     c.pif = a.w.pi_frame;
@@ -1603,7 +1604,8 @@ __device__ __forceinline__ void jacobi_rotation(double d, double h, double& cs, 
     sn = (d >= 0.0 ? h : -h) * winv;
 }
 // cyclic Jacobi by ONE wave (large batches: a wave per window): T.D -> eigenvalues on the diagonal of Am, eigenvectors in the columns of V
-__device__ __forceinline__ void jacobi15_wave(LdsTiles& T, double* V, double* Am, double* rot) {
+template <class TILES>
+__device__ __forceinline__ void jacobi15_wave(TILES& T, double* V, double* Am, double* rot) {
     const int lane = threadIdx.x & 63;
     // ---- symmetric eigen-decomposition by cyclic Jacobi (15x15), A -> Am, eigenvectors -> V (columns).
     // Jacobi, not tridiagonalisation + QL: Delta_H is graded over 1e11 (pose rows) ... 1e2 (bias rows), and only Jacobi keeps the small
@@ -1679,7 +1681,8 @@ __device__ __forceinline__ void jacobi15_wave(LdsTiles& T, double* V, double* Am
 }
 
 // eigen square root and prior write-back (solver.cpp:390-441) by ONE wave: Am (eigenvalues on the diagonal), V (eigenvectors in columns)
-__device__ __forceinline__ void marg_tail(const MargArgs& a, const int b, LdsTiles& T, const double* V, const double* Am) {
+template <class TILES>
+__device__ __forceinline__ void marg_tail(const MargArgs& a, const int b, TILES& T, const double* V, const double* Am) {
     const int lane = threadIdx.x & 63, n = a.n;
     double* oX = a.out_X ? a.out_X : a.prior_X; double* oJ = a.out_J ? a.out_J : a.prior_J; double* oR = a.out_R ? a.out_R : a.prior_R;
     int* oHas = a.out_has ? a.out_has : a.has_prior;
@@ -1709,7 +1712,8 @@ __device__ __forceinline__ void marg_tail(const MargArgs& a, const int b, LdsTil
     if (lane == 0) oHas[b] = 1;
     STAMPM(5003);
 }
-__device__ __forceinline__ void marg_schur_body(const MargArgs& a, const int b, LdsTiles& T, double* V, double* Am, double* rot) {
+template <class TILES>
+__device__ __forceinline__ void marg_schur_body(const MargArgs& a, const int b, TILES& T, double* V, double* Am, double* rot) {
     const int lane = threadIdx.x & 63;
     if (a.gate && !a.gate[b].done) { if (a.status && lane == 0) a.status[b] = 2; return; }
     if (!marg_chain(a, b, T)) return;
@@ -1732,19 +1736,15 @@ __device__ __forceinline__ int jacobi15_block(const double* D, double* A2, doubl
     int cur = 0;
     // coefficients of index i in round rnd: new_i = g * x_i + s * x_partner.  partner = (2 rnd - i) mod 15 (the pairs of a round are the
     // index pairs that sum to 2 rnd), none for i = rnd and for the padding index 15.
-    auto coeff = [&](const double* A, int i, int rnd, int& partner, double& g, double& sg) {
-        partner = i; g = 1.0; sg = 0.0;
-        if (i >= 15) return;
+    // A round is ONE LDS round trip (round 5): the partner indices are integer arithmetic on (thread, round), so the three matrix entries
+    // behind each of the thread's two rotations and the six entries of its two-sided update are all loaded up front, unconditionally
+    // (an index without a partner pairs with itself: finite garbage, discarded by the selects below); until then the zero test of a_pq
+    // and the "no partner" exits were branches in front of the diagonal loads, and the update's loads sat behind both rotations — three
+    // dependent LDS round trips and two divergent regions in a round of ~1 190 cycles (tools/clk_probe_track.py: 4 sweeps = 60 rounds in
+    // 71.6 k cycles).  Same rotations, same order, same arithmetic: bit-identical results.
+    auto partner_of = [](int i, int rnd) {
         int pr = 2 * rnd - i; pr += pr < 0 ? 15 : 0; pr -= pr >= 15 ? 15 : 0;
-        if (pr == i) return;
-        const int P = i < pr ? i : pr, Q = i < pr ? pr : i;
-        const double apq = A[P * 16 + Q];
-        partner = pr;
-        if (apq == 0.0) return;
-        const double d = A[Q * 16 + Q] - A[P * 16 + P], h = 2.0 * apq;
-        double cs, sn;
-        jacobi_rotation(d, h, cs, sn);
-        g = cs; sg = i == P ? -sn : sn;
+        return i >= 15 ? i : pr;
     };
     for (int sweep = 0; sweep < 60; ++sweep) {
         const double* A = A2 + 256 * cur;
@@ -1759,17 +1759,30 @@ __device__ __forceinline__ int jacobi15_block(const double* D, double* A2, doubl
         for (int rnd = 0; rnd < 15; ++rnd) {
             const double* Ac = A2 + 256 * cur; const double* Vc = V2 + 256 * cur;
             double* An = A2 + 256 * (1 - cur); double* Vn = V2 + 256 * (1 - cur);
-            int rp, cp;
-            double gr, sr, gc, sc;
-            coeff(Ac, r, rnd, rp, gr, sr);
-            coeff(Ac, c, rnd, cp, gc, sc);
-            const double b0 = gc * Ac[r * 16 + c] + sc * Ac[r * 16 + cp];      // (A G)[r][c]
-            const double b1 = gc * Ac[rp * 16 + c] + sc * Ac[rp * 16 + cp];    // (A G)[r'][c]
+            const int rp = partner_of(r, rnd), cp = partner_of(c, rnd);
+            const int rP = r < rp ? r : rp, rQ = r < rp ? rp : r, cP = c < cp ? c : cp, cQ = c < cp ? cp : c;
+            // every load of the round
+            const double r_pq = Ac[rP * 16 + rQ], r_qq = Ac[rQ * 16 + rQ], r_pp = Ac[rP * 16 + rP];
+            const double c_pq = Ac[cP * 16 + cQ], c_qq = Ac[cQ * 16 + cQ], c_pp = Ac[cP * 16 + cP];
+            const double x00 = Ac[r * 16 + c], x01 = Ac[r * 16 + cp], x10 = Ac[rp * 16 + c], x11 = Ac[rp * 16 + cp];
+            const double v0 = Vc[r * 16 + c], v1 = Vc[r * 16 + cp];
+            // the two rotations, side by side (independent dependent chains: they interleave)
+            double rcs, rsn, ccs, csn;
+            jacobi_rotation(r_qq - r_pp, 2.0 * r_pq, rcs, rsn);
+            jacobi_rotation(c_qq - c_pp, 2.0 * c_pq, ccs, csn);
+            const bool ron = rp != r && r_pq != 0.0, con = cp != c && c_pq != 0.0;
+            const double gr = ron ? rcs : 1.0, sr = ron ? (r == rP ? -rsn : rsn) : 0.0;
+            const double gc = con ? ccs : 1.0, sc = con ? (c == cP ? -csn : csn) : 0.0;
+            const double b0 = gc * x00 + sc * x01;      // (A G)[r][c]
+            const double b1 = gc * x10 + sc * x11;      // (A G)[r'][c]
             An[t] = gr * b0 + sr * b1;
-            Vn[t] = gc * Vc[r * 16 + c] + sc * Vc[r * 16 + cp];
+            Vn[t] = gc * v0 + sc * v1;
             __syncthreads();
             cur = 1 - cur;
         }
+#ifdef LIW_CLK
+        if (t == 0 && blockIdx.x == 0) g_clk[5010] = sweep + 1;   // rotation sweeps executed (tools/clk_probe_track.py)
+#endif
     }
     return cur;
 }
@@ -1789,10 +1802,21 @@ __global__ __launch_bounds__(256, 1) void k_marg_schur4(MargArgs a) {
     if (wave == 0) marg_tail(a, b, T, V2 + 256 * cur, A2 + 256 * cur);
 }
 
-__global__ __launch_bounds__(64, 2) void k_marg_schur(MargArgs a) {
-    __shared__ LdsTiles T;
-    __shared__ double V[256], Am[256], rot[16];
-    marg_schur_body(a, (int)blockIdx.x, T, V, Am, rot);
+// One wave per window (large batches).  The kernel is a chain of dependent 15x15 steps on ONE wave — latency-bound — so what it needs is
+// waves per SIMD: 151 registers allow three, the 20 kB of LdsTiles + eigen buffers allowed two (eight waves per CU).  LdsMarg keeps only
+// the tiles the marginalisation topology touches (no arrow / carried-arrow tiles, no LM vectors) and the eigen phase re-uses tiles that are
+// dead after the chain (V in the never-read arrow tile R, the rotated matrix in O, the rotation parameters in Cg): 12.9 kB, twelve waves per CU.
+struct LdsMarg {
+    double D[256], O[256], R[256], W[256], Wa[256], CD[256];
+    double g[16], Cg[16], y0[16], tmp[ASM_TMP];
+};
+#ifndef LIW_MARG_OCC
+#define LIW_MARG_OCC 3
+#endif
+__global__ __launch_bounds__(64, LIW_MARG_OCC) void k_marg_schur(MargArgs a) {
+    __shared__ LdsMarg T;
+    static_assert(sizeof(LdsMarg) * 12 <= 160 * 1024, "twelve waves per CU");
+    marg_schur_body(a, (int)blockIdx.x, T, T.R, T.O, T.Cg);
 }
 
 #ifdef LIW_CLK
