@@ -195,7 +195,7 @@ def cpu_quota():
     return {"cgroup_cpu_quota": round(q, 2) if q else None, "affinity_cpus": aff, "logical_cpus": os.cpu_count()}
 
 
-def replay_leg(liw, synth, prm, path, seconds, keep, seed=11):
+def replay_leg(liw, synth, prm, path, seconds, keep, seed=11, teacher_forced=False):
     """BASELINE config C3 in one command: a flat sensor log (tools/replay_log's format; rosbag_reader.bag_to_flatlog
     converts an OpenLORIS bag) through the C++ driver on the GPU and through the oracle's twin on the host, same run: frames / s side by
     side, poses compared, the reference-shaped record table.  Default log: synthetic, corridor-rate sensors (IMU 200 Hz, odometry 20 Hz,
@@ -228,6 +228,7 @@ def replay_leg(liw, synth, prm, path, seconds, keep, seed=11):
     status, frames, tracked, inits, keyframes, sstat = struct.unpack("<6i", raw[:24])
     lp = liw.laser.office_laser_params(prm)
     orc = pyoracle.TrajectoryOracle(prm, lp, keep_window_size=keep)
+    orc.set_capture(bool(teacher_forced))
     t0 = time.perf_counter()
     for m in msgs:
         if m["type"] == 0:
@@ -253,7 +254,32 @@ def replay_leg(liw, synth, prm, path, seconds, keep, seed=11):
     except (OSError, ValueError):
         pass
     scans = sum(1 for m in msgs if m["type"] not in (0, 1))
-    return {"log": src, "messages": len(msgs), "laser_scans": scans, "keep_window_size": keep,
+    tf = None
+    if teacher_forced:
+        # north_star's per-solve statement on THIS log: every tracking solve of the oracle twin's replay (the window + carried prior it
+        # started from) re-run on the MI355X through lvio_2d::solver's C ABI; counted: solves whose states are within 1e-6 of the oracle's
+        # with the same iteration count and termination (free-running trajectories part ways through the driver's own sensitivity, below)
+        caps = orc.captures()
+        slv = liw.Solver(prm)
+        ok = same_it = 0
+        worst, t_g = 0.0, 0.0
+        for cp_ in caps:
+            w = liw.Window(cp_)
+            slv.set_prior((cp_["prior_X"], cp_["prior_J"].reshape(15, 15), cp_["prior_R"]) if cp_["has_prior"] else None)
+            t0 = time.perf_counter()
+            slv.set_window(w)
+            sg = slv.solve()
+            t_g += time.perf_counter() - t0
+            e = float(np.abs(w["states"].reshape(-1) - cp_["states_after"]).max() / max(np.abs(cp_["states_after"]).max(), 1e-12))
+            same = (sg["iterations"], sg["termination"]) == (cp_["iterations"], cp_["termination"])
+            same_it += int(same)
+            ok += int(same and e <= 1e-6)
+            worst = max(worst, e)
+        tf = {"solves": len(caps), "within_1e-6_with_equal_iterations_and_termination": ok, "equal_iterations_and_termination": same_it,
+              "max_rel_state_err": float("%.3e" % worst), "largest_window_frames": int(max([q_["n"] for q_ in caps] or [0])),
+              "largest_window_laser_blocks": int(max([q_["L"] for q_ in caps] or [0])), "gpu_ms_per_solve": round(1e3 * t_g / max(len(caps), 1), 3),
+              "note": "each solve starts from the oracle's own input (window + prior), so this counts per-solve parity, not trajectory divergence"}
+    return {"log": src, "teacher_forced_tracking_solves": tf, "messages": len(msgs), "laser_scans": scans, "keep_window_size": keep,
             "gpu": {"seconds": round(t_gpu, 3), "scans_per_s": round(scans / t_gpu, 1), "frames": frames, "tracked": tracked, "initializations": inits,
                     "note": "tools/replay_log: process start, log read, dispatch, pre-integration, laser front-end (host) and every solve / marginalisation (MI355X) included"},
             "cpu_oracle": {"seconds": round(t_cpu, 3), "scans_per_s": round(scans / t_cpu, 1), "frames": c["frames"], "tracked": c["tracked"], "initializations": c["initializations"],
@@ -347,6 +373,7 @@ def main():
                          "GPU and the oracle twin on the host; runs by default at N = 1 unless --no-single")
     ap.add_argument("--replay-seconds", type=float, default=60.0)
     ap.add_argument("--replay-keep", type=int, default=1, help="frames kept after a tracking solve (1 = the reference's policy; 29 = the C3 30-KF window)")
+    ap.add_argument("--replay-keep30-seconds", type=float, default=20.0, help="length of the synthetic log of the second replay leg (keep = 29: BASELINE C3's 30-KF window; 0 = skip it)")
     ap.add_argument("--distinct", type=int, default=64, help="fully generated windows with distinct seeds per rank (the rest of the batch tiles them with state jitter)")
     ap.add_argument("--gate-windows", type=int, default=4, help="windows of the timed batch whose results are checked against the oracle (parity gate)")
     ap.add_argument("--cpu-procs", type=int, default=64, help="processes of the all-cores CPU baseline leg (capped at the core count)")
@@ -631,12 +658,19 @@ def main():
             "iteration_serial_ms": round(kt["k_lin_laser"] + kt["k_lin_imu"] + kt["k_lin_small"] + kt["k_lm_step"], 4)}
 
     # ---- C3 leg: sensor-log replay, GPU and CPU oracle in the same run
-    replay_out = None
+    replay_out = replay30_out = None
     if rank == 0 and world == 1 and (args.replay is not None or not args.no_single):
         try:
-            replay_out = replay_leg(liw, synth, prm, args.replay or None, args.replay_seconds, args.replay_keep)
+            replay_out = replay_leg(liw, synth, prm, args.replay or None, args.replay_seconds, args.replay_keep, teacher_forced=args.replay_keep > 1)
         except Exception as e:   # a side measurement must never take the headline line down
             replay_out = {"error": repr(e)[:300]}
+        # BASELINE C3 at its stated window: the same driver with keep = 29 (30 frames at solve time), GPU and oracle twin on the same policy in
+        # the same run, every tracking solve also teacher-forced
+        if args.replay_keep == 1 and args.replay_keep30_seconds > 0:
+            try:
+                replay30_out = replay_leg(liw, synth, prm, args.replay or None, args.replay_keep30_seconds, 29, teacher_forced=True)
+            except Exception as e:
+                replay30_out = {"error": repr(e)[:300]}
 
     # ---- CPU baseline: the oracle (port of the reference algorithm) on the host cores, rank 0, N = 1 only
     cpu = None
@@ -956,6 +990,10 @@ def main():
             out["roofline"]["mfma_util_k_lin_imu"] = ktimes["k_lin_imu"]["mfma_util"]
         if replay_out:
             out["c3_replay"] = replay_out
+        if replay30_out:
+            out["c3_replay_keep30"] = replay30_out
+            if isinstance(replay30_out, dict) and "error" not in replay30_out:
+                out["c3_replay_keep30"]["policy_note"] = "keep-N is this repository's window policy for BASELINE C3 / C5 (30 frames at solve time), not a reference behaviour (the reference keeps 1 frame, trajectory.cpp:590-617)"
         if sharded:
             out["factor_sharded"] = sharded
         print(json.dumps(out))

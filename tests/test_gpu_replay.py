@@ -126,6 +126,7 @@ def _teacher_forced_tracking(liw, pyoracle, prm, caps, tol=1e-6):
     from parity_util import rel_inf
     slv = liw.Solver(prm)
     worst = dict(state=0.0, dH=0.0, dg=0.0, prior=0.0)
+    referee = []
     for k, c in enumerate(caps):
         w = liw.Window(c)
         slv.set_prior((c["prior_X"], c["prior_J"].reshape(15, 15), c["prior_R"]) if c["has_prior"] else None)
@@ -133,11 +134,16 @@ def _teacher_forced_tracking(liw, pyoracle, prm, caps, tol=1e-6):
         s = slv.solve()
         assert (s["iterations"], s["termination"]) == (c["iterations"], c["termination"]), (k, c["n"], s, c["iterations"], c["termination"])
         e = rel_inf(w["states"].reshape(-1), c["states_after"])
-        # a solve cut off by the iteration cap (termination 4) is stopped in the middle of a crawl along the ground_factor_q cone, where
-        # round-off differences between two correct implementations grow ~2.5x per iteration beyond iteration ~35 (this very list
-        # of solves spreads from 1e-14 to 1e-6 at the cap and moves with every recompilation: hipcc contracts FMAs differently): 10x the
-        # bar there, the bar itself for every solve that converged
-        assert e <= (tol if c["termination"] != 4 else 10 * tol), (k, c["n"], c["termination"], e)
+        # The bar is 1e-6 on EVERY solve.  A solve cut off by the iteration cap (termination 4) is stopped in the middle of a crawl along the
+        # ground_factor_q cone, where round-off differences between two correct implementations grow ~2.5x per iteration beyond iteration
+        # ~35: one that misses the bar there is judged PER SOLVE by the oracle against itself — the same solve with its
+        # pre-integrated IMU means scaled by 1 + 1e-13 N(0,1), the size of a round-off difference (the referee of
+        # test_soak_outliers_are_within_the_problems_own_round_off_sensitivity).  No blanket slack (it was 10x until round 4).
+        if e > tol:
+            assert c["termination"] == 4, (k, c["n"], c["termination"], e)
+            sens = oracle_round_off_sensitivity(pyoracle, prm, c)
+            referee.append((k, e, sens))
+            assert e <= 3.0 * sens, (k, c["n"], e, sens)
         # marginalise at the oracle's post-solve point so that the comparison is at one linearisation point
         w["states"].reshape(-1)[:] = c["states_after"]
         w["match_pose"].reshape(-1)[:] = c["match_after"]
@@ -149,7 +155,27 @@ def _teacher_forced_tracking(liw, pyoracle, prm, caps, tol=1e-6):
         eP = max(rel_inf(Xg, c["post_X"]), rel_inf(Jg.T @ Jg, Jo.T @ Jo))
         assert eH <= tol and eg <= tol and eP <= tol, (k, eH, eg, eP)
         worst = dict(state=max(worst["state"], e), dH=max(worst["dH"], eH), dg=max(worst["dg"], eg), prior=max(worst["prior"], eP))
+    worst["solves"], worst["beyond_1e-6_judged_by_the_referee"] = len(caps), [(k, float("%.2e" % e), float("%.2e" % sn)) for k, e, sn in referee]
     return worst
+
+
+def oracle_round_off_sensitivity(pyoracle, prm, c, trials=3):
+    """how far the ORACLE's tracking solve of the captured input `c` moves when its pre-integrated IMU means are scaled by 1 + 1e-13 N(0,1)"""
+    from parity_util import rel_inf
+
+    def run(win):
+        o = pyoracle.Oracle(prm)
+        o.set_prior((win["prior_X"], win["prior_J"].reshape(15, 15), win["prior_R"]) if win["has_prior"] else None)
+        w = pyoracle.Window(win)
+        o.solve(w)
+        return w["states"].reshape(-1).copy()
+    x0 = run(c)
+    rp, sens = np.random.default_rng(7), 0.0
+    for _ in range(trials):
+        alt = dict(c)
+        alt["imu_X"] = np.asarray(c["imu_X"]) * (1.0 + 1e-13 * rp.standard_normal(np.asarray(c["imu_X"]).shape))
+        sens = max(sens, rel_inf(run(alt), x0))
+    return sens
 
 
 @pytest.mark.parametrize("keep,duration,seed", [(29, 6.0, 1), (49, 8.0, 2)])
