@@ -226,7 +226,9 @@ __device__ void asm_commit(const AsmCtx& c, int i, const AsmRegs& R, const Tiles
         const bool pl = lane < 36;
         const int r = pl ? lane / 6 : 0, cc = pl ? lane % 6 : 0;
         dP = R.t1 + (hasm ? R.t2 : 0.0) + (hasp ? R.t3 : 0.0) + R.t4;
-        if (i == 0) {   // every laser frame's Haa lands on frame 0's pose: 4 independent partial sums keep the n loads in flight together
+        // (only the init topology has a free pose `a`: in the tracking / marginalisation topologies the Haa | ga slots are structural zeros,
+        //  laser_slot_code<false>, and the n dependent loads behind the main batch are skipped)
+        if (i == 0 && c.mode == LIW_MODE_INIT) {   // every laser frame's Haa lands on frame 0's pose: 4 independent partial sums keep the n loads in flight together
             double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
             int j = 0;
             for (; j + 4 <= n; j += 4) {
@@ -245,7 +247,7 @@ __device__ void asm_commit(const AsmCtx& c, int i, const AsmRegs& R, const Tiles
         const int r = lane < 15 ? lane : 0;
         if (r < 6) {
             gg = R.g1 + (hasm ? R.g2 : 0.0) + (hasp ? R.g3 : 0.0) + R.g4;
-            if (i == 0) {
+            if (i == 0 && c.mode == LIW_MODE_INIT) {
                 double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
                 int j = 0;
                 for (; j + 4 <= n; j += 4) {
@@ -443,6 +445,12 @@ struct LdsStep {    // k_lm_step (lane layout): M = assembled frame, C = carried
     double tmp[ASM_TMP], D0acc[36], g0acc[8];
 };
 constexpr int LW = 0, LLI = 240, LWA = 480;   // offsets of W / Li / Wa inside LdsStep::M
+struct LdsDense2 {  // k_lm_step_dense2: both frames of a two-frame window assembled in the tile layout (+ LdsStep for the shared helpers)
+    LdsStep S;
+    double D1[256], O1[256], R1[256], D0[256], O0[256], R0[256], g1[16], g0[16];
+};
+__device__ __forceinline__ LdsStep& step_lds(LdsStep& T) { return T; }
+__device__ __forceinline__ LdsStep& step_lds(LdsDense2& T) { return T.S; }
 
 // ---------------------------------------------------------------------------------------------------
 // Right-looking Cholesky of the 15x15 matrix whose column j lives in lane j (a[r] = A[r][j]) fused with the forward
@@ -465,6 +473,27 @@ __device__ __forceinline__ bool fused_chol_solve(double (&a)[15]) {
         a[k] = wk;
 #pragma unroll
         for (int r = k + 1; r < 15; ++r) a[r] -= rdlane(wk, r) * wk;
+    }
+    return ok;
+}
+
+// The same fused pass for a DENSE system of 30 unknowns (a two-frame window, k_lm_step_dense2): matrix lanes 0..29, any other lane a
+// right-hand side.
+// inert (uniform): bit k set = unknown k is a constant of the problem — a unit pivot with a zero row and column (solver.cpp:787-794: the
+// older frame's pose while tracking, its biases too in fast mode).  Its step would change nothing (L_kk = 1, every L[r][k] = 0): skipped,
+// 159 of the 435 row updates for the six pose entries alone.
+__device__ __forceinline__ bool fused_chol_solve30(double (&a)[30], unsigned inert) {
+    bool ok = true;
+#pragma unroll
+    for (int k = 0; k < 30; ++k) {
+        if (k < 15 && ((inert >> k) & 1u)) continue;   // (only frame 0 has constants)
+        const double piv = rdlane(a[k], k);
+        if (k == 29 && (!(piv > 0.0) || !isfinite(piv))) ok = false;   // (a bad pivot poisons every later one)
+        const double inv = fast_rsqrt(piv);
+        const double wk = a[k] * inv;
+        a[k] = wk;
+#pragma unroll
+        for (int r = k + 1; r < 30; ++r) a[r] -= rdlane(wk, r) * wk;
     }
     return ok;
 }
@@ -507,9 +536,12 @@ __device__ double frame_diag(const AsmCtx& c, int i, LdsStep& T) {
 // THROUGHPUT = false: 2 waves per SIMD, the next frame's loads are issued one frame ahead in the elimination sweep (lowest
 // latency of one window).  THROUGHPUT = true: 3 waves per SIMD (<= 168 VGPRs, no look-ahead there): the other waves hide
 // the round trip instead (large batches).
-template <bool THROUGHPUT>
-__device__ __forceinline__ void lm_step_body(const StepArgs& a, const int b, LdsStep& T) {   // one wave = one window
+// DENSE2 (n == 2 only; k_lm_step_dense2): the two-frame window the reference's tracking loop solves every laser frame
+// (trajectory.cpp:525-560, solver.cpp:631-820) as ONE dense 30 x 30 system instead of two chained frame eliminations — see the sweep below.
+template <bool THROUGHPUT, bool DENSE2 = false, class LDS = LdsStep>
+__device__ __forceinline__ void lm_step_body(const StepArgs& a, const int b, LDS& TL) {   // one wave = one window
     constexpr bool LIW_PF1 = !THROUGHPUT, LIW_PF2 = true;
+    LdsStep& T = step_lds(TL);
     const int lane = threadIdx.x & 63;
     LmState& st = a.w.lm[b];
     if (st.done) return;
@@ -625,157 +657,227 @@ __device__ __forceinline__ void lm_step_body(const StepArgs& a, const int b, Lds
     double* dgl = st.diagonal;
     double* sws = a.w.solve_ws + (size_t)b * n * SOLVE_WS;
 
-    // ---- single pass: eliminate frames n-1 .. 1, then 0, of (S H S + D^2) y = S g.
-    // Register-resident elimination: lane j < 15 owns column j of the damped diagonal tile, lanes 16..30 the columns of
-    // O^T, lanes 32..37 the columns of R^T, lane 40 the gradient.  One fused pass (fused_chol_solve) turns the matrix
-    // lanes into the rows of L and every right-hand-side lane into L^-1 b, using v_readlane broadcasts only.
-    for (int e = lane; e < 720; e += 64) { T.M[e] = 0.0; if (e < 15 * MS) T.C[e] = 0.0; }
-    if (lane < 16) T.Z[lane] = 0.0;
-    if (lane < 36) T.D0acc[lane] = 0.0;
-    if (lane < 8) T.g0acc[lane] = 0.0;
-    const double sc0reg = scl[lane < 15 ? lane : 0];           // scale of frame 0 (rows of the arrow block)
-    lds_sync();
+    const int iteration_dbg = iteration; (void)iteration_dbg;
     bool solved = true;
     double gmax = 0.0, gsum = 0.0;
-    const int iteration_dbg = iteration; (void)iteration_dbg;
-    STAMP(0); SPAN(0);
-    const Tiles<1> TM{T.M, nullptr, nullptr, nullptr};
-    AsmRegs areg;
-    PriorRegs preg;
     const double inv_radius = 1.0 / radius;   // (one division per step instead of one per frame; 1 ulp from diagonal / radius)
-    if constexpr (LIW_PF1) areg = asm_issue(c, n - 1, scl, dgl);
-    for (int i = n - 1; i >= 0; --i) {
-        STAMP(10 + i * 8 + 0);
-        // the lane id is laundered once per frame: lane-derived addresses and masks are recomputed (a few integer ops)
-        // instead of being hoisted out of the loop into registers that then spill
-        int ln = lane;
-        asm volatile("" : "+v"(ln));
-        FrameExtra ex;
-        if constexpr (!LIW_PF1) areg = asm_issue(c, i, scl, dgl, ln);
-        asm_commit<1>(c, i, areg, TM, T.tmp, &ex, ln, -1, (LIW_PF1 && c.prior_on && i == n - 2) ? &preg : nullptr);
-        STAMP(10 + i * 8 + 1);
-        // LM diagonal of this frame (LevenbergMarquardtStrategy::ComputeStep), |x - Plus(x,-g)|
-        const bool cstl = ln < 15 && var_is_const(a.mode, a.fast_mode, n, i, ln);
-        const double gl = ln < 15 ? T.M[ln * MS + 40] : 0.0;          // tangent gradient entry of this lane
-        gsum += gl;
-        double dgv = ex.dg_i;
-        if (ln < 15) {
-            if (!reuse) { dgv = fmin(fmax(T.M[ln * MS + ln] * ex.sc_i * ex.sc_i, kMinDiag), kMaxDiag); dgl[i * 15 + ln] = dgv; }
-            sws[(size_t)i * SOLVE_WS + REC_GS + ln] = gl * ex.sc_i;          // original scaled gradient (model decrease)
-        }
-        {
-            const double qv[3] = {rdlane(ex.x_i, 3), rdlane(ex.x_i, 4), rdlane(ex.x_i, 5)};
-            const double ng[3] = {-rdlane(gl, 3), -rdlane(gl, 4), -rdlane(gl, 5)};
-            double qn[3];
-            so3_plus(qv, ng, qn);                                          // uniform: every lane, no divergence
+    // DENSE2 state that lives from the elimination to the back substitution (lane e < 30 = unknown e = entry e % 15 of frame e / 15)
+    double dcol[DENSE2 ? 30 : 1];
+    double d_x = 0.0, d_sc = 1.0, d_dg = 0.0, d_gs = 0.0;
+    bool d_cst = false;
+    if constexpr (DENSE2) {
+        // ---- the whole window as ONE dense system.  Both frames are assembled in the tile layout by the SAME code as everywhere else
+        // (asm_issue / asm_commit<0>: tangent space, constants masked, prior, the init topology's arrow folded into the coupling tile,
+        // hub sums on frame 0), then: lane e < 30 owns column e of  A = S H S + D^2 / radius  (unit pivots on constant entries), lane 30
+        // the scaled gradient, lanes 31 .. 60 the unit vectors; ONE fused Cholesky / forward substitution over 30 pivots (v_readlane
+        // broadcasts, no LDS) leaves z = L^-1 g_s in lane 30 and column m of L^-1 in lane 31 + m, so that the solution is 30 FMAs per
+        // lane: y_m = (L^-1 e_m) . z.  No Schur products, no factor record, no second sweep through memory: the chained kernel spent
+        // 39 k of its 50 k cycles per step on a two-frame window in those (tools/clk_probe_track.py).
+        STAMP(0);
+        // one memory round trip for everything the step reads: both frames' partial sums, the prior, this lane's state / scale / diagonal
+        const int e = lane < 30 ? lane : 0, ei = e / 15, ev = e % 15;
+        const AsmRegs r1 = asm_issue(c, 1, nullptr, nullptr);
+        const AsmRegs r0 = asm_issue(c, 0, nullptr, nullptr);
+        PriorRegs preg;
+        if (c.prior_on) preg = prior_issue(c, lane);
+        d_x = xw[e]; d_sc = scl[e]; d_dg = dgl[e];
+        unsigned inert = 0;
+        for (int v = 0; v < 15; ++v) inert |= var_is_const(a.mode, a.fast_mode, n, 0, v) ? (1u << v) : 0u;
+        __builtin_amdgcn_sched_barrier(0);
+        asm_commit<0>(c, 1, r1, Tiles<0>{TL.D1, TL.O1, TL.R1, TL.g1}, T.tmp);
+        STAMP(20);
+        asm_commit<0>(c, 0, r0, Tiles<0>{TL.D0, TL.O0, TL.R0, TL.g0}, T.tmp, nullptr, lane, -1, c.prior_on ? &preg : nullptr);
+        STAMP(21);
+        const double* De = ei ? TL.D1 : TL.D0;
+        const double gl = lane < 30 ? (ei ? TL.g1[ev] : TL.g0[ev]) : 0.0;         // tangent gradient entry (constants masked)
+        d_cst = lane < 30 && var_is_const(a.mode, a.fast_mode, n, ei, ev);
+        gsum = gl;
+        if (lane < 30 && !reuse) { d_dg = fmin(fmax(De[ev * 16 + ev] * d_sc * d_sc, kMinDiag), kMaxDiag); dgl[e] = d_dg; }
+        d_gs = lane < 30 ? gl * d_sc : 0.0;
+        {   // gradient max-norm |x - Plus(x, -g)| (rotation entries through so3 Plus), constants left out
             double m = fabs(gl);
-            if (ln >= 3 && ln < 6) m = fabs(ex.x_i - (ln == 3 ? qn[0] : (ln == 4 ? qn[1] : qn[2])));
-            if (ln < 15 && !cstl) gmax = fmax(gmax, m);
-        }
-        STAMP(10 + i * 8 + 2);
-        // this lane's column: scale (Jacobi), damp (LM), add the carried Schur terms.  Lane roles: j < 15 column j of
-        // the diagonal tile, 16..30 columns of O^T, 32..37 columns of R^T, 40 the gradient.
-        // (shuffles run in uniform control flow: ds_bpermute only sees data of active source lanes)
-        const double s_m = __shfl(ex.sc_m, (ln - 16) & 63, 64), s_0 = __shfl(sc0reg, (ln - 32) & 63, 64);
-        double slane = 0.0;
-        if (ln < 15) slane = ex.sc_i;
-        else if (ln >= 16 && ln < 31) slane = i >= 1 ? s_m : 0.0;
-        else if (ln >= 32 && ln < 38) slane = i >= 2 ? s_0 : 0.0;
-        else if (ln == 40) slane = 1.0;
-        // LM damping and the unit pivots of constant entries go into the carried-terms tile BEFORE the columns are read: patching
-        // col[ln] afterwards is a dynamic register index = 7 instructions per row.  (A constant entry's row / column of M and of
-        // the carried terms is zero, and the hub accumulators only exist in the init topology, which has no constants.)
-        if (ln < 15) {
-            double& cd = T.C[ln * MS + ln];
-            cd = cstl ? 1.0 : cd + dgv * inv_radius;
-        }
-        lds_sync();
-        double col[15];
-        const int lc = ln < MS ? ln : MS - 1;   // lanes beyond the last column read a valid word they never use
 #pragma unroll
-        for (int r = 0; r < 15; ++r) col[r] = T.M[r * MS + lc] * (rdlane(ex.sc_i, r) * slane) + T.C[r * MS + lc];
-        if (i == 1) {   // frame 0 is both the chain neighbour and the arrow target: fold R^T into O^T
-            const bool mg = ln >= 16 && ln < 22;
-            const int src = mg ? ln + 16 : lc;
-            const double s0 = __shfl(sc0reg, mg ? ln - 16 : 0, 64);
-#pragma unroll
-            for (int r = 0; r < 15; ++r) {
-                const double v = T.M[r * MS + src] * (rdlane(ex.sc_i, r) * s0) + T.C[r * MS + src];
-                if (mg) col[r] += v;
-                if (ln >= 32 && ln < 38) col[r] = 0.0;
+            for (int fi = 0; fi < 2; ++fi) {
+                const double qv[3] = {rdlane(d_x, 15 * fi + 3), rdlane(d_x, 15 * fi + 4), rdlane(d_x, 15 * fi + 5)};
+                const double ng[3] = {-rdlane(gl, 15 * fi + 3), -rdlane(gl, 15 * fi + 4), -rdlane(gl, 15 * fi + 5)};
+                double qn[3];
+                so3_plus(qv, ng, qn);
+                if (lane >= 15 * fi + 3 && lane < 15 * fi + 6) m = fabs(d_x - qn[lane - 15 * fi - 3]);
             }
+            if (lane < 30 && !d_cst) gmax = m;
         }
-        if (i == 0) {
-            if (ln < 6) {
-#pragma unroll
-                for (int r = 0; r < 6; ++r) col[r] += T.D0acc[r * 6 + ln];
-            }
-            if (ln == 40) {
-#pragma unroll
-                for (int r = 0; r < 6; ++r) col[r] += T.g0acc[r];
-            }
-        }
-        STAMP(10 + i * 8 + 3);
-        // software pipeline: the next frame's loads are in flight while this one is factorised
-        if constexpr (LIW_PF1) {
-        __builtin_amdgcn_sched_barrier(0);
-        if (i > 0) areg = asm_issue(c, i - 1, scl, dgl, ln);
-        if (c.prior_on && i - 1 == n - 2) preg = prior_issue(c, ln);
-        __builtin_amdgcn_sched_barrier(0);
-        }
-        // lanes 41..55 carry the unit vectors: the fused pass leaves the columns of L^-1 in them
-        if (ln >= 41 && ln < 56) {
-#pragma unroll
-            for (int r = 0; r < 15; ++r) col[r] = (r == ln - 41) ? 1.0 : 0.0;
-        }
-        if (!fused_chol_solve(col)) { solved = false; break; }
-        STAMP(10 + i * 8 + 4);
-        // MFMA operand tiles: W = L^-1 [O^T | g], Wa = L^-1 R^T, Li = L^-1
         {
-            const int toff = (ln >= 16 && ln < 31) ? LW + (ln - 16) : ((ln >= 32 && ln < 38) ? LWA + (ln - 32) : (ln == 40 ? LW + 15 : ((ln >= 41 && ln < 56) ? LLI + (ln - 41) : -1)));
-            if (toff >= 0) {
+            const double diag_add = d_cst ? 1.0 : d_dg * inv_radius;
+            const int cc = lane < 15 ? lane : (lane < 30 ? lane - 15 : 0);
+            // H[r][column of this lane]: D0 | O1 (rows: frame 0, columns: frame 1) | its transpose | D1 — per lane two bases and a stride
+            const double* const top = (lane < 15 ? TL.D0 : TL.O1) + cc;                      // rows 0 .. 14: element r at top[16 r]
+            const double* const bot = lane < 15 ? TL.O1 + cc * 16 : TL.D1 + cc;              // rows 15 .. 29: element r' at bot[bs r']
+            const int bs = lane < 15 ? 1 : 16;
+            // one formula for every lane: matrix lanes (column scale csc = own scale, diagonal term on row = lane), the gradient lane (m30),
+            // the unit-vector lanes (csc = 0, "diagonal term" 1 on row = lane - 31) — as three nested selects per row this loop was ~20
+            // instructions per row.  (Row scales by v_readlane: through LDS broadcasts the loop was slower, measured.)
+            const double csc = lane < 30 ? d_sc : 0.0, m30 = lane == 30 ? 1.0 : 0.0;
+            const int ridx = lane < 30 ? lane : lane - 31;
+            const double dadd = lane < 30 ? diag_add : (lane == 30 ? 0.0 : 1.0);
 #pragma unroll
-                for (int r = 0; r < 15; ++r) T.M[toff + r * 16] = col[r];
+            for (int r = 0; r < 30; ++r) {
+                const double sr = rdlane(d_sc, r), gr = rdlane(d_gs, r);   // (broadcasts in uniform control flow)
+                const double h = r < 15 ? top[r * 16] : bot[(r - 15) * bs];
+                dcol[r] = __builtin_fma(gr, m30, h * (sr * csc) + (ridx == r ? dadd : 0.0));
             }
         }
+        STAMP(22);
+        solved = fused_chol_solve30(dcol, inert);
+        STAMP(23);
+    } else {
+    // ---- single pass: eliminate frames n-1 .. 1, then 0, of (S H S + D^2) y = S g.
+        // Register-resident elimination: lane j < 15 owns column j of the damped diagonal tile, lanes 16..30 the columns of
+        // O^T, lanes 32..37 the columns of R^T, lane 40 the gradient.  One fused pass (fused_chol_solve) turns the matrix
+        // lanes into the rows of L and every right-hand-side lane into L^-1 b, using v_readlane broadcasts only.
+        for (int e = lane; e < 720; e += 64) { T.M[e] = 0.0; if (e < 15 * MS) T.C[e] = 0.0; }
+        if (lane < 16) T.Z[lane] = 0.0;
+        if (lane < 36) T.D0acc[lane] = 0.0;
+        if (lane < 8) T.g0acc[lane] = 0.0;
+        const double sc0reg = scl[lane < 15 ? lane : 0];           // scale of frame 0 (rows of the arrow block)
         lds_sync();
-        STAMP(10 + i * 8 + 5);
-        // Back-substitution operators of this frame, y_i = yz - Yo y_{i-1} - Yr y_0 with [Yo | Yr | yz] = D^-1 [O^T | R^T | g]
-        // = L^-T (L^-1 [..]): two more products on the matrix cores instead of a second triangular solve, so the record is
-        // 22 columns (not L + W: 37) and the second sweep is a matrix-vector product.  rec[r][22]: 0..14 Yo, 15..20 Yr, 21 yz.
-        {
-            const d4 y1 = xty15<16, 16>(T.M + LLI, T.M + LW, T.Z), y2 = xty15<16, 16>(T.M + LLI, T.M + LWA, T.Z);
-            double* f = sws + (size_t)i * SOLVE_WS;
-            const int colx = ln & 15;
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int row = (ln >> 4) + 4 * r;
-                if (row < 15) {
-                    f[row * REC_LD + (colx < 15 ? colx : 21)] = y1[r];
-                    if (colx < 6) f[row * REC_LD + 15 + colx] = y2[r];
-                }
+        STAMP(0); SPAN(0);
+        const Tiles<1> TM{T.M, nullptr, nullptr, nullptr};
+        AsmRegs areg;
+        PriorRegs preg;
+        if constexpr (LIW_PF1) areg = asm_issue(c, n - 1, scl, dgl);
+        for (int i = n - 1; i >= 0; --i) {
+            STAMP(10 + i * 8 + 0);
+            // the lane id is laundered once per frame: lane-derived addresses and masks are recomputed (a few integer ops)
+            // instead of being hoisted out of the loop into registers that then spill
+            int ln = lane;
+            asm volatile("" : "+v"(ln));
+            FrameExtra ex;
+            if constexpr (!LIW_PF1) areg = asm_issue(c, i, scl, dgl, ln);
+            asm_commit<1>(c, i, areg, TM, T.tmp, &ex, ln, -1, (LIW_PF1 && c.prior_on && i == n - 2) ? &preg : nullptr);
+            STAMP(10 + i * 8 + 1);
+            // LM diagonal of this frame (LevenbergMarquardtStrategy::ComputeStep), |x - Plus(x,-g)|
+            const bool cstl = ln < 15 && var_is_const(a.mode, a.fast_mode, n, i, ln);
+            const double gl = ln < 15 ? T.M[ln * MS + 40] : 0.0;          // tangent gradient entry of this lane
+            gsum += gl;
+            double dgv = ex.dg_i;
+            if (ln < 15) {
+                if (!reuse) { dgv = fmin(fmax(T.M[ln * MS + ln] * ex.sc_i * ex.sc_i, kMinDiag), kMaxDiag); dgl[i * 15 + ln] = dgv; }
+                sws[(size_t)i * SOLVE_WS + REC_GS + ln] = gl * ex.sc_i;          // original scaled gradient (model decrease)
             }
-        }
-        d4 p1 = {0.0, 0.0, 0.0, 0.0}, p2 = p1, p3 = p1;
-        if (i >= 1) {   // Schur products on the matrix cores
-            p1 = xty15<16, 16>(T.M + LW, T.M + LW, T.Z);      // [Wo|z]^T [Wo|z]
-            p2 = xty15<16, 16>(T.M + LWA, T.M + LW, T.Z);     // Wr^T [Wo|z]   (rows < 6)
-            p3 = xty15<16, 16>(T.M + LWA, T.M + LWA, T.Z);    // Wr^T Wr       (rows, cols < 6)
-        }
-        if (i >= 1) {
-            // written back in the lane layout of the next frame
-            lds_sync();
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int row = (ln >> 4) + 4 * r, colx = ln & 15;
-                if (row < 15) T.C[row * MS + (colx < 15 ? colx : 40)] = -p1[r];      // diagonal tile (+ gradient, column 15 -> lane 40) of frame i-1
-                if (row < 6 && colx < 15) T.C[colx * MS + 32 + row] = -p2[r];        // arrow block H[0, i-1] (as R^T)
-                if (i >= 2) {
-                    if (row < 6 && colx == 15) T.g0acc[row] -= p2[r];
-                    if (row < 6 && colx < 6) T.D0acc[row * 6 + colx] -= p3[r];
-                }
+            {
+                const double qv[3] = {rdlane(ex.x_i, 3), rdlane(ex.x_i, 4), rdlane(ex.x_i, 5)};
+                const double ng[3] = {-rdlane(gl, 3), -rdlane(gl, 4), -rdlane(gl, 5)};
+                double qn[3];
+                so3_plus(qv, ng, qn);                                          // uniform: every lane, no divergence
+                double m = fabs(gl);
+                if (ln >= 3 && ln < 6) m = fabs(ex.x_i - (ln == 3 ? qn[0] : (ln == 4 ? qn[1] : qn[2])));
+                if (ln < 15 && !cstl) gmax = fmax(gmax, m);
+            }
+            STAMP(10 + i * 8 + 2);
+            // this lane's column: scale (Jacobi), damp (LM), add the carried Schur terms.  Lane roles: j < 15 column j of
+            // the diagonal tile, 16..30 columns of O^T, 32..37 columns of R^T, 40 the gradient.
+            // (shuffles run in uniform control flow: ds_bpermute only sees data of active source lanes)
+            const double s_m = __shfl(ex.sc_m, (ln - 16) & 63, 64), s_0 = __shfl(sc0reg, (ln - 32) & 63, 64);
+            double slane = 0.0;
+            if (ln < 15) slane = ex.sc_i;
+            else if (ln >= 16 && ln < 31) slane = i >= 1 ? s_m : 0.0;
+            else if (ln >= 32 && ln < 38) slane = i >= 2 ? s_0 : 0.0;
+            else if (ln == 40) slane = 1.0;
+            // LM damping and the unit pivots of constant entries go into the carried-terms tile BEFORE the columns are read: patching
+            // col[ln] afterwards is a dynamic register index = 7 instructions per row.  (A constant entry's row / column of M and of
+            // the carried terms is zero, and the hub accumulators only exist in the init topology, which has no constants.)
+            if (ln < 15) {
+                double& cd = T.C[ln * MS + ln];
+                cd = cstl ? 1.0 : cd + dgv * inv_radius;
             }
             lds_sync();
+            double col[15];
+            const int lc = ln < MS ? ln : MS - 1;   // lanes beyond the last column read a valid word they never use
+#pragma unroll
+            for (int r = 0; r < 15; ++r) col[r] = T.M[r * MS + lc] * (rdlane(ex.sc_i, r) * slane) + T.C[r * MS + lc];
+            if (i == 1) {   // frame 0 is both the chain neighbour and the arrow target: fold R^T into O^T
+                const bool mg = ln >= 16 && ln < 22;
+                const int src = mg ? ln + 16 : lc;
+                const double s0 = __shfl(sc0reg, mg ? ln - 16 : 0, 64);
+#pragma unroll
+                for (int r = 0; r < 15; ++r) {
+                    const double v = T.M[r * MS + src] * (rdlane(ex.sc_i, r) * s0) + T.C[r * MS + src];
+                    if (mg) col[r] += v;
+                    if (ln >= 32 && ln < 38) col[r] = 0.0;
+                }
+            }
+            if (i == 0) {
+                if (ln < 6) {
+#pragma unroll
+                    for (int r = 0; r < 6; ++r) col[r] += T.D0acc[r * 6 + ln];
+                }
+                if (ln == 40) {
+#pragma unroll
+                    for (int r = 0; r < 6; ++r) col[r] += T.g0acc[r];
+                }
+            }
+            STAMP(10 + i * 8 + 3);
+            // software pipeline: the next frame's loads are in flight while this one is factorised
+            if constexpr (LIW_PF1) {
+            __builtin_amdgcn_sched_barrier(0);
+            if (i > 0) areg = asm_issue(c, i - 1, scl, dgl, ln);
+            if (c.prior_on && i - 1 == n - 2) preg = prior_issue(c, ln);
+            __builtin_amdgcn_sched_barrier(0);
+            }
+            // lanes 41..55 carry the unit vectors: the fused pass leaves the columns of L^-1 in them
+            if (ln >= 41 && ln < 56) {
+#pragma unroll
+                for (int r = 0; r < 15; ++r) col[r] = (r == ln - 41) ? 1.0 : 0.0;
+            }
+            if (!fused_chol_solve(col)) { solved = false; break; }
+            STAMP(10 + i * 8 + 4);
+            // MFMA operand tiles: W = L^-1 [O^T | g], Wa = L^-1 R^T, Li = L^-1
+            {
+                const int toff = (ln >= 16 && ln < 31) ? LW + (ln - 16) : ((ln >= 32 && ln < 38) ? LWA + (ln - 32) : (ln == 40 ? LW + 15 : ((ln >= 41 && ln < 56) ? LLI + (ln - 41) : -1)));
+                if (toff >= 0) {
+#pragma unroll
+                    for (int r = 0; r < 15; ++r) T.M[toff + r * 16] = col[r];
+                }
+            }
+            lds_sync();
+            STAMP(10 + i * 8 + 5);
+            // Back-substitution operators of this frame, y_i = yz - Yo y_{i-1} - Yr y_0 with [Yo | Yr | yz] = D^-1 [O^T | R^T | g]
+            // = L^-T (L^-1 [..]): two more products on the matrix cores instead of a second triangular solve, so the record is
+            // 22 columns (not L + W: 37) and the second sweep is a matrix-vector product.  rec[r][22]: 0..14 Yo, 15..20 Yr, 21 yz.
+            {
+                const d4 y1 = xty15<16, 16>(T.M + LLI, T.M + LW, T.Z), y2 = xty15<16, 16>(T.M + LLI, T.M + LWA, T.Z);
+                double* f = sws + (size_t)i * SOLVE_WS;
+                const int colx = ln & 15;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int row = (ln >> 4) + 4 * r;
+                    if (row < 15) {
+                        f[row * REC_LD + (colx < 15 ? colx : 21)] = y1[r];
+                        if (colx < 6) f[row * REC_LD + 15 + colx] = y2[r];
+                    }
+                }
+            }
+            d4 p1 = {0.0, 0.0, 0.0, 0.0}, p2 = p1, p3 = p1;
+            if (i >= 1) {   // Schur products on the matrix cores
+                p1 = xty15<16, 16>(T.M + LW, T.M + LW, T.Z);      // [Wo|z]^T [Wo|z]
+                p2 = xty15<16, 16>(T.M + LWA, T.M + LW, T.Z);     // Wr^T [Wo|z]   (rows < 6)
+                p3 = xty15<16, 16>(T.M + LWA, T.M + LWA, T.Z);    // Wr^T Wr       (rows, cols < 6)
+            }
+            if (i >= 1) {
+                // written back in the lane layout of the next frame
+                lds_sync();
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int row = (ln >> 4) + 4 * r, colx = ln & 15;
+                    if (row < 15) T.C[row * MS + (colx < 15 ? colx : 40)] = -p1[r];      // diagonal tile (+ gradient, column 15 -> lane 40) of frame i-1
+                    if (row < 6 && colx < 15) T.C[colx * MS + 32 + row] = -p2[r];        // arrow block H[0, i-1] (as R^T)
+                    if (i >= 2) {
+                        if (row < 6 && colx == 15) T.g0acc[row] -= p2[r];
+                        if (row < 6 && colx < 6) T.D0acc[row * 6 + colx] -= p3[r];
+                    }
+                }
+                lds_sync();
+            }
         }
     }
     STAMP(1);
@@ -821,6 +923,32 @@ __device__ __forceinline__ void lm_step_body(const StepArgs& a, const int b, Lds
     wave_mem_sync();   // factor records (global) written above are read by other lanes below
     STAMP(4005);
     if (solved) {
+      if constexpr (DENSE2) {
+        // y = L^-T z: lane 31 + m holds column m of L^-1, lane 30 holds z
+        double yv = 0.0;
+#pragma unroll
+        for (int k = 0; k < 30; ++k) yv = __builtin_fma(dcol[k], rdlane(dcol[k], 30), yv);
+        const double t = __shfl(yv, (lane + 31) & 63, 64);                      // unknown e's solution into lane e
+        const bool lv = lane < 30;
+        const double del = (lv && !d_cst) ? -t * d_sc : 0.0;
+        double xnew = d_x + del;
+#pragma unroll
+        for (int fi = 0; fi < 2; ++fi) {                                         // so3 Plus on the rotation entries of both frames
+            const double qv[3] = {rdlane(d_x, 15 * fi + 3), rdlane(d_x, 15 * fi + 4), rdlane(d_x, 15 * fi + 5)};
+            const double dq[3] = {rdlane(del, 15 * fi + 3), rdlane(del, 15 * fi + 4), rdlane(del, 15 * fi + 5)};
+            double qn[3];
+            so3_plus(qv, dq, qn);
+            if (lane >= 15 * fi + 3 && lane < 15 * fi + 6) xnew = var_is_const(a.mode, a.fast_mode, n, fi, 3) ? d_x : qn[lane - 15 * fi - 3];
+        }
+        double sn2 = 0.0, ytg = 0.0, dsum = 0.0;
+        if (lv) {
+            xc[lane] = xnew;
+            if (!d_cst) { sn2 = (d_x - xnew) * (d_x - xnew); ytg = t * d_gs; dsum = d_dg * inv_radius * t * t; }
+        }
+        step_norm = sqrt(wave_sum(sn2));
+        model_cost_change = 0.5 * (wave_sum(ytg) + wave_sum(dsum));
+        valid = model_cost_change > 0.0 && isfinite(model_cost_change);
+      } else {
         // ---- back substitution, frame 0 first.  Lane r owns unknown r: row r of Yo / Yr.
         double ytg = 0.0, dsum = 0.0, sn2 = 0.0;
         double yprev = 0.0, y0v = 0.0;   // lane r < 15: y_{i-1}[r], y_0[r]
@@ -900,6 +1028,7 @@ __device__ __forceinline__ void lm_step_body(const StepArgs& a, const int b, Lds
         // model cost change -(s'g_s + s'A s/2) with s = -y and (A + D^2) y = g_s  ==  (y'g_s + y'D^2 y)/2
         model_cost_change = 0.5 * (wave_sum(ytg) + wave_sum(dsum));
         valid = model_cost_change > 0.0 && isfinite(model_cost_change);
+      }
     }
     // max_num_consecutive_invalid_steps reached: FAILURE, which hands back the states the solve started from
     const bool fail5 = !valid && st.invalid_steps + 1 >= 5;
@@ -929,6 +1058,13 @@ __global__ __launch_bounds__(64, 2) void k_lm_step(StepArgs a) {
     __shared__ LdsStep T;
     if ((int)blockIdx.x >= a.B) return;
     lm_step_body<THROUGHPUT>(a, (int)blockIdx.x, T);
+}
+
+// The two-frame window as one dense system (lm_step_body<.., DENSE2>): the steady-state tracking frame of the reference's front end.
+__global__ __launch_bounds__(64, 1) void k_lm_step_dense2(StepArgs a) {
+    __shared__ LdsDense2 T;
+    if ((int)blockIdx.x >= a.B) return;
+    lm_step_body<false, true, LdsDense2>(a, (int)blockIdx.x, T);
 }
 
 // ---------------------------------------------------------------------------------------------------
@@ -1828,7 +1964,7 @@ void launch_lm_begin(int B, int n, LmState* lm, int max_iters, hipStream_t s) {
     hipLaunchKernelGGL(k_lm_begin, dim3((B + 63) / 64), dim3(64), 0, s, B, n, lm, max_iters);
 }
 void launch_lm_step(const StepArgs& a, hipStream_t s) {
-    // LIW_STEP_VARIANT (read per launch) 0 / 1 / 2 / 3: force the one-wave latency / one-wave throughput / four-wave / quad variant (profiling, tests)
+    // LIW_STEP_VARIANT (read per launch) 0 / 1 / 2 / 3 / 4: force the one-wave latency / one-wave throughput / four-wave / quad / dense two-frame variant (profiling, tests)
     const char* env = getenv("LIW_STEP_VARIANT");
     const bool tp = env ? env[0] == '1' : a.B > 2048;
     // two waves per window while that does not take CUs away from other windows, and the chain is long enough to be worth cutting
@@ -1843,7 +1979,10 @@ void launch_lm_step(const StepArgs& a, hipStream_t s) {
         hipLaunchKernelGGL(k_lm_step<true>, dim3(a.B), dim3(64), 0, s, a2);
         return;
     }
-    if (tw) hipLaunchKernelGGL(k_lm_step_tw, dim3(a.B), dim3(256), 0, s, a);
+    // a two-frame window (what the reference's tracking loop solves every laser frame) is ONE dense 30 x 30 system; variant 4 forces it
+    const bool dense2 = a.n == 2 && (env ? env[0] == '4' : true);
+    if (dense2) hipLaunchKernelGGL(k_lm_step_dense2, dim3(a.B), dim3(64), 0, s, a);
+    else if (tw) hipLaunchKernelGGL(k_lm_step_tw, dim3(a.B), dim3(256), 0, s, a);
     else if (tp) hipLaunchKernelGGL(k_lm_step<true>, dim3(a.B), dim3(64), 0, s, a);
     else hipLaunchKernelGGL(k_lm_step<false>, dim3(a.B), dim3(64), 0, s, a);
 }

@@ -378,6 +378,7 @@ def main():
     ap.add_argument("--gate-windows", type=int, default=4, help="windows of the timed batch whose results are checked against the oracle (parity gate)")
     ap.add_argument("--cpu-procs", type=int, default=64, help="processes of the all-cores CPU baseline leg (capped at the core count)")
     ap.add_argument("--skip-sharded", action="store_true")
+    ap.add_argument("--sharded-windows", type=int, default=256, help="windows of the factor-sharded C4 section (256; tests of the 8-rank control flow on one GPU use fewer)")
     ap.add_argument("--converging-scale", type=float, default=0.1, help="initial state error of the `converging_c2` side measurement, as a fraction of the C2 perturbation")
     ap.add_argument("--no-single", action="store_true", help="skip the B=1 latency measurement (clean per-kernel profiles)")
     ap.add_argument("--record-md", default=None, help="after the timed region, write a reference-shaped `record` table (labels "
@@ -865,7 +866,7 @@ def main():
     sharded = None
     if not args.skip_sharded:
         try:
-            Bs, Ls, Ks = 256, 20000, 10
+            Bs, Ls, Ks = args.sharded_windows, 20000, 10
             hp = liw.HostPreint(prm)
             wfull = [synth.make_window(hp, prm, seed=4242 + k, n=n, L=Ls) for k in range(2)]   # same seeds on every rank
             tile_s = dict(B=Bs, states=np.stack([np.asarray(wfull[k % 2]["states"], dtype=np.float64).reshape(n, 15) for k in range(Bs)]),

@@ -87,7 +87,8 @@ def test_eight_rank_control_flow_on_one_gpu():
     env = dict(os.environ, LIW_BENCH_SHARE_GPU="1")
     for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
         env.pop(k, None)
-    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "8", "--batch", "512", "--steps", "1", "--warmup", "0", "--distinct", "4"],
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "8", "--batch", "512", "--steps", "1", "--warmup", "0", "--distinct", "4",
+                        "--sharded-windows", "32"],
                        capture_output=True, cwd=ROOT, env=env, timeout=1500)
     assert r.returncode == 0, r.stderr.decode()[-2000:]
     d = last_json(r.stdout)

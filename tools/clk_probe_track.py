@@ -45,6 +45,8 @@ d = lambda a, b: int(clk[b] - clk[a])
 print("iterations", sg["iterations"])
 print("k_lm_step: entry->cost %d | accept %d | barrier %d | to-sweep %d | sweep1 %d | term-check %d | barrier %d | sweep2 %d | tail %d | total %d"
       % (d(4000, 4001), d(4001, 4002), d(4002, 4003), d(4003, 0), d(0, 1), d(1, 4004), d(4004, 4005), d(4005, 3), d(3, 4006), d(4000, 4006)))
+if clk[21] > clk[0] > 0:   # dense two-frame step (k_lm_step_dense2)
+    print(" dense2: assemble frame 1 %d | frame 0 %d | entries + columns %d | chol30 %d | checks %d | solve + candidate %d" % (d(0, 20), d(20, 21), d(21, 22), d(22, 23), d(23, 4004), d(4005, 4006)))
 for i in (1, 0):
     t = clk[10 + i * 8:10 + i * 8 + 6]
     print(" frame", i, "assemble", t[1] - t[0], "diag/gmax", t[2] - t[1], "colload", t[3] - t[2], "chol", t[4] - t[3], "ldsW", t[5] - t[4],
