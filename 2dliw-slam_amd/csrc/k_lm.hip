@@ -1674,22 +1674,23 @@ __device__ __forceinline__ bool marg_chain(const MargArgs& a, const int b, TILES
         __builtin_amdgcn_sched_barrier(0);
         if (i + 2 < n) areg = asm_issue(c, i + 2, nullptr, nullptr);
         __builtin_amdgcn_sched_barrier(0);
+        // this lane's column as the sum of two strided LDS reads (matrix lanes: D + carried term; coupling lanes: O + a word of the arrow
+        // tile R, which is all zeros in this topology; gradient lane: g + carried gradient, stride 1) — written as a chain of lane tests the
+        // loop was five reads and a nest of selects per row
         double col[15];
+        {
+            const bool ml_ = lane < 15, ol_ = lane >= 16 && lane < 31, gl_ = lane == 40;
+            const double* pA = ml_ ? Dc + lane : (ol_ ? T.O + (lane - 16) : (gl_ ? gc : T.R));
+            const double* pB = ml_ ? T.CD + lane : (gl_ ? T.Cg : T.R);
+            const int st = gl_ ? 1 : 16;
 #pragma unroll
-        for (int r = 0; r < 15; ++r) {
-            double v = 0.0;
-            if (lane < 15) v = Dc[r * 16 + lane] + T.CD[r * 16 + lane];
-            else if (lane >= 16 && lane < 31) v = T.O[r * 16 + (lane - 16)];
-            else if (lane == 40) v = gc[r] + T.Cg[r];
-            col[r] = v;
+            for (int r = 0; r < 15; ++r) col[r] = pA[r * st] + pB[r * st];
         }
         if (!fused_chol_solve(col)) { ok = false; break; }
-        if (lane >= 16 && lane < 31) {
+        if ((lane >= 16 && lane < 31) || lane == 40) {
+            double* const wc = T.W + (lane == 40 ? 15 : lane - 16);
 #pragma unroll
-            for (int r = 0; r < 15; ++r) T.W[r * 16 + (lane - 16)] = col[r];
-        } else if (lane == 40) {
-#pragma unroll
-            for (int r = 0; r < 15; ++r) T.W[r * 16 + 15] = col[r];
+            for (int r = 0; r < 15; ++r) wc[r * 16] = col[r];
         }
         lds_sync();
         const d4 p1 = xty16(T.W, T.W);           // [W | z]^T [W | z]: Schur terms for D_{i+1} and g_{i+1}

@@ -1,3 +1,4 @@
+"""Phase stamps (s_memtime) of k_lm_step on C2 windows of a batch (LIW_CLK=1 build: 2dliw-slam_amd/build.py): python tools/clk_probe.py [B]"""
 import importlib, sys, ctypes as C
 sys.path.insert(0,'/root/repo')
 import numpy as np, torch
