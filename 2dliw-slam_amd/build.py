@@ -15,6 +15,8 @@ if os.environ.get("LIW_SMALL_OCC"):   # A/B aid: waves per SIMD k_lin_small is c
     FLAGS.append("-DLIW_SMALL_OCC=" + os.environ["LIW_SMALL_OCC"])
 if os.environ.get("LIW_QUAD_BSD"):   # second-sweep staging depth of the quad step kernel (2 / 3)
     FLAGS.append("-DLIW_QUAD_BSD=" + os.environ["LIW_QUAD_BSD"])
+if os.environ.get("LIW_SLAB_ROWS"):   # A/B aid: rows of end points in flight per wave of k_lin_laser_slab (2 / 3 / 4)
+    FLAGS.append("-DLIW_SLAB_ROWS=" + os.environ["LIW_SLAB_ROWS"])
 if os.environ.get("LIW_MARG_OCC"):   # A/B aid: waves per SIMD k_marg_schur (one wave per window) is compiled for
     FLAGS.append("-DLIW_MARG_OCC=" + os.environ["LIW_MARG_OCC"])
 if os.environ.get("LIW_QUAD_TILE_ALIAS"):

@@ -83,14 +83,19 @@ constexpr int ROWD = 8 * SLAB;        // doubles per packed row
 
 }  // namespace
 
-// One wave per SIMD with the whole 512-entry register file (256 + 74): 45 accumulators and FIVE rows of end points in flight (four rows
-// = 16 KiB per wave ahead of the arithmetic); the two transform records live in LDS, [entry][lane], and are re-read per block (in registers
-// they sat in the accumulation half of the file at one v_accvgpr_read per use).  Measured on 24 576 C2 windows (tools/ktimes.py,
-// tools/slab_pmc.sh): 1.16 ms against 1.68 ms for k_lin_laser; a wave issues ~350 VALU instructions per row of 64 blocks where k_lin_laser issues ~1 000
-// per 64-block chunk, and the one wave of a SIMD issues VALU work in 52 % of its cycles.
-// What did not help (each built and timed): a <= 256-register build for two waves per SIMD (it spills the rows in flight: 1.56 ms), blocks
-// taken in pairs or as branch-free straight-line code for more instruction-level parallelism (register pressure: 1.23 ms / spills).
-__global__ __launch_bounds__(64, 1) void k_lin_laser_slab(LinArgs A, DevParams P) {
+// TWO waves per SIMD, eight per CU (round 5; one wave with the whole 512-entry register file until then: 256 + 74 registers, 24.5 kB of LDS).
+// What made the <= 256-register build possible is not fewer values but shorter live ranges: left alone, the scheduler interleaves the
+// phases of a block (transforms, line direction, the two residual rows, 90 pair products) and the blocks of the unrolled loop for
+// instruction-level parallelism and needs ~370 registers (113 spilled at a 256 budget: 1.56 ms per 24 576 windows in round 4);
+// __builtin_amdgcn_sched_barrier(0) between the phases and between the blocks keeps the order written here: 250 registers, no scratch, with
+// 45 accumulators and TWO rows of end points in flight (the second wave of the SIMD covers the load latency that five rows in flight
+// covered before; three rows: 6 spills, same time; four: 29 spills, 1.5x slower).  LDS: 20 of a transform record's 24 entries per pose,
+// [entry][lane], re-read per block (40 ds_read_b64); the 2 x 2 matrices M of both poses stay in registers: 20 kB per wave.
+// Measured per 49 152 C2 windows (tools/ktimes.py): 2.26 -> 1.94 ms (1.87 on a faster box of the pool); a block is ~360 fp64 instructions
+// (ISA count; 289 by hand), i.e. the two waves keep the SIMD's fp64 pipe ~55 % busy.
+// What did not help (each built and timed in round 4): blocks taken in pairs or as branch-free straight-line code for more instruction-level
+// parallelism (register pressure: 1.23 ms / spills).
+__global__ __launch_bounds__(64, 2) void k_lin_laser_slab(LinArgs A, DevParams P) {
     const int lane = threadIdx.x & 63, n = A.n;
     const int s = (int)blockIdx.x / n, f = (int)blockIdx.x % n;
     const int b = s * SLAB + lane;
@@ -106,9 +111,10 @@ __global__ __launch_bounds__(64, 1) void k_lin_laser_slab(LinArgs A, DevParams P
     for (int o = 32; o > 0; o >>= 1) maxc = max(maxc, __shfl_xor(maxc, o, 64));
     maxc = __builtin_amdgcn_readfirstlane(maxc);
     const int psel = (in && A.lm) ? (A.candidate ? 1 - A.lm[bb].cur : A.lm[bb].cur) : 0;
-    // transform records of pose a (frame 0 of the lane's window) and pose b (frame f): [entry][lane] in LDS, re-read per block — in
-    // registers they ended up in the accumulation half of the file and cost a v_accvgpr_read per use (96 of a block's ~670 instructions)
-    __shared__ double lta[TF2 * SLAB], ltb[TF2 * SLAB];
+    // transform records of pose a (frame 0 of the lane's window) and pose b (frame f): [entry][lane] in LDS, re-read per block
+    constexpr int TFR = 4;                       // the first TFR entries of a record (M) stay in registers: 2 x 20 x 64 doubles of LDS = 20 kB per wave, eight waves per CU
+    __shared__ double lta[(TF2 - TFR) * SLAB], ltb[(TF2 - TFR) * SLAB];
+    double ra[TFR], rb[TFR];
     {
         double t2[TF2];
         if (in && maxc > 0) frame_tf2(P, A.x + (size_t)bb * n * 15, t2);
@@ -117,10 +123,10 @@ __global__ __launch_bounds__(64, 1) void k_lin_laser_slab(LinArgs A, DevParams P
             for (int k = 0; k < TF2; ++k) t2[k] = 0.0;
         }
 #pragma unroll
-        for (int k = 0; k < TF2; ++k) lta[k * SLAB + lane] = t2[k];
+        for (int k = 0; k < TF2; ++k) { if (k < TFR) ra[k] = t2[k]; else lta[(k - TFR) * SLAB + lane] = t2[k]; }
         if (in && maxc > 0) frame_tf2(P, A.x + ((size_t)bb * n + f) * 15, t2);
 #pragma unroll
-        for (int k = 0; k < TF2; ++k) ltb[k * SLAB + lane] = t2[k];
+        for (int k = 0; k < TF2; ++k) { if (k < TFR) rb[k] = t2[k]; else ltb[(k - TFR) * SLAB + lane] = t2[k]; }
     }
     lds_sync();
     double acc[45];
@@ -133,8 +139,8 @@ __global__ __launch_bounds__(64, 1) void k_lin_laser_slab(LinArgs A, DevParams P
         for (int c = 0; c < 8; ++c) q[c] = r[c * SLAB];
     };
     const double w0 = P.laser_sqrt_info;
-#define TA(k) lta[(k) * SLAB + lane]
-#define TB(k) ltb[(k) * SLAB + lane]
+#define TA(k) ((k) < TFR ? ra[(k) < TFR ? (k) : 0] : lta[((k) < TFR ? 0 : (k) - TFR) * SLAB + lane])
+#define TB(k) ((k) < TFR ? rb[(k) < TFR ? (k) : 0] : ltb[((k) < TFR ? 0 : (k) - TFR) * SLAB + lane])
     auto block = [&](const double* p) {     // one laser_factor block (k_lin_laser_body.inc, 2-D, both poses free): rows + pair products
         const double d1x = p[0] - p[2], d1y = p[1] - p[3];
         const double d2x = p[4] - p[6], d2y = p[5] - p[7];
@@ -149,6 +155,7 @@ __global__ __launch_bounds__(64, 1) void k_lin_laser_slab(LinArgs A, DevParams P
             C[0][r] = TB(4 + r) + TB(r * 2) * p[4] + TB(r * 2 + 1) * p[5];
             C[1][r] = TB(4 + r) + TB(r * 2) * p[6] + TB(r * 2 + 1) * p[7];
         }
+        __builtin_amdgcn_sched_barrier(0);
         const double ux = Bp[0] - Ap[0], uy = Bp[1] - Ap[1];
         const double zz = ux * ux + uy * uy;
         const bool regular = zz > 0.0;
@@ -169,8 +176,10 @@ __global__ __launch_bounds__(64, 1) void k_lin_laser_slab(LinArgs A, DevParams P
             dly[k] = (duy - ly * pr) * rlen;
         }
         const double w = sum * w0;
+        __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int k = 0; k < 2; ++k) {
+            __builtin_amdgcn_sched_barrier(0);
             const double pt0 = p[4 + 2 * k], pt1 = p[5 + 2 * k];
             const double ex = C[k][0] - Bp[0], ey = C[k][1] - Bp[1];
             double dCx[3], dCy[3];
@@ -205,6 +214,7 @@ __global__ __launch_bounds__(64, 1) void k_lin_laser_slab(LinArgs A, DevParams P
                     jc[5 + m] = nx * dCx[m] + ny * dCy[m];
                 }
             }
+            __builtin_amdgcn_sched_barrier(0);
             double rw[9];
 #pragma unroll
             for (int c = 0; c < 8; ++c) rw[c] = ws * jc[c];
@@ -215,26 +225,64 @@ __global__ __launch_bounds__(64, 1) void k_lin_laser_slab(LinArgs A, DevParams P
                 for (int c2 = c1; c2 < 9; ++c2) acc[c1 * 9 - c1 * (c1 - 1) / 2 + (c2 - c1)] += rw[c1] * rw[c2];
         }
     };
-    // rows four ahead in flight (five register sets in rotation).  The loads are UNCONDITIONAL (row index clamped to the slab's last row):
+    // rows in flight: LIW_SLAB_ROWS register sets in rotation.  The loads are UNCONDITIONAL (row index clamped to the slab's last row):
     // behind a branch the compiler can no longer count them and waits for every outstanding load before each block
-    double q0[8], q1[8], q2[8], q3[8], q4[8];
+#ifndef LIW_SLAB_ROWS
+#define LIW_SLAB_ROWS 2
+#endif
     const int last = maxc - 1;
+#if LIW_SLAB_ROWS == 2
+    double q0[8], q1[8];
     if (maxc > 0) {
-        load_row(q0, 0); load_row(q1, min(1, last)); load_row(q2, min(2, last)); load_row(q3, min(3, last));
-        for (int j = 0; j < maxc; j += 5) {
+        load_row(q0, 0);
+        for (int j = 0; j < maxc; j += 2) {
             asm volatile("" ::: "memory");
-            load_row(q4, min(j + 4, last));
+            load_row(q1, min(j + 1, last));
             if (j < cnt) block(q0);
-            load_row(q0, min(j + 5, last));
+            __builtin_amdgcn_sched_barrier(0);
+            load_row(q0, min(j + 2, last));
             if (j + 1 < cnt) block(q1);
-            load_row(q1, min(j + 6, last));
-            if (j + 2 < cnt) block(q2);
-            load_row(q2, min(j + 7, last));
-            if (j + 3 < cnt) block(q3);
-            load_row(q3, min(j + 8, last));
-            if (j + 4 < cnt) block(q4);
+            __builtin_amdgcn_sched_barrier(0);
         }
     }
+#elif LIW_SLAB_ROWS == 3
+    double q0[8], q1[8], q2[8];
+    if (maxc > 0) {
+        load_row(q0, 0); load_row(q1, min(1, last));
+        for (int j = 0; j < maxc; j += 3) {
+            asm volatile("" ::: "memory");
+            load_row(q2, min(j + 2, last));
+            if (j < cnt) block(q0);
+            __builtin_amdgcn_sched_barrier(0);
+            load_row(q0, min(j + 3, last));
+            if (j + 1 < cnt) block(q1);
+            __builtin_amdgcn_sched_barrier(0);
+            load_row(q1, min(j + 4, last));
+            if (j + 2 < cnt) block(q2);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    }
+#else
+    double q0[8], q1[8], q2[8], q3[8];
+    if (maxc > 0) {
+        load_row(q0, 0); load_row(q1, min(1, last)); load_row(q2, min(2, last));
+        for (int j = 0; j < maxc; j += 4) {
+            asm volatile("" ::: "memory");
+            load_row(q3, min(j + 3, last));
+            if (j < cnt) block(q0);
+            __builtin_amdgcn_sched_barrier(0);
+            load_row(q0, min(j + 4, last));
+            if (j + 1 < cnt) block(q1);
+            __builtin_amdgcn_sched_barrier(0);
+            load_row(q1, min(j + 5, last));
+            if (j + 2 < cnt) block(q2);
+            __builtin_amdgcn_sched_barrier(0);
+            load_row(q2, min(j + 6, last));
+            if (j + 3 < cnt) block(q3);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    }
+#endif
 #undef TA
 #undef TB
     if (in) {
