@@ -14,4 +14,5 @@ clk = np.zeros(512, dtype=np.int64)
 liw.lib().liw_debug_clk_lin(clk.ctypes.data_as(C.c_void_p), C.c_int(512))
 c = clk
 print('imu wave: alpha/beta rows', c[302] - c[300], ' gamma rows', c[303] - c[302], ' sync + codes + first sqrt_info group', c[305] - c[303])
-print('   matrix-core groups (7 blocks each):', c[306] - c[305], c[307] - c[306], c[311] - c[307], ' total', c[311] - c[300])
+g = [int(c[305 + k]) for k in range(7) if c[305 + k] > 0]
+print('   matrix-core groups (k_lin_imu: 7 blocks each; k_lin_imu_chain: 4):', [g[k + 1] - g[k] for k in range(len(g) - 1)], ' last group + tail', int(c[311]) - g[-1], ' total', int(c[311] - c[300]))
