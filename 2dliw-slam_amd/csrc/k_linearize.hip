@@ -349,6 +349,16 @@ __device__ __forceinline__ void imu_blocks(const LinArgs& A, const DevParams& P,
     }
     const unsigned long long onmask = __ballot(on);           // lane LPB q = block q is live (in range, window still iterating)
     d4 chain11 = {0.0, 0.0, 0.0, 0.0};                         // CHAIN: the jj tile of the block before (zero in front of a window's first block)
+    // CHAIN: staging offsets of this lane's accumulator entries (row = mk + 4 r, column ml): ij | g_j image at row * 15 + ml (row 15 = the
+    // gradient row g_j at 225 + ml), diagonal image at the packed-triangle index (column 15 = g_i at 120 + row); no word: the spare one
+    constexpr int IMU_SPARE = 242;                             // (a pad word of the 244-double staging area)
+    int so_ij[4], so_d[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const int row = mk + 4 * r;
+        so_ij[r] = ml < 15 ? row * 15 + ml : IMU_SPARE;        // (row <= 15)
+        so_d[r] = row < 15 ? (ml == 15 ? 120 + row : (ml >= row ? row * 15 - (row * (row - 1)) / 2 + (ml - row) : IMU_SPARE)) : IMU_SPARE;
+    }
     if constexpr (ND == 3) {
 #pragma unroll
         for (int q = 0; q < GRP; ++q) load_sop(q, sop[q]);
@@ -408,21 +418,16 @@ __device__ __forceinline__ void imu_blocks(const LinArgs& A, const DevParams& P,
                     for (int e = 2 * lane; e < nd; e += 128) *reinterpret_cast<dbl2*>(dst + e) = *reinterpret_cast<const dbl2*>(img + e);
                     lds_sync();
                 };
+                // staging writes are UNCONDITIONAL: every lane's four (tile row group -> staging word) offsets are constants of the wave
+                // (so_ij / so_d below, built once), lanes without a word of theirs write a spare word.  As `if (row < 15 && ml < 15 ...)` each of the
+                // ~20 writes of a block sat under its own exec mask: ~150 scalar mask / branch instructions per block (round 5, ISA count)
 #pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const int row = mk + 4 * r;
-                    if (row < 15 && ml < 15) img[row * 15 + ml] = g01[r];
-                    if (r == 3 && row == 15 && ml < 15) img[225 + ml] = g01[r];
-                }
+                for (int r = 0; r < 4; ++r) img[so_ij[r]] = g01[r];
                 flush(rf + PIFS + PIF_IJ, 240);
                 static_assert(PIF_GJ == PIF_IJ + 225 && PIF_IJ % 2 == 0 && PIFS % 2 == 0 && PIF_GI % 2 == 0, "staged ranges");
                 auto diag_out = [&](const d4& gd, double* rec, bool with_gi) {   // upper triangle of a diagonal tile -> slots 0 .. 119, its column 15 -> g_i
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) {
-                        const int row = mk + 4 * r;
-                        if (row < 15 && ml < 15 && ml >= row) img[row * 15 - (row * (row - 1)) / 2 + (ml - row)] = gd[r];
-                        if (row < 15 && ml == 15) img[120 + row] = with_gi ? gd[r] : 0.0;
-                    }
+                    for (int r = 0; r < 4; ++r) img[so_d[r]] = (ml == 15 && !with_gi) ? 0.0 : gd[r];
                     lds_sync();
                     if (lane < 60) *reinterpret_cast<dbl2*>(rec + PIF_D + 2 * lane) = *reinterpret_cast<const dbl2*>(img + 2 * lane);
                     if (lane < 15) rec[PIF_GI + lane] = img[120 + lane];
