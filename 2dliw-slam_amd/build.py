@@ -19,6 +19,8 @@ if os.environ.get("LIW_SLAB_ROWS"):   # A/B aid: rows of end points in flight pe
     FLAGS.append("-DLIW_SLAB_ROWS=" + os.environ["LIW_SLAB_ROWS"])
 if os.environ.get("LIW_MARG_OCC"):   # A/B aid: waves per SIMD k_marg_schur (one wave per window) is compiled for
     FLAGS.append("-DLIW_MARG_OCC=" + os.environ["LIW_MARG_OCC"])
+if os.environ.get("LIW_EXTRA_FLAGS"):   # A/B aid: any further -D... for a probe build (part of the source hash like every flag)
+    FLAGS += os.environ["LIW_EXTRA_FLAGS"].split()
 if os.environ.get("LIW_QUAD_TILE_ALIAS"):
     FLAGS.append("-DLIW_QUAD_TILE_ALIAS")
 if os.environ.get("LIW_CLK"):   # phase-timing build for tools/clk_probe.py

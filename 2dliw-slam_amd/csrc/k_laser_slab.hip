@@ -78,6 +78,45 @@ template <int S_> __device__ __forceinline__ void slab_store(double* out, const 
     }
 }
 
+// Epilogue (round 5, late): the 64 records of a wave lie 1 KiB x n apart, so a lane that stores its own record writes 16 bytes into 64
+// different cache lines per instruction -- 0.47 of the kernel's 1.79 ms per 49 152 C2 windows went into those partial-line writes
+// (probe build without the stores).  The records are staged through LDS instead, 32 slots of every lane at a time ([lane][32 + 2 pad]),
+// and leave as 256-byte runs: a store instruction covers four windows x 16 lanes x 16 bytes = eight full lines.
+#ifndef LIW_SLAB_NT
+#define LIW_SLAB_NT 3                 // bit 0: the packed rows are loaded, bit 1: the records stored with the nontemporal hint (both are touched once per
+#endif                                // launch; 1.67 -> 1.53 ms per 49 152 C2 windows on one box, 1.64 / 1.58 with one of the two)
+constexpr int STG = 34;               // doubles per lane of a staged chunk (32 slots + 2 of padding: conflict-free 16-byte accesses)
+template <int C_, int I_ = 0> __device__ __forceinline__ void slab_stage(double* st, const double* acc) {
+    if constexpr (I_ < 16) {
+        typedef double __attribute__((ext_vector_type(2))) dbl2;
+        dbl2 v;
+        v.x = slab_slot<32 * C_ + 2 * I_>(acc); v.y = slab_slot<32 * C_ + 2 * I_ + 1>(acc);
+        *reinterpret_cast<dbl2*>(st + 2 * I_) = v;
+        slab_stage<C_, I_ + 1>(st, acc);
+    }
+}
+template <int C_> __device__ __forceinline__ void slab_flush(double* lds, const unsigned long long* pw, const double* acc, int lane) {
+    if constexpr (C_ < 4) {
+        typedef double __attribute__((ext_vector_type(2))) dbl2;
+        lds_sync();
+        slab_stage<C_>(lds + lane * STG, acc);
+        lds_sync();
+        const int wq = lane >> 4, pc = lane & 15;
+#pragma unroll
+        for (int t = 0; t < 16; ++t) {
+            const int w = 4 * t + wq;
+            const unsigned long long p = pw[w];
+            const dbl2 v = *reinterpret_cast<const dbl2*>(lds + w * STG + 2 * pc);
+#if LIW_SLAB_NT & 2
+            if (p) __builtin_nontemporal_store(v, reinterpret_cast<dbl2*>(reinterpret_cast<double*>(p) + 32 * C_ + 2 * pc));
+#else
+            if (p) *reinterpret_cast<dbl2*>(reinterpret_cast<double*>(p) + 32 * C_ + 2 * pc) = v;
+#endif
+        }
+        slab_flush<C_ + 1>(lds, pw, acc, lane);
+    }
+}
+
 constexpr int SLAB = 64;
 constexpr int ROWD = 8 * SLAB;        // doubles per packed row
 
@@ -113,7 +152,9 @@ __global__ __launch_bounds__(64, 2) void k_lin_laser_slab(LinArgs A, DevParams P
     const int psel = (in && A.lm) ? (A.candidate ? 1 - A.lm[bb].cur : A.lm[bb].cur) : 0;
     // transform records of pose a (frame 0 of the lane's window) and pose b (frame f): [entry][lane] in LDS, re-read per block
     constexpr int TFR = 4;                       // the first TFR entries of a record (M) stay in registers: 2 x 20 x 64 doubles of LDS = 20 kB per wave, eight waves per CU
-    __shared__ double lta[(TF2 - TFR) * SLAB], ltb[(TF2 - TFR) * SLAB];
+    __shared__ double lds[2 * (TF2 - TFR) * SLAB];      // (the epilogue stages the records through the same 20 kB)
+    double* const lta = lds;
+    double* const ltb = lds + (TF2 - TFR) * SLAB;
     double ra[TFR], rb[TFR];
     {
         double t2[TF2];
@@ -134,14 +175,28 @@ __global__ __launch_bounds__(64, 2) void k_lin_laser_slab(LinArgs A, DevParams P
     for (int e = 0; e < 45; ++e) acc[e] = 0.0;
     const double* row0 = A.laser_pk + (size_t)A.laser_slab_off[(size_t)s * n + f] * ROWD + lane;
     auto load_row = [&](double* q, int j) {
+#if defined(LIW_SLAB_PROBE) && LIW_SLAB_PROBE == 1
+        const double* r = row0 + (size_t)(j & 1) * ROWD;       // probe: every load hits the slab's first two rows (cache-resident): compute-only time
+#else
         const double* r = row0 + (size_t)j * ROWD;
+#endif
 #pragma unroll
+#if LIW_SLAB_NT & 1
+        for (int c = 0; c < 8; ++c) q[c] = __builtin_nontemporal_load(r + c * SLAB);
+#else
         for (int c = 0; c < 8; ++c) q[c] = r[c * SLAB];
+#endif
     };
     const double w0 = P.laser_sqrt_info;
 #define TA(k) ((k) < TFR ? ra[(k) < TFR ? (k) : 0] : lta[((k) < TFR ? 0 : (k) - TFR) * SLAB + lane])
 #define TB(k) ((k) < TFR ? rb[(k) < TFR ? (k) : 0] : ltb[((k) < TFR ? 0 : (k) - TFR) * SLAB + lane])
     auto block = [&](const double* p) {     // one laser_factor block (k_lin_laser_body.inc, 2-D, both poses free): rows + pair products
+#if defined(LIW_SLAB_PROBE) && LIW_SLAB_PROBE == 2
+        // probe: no arithmetic, the loads only (memory-only time)
+#pragma unroll
+        for (int c = 0; c < 8; ++c) acc[c] += p[c];
+        return;
+#endif
         const double d1x = p[0] - p[2], d1y = p[1] - p[3];
         const double d2x = p[4] - p[6], d2y = p[5] - p[7];
         const double l2 = fmin(d1x * d1x + d1y * d1y, d2x * d2x + d2y * d2y);
@@ -225,6 +280,93 @@ __global__ __launch_bounds__(64, 2) void k_lin_laser_slab(LinArgs A, DevParams P
                 for (int c2 = c1; c2 < 9; ++c2) acc[c1 * 9 - c1 * (c1 - 1) / 2 + (c2 - c1)] += rw[c1] * rw[c2];
         }
     };
+#ifndef LIW_SLAB_ALG
+#define LIW_SLAB_ALG 1      // 0: every block through the general form (A/B aid)
+#endif
+#if LIW_SLAB_ALG == 1
+    // The same block with the algebra folded (round 5, late): only DIFFERENCES of mapped points enter the rows, so the reference segment's
+    // direction is M_a (B - A) (no translation, no mapped A), the whole row is scaled by the block's weight ONCE through the line
+    // direction (l_w = w l: the sign of the distance then needs no select — the pair products of a row are even in it, and the products
+    // with the residual carry w^2 J sg), the theta_b columns are affine in the point with per-block coefficients
+    // (lx dCy - ly dCx = alpha + beta x + gamma y), the theta_a columns share kappa_m = l_w x dB_m between the two points, and the
+    // reference's norm()-of-a-zero-Jet test (common.h:94) is only evaluated where |sg| is at round-off level.
+    bool irregular = false;
+    auto block_fast = [&](const double* p) {
+        const double d1x = p[0] - p[2], d1y = p[1] - p[3];
+        const double d2x = p[4] - p[6], d2y = p[5] - p[7];
+        const double l2 = fmin(d1x * d1x + d1y * d1y, d2x * d2x + d2y * d2y);
+        const double lmin25 = l2 > 0.0 ? 25.0 * (l2 * fast_rsqrt(l2)) : 0.0;
+        const double sum = lmin25 > 0.0 ? lmin25 * fast_rsqrt(lmin25) : 0.0;
+        const double w = sum * w0;
+        const double ux = -(ra[0] * d1x + ra[1] * d1y), uy = -(ra[2] * d1x + ra[3] * d1y);
+        const double zz = ux * ux + uy * uy;
+        if (__builtin_expect(!(zz > 0.0), 0)) { irregular = true; return; }      // zero-length reference segment (or NaN input): the general form, in a pass of its own behind the loop
+        const double Bx = TA(4) + ra[0] * p[2] + ra[1] * p[3], By = TA(5) + ra[2] * p[2] + ra[3] * p[3];
+        const double tbx = TB(4), tby = TB(5);
+        double ex[2], ey[2];      // C - B with both mapped points formed as the reference forms them: a point that coincides with B gives an exact zero
+#pragma unroll
+        for (int k = 0; k < 2; ++k) {
+            ex[k] = (tbx + rb[0] * p[4 + 2 * k] + rb[1] * p[5 + 2 * k]) - Bx;
+            ey[k] = (tby + rb[2] * p[4 + 2 * k] + rb[3] * p[5 + 2 * k]) - By;
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        const double rlen = fast_rsqrt(zz);
+        const double lx = ux * rlen, ly = uy * rlen;
+        const double rlw = rlen * w;
+        const double lxw = ux * rlw, lyw = uy * rlw;
+        double dlxw[3], dlyw[3], kap[3];
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            const double m0 = TA(6 + 4 * k), m1 = TA(6 + 4 * k + 1), m3 = TA(6 + 4 * k + 2), m4 = TA(6 + 4 * k + 3);
+            const double dux = -(m0 * d1x + m1 * d1y), duy = -(m3 * d1x + m4 * d1y);
+            const double pr = lx * dux + ly * duy;
+            dlxw[k] = (dux - lx * pr) * rlw;
+            dlyw[k] = (duy - ly * pr) * rlw;
+            const double dBx = TA(18 + 2 * k) + m0 * p[2] + m1 * p[3];
+            const double dBy = TA(18 + 2 * k + 1) + m3 * p[2] + m4 * p[3];
+            kap[k] = lyw * dBx - lxw * dBy;
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        double al[3], be[3], ga[3];
+#pragma unroll
+        for (int m = 0; m < 3; ++m) {
+            al[m] = lxw * TB(18 + 2 * m + 1) - lyw * TB(18 + 2 * m);
+            be[m] = lxw * TB(6 + 4 * m + 2) - lyw * TB(6 + 4 * m);
+            ga[m] = lxw * TB(6 + 4 * m + 3) - lyw * TB(6 + 4 * m + 1);
+        }
+        const double tiny = 1e-13 * w;
+#pragma unroll
+        for (int k = 0; k < 2; ++k) {
+            __builtin_amdgcn_sched_barrier(0);
+            const double pt0 = p[4 + 2 * k], pt1 = p[5 + 2 * k];
+            double rw[9];
+            rw[0] = lyw; rw[1] = -lxw;
+            rw[8] = lxw * ey[k] - lyw * ex[k];               // w sg, signed
+#pragma unroll
+            for (int m = 0; m < 3; ++m) {
+                rw[2 + m] = dlxw[m] * ey[k] - dlyw[m] * ex[k] + kap[m];
+                rw[5 + m] = al[m] + be[m] * pt0 + ga[m] * pt1;
+            }
+            if (__builtin_expect(fabs(rw[8]) <= tiny * (fabs(ex[k]) + fabs(ey[k])), 0)) {
+                // a point exactly on the line: norm() of a zero Jet in the reference (common.h:94) -> NaN derivative (k_lin_laser_body.inc)
+                const double prj = lx * ex[k] + ly * ey[k];
+                const double vx = ex[k] - prj * lx, vy = ey[k] - prj * ly;
+                if (vx * vx + vy * vy == 0.0) {
+#pragma unroll
+                    for (int c = 0; c < 8; ++c) rw[c] = __builtin_nan("");
+                }
+            }
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int c1 = 0; c1 < 9; ++c1)
+#pragma unroll
+                for (int c2 = c1; c2 < 9; ++c2) acc[c1 * 9 - c1 * (c1 - 1) / 2 + (c2 - c1)] += rw[c1] * rw[c2];
+        }
+    };
+#define LIW_SLAB_BLOCK block_fast
+#else
+#define LIW_SLAB_BLOCK block
+#endif
     // rows in flight: LIW_SLAB_ROWS register sets in rotation.  The loads are UNCONDITIONAL (row index clamped to the slab's last row):
     // behind a branch the compiler can no longer count them and waits for every outstanding load before each block
 #ifndef LIW_SLAB_ROWS
@@ -238,10 +380,10 @@ __global__ __launch_bounds__(64, 2) void k_lin_laser_slab(LinArgs A, DevParams P
         for (int j = 0; j < maxc; j += 2) {
             asm volatile("" ::: "memory");
             load_row(q1, min(j + 1, last));
-            if (j < cnt) block(q0);
+            if (j < cnt) LIW_SLAB_BLOCK(q0);
             __builtin_amdgcn_sched_barrier(0);
             load_row(q0, min(j + 2, last));
-            if (j + 1 < cnt) block(q1);
+            if (j + 1 < cnt) LIW_SLAB_BLOCK(q1);
             __builtin_amdgcn_sched_barrier(0);
         }
     }
@@ -252,13 +394,13 @@ __global__ __launch_bounds__(64, 2) void k_lin_laser_slab(LinArgs A, DevParams P
         for (int j = 0; j < maxc; j += 3) {
             asm volatile("" ::: "memory");
             load_row(q2, min(j + 2, last));
-            if (j < cnt) block(q0);
+            if (j < cnt) LIW_SLAB_BLOCK(q0);
             __builtin_amdgcn_sched_barrier(0);
             load_row(q0, min(j + 3, last));
-            if (j + 1 < cnt) block(q1);
+            if (j + 1 < cnt) LIW_SLAB_BLOCK(q1);
             __builtin_amdgcn_sched_barrier(0);
             load_row(q1, min(j + 4, last));
-            if (j + 2 < cnt) block(q2);
+            if (j + 2 < cnt) LIW_SLAB_BLOCK(q2);
             __builtin_amdgcn_sched_barrier(0);
         }
     }
@@ -269,27 +411,51 @@ __global__ __launch_bounds__(64, 2) void k_lin_laser_slab(LinArgs A, DevParams P
         for (int j = 0; j < maxc; j += 4) {
             asm volatile("" ::: "memory");
             load_row(q3, min(j + 3, last));
-            if (j < cnt) block(q0);
+            if (j < cnt) LIW_SLAB_BLOCK(q0);
             __builtin_amdgcn_sched_barrier(0);
             load_row(q0, min(j + 4, last));
-            if (j + 1 < cnt) block(q1);
+            if (j + 1 < cnt) LIW_SLAB_BLOCK(q1);
             __builtin_amdgcn_sched_barrier(0);
             load_row(q1, min(j + 5, last));
-            if (j + 2 < cnt) block(q2);
+            if (j + 2 < cnt) LIW_SLAB_BLOCK(q2);
             __builtin_amdgcn_sched_barrier(0);
             load_row(q2, min(j + 6, last));
-            if (j + 3 < cnt) block(q3);
+            if (j + 3 < cnt) LIW_SLAB_BLOCK(q3);
             __builtin_amdgcn_sched_barrier(0);
+        }
+    }
+#endif
+#if LIW_SLAB_ALG == 1
+    if (__builtin_expect(__any(irregular), 0)) {
+        // the blocks block_fast left out (their pair products join the lane's sums behind the regular ones): same test, general form.
+        // Kept out of the main loop so that its live ranges do not count against the rows in flight there.
+        for (int j = 0; j < maxc; ++j) {
+            double q[8];
+            load_row(q, j);
+            const double d1x = q[0] - q[2], d1y = q[1] - q[3];
+            const double ux = -(ra[0] * d1x + ra[1] * d1y), uy = -(ra[2] * d1x + ra[3] * d1y);
+            if (irregular && j < cnt && !(ux * ux + uy * uy > 0.0)) block(q);
         }
     }
 #endif
 #undef TA
 #undef TB
+#undef LIW_SLAB_BLOCK
+#if defined(LIW_SLAB_DIRECT_STORE)
     if (in) {
         double* out = (psel ? A.PL[1] : A.PL[0]) + ((size_t)bb * n + f) * LP;
         slab_store<0>(out, acc);
-        if (A.CS[0]) (psel ? A.CS[1] : A.CS[0])[cs_index(n, bb, CS_LASER, f)] = acc[slab_pairidx(8, 8)];
     }
+#else
+    {
+        static_assert(SLAB * STG + SLAB <= 2 * (TF2 - TFR) * SLAB && LP == 128, "staging area of the record epilogue");
+        unsigned long long* pw = reinterpret_cast<unsigned long long*>(lds + SLAB * STG);
+        lds_sync();                                  // every lane is past its last transform read
+        pw[lane] = in ? (unsigned long long)((psel ? A.PL[1] : A.PL[0]) + ((size_t)bb * n + f) * LP) : 0ull;
+        slab_flush<0>(lds, pw, acc, lane);
+    }
+#endif
+    if (in && A.CS[0]) (psel ? A.CS[1] : A.CS[0])[cs_index(n, bb, CS_LASER, f)] = acc[slab_pairidx(8, 8)];
 }
 
 // longest group of every (slab, frame): mx[s * n + f] = max over the slab's windows of the block count of (window, f)

@@ -415,7 +415,7 @@ __device__ __forceinline__ void imu_blocks(const LinArgs& A, const DevParams& P,
                 typedef double __attribute__((ext_vector_type(2))) dbl2;
                 auto flush = [&](double* dst, int nd) {          // nd doubles (even) from img to dst, 16 bytes per lane
                     lds_sync();
-                    for (int e = 2 * lane; e < nd; e += 128) *reinterpret_cast<dbl2*>(dst + e) = *reinterpret_cast<const dbl2*>(img + e);
+                    for (int e = 2 * lane; e < nd; e += 128) nt_store<4>(reinterpret_cast<dbl2*>(dst + e), *reinterpret_cast<const dbl2*>(img + e));
                     lds_sync();
                 };
                 // staging writes are UNCONDITIONAL: every lane's four (tile row group -> staging word) offsets are constants of the wave
@@ -429,7 +429,7 @@ __device__ __forceinline__ void imu_blocks(const LinArgs& A, const DevParams& P,
 #pragma unroll
                     for (int r = 0; r < 4; ++r) img[so_d[r]] = (ml == 15 && !with_gi) ? 0.0 : gd[r];
                     lds_sync();
-                    if (lane < 60) *reinterpret_cast<dbl2*>(rec + PIF_D + 2 * lane) = *reinterpret_cast<const dbl2*>(img + 2 * lane);
+                    if (lane < 60) nt_store<4>(reinterpret_cast<dbl2*>(rec + PIF_D + 2 * lane), *reinterpret_cast<const dbl2*>(img + 2 * lane));
                     if (lane < 15) rec[PIF_GI + lane] = img[120 + lane];
                     lds_sync();
                 };
@@ -653,7 +653,7 @@ __device__ __forceinline__ void wheel_blocks(const LinArgs& A, const DevParams& 
             const double* Yq = lds + q * 64;
             const int rc = rc_tab[e], r = rc >> 8, c = rc & 255;
             const double v = rc >= 0 ? Yq[r] * Yq[c] + Yq[13 + r] * Yq[13 + c] + Yq[26 + r] * Yq[26 + c] : 0.0;
-            (sel ? A.PW[1] : A.PW[0])[(size_t)meta[32 + q] * PWS + e] = v;
+            nt_store<8>(&(sel ? A.PW[1] : A.PW[0])[(size_t)meta[32 + q] * PWS + e], v);
             if (COSTCOPY && e == PW_C && A.CS[0]) (sel ? A.CS[1] : A.CS[0])[meta[64 + q]] = v;
         }
     }
@@ -715,7 +715,7 @@ __device__ __forceinline__ void ground_frames(const LinArgs& A, const DevParams&
             const double* Yq = lds + q * 16;
             const int rc = rc_tab[e], r = rc >> 8, c = rc & 255;
             const double v = mult * (Yq[r] * Yq[c] + Yq[7 + r] * Yq[7 + c]);
-            (sel ? A.PG[1] : A.PG[0])[(size_t)meta[32 + q] * PGS + e] = v;
+            nt_store<8>(&(sel ? A.PG[1] : A.PG[0])[(size_t)meta[32 + q] * PGS + e], v);
             if (COSTCOPY && e == PG_C && A.CS[0]) (sel ? A.CS[1] : A.CS[0])[meta[64 + q]] = v;
         }
     }

@@ -72,6 +72,7 @@ __device__ int g_qprobe;       // LIW_QUAD_PROBE (diagnosis only, results are wr
 #ifdef LIW_QUAD_TILE_ALIAS   // occupancy experiment only (WRONG results): the tile aliases the IMU record's ii block, LDS = the records alone
 constexpr int QTR = 0;
 #else
+constexpr int QNT1 = (LIW_NT_MASK & 16) ? 2 : 0, QNT2 = (LIW_NT_MASK & 64) ? 2 : 0;   // cache policy of the LDS-DMA pieces (2 = nt)
 constexpr int QTR = 4 * 15 * 6;                           // transposition tile of the carried arrow block (below)
 #endif
 // Gather table of the assembly phase: one 16-bit LDS byte offset per (read, lane) — see the kernel.  Reads: K_A laser Hbb | gb, K_B wheel
@@ -340,13 +341,13 @@ __global__ __launch_bounds__(64, LIW_QUAD_OCC) void k_lm_step_quad(StepArgs a) {
             sfor<0, 4>([&](auto W) {                // per-frame IMU record: 3 pieces per row (the immediate offset moves the global AND the LDS address)
                 constexpr int ws = KI(W);
                 const double* g = PI0 + rPI[ws] + (unsigned)(f * PIFS) + lane2;
-                sfor<0, 3>([&](auto Q) { __builtin_amdgcn_global_load_lds(g, (lds_t)(S + S_IMU + ws * PIFS), 16, KI(Q) * 1024, 0); });
+                sfor<0, 3>([&](auto Q) { __builtin_amdgcn_global_load_lds(g, (lds_t)(S + S_IMU + ws * PIFS), 16, KI(Q) * 1024, QNT1); });
             });
         }
         sfor<0, 4>([&](auto W) {                    // laser group record: exactly one piece
             constexpr int ws = KI(W);
             static_assert(LP == 128, "one piece");
-            __builtin_amdgcn_global_load_lds(PL0 + rPL[ws] + (unsigned)(f * LP) + lane2, (lds_t)(S + S_PL + ws * LP), 16, 0, 0);
+            __builtin_amdgcn_global_load_lds(PL0 + rPL[ws] + (unsigned)(f * LP) + lane2, (lds_t)(S + S_PL + ws * LP), 16, 0, QNT1);
         });
         // wheel partials (block f-1; frame 0 re-reads block 0, unused) and ground partials of the four rows: the 4 x 92 + 4 x 28 doubles that lie
         // back to back in LDS are cut into 128-double pieces wherever the cuts fall (4 pieces; a piece per wheel record + one for the ground
@@ -365,7 +366,7 @@ __global__ __launch_bounds__(64, LIW_QUAD_OCC) void k_lm_step_quad(StepArgs a) {
                         if constexpr (st <= q0) off = v; else off = lane2 >= st - q0 ? v : off;
                     }
                 });
-                __builtin_amdgcn_global_load_lds(PW0 + off, (lds_t)(S + S_PW + q0), 16, 0, 0);
+                __builtin_amdgcn_global_load_lds(PW0 + off, (lds_t)(S + S_PW + q0), 16, 0, QNT1);
             });
         }
         asm volatile("" ::: "memory");
@@ -665,8 +666,8 @@ __global__ __launch_bounds__(64, LIW_QUAD_OCC) void k_lm_step_quad(StepArgs a) {
             const unsigned of = oWS + (unsigned)(i * SOLVE_WS);
             sfor<0, 15>([&](auto K) {
                 constexpr int k = KI(K);
-                WS[of + (unsigned)(k * REC_LD + (l15 ? 21 : j))] = o[k];
-                if (l6) WS[of + (unsigned)(k * REC_LD + 15 + j)] = rr[k];
+                nt_store<32>(&WS[of + (unsigned)(k * REC_LD + (l15 ? 21 : j))], o[k]);
+                if (l6) nt_store<32>(&WS[of + (unsigned)(k * REC_LD + 15 + j)], rr[k]);
             });
         }
         QSTAMP(10);
@@ -735,7 +736,7 @@ __global__ __launch_bounds__(64, LIW_QUAD_OCC) void k_lm_step_quad(StepArgs a) {
                     if constexpr (st <= q0) off = v; else off = lane2 >= st - q0 ? v : off;
                 }
             });
-            __builtin_amdgcn_global_load_lds(WS + off, (lds_t)(dst + q0), 16, 0, 0);
+            __builtin_amdgcn_global_load_lds(WS + off, (lds_t)(dst + q0), 16, 0, QNT2);
         });
         const unsigned* const X32 = reinterpret_cast<const unsigned*>(X);
         const unsigned* const L32 = reinterpret_cast<const unsigned*>(LMD);
@@ -752,7 +753,7 @@ __global__ __launch_bounds__(64, LIW_QUAD_OCC) void k_lm_step_quad(StepArgs a) {
             // (X is the CALLER's array: the lanes behind the last row's 30 dwords re-read its first ones instead of reading on past the
             // end of the allocation; everything else staged here lies inside the workspace, where reading on is harmless)
             if constexpr (q0 + 64 > 120) off = ln >= 120 - q0 ? 2u * (rX[3] + fx) + (unsigned)(ln - (120 - q0)) : off;
-            __builtin_amdgcn_global_load_lds(X32 + off, (lds_t)(dst + RECP * 128 + KI(P) * 32), 4, 0, 0);
+            __builtin_amdgcn_global_load_lds(X32 + off, (lds_t)(dst + RECP * 128 + KI(P) * 32), 4, 0, QNT2);
         });
         sfor<0, LP_>([&](auto P) {                               // Jacobi scale (rows 0 .. 3), then LM diagonal (rows 0 .. 3)
             constexpr int q0 = KI(P) * 64;
@@ -764,7 +765,7 @@ __global__ __launch_bounds__(64, LIW_QUAD_OCC) void k_lm_step_quad(StepArgs a) {
                     if constexpr (st <= q0) off = v; else off = ln >= st - q0 ? v : off;
                 }
             });
-            __builtin_amdgcn_global_load_lds(L32 + off, (lds_t)(dst + RECP * 128 + XP * 32 + KI(P) * 32), 4, 0, 0);
+            __builtin_amdgcn_global_load_lds(L32 + off, (lds_t)(dst + RECP * 128 + XP * 32 + KI(P) * 32), 4, 0, QNT2);
         });
         asm volatile("" ::: "memory");
     };

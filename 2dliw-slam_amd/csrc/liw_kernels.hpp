@@ -212,6 +212,15 @@ __device__ __forceinline__ void wave_mem_sync() {
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
 }
 
+// A/B aid: nontemporal hints on the streams a launch touches once (bits: 4 IMU frame records stored, 8 wheel / ground records stored,
+// 16 first-sweep LDS-DMA pieces of the quad step kernel, 32 its back-substitution record stored, 64 its second-sweep pieces)
+#ifndef LIW_NT_MASK
+#define LIW_NT_MASK 4       // measured per 49 152 C2 windows: 4 -> k_lin_imu_chain 2.19 -> 2.12 ms; 8 / 16 / 32 / 64: no change (left off)
+#endif
+template <int BIT, typename T> __device__ __forceinline__ void nt_store(T* p, T v) {
+    if constexpr ((LIW_NT_MASK & BIT) != 0) __builtin_nontemporal_store(v, p); else *p = v;
+}
+
 // reciprocal square root / reciprocal from the hardware estimate + two Newton steps (7 / 5 instructions; the library rsqrt() and
 // an IEEE division expand to 3-4 times that, on the dependent chain of single-wave code)
 __device__ __forceinline__ double fast_rsqrt(double x) {   // v_rsq_f64 + two Newton steps

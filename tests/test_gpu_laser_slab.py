@@ -122,3 +122,36 @@ def test_a_block_on_its_line_fails_only_its_window_on_the_slab_path(liw, synth, 
     assert np.array_equal(X[72], x0)
     assert all(s["termination"] != 6 for k, s in enumerate(info) if k != 72)
     bs.close()
+
+
+def test_a_zero_length_reference_segment_takes_the_general_form_on_the_slab_path(liw, synth, pyoracle, monkeypatch):
+    """The lane-per-group kernel evaluates regular blocks with folded algebra and leaves blocks whose mapped reference segment has
+    zero length (normalized() of a zero vector in the reference, src/utilies/common.h:86-95) to the general form in a pass of its own:
+    the records of such a window must be those of the lane-per-block kernel (same NaN pattern, sums to round-off)."""
+    prm, orc, base, wins = _batch(liw, synth, pyoracle)
+    n = 30
+    ws = list(wins)
+    picks = []
+    for k in (5, 70, len(wins) - 1):
+        bad = {key: (np.array(v, copy=True) if isinstance(v, np.ndarray) else v) for key, v in ws[k].items()}
+        fr = int(np.bincount(bad["laser_frame"], minlength=n).argmax())     # (the windows are ragged: take a frame that owns blocks)
+        picks.append((k, fr))
+        js = np.flatnonzero(bad["laser_frame"] == fr)
+        for j in (int(js[0]), int(js[-1])):
+            bad["laser_pts"][j, 3:6] = bad["laser_pts"][j, 0:3]
+        ws[k] = bad
+    monkeypatch.setenv("LIW_NO_LASER_SLAB", "1")
+    a = liw.BatchSolver(prm, ws, history_records=0)
+    ra = _records(liw, a)
+    monkeypatch.delenv("LIW_NO_LASER_SLAB")
+    b = liw.BatchSolver(prm, ws)
+    rb = _records(liw, b)
+    assert not np.array_equal(ra, rb, equal_nan=True)             # (the lane-per-group kernel did run)
+    assert np.array_equal(np.isnan(ra), np.isnan(rb))
+    for k, fr in picks:
+        o, v = ra[k, fr], rb[k, fr]
+        fin = ~np.isnan(o)
+        assert np.abs(v[fin] - o[fin]).max() <= 1e-12 * max(np.abs(o[fin]).max(), 1e-300), (k, fr)
+    fin = ~np.isnan(ra)
+    assert np.abs(rb[fin] - ra[fin]).max() <= 1e-11 * np.abs(ra[fin]).max()
+    a.close(); b.close()
