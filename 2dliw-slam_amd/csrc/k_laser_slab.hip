@@ -117,8 +117,16 @@ template <int C_> __device__ __forceinline__ void slab_flush(double* lds, const 
     }
 }
 
+// sqrt(min(len1, len2) / 0.04) of a block (laser_factor.h:38-42) from the two segments' difference vectors
+__device__ __forceinline__ double slab_weight(double d1x, double d1y, double d2x, double d2y) {
+    const double l2 = fmin(d1x * d1x + d1y * d1y, d2x * d2x + d2y * d2y);
+    const double lmin25 = l2 > 0.0 ? 25.0 * (l2 * fast_rsqrt(l2)) : 0.0;
+    return lmin25 > 0.0 ? lmin25 * fast_rsqrt(lmin25) : 0.0;
+}
+
 constexpr int SLAB = 64;
-constexpr int ROWD = 8 * SLAB;        // doubles per packed row
+constexpr int ROWD = LASER_SLAB_ROWD;  // doubles per packed row
+constexpr int NPL = ROWD / SLAB;       // planes per row: 8 end-point components (+ the block weight)
 
 }  // namespace
 
@@ -182,9 +190,9 @@ __global__ __launch_bounds__(64, 2) void k_lin_laser_slab(LinArgs A, DevParams P
 #endif
 #pragma unroll
 #if LIW_SLAB_NT & 1
-        for (int c = 0; c < 8; ++c) q[c] = __builtin_nontemporal_load(r + c * SLAB);
+        for (int c = 0; c < NPL; ++c) q[c] = __builtin_nontemporal_load(r + c * SLAB);
 #else
-        for (int c = 0; c < 8; ++c) q[c] = r[c * SLAB];
+        for (int c = 0; c < NPL; ++c) q[c] = r[c * SLAB];
 #endif
     };
     const double w0 = P.laser_sqrt_info;
@@ -293,11 +301,12 @@ __global__ __launch_bounds__(64, 2) void k_lin_laser_slab(LinArgs A, DevParams P
     bool irregular = false;
     auto block_fast = [&](const double* p) {
         const double d1x = p[0] - p[2], d1y = p[1] - p[3];
+#if LIW_SLAB_WPLANE
+        const double w = p[8] * w0;                 // the block's weight from the ninth plane of the row (slab_weight, computed once per solve by the re-pack)
+#else
         const double d2x = p[4] - p[6], d2y = p[5] - p[7];
-        const double l2 = fmin(d1x * d1x + d1y * d1y, d2x * d2x + d2y * d2y);
-        const double lmin25 = l2 > 0.0 ? 25.0 * (l2 * fast_rsqrt(l2)) : 0.0;
-        const double sum = lmin25 > 0.0 ? lmin25 * fast_rsqrt(lmin25) : 0.0;
-        const double w = sum * w0;
+        const double w = slab_weight(d1x, d1y, d2x, d2y) * w0;
+#endif
         const double ux = -(ra[0] * d1x + ra[1] * d1y), uy = -(ra[2] * d1x + ra[3] * d1y);
         const double zz = ux * ux + uy * uy;
         if (__builtin_expect(!(zz > 0.0), 0)) { irregular = true; return; }      // zero-length reference segment (or NaN input): the general form, in a pass of its own behind the loop
@@ -374,7 +383,7 @@ __global__ __launch_bounds__(64, 2) void k_lin_laser_slab(LinArgs A, DevParams P
 #endif
     const int last = maxc - 1;
 #if LIW_SLAB_ROWS == 2
-    double q0[8], q1[8];
+    double q0[NPL], q1[NPL];
     if (maxc > 0) {
         load_row(q0, 0);
         for (int j = 0; j < maxc; j += 2) {
@@ -388,7 +397,7 @@ __global__ __launch_bounds__(64, 2) void k_lin_laser_slab(LinArgs A, DevParams P
         }
     }
 #elif LIW_SLAB_ROWS == 3
-    double q0[8], q1[8], q2[8];
+    double q0[NPL], q1[NPL], q2[NPL];
     if (maxc > 0) {
         load_row(q0, 0); load_row(q1, min(1, last));
         for (int j = 0; j < maxc; j += 3) {
@@ -405,7 +414,7 @@ __global__ __launch_bounds__(64, 2) void k_lin_laser_slab(LinArgs A, DevParams P
         }
     }
 #else
-    double q0[8], q1[8], q2[8], q3[8];
+    double q0[NPL], q1[NPL], q2[NPL], q3[NPL];
     if (maxc > 0) {
         load_row(q0, 0); load_row(q1, min(1, last)); load_row(q2, min(2, last));
         for (int j = 0; j < maxc; j += 4) {
@@ -430,7 +439,7 @@ __global__ __launch_bounds__(64, 2) void k_lin_laser_slab(LinArgs A, DevParams P
         // the blocks block_fast left out (their pair products join the lane's sums behind the regular ones): same test, general form.
         // Kept out of the main loop so that its live ranges do not count against the rows in flight there.
         for (int j = 0; j < maxc; ++j) {
-            double q[8];
+            double q[NPL];
             load_row(q, j);
             const double d1x = q[0] - q[2], d1y = q[1] - q[3];
             const double ux = -(ra[0] * d1x + ra[1] * d1y), uy = -(ra[2] * d1x + ra[3] * d1y);
@@ -520,6 +529,17 @@ __global__ __launch_bounds__(256) void k_laser_slab_pack(int B, int n, long Ltot
             for (int r = t >> 6; r < rows; r += 4) base[(size_t)(jb + r) * ROWD + c * SLAB + (t & 63)] = tile[r * 65 + (t & 63)];
             __syncthreads();
         }
+#if LIW_SLAB_WPLANE
+        {   // ninth plane: the weights of the rows just written (read back lane-linear: the lines are still in the cache)
+            __threadfence_block();
+            __syncthreads();
+            const int rows = min(64, maxc - jb);
+            for (int r = t >> 6; r < rows; r += 4) {
+                const double* q = base + (size_t)(jb + r) * ROWD + (t & 63);
+                base[(size_t)(jb + r) * ROWD + 8 * SLAB + (t & 63)] = slab_weight(q[0] - q[2 * SLAB], q[SLAB] - q[3 * SLAB], q[4 * SLAB] - q[6 * SLAB], q[5 * SLAB] - q[7 * SLAB]);
+            }
+        }
+#endif
     }
 }
 

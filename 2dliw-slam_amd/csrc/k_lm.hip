@@ -1060,6 +1060,30 @@ __global__ __launch_bounds__(64, 2) void k_lm_step(StepArgs a) {
     lm_step_body<THROUGHPUT>(a, (int)blockIdx.x, T);
 }
 
+// Behind k_lm_step_quad: the windows that kernel left out of this launch (a rotation vector outside the |theta| <= pi ball; it marked the
+// ones it stepped in LmState::pad_) are stepped by the one-wave body.  One wave LOOKS at 64 windows (a lane each) and then takes the few
+// that are left, one after the other: as a launch of one wave per window (until late round 5) the 49 152 waves of the bench batch, nearly
+// all of which returned at once, kept the chip busy for 27 us of every LM iteration.
+__global__ __launch_bounds__(64, 1) void k_lm_step_slow(StepArgs a) {
+    __shared__ LdsStep T;
+    const int lane = threadIdx.x & 63, b = (int)blockIdx.x * 64 + lane;
+    bool mine = false;
+    if (b < a.B) {
+        LmState& st = a.w.lm[b];
+        if (!st.done) { if (st.pad_) st.pad_ = 0; else mine = true; }
+    }
+    unsigned long long m = __ballot(mine);
+    if (!m) return;
+    wave_mem_sync();
+    // (a.only_slow stays set — a modified copy of the kernel arguments would live in scratch —: the body's own look at pad_ finds 0)
+    while (m) {
+        const int l = __builtin_amdgcn_readfirstlane(__builtin_ctzll(m));
+        m &= m - 1;
+        lm_step_body<true>(a, (int)blockIdx.x * 64 + l, T);
+        lds_sync();
+    }
+}
+
 // The two-frame window as one dense system (lm_step_body<.., DENSE2>): the steady-state tracking frame of the reference's front end.
 __global__ __launch_bounds__(64, 1) void k_lm_step_dense2(StepArgs a) {
     __shared__ LdsDense2 T;
@@ -1977,7 +2001,7 @@ void launch_lm_step(const StepArgs& a, hipStream_t s) {
         launch_lm_step_quad(a, s);
         StepArgs a2 = a;
         a2.only_slow = 1;
-        hipLaunchKernelGGL(k_lm_step<true>, dim3(a.B), dim3(64), 0, s, a2);
+        hipLaunchKernelGGL(k_lm_step_slow, dim3((unsigned)((a.B + 63) / 64)), dim3(64), 0, s, a2);
         return;
     }
     // a two-frame window (what the reference's tracking loop solves every laser frame) is ONE dense 30 x 30 system; variant 4 forces it

@@ -318,7 +318,7 @@ static int laser_slab_begin(liw_ctx* c, const liw_batch* b, int mode, const WsVi
     const long long rows = tail[0];
     if (tail[1] != 0 || rows <= 0) return LIW_OK;                               // 3-D end points: the lane-per-block kernel handles them
     if (rows * 64 > 4 * (long long)b->Ltot + 64ll * N) return LIW_OK;           // very ragged groups: padding would exceed 4x the data
-    if (c->lpk.ensure(sizeof(double) * 512 * (size_t)rows)) { c->lpk.release(); return LIW_OK; }   // (no memory for the copy: not an error)
+    if (c->lpk.ensure(sizeof(double) * LASER_SLAB_ROWD * (size_t)rows)) { c->lpk.release(); return LIW_OK; }   // (no memory for the copy: not an error)
     launch_laser_slab_pack(b->B, b->n, (long)b->Ltot, v.group_off, b->laser_pts, c->lpk_off.as<long long>(), c->lpk_mx.as<int>(), c->lpk.as<double>(), s);
     c->lpk_key = {ws, b->laser_pts, b->laser_frame, b->B, b->n, (long)b->Ltot};
     c->lpk_on = true;

@@ -309,6 +309,12 @@ void launch_laser_z_scan(long Ltot, const double* laser_pts, int* flag, hipStrea
 // k_laser_slab.hip: lane-per-(window, frame) laser role of large 2-D batches
 int laser_slab_count(int B);
 void launch_laser_slab_prepare(int B, int n, const int* group_off, int* mx, long long* off, const int* hz, hipStream_t s);
+#ifndef LIW_SLAB_WPLANE
+#define LIW_SLAB_WPLANE 0     // 1: the re-pack appends the block's weight sqrt(min(len1, len2) / 0.04) (laser_factor.h:38-42, constant over the LM
+                              // iterations) as a ninth plane: -30 of a block's 274 VALU instructions for +12.5 % of row bytes.  Measured twice (round 5): the
+                              // kernel alone 1.51 -> 1.56 ms (it is bandwidth-bound), the linearise bracket 3.907 -> 3.897 ms, 130.2 k -> 130.7 k solves/s: off
+#endif
+constexpr int LASER_SLAB_ROWD = (8 + LIW_SLAB_WPLANE) * 64;      // doubles per packed row of k_laser_slab.hip
 void launch_laser_slab_pack(int B, int n, long Ltot, const int* group_off, const double* pts, const long long* off, const int* mx, double* pk, hipStream_t s);
 void launch_lin_laser_slab(const LinArgs& A, const DevParams& P, hipStream_t s);
 void launch_imu_pack(int B, int n, const double* imu_X, const double* imu_J, const double* imu_sqrtP, const double* imu_Dt, double* pk, int* bad, hipStream_t s);

@@ -639,8 +639,8 @@ def main():
                             "essential_flops_per_block": laser_flops,
                             "flops_frac": round(lb * laser_flops / t["k_lin_laser"] / F64, 4),
                             "kernel": "k_lin_laser_slab (a lane per (window, frame) group over per-solve packed rows: batches of >= 2 048 (slab, frame) waves of 2-D scans)" if (B + 63) // 64 * n >= 2048 and not os.environ.get("LIW_NO_LASER_SLAB") else "k_lin_laser<true> (a lane per block, wave reduction per group)",
-                            "instructions": "lane-per-group kernel: ~350 VALU instructions per row of 64 blocks (~290 of them the blocks' own fp64 arithmetic), no cross-lane reduction; lane-per-block kernel: ~1000 per 64-block chunk (per-group wave reduction ~260 per group end, second masked round of pair products where a chunk straddles two groups, transform reads from LDS, masks)",
-                            "valu_issue_frac": issue("k_lin_laser"), "bound": "fp64 VALU issue (lane-per-group kernel: one wave per SIMD, 52 % VALU-busy; lane-per-block kernel: two waves per SIMD)"},
+                            "instructions": "lane-per-group kernel: ~274 VALU instructions per row of 64 blocks (446 until the block algebra was folded late in round 5), no cross-lane reduction, records staged through LDS and stored as 256-byte runs; lane-per-block kernel: ~1000 per 64-block chunk (per-group wave reduction ~260 per group end, second masked round of pair products where a chunk straddles two groups, transform reads from LDS, masks)",
+                            "valu_issue_frac": issue("k_lin_laser"), "bound": "lane-per-group kernel alone: HBM at the practical rate of its read / write mix (8.0 GB per launch, probe builds: 1.30 ms cache-resident rows, 1.14 ms loads only; tools/ubench/hbm_stream: 5.3 - 5.7 TB/s for such mixes); inside the linearise bracket the three role kernels share the SIMDs and the bracket follows the SUM of their fp64 instruction streams; lane-per-block kernel: fp64 VALU issue"},
             "k_lin_imu": {"ms": round(kt["k_lin_imu"], 4), "hbm_GBps": hbm_role("imu", "k_lin_imu"), "hbm_frac": hbm_role("imu", "k_lin_imu", True), "mfma_insts": int(ib * 20), "mfma_util": round(ib * 20 * mf / t["k_lin_imu"] / F64, 4),
                           "flops_frac": round(ib * (20 * mf + 3 * 2600.0) / t["k_lin_imu"] / F64, 4), "valu_issue_frac": issue("k_lin_imu"),
                           "bound": "fp64 pipe shared by MFMA and VALU (their times add), two waves per SIMD"},

@@ -49,6 +49,50 @@ template <int WIDE, int R, int WPS> void run(const double* src, double* out, int
     const double bytes = (double)waves * rows * 4096;
     printf("%s rows in flight %d, %d waves/SIMD: %.3f ms  %.0f GB/s\n", WIDE ? "16 B/lane" : " 8 B/lane", R, WPS, best, bytes / best * 1e-6);
 }
+// Mixed stream: a wave reads RD rows and writes WR rows of 4 KiB per round (16 bytes per lane, consecutive addresses; NT: nontemporal
+// hint on loads and stores) -- the practical chip-wide rate of a read / write mix, which is what bounds the record-passing kernels.
+template <int RD, int WR, int NT>
+__global__ __launch_bounds__(64, 2) void k_mix(const double* src, double* dst, int rounds, double* out) {
+    __shared__ double pad[2560];
+    const int lane = threadIdx.x;
+    const dbl2* rp = reinterpret_cast<const dbl2*>(src + (size_t)blockIdx.x * rounds * RD * 512) + lane;
+    dbl2* wp = reinterpret_cast<dbl2*>(dst + (size_t)blockIdx.x * rounds * WR * 512) + lane;
+    dbl2 acc = {0.0, 0.0};
+    dbl2 q[2][RD * 4];
+    auto load = [&](dbl2* d, int r) {
+#pragma unroll
+        for (int c = 0; c < RD * 4; ++c) d[c] = NT ? __builtin_nontemporal_load(rp + (size_t)r * RD * 256 + c * 64) : rp[(size_t)r * RD * 256 + c * 64];
+    };
+    load(q[0], 0);
+    for (int r = 0; r < rounds; r += 2) {
+#pragma unroll
+        for (int k = 0; k < 2; ++k) {
+            load(q[1 - k], r + k + 1 < rounds ? r + k + 1 : rounds - 1);
+#pragma unroll
+            for (int c = 0; c < RD * 4; ++c) acc += q[k][c];
+#pragma unroll
+            for (int c = 0; c < WR * 4; ++c) {
+                dbl2* a = wp + (size_t)(r + k) * WR * 256 + c * 64;
+                if (NT) __builtin_nontemporal_store(acc, a); else *a = acc;
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    }
+    pad[lane] = acc.x + acc.y;
+    out[(size_t)blockIdx.x * 64 + lane] = pad[63 - lane];
+}
+template <int RD, int WR, int NT> void run_mix(const double* src, double* dst, double* out, int waves, int rounds) {
+    hipEvent_t e0, e1; (void)hipEventCreate(&e0); (void)hipEventCreate(&e1);
+    float best = 1e9f;
+    for (int rep = 0; rep < 4; ++rep) {
+        (void)hipEventRecord(e0, 0);
+        hipLaunchKernelGGL((k_mix<RD, WR, NT>), dim3(waves), dim3(64), 0, 0, src, dst, rounds, out);
+        (void)hipEventRecord(e1, 0); (void)hipEventSynchronize(e1);
+        float ms; (void)hipEventElapsedTime(&ms, e0, e1); if (rep && ms < best) best = ms;
+    }
+    const double bytes = (double)waves * rounds * (RD + WR) * 4096;
+    printf("mix %d read : %d written%s: %.3f ms  %.0f GB/s\n", RD, WR, NT ? " (nontemporal)" : "", best, bytes / best * 1e-6);
+}
 int main() {
     const int waves = 22272, rows = 67;
     double* src; double* out;
@@ -61,5 +105,10 @@ int main() {
     run<0, 2, 4>(src, out, waves, rows); run<1, 2, 4>(src, out, waves, rows);
     run<0, 4, 4>(src, out, waves, rows); run<1, 4, 4>(src, out, waves, rows);
     run<1, 4, 8>(src, out, waves, rows);
+    double* dst; (void)hipMalloc(&dst, (size_t)waves * rows * 4096);
+    run_mix<4, 1, 0>(src, dst, out, waves, 16); run_mix<4, 1, 1>(src, dst, out, waves, 16);
+    run_mix<2, 1, 0>(src, dst, out, waves, 22); run_mix<2, 1, 1>(src, dst, out, waves, 22);
+    run_mix<1, 1, 0>(src, dst, out, waves, 33); run_mix<1, 1, 1>(src, dst, out, waves, 33);
+    run_mix<1, 2, 0>(src, dst, out, waves, 22); run_mix<1, 2, 1>(src, dst, out, waves, 22);
     return 0;
 }
