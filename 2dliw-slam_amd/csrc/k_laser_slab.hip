@@ -14,8 +14,18 @@
 // Same per-block arithmetic as k_lin_laser_body.inc (reference src/factor/laser_factor.h:45-89, src/utilies/common.h:86-95 incl. the NaN
 // of a point exactly on the line); the sums differ from k_lin_laser's tree order by round-off only (tests/test_gpu_laser_slab.py).
 #include "liw_kernels.hpp"
+#include <algorithm>
+#include <cstdlib>
 
 namespace liw {
+
+#ifdef LIW_CLK     // s_memtime stamps of the middle work-group's wave (tools/clk_probe_slab.py)
+__device__ long long g_clk_slab[16];
+#define SSTAMP(id) do { asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory"); if (item == slab_items_probe && (threadIdx.x & 63) == 0) g_clk_slab[(id)] = clock64(); } while (0)
+__device__ int slab_items_probe = 11000;
+#else
+#define SSTAMP(id) do { } while (0)
+#endif
 
 namespace {
 
@@ -142,42 +152,54 @@ constexpr int NPL = ROWD / SLAB;       // planes per row: 8 end-point components
 // (ISA count; 289 by hand), i.e. the two waves keep the SIMD's fp64 pipe ~55 % busy.
 // What did not help (each built and timed in round 4): blocks taken in pairs or as branch-free straight-line code for more instruction-level
 // parallelism (register pressure: 1.23 ms / spills).
-__global__ __launch_bounds__(64, 2) void k_lin_laser_slab(LinArgs A, DevParams P) {
+__device__ __forceinline__ void slab_item(const LinArgs& A, const DevParams& P, const int item) {
     const int lane = threadIdx.x & 63, n = A.n;
-    const int s = (int)blockIdx.x / n, f = (int)blockIdx.x % n;
+    const int s = item / n, f = item % n;
+    SSTAMP(0);
     const int b = s * SLAB + lane;
     bool in = b < A.B;
     const int bb = in ? b : 0;
+    // every index / state load of the prologue in ONE batch, unconditionally (bb is a valid window): as written until late round 5 — live
+    // test, then the group range, then the partial-buffer selector, then the poses — a wave spent 13 k cycles on four dependent round trips
+    const int g0 = A.group_off[bb * (n + 1) + f], g1 = A.group_off[bb * (n + 1) + f + 1];
+    const int hm = A.has_match[bb * n + f];
+    const int curv = A.lm ? A.lm[bb].cur : 0;
+    double pa6[6], pb6[6];
+#pragma unroll
+    for (int k = 0; k < 6; ++k) { pa6[k] = A.x[(size_t)bb * n * 15 + k]; pb6[k] = A.x[((size_t)bb * n + f) * 15 + k]; }
     if (in) in = window_live(A, bb);
     if (!__any(in)) return;
-    const int g0 = A.group_off[bb * (n + 1) + f], g1 = A.group_off[bb * (n + 1) + f + 1];
-    const bool fon = in && A.has_match[bb * n + f] != 0;
+    const bool fon = in && hm != 0;
     const int cnt = fon ? g1 - g0 : 0;
     int maxc = cnt;
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) maxc = max(maxc, __shfl_xor(maxc, o, 64));
     maxc = __builtin_amdgcn_readfirstlane(maxc);
-    const int psel = (in && A.lm) ? (A.candidate ? 1 - A.lm[bb].cur : A.lm[bb].cur) : 0;
+    const int psel = (in && A.lm) ? (A.candidate ? 1 - curv : curv) : 0;
     // transform records of pose a (frame 0 of the lane's window) and pose b (frame f): [entry][lane] in LDS, re-read per block
     constexpr int TFR = 4;                       // the first TFR entries of a record (M) stay in registers: 2 x 20 x 64 doubles of LDS = 20 kB per wave, eight waves per CU
     __shared__ double lds[2 * (TF2 - TFR) * SLAB];      // (the epilogue stages the records through the same 20 kB)
     double* const lta = lds;
     double* const ltb = lds + (TF2 - TFR) * SLAB;
     double ra[TFR], rb[TFR];
+    SSTAMP(1);
     {
-        double t2[TF2];
-        if (in && maxc > 0) frame_tf2(P, A.x + (size_t)bb * n * 15, t2);
+        // both records under ONE condition: the two dual-number chains are independent and interleave (as two conditionals they ran one
+        // after the other: 18 k cycles of a wave's 260 k)
+        double ta2[TF2], tb2[TF2];
+        if (in && maxc > 0) { frame_tf2(P, pa6, ta2); frame_tf2(P, pb6, tb2); }
         else {
 #pragma unroll
-            for (int k = 0; k < TF2; ++k) t2[k] = 0.0;
+            for (int k = 0; k < TF2; ++k) { ta2[k] = 0.0; tb2[k] = 0.0; }
         }
 #pragma unroll
-        for (int k = 0; k < TF2; ++k) { if (k < TFR) ra[k] = t2[k]; else lta[(k - TFR) * SLAB + lane] = t2[k]; }
-        if (in && maxc > 0) frame_tf2(P, A.x + ((size_t)bb * n + f) * 15, t2);
-#pragma unroll
-        for (int k = 0; k < TF2; ++k) { if (k < TFR) rb[k] = t2[k]; else ltb[(k - TFR) * SLAB + lane] = t2[k]; }
+        for (int k = 0; k < TF2; ++k) {
+            if (k < TFR) { ra[k] = ta2[k]; rb[k] = tb2[k]; }
+            else { lta[(k - TFR) * SLAB + lane] = ta2[k]; ltb[(k - TFR) * SLAB + lane] = tb2[k]; }
+        }
     }
     lds_sync();
+    SSTAMP(2);
     double acc[45];
 #pragma unroll
     for (int e = 0; e < 45; ++e) acc[e] = 0.0;
@@ -447,6 +469,7 @@ __global__ __launch_bounds__(64, 2) void k_lin_laser_slab(LinArgs A, DevParams P
         }
     }
 #endif
+    SSTAMP(3);
 #undef TA
 #undef TB
 #undef LIW_SLAB_BLOCK
@@ -465,7 +488,12 @@ __global__ __launch_bounds__(64, 2) void k_lin_laser_slab(LinArgs A, DevParams P
     }
 #endif
     if (in && A.CS[0]) (psel ? A.CS[1] : A.CS[0])[cs_index(n, bb, CS_LASER, f)] = acc[slab_pairidx(8, 8)];
+    SSTAMP(4);
 }
+__global__ __launch_bounds__(64, 2) void k_lin_laser_slab(LinArgs A, DevParams P) { slab_item(A, P, (int)blockIdx.x); }
+// (Measured late in round 5, tools/bracket_time.py: a grid capped at 768 ... 2 048 persistent work-groups, so that the IMU role's waves run
+//  NEXT TO this kernel's instead of behind them, makes the linearise bracket slower — 4.45 - 4.65 against 4.38 ms per 49 152 windows: the
+//  throughput of either kernel follows its resident waves, a memory-bound and a pipe-bound wave on one SIMD do not add up.)
 
 // longest group of every (slab, frame): mx[s * n + f] = max over the slab's windows of the block count of (window, f)
 __global__ void k_laser_slab_max(int B, int n, const int* group_off, int* mx) {
@@ -543,6 +571,9 @@ __global__ __launch_bounds__(256) void k_laser_slab_pack(int B, int n, long Ltot
     }
 }
 
+#ifdef LIW_CLK
+extern "C" void liw_debug_clk_slab(long long* out, int nn) { hipMemcpyFromSymbol(out, HIP_SYMBOL(g_clk_slab), sizeof(long long) * nn); }
+#endif
 int laser_slab_count(int B) { return (B + SLAB - 1) / SLAB; }
 void launch_laser_slab_prepare(int B, int n, const int* group_off, int* mx, long long* off, const int* hz, hipStream_t s) {
     const int N = laser_slab_count(B) * n;

@@ -19,6 +19,9 @@
 // auto_diff::compute_res_and_jacobi (src/utilies/common.h:201-217); the so3 local parameterisation is applied at assembly.
 #include "liw_kernels.hpp"
 
+#ifndef LIW_IMU_PROBE_NOSTORE
+#define LIW_IMU_PROBE_NOSTORE 0     // probe build (wrong results): k_lin_imu_chain without its frame-record stores
+#endif
 namespace liw {
 
 // ------------------------------------------------------------------------------------------- laser
@@ -415,7 +418,7 @@ __device__ __forceinline__ void imu_blocks(const LinArgs& A, const DevParams& P,
                 typedef double __attribute__((ext_vector_type(2))) dbl2;
                 auto flush = [&](double* dst, int nd) {          // nd doubles (even) from img to dst, 16 bytes per lane
                     lds_sync();
-                    for (int e = 2 * lane; e < nd; e += 128) nt_store<4>(reinterpret_cast<dbl2*>(dst + e), *reinterpret_cast<const dbl2*>(img + e));
+                    for (int e = 2 * lane; e < nd && !LIW_IMU_PROBE_NOSTORE; e += 128) nt_store<4>(reinterpret_cast<dbl2*>(dst + e), *reinterpret_cast<const dbl2*>(img + e));
                     lds_sync();
                 };
                 // staging writes are UNCONDITIONAL: every lane's four (tile row group -> staging word) offsets are constants of the wave
@@ -429,7 +432,7 @@ __device__ __forceinline__ void imu_blocks(const LinArgs& A, const DevParams& P,
 #pragma unroll
                     for (int r = 0; r < 4; ++r) img[so_d[r]] = (ml == 15 && !with_gi) ? 0.0 : gd[r];
                     lds_sync();
-                    if (lane < 60) nt_store<4>(reinterpret_cast<dbl2*>(rec + PIF_D + 2 * lane), *reinterpret_cast<const dbl2*>(img + 2 * lane));
+                    if (lane < 60 && !LIW_IMU_PROBE_NOSTORE) nt_store<4>(reinterpret_cast<dbl2*>(rec + PIF_D + 2 * lane), *reinterpret_cast<const dbl2*>(img + 2 * lane));
                     if (lane < 15) rec[PIF_GI + lane] = img[120 + lane];
                     lds_sync();
                 };
