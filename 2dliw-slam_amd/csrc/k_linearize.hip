@@ -17,6 +17,7 @@
 // Every role reduces G = Y^T Y with Y = [J | r] deterministically (no atomics).  G blocks go to the partial-sum slots
 // described in liw_kernels.hpp; k_lm.hip assembles them.  Jacobians here are w.r.t. the AMBIENT parameters, exactly like
 // auto_diff::compute_res_and_jacobi (src/utilies/common.h:201-217); the so3 local parameterisation is applied at assembly.
+#include <type_traits>
 #include "liw_kernels.hpp"
 
 #ifndef LIW_IMU_PROBE_NOSTORE
@@ -647,6 +648,7 @@ __device__ __forceinline__ void wheel_blocks(const LinArgs& A, const DevParams& 
         rc_tab[e] = e <= PW_C ? (r << 8) | c : -1;
     }
     lds_sync();
+#ifdef LIW_SMALL_OLDOUT
     {
         const long gb0 = (long)wave * A.small_per_wave;
         const int nblk = (int)min((long)A.small_per_wave, total - gb0);
@@ -660,6 +662,48 @@ __device__ __forceinline__ void wheel_blocks(const LinArgs& A, const DevParams& 
             if (COSTCOPY && e == PW_C && A.CS[0]) (sel ? A.CS[1] : A.CS[0])[meta[64 + q]] = v;
         }
     }
+#else
+    {   // a record (PWS = 92 doubles) leaves as 46 lanes x 16 bytes, one store per block; a lane's two (r, c) pairs are fixed for the
+        // wave and the block meta words sit in registers (lane q holds block q's, read by v_readlane), so a block costs twelve LDS reads
+        // at addresses known up front instead of four dependent LDS round trips per element (block meta -> (r, c) -> Y -> record index)
+        const long gb0 = (long)wave * A.small_per_wave;
+        const int nblk = (int)min((long)A.small_per_wave, total - gb0);
+        const int ml = lane < MAXB ? lane : 0;
+        const int selv = meta[ml], fkv = meta[32 + ml], csv = meta[64 + ml];
+        const bool all_on = __builtin_amdgcn_ballot_w64(lane < nblk && selv < 0) == 0;   // (uniform; false only without the list of live windows)
+        if (lane < PWS / 2) {
+            const int rc0 = rc_tab[2 * lane], rc1 = rc_tab[2 * lane + 1];
+            const int r0 = rc0 >> 8, c0 = rc0 & 255;
+            const int r1 = rc1 >= 0 ? rc1 >> 8 : 0, c1 = rc1 >= 0 ? rc1 & 255 : 0;
+            auto block = [&](int q) {
+                const double* Yq = lds + q * 64;
+                double2 v;
+                v.x = __builtin_fma(Yq[26 + r0], Yq[26 + c0], __builtin_fma(Yq[r0], Yq[c0], Yq[13 + r0] * Yq[13 + c0]));
+                const double w1 = __builtin_fma(Yq[26 + r1], Yq[26 + c1], __builtin_fma(Yq[r1], Yq[c1], Yq[13 + r1] * Yq[13 + c1]));
+                v.y = rc1 >= 0 ? w1 : 0.0;                     // entry 91 is padding
+                return v;
+            };
+            auto put = [&](int q, const double2& v) {
+                const int sel = __builtin_amdgcn_readlane(selv, q);
+                nt_store<8>(reinterpret_cast<double2*>(&(sel ? A.PW[1] : A.PW[0])[(size_t)__builtin_amdgcn_readlane(fkv, q) * PWS + 2 * lane]), v);
+            };
+            int q = 0;
+            if (all_on)
+                for (; q + 3 <= nblk; q += 3) {                // three blocks' LDS reads in flight (21 blocks per wave)
+                    const double2 va = block(q), vb = block(q + 1), vc = block(q + 2);
+                    put(q, va); put(q + 1, vb); put(q + 2, vc);
+                }
+            for (; q < nblk; ++q) {
+                const double2 v = block(q);
+                if (__builtin_amdgcn_readlane(selv, q) >= 0) put(q, v);
+            }
+        }
+        if (COSTCOPY && A.CS[0] && lane < nblk && selv >= 0) {   // compact cost array: lane q writes block q's sum r^2, the same operations as record entry PW_C
+            const double* Yq = lds + lane * 64;
+            (selv ? A.CS[1] : A.CS[0])[csv] = __builtin_fma(Yq[38], Yq[38], __builtin_fma(Yq[12], Yq[12], Yq[25] * Yq[25]));
+        }
+    }
+#endif
 }
 
 // ------------------------------------------------------------------------------------------- ground
@@ -708,6 +752,7 @@ __device__ __forceinline__ void ground_frames(const LinArgs& A, const DevParams&
         rc_tab[lane] = (r << 8) | (c + r);
     }
     lds_sync();
+#ifdef LIW_SMALL_OLDOUT
     {   // n * Y^T Y (7 x 7 per frame; the block set is added once per outer frame index, solver.cpp:142-159), coalesced as in the wheel role
         const long gf0 = (long)wave * GROUND_PER_WAVE;
         const int nfr = (int)min((long)GROUND_PER_WAVE, total - gf0);
@@ -722,6 +767,45 @@ __device__ __forceinline__ void ground_frames(const LinArgs& A, const DevParams&
             if (COSTCOPY && e == PG_C && A.CS[0]) (sel ? A.CS[1] : A.CS[0])[meta[64 + q]] = v;
         }
     }
+#else
+    {   // n * Y^T Y (7 x 7 per frame; the block set is added once per outer frame index, solver.cpp:142-159): a record (PGS = 28 doubles)
+        // leaves as 14 lanes x 16 bytes, four frames per store instruction; (r, c) pairs fixed per lane as in the wheel role
+        const long gf0 = (long)wave * GROUND_PER_WAVE;
+        const int nfr = (int)min((long)GROUND_PER_WAVE, total - gf0);
+        const double mult = (double)n;
+        constexpr int LPF = PGS / 2;                           // lanes per frame
+        const int j = lane / LPF, pr = lane - j * LPF;
+        const bool all_on = __builtin_amdgcn_ballot_w64(lane < nfr && meta[lane & 31] < 0) == 0;   // (uniform)
+        if (j < 4) {
+            const int rc0 = rc_tab[2 * pr], rc1 = rc_tab[2 * pr + 1];
+            const int r0 = rc0 >> 8, c0 = rc0 & 255, r1 = rc1 >> 8, c1 = rc1 & 255;
+            auto frame = [&](int q) {
+                const double* Yq = lds + q * 16;
+                double2 v;
+                v.x = mult * __builtin_fma(Yq[7 + r0], Yq[7 + c0], Yq[r0] * Yq[c0]);
+                v.y = mult * __builtin_fma(Yq[7 + r1], Yq[7 + c1], Yq[r1] * Yq[c1]);
+                return v;
+            };
+            auto put = [&](int sel, int fq, const double2& v) { nt_store<8>(reinterpret_cast<double2*>(&(sel ? A.PG[1] : A.PG[0])[(size_t)fq * PGS + 2 * pr]), v); };
+            int q = j;
+            if (all_on)
+                for (; q + 4 < nfr; q += 8) {                  // two rounds of four frames in flight
+                    const int sa = meta[q], fa = meta[32 + q], sb = meta[q + 4], fb = meta[36 + q];
+                    const double2 va = frame(q), vb = frame(q + 4);
+                    put(sa, fa, va); put(sb, fb, vb);
+                }
+            for (; q < nfr; q += 4) {
+                const int sel = meta[q], fq = meta[32 + q];
+                const double2 v = frame(q);
+                if (sel >= 0) put(sel, fq, v);
+            }
+        }
+        if (COSTCOPY && A.CS[0] && lane < nfr && meta[lane & 31] >= 0) {   // compact cost array: lane q writes frame q's entry, the same operations as record entry PG_C
+            const double* Yq = lds + lane * 16;
+            (meta[lane] ? A.CS[1] : A.CS[0])[meta[64 + lane]] = mult * __builtin_fma(Yq[13], Yq[13], Yq[6] * Yq[6]);
+        }
+    }
+#endif
 }
 
 // ------------------------------------------------------------------------------------------- dispatch
