@@ -162,6 +162,7 @@ __device__ __forceinline__ void imu_blocks(const LinArgs& A, const DevParams& P,
     constexpr int MAXB = 63 / LPB;
     typedef LJN<ND> JN;
     const int lane = threadIdx.x & 63, blk = lane / LPB, g = lane % LPB;
+    LSTAMP(299);
     const int f = g / (LPB / 3), e0 = ND == 3 ? 0 : g % 3;
     const int n = A.n, nb = n - 1, ipw = A.imu_per_wave;   // blocks per wave: IMU_PER_WAVE for throughput, fewer for latency
     // blocks are indexed over the windows that are still iterating (compacted list), so finished windows cost no lanes
@@ -648,21 +649,6 @@ __device__ __forceinline__ void wheel_blocks(const LinArgs& A, const DevParams& 
         rc_tab[e] = e <= PW_C ? (r << 8) | c : -1;
     }
     lds_sync();
-#ifdef LIW_SMALL_OLDOUT
-    {
-        const long gb0 = (long)wave * A.small_per_wave;
-        const int nblk = (int)min((long)A.small_per_wave, total - gb0);
-        for (int idx = lane; idx < nblk * PWS; idx += 64) {
-            const int q = idx / PWS, e = idx - q * PWS, sel = meta[q];
-            if (sel < 0) continue;
-            const double* Yq = lds + q * 64;
-            const int rc = rc_tab[e], r = rc >> 8, c = rc & 255;
-            const double v = rc >= 0 ? Yq[r] * Yq[c] + Yq[13 + r] * Yq[13 + c] + Yq[26 + r] * Yq[26 + c] : 0.0;
-            nt_store<8>(&(sel ? A.PW[1] : A.PW[0])[(size_t)meta[32 + q] * PWS + e], v);
-            if (COSTCOPY && e == PW_C && A.CS[0]) (sel ? A.CS[1] : A.CS[0])[meta[64 + q]] = v;
-        }
-    }
-#else
     {   // a record (PWS = 92 doubles) leaves as 46 lanes x 16 bytes, one store per block; a lane's two (r, c) pairs are fixed for the
         // wave and the block meta words sit in registers (lane q holds block q's, read by v_readlane), so a block costs twelve LDS reads
         // at addresses known up front instead of four dependent LDS round trips per element (block meta -> (r, c) -> Y -> record index)
@@ -703,7 +689,6 @@ __device__ __forceinline__ void wheel_blocks(const LinArgs& A, const DevParams& 
             (selv ? A.CS[1] : A.CS[0])[csv] = __builtin_fma(Yq[38], Yq[38], __builtin_fma(Yq[12], Yq[12], Yq[25] * Yq[25]));
         }
     }
-#endif
 }
 
 // ------------------------------------------------------------------------------------------- ground
@@ -752,22 +737,6 @@ __device__ __forceinline__ void ground_frames(const LinArgs& A, const DevParams&
         rc_tab[lane] = (r << 8) | (c + r);
     }
     lds_sync();
-#ifdef LIW_SMALL_OLDOUT
-    {   // n * Y^T Y (7 x 7 per frame; the block set is added once per outer frame index, solver.cpp:142-159), coalesced as in the wheel role
-        const long gf0 = (long)wave * GROUND_PER_WAVE;
-        const int nfr = (int)min((long)GROUND_PER_WAVE, total - gf0);
-        const double mult = (double)n;
-        for (int idx = lane; idx < nfr * PGS; idx += 64) {
-            const int q = idx / PGS, e = idx % PGS, sel = meta[q];
-            if (sel < 0) continue;
-            const double* Yq = lds + q * 16;
-            const int rc = rc_tab[e], r = rc >> 8, c = rc & 255;
-            const double v = mult * (Yq[r] * Yq[c] + Yq[7 + r] * Yq[7 + c]);
-            nt_store<8>(&(sel ? A.PG[1] : A.PG[0])[(size_t)meta[32 + q] * PGS + e], v);
-            if (COSTCOPY && e == PG_C && A.CS[0]) (sel ? A.CS[1] : A.CS[0])[meta[64 + q]] = v;
-        }
-    }
-#else
     {   // n * Y^T Y (7 x 7 per frame; the block set is added once per outer frame index, solver.cpp:142-159): a record (PGS = 28 doubles)
         // leaves as 14 lanes x 16 bytes, four frames per store instruction; (r, c) pairs fixed per lane as in the wheel role
         const long gf0 = (long)wave * GROUND_PER_WAVE;
@@ -805,7 +774,6 @@ __device__ __forceinline__ void ground_frames(const LinArgs& A, const DevParams&
             (meta[lane] ? A.CS[1] : A.CS[0])[meta[64 + lane]] = mult * __builtin_fma(Yq[13], Yq[13], Yq[6] * Yq[6]);
         }
     }
-#endif
 }
 
 // ------------------------------------------------------------------------------------------- dispatch

@@ -56,7 +56,7 @@ print("k_marg_schur: chain %d | eigen %d | tail %d | Jacobi sweeps %d" % (d(5000
 slv.linearize(liw.LIW_MODE_TRACK)
 cl = np.zeros(512, dtype=np.int64)
 liw.lib().liw_debug_clk_lin(cl.ctypes.data_as(C.c_void_p), C.c_int(512))
-print("imu role (1 block): alpha/beta rows + dual exp %d | gamma rows (dE products, log_SO3) %d | sync %d | MFMA + stores %d | total %d"
-      % (cl[302] - cl[300], cl[303] - cl[302], cl[304] - cl[303], cl[311] - cl[304], cl[311] - cl[300]))
+print("imu role (1 block): entry -> operand fetch issued %d | alpha/beta rows + dual exp %d | gamma rows (dE products, log_SO3) %d | sync %d | entry codes %d | MFMA + stores %d | total %d"
+      % (cl[300] - cl[299], cl[302] - cl[300], cl[303] - cl[302], cl[304] - cl[303], cl[305] - cl[304], cl[311] - cl[305], cl[311] - cl[299]))
 print("k_lin_all role waves (cycles, start-to-end; n = 2: laser f0, laser f1, imu, wheel, ground):", [int(cl[401 + 2 * v] - cl[400 + 2 * v]) for v in range(5)],
       "kernel span", int(max(cl[401 + 2 * v] for v in range(5)) - min(cl[400 + 2 * v] for v in range(5))))
