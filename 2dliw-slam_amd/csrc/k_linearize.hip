@@ -112,7 +112,7 @@ constexpr int IR_XS = 10, IR_RB = 90, IR_RT = 96, IR_RTDT = 105, IR_JB = 114, IM
 
 // column `col` (0..30: x_i 15 | r_raw | x_j 15) of row kk of [J_raw | r_raw] as (record offset | negate flag) or a constant:
 // returns offset >= 0 (bit 30 = negated) or -1 with *cst set
-__device__ __forceinline__ int imu_entry_code(int kk, int col, double* cst) {
+__host__ __device__ constexpr int imu_entry_code(int kk, int col, double* cst) {
     *cst = 0.0;
     if (kk >= 15 || col > 30) return -1;
     const int rg = kk / 3, rr = kk % 3;
@@ -139,6 +139,26 @@ __device__ __forceinline__ int imu_entry_code(int kk, int col, double* cst) {
     }
 }
 
+// The operand entry codes of a lane of the matrix-core part (lane = 16 mk + ml: x0 = column ml of [J_raw wrt x_i | r_raw], x1 = column ml
+// of [J_raw wrt x_j], rows kk = mk + 4 c) are constants of the lane: a table in constant memory, fetched with the block's inputs.
+// Evaluated per wave they were 2.5 k of the 19.8 k cycles of the IMU wave a tracking frame waits for (tools/clk_probe_track.py).
+struct ImuLaneOps { int code0[4], code1[4]; double cst0[4], cst1[4]; };
+struct ImuOpTab { ImuLaneOps lane[64]; };
+constexpr ImuOpTab make_imu_optab() {
+    ImuOpTab t{};
+    for (int l = 0; l < 64; ++l) {
+        const int ml = l & 15, mk = l >> 4;
+        for (int c = 0; c < 4; ++c) {
+            double k0 = 0.0, k1 = 0.0;
+            t.lane[l].code0[c] = imu_entry_code(mk + 4 * c, ml, &k0);
+            t.lane[l].code1[c] = imu_entry_code(mk + 4 * c, ml < 15 ? 16 + ml : 31, &k1);
+            t.lane[l].cst0[c] = k0; t.lane[l].cst1[c] = k1;
+        }
+    }
+    return t;
+}
+__constant__ ImuOpTab c_imu_optab = make_imu_optab();
+
 __device__ __forceinline__ V3<double> mulc(const double* m, int ld, const V3<double>& v) {   // 3x3 block of a row-major matrix times v
     return V3<double>(m[0] * v.x + m[1] * v.y + m[2] * v.z, m[ld] * v.x + m[ld + 1] * v.y + m[ld + 2] * v.z,
                       m[2 * ld] * v.x + m[2 * ld + 1] * v.y + m[2 * ld + 2] * v.z);
@@ -163,6 +183,8 @@ __device__ __forceinline__ void imu_blocks(const LinArgs& A, const DevParams& P,
     typedef LJN<ND> JN;
     const int lane = threadIdx.x & 63, blk = lane / LPB, g = lane % LPB;
     LSTAMP(299);
+    ImuLaneOps ops;
+    if constexpr (ND == 1) ops = c_imu_optab.lane[lane];      // a wave per block (latency): in flight with the block's inputs; used by the matrix-core part
     const int f = g / (LPB / 3), e0 = ND == 3 ? 0 : g % 3;
     const int n = A.n, nb = n - 1, ipw = A.imu_per_wave;   // blocks per wave: IMU_PER_WAVE for throughput, fewer for latency
     // blocks are indexed over the windows that are still iterating (compacted list), so finished windows cost no lanes
@@ -345,13 +367,11 @@ __device__ __forceinline__ void imu_blocks(const LinArgs& A, const DevParams& P,
     LSTAMP(304);
     // ---- matrix-core part, one block at a time (the whole wave cooperates).  Operand entry codes of this lane: x0 = column ml of
     // [J_raw wrt x_i | r_raw], x1 = column ml of [J_raw wrt x_j] for the four k-chunks (row kk = mk + 4c)
+    if constexpr (ND != 1) ops = c_imu_optab.lane[lane];      // (throughput kernels: 24 registers that must not live across the dual-number part)
     int code0[4], code1[4];
     double cst0[4], cst1[4];
 #pragma unroll
-    for (int c = 0; c < 4; ++c) {
-        code0[c] = imu_entry_code(mk + 4 * c, ml, &cst0[c]);
-        code1[c] = imu_entry_code(mk + 4 * c, ml < 15 ? 16 + ml : 31, &cst1[c]);
-    }
+    for (int c = 0; c < 4; ++c) { code0[c] = ops.code0[c]; code1[c] = ops.code1[c]; cst0[c] = ops.cst0[c]; cst1[c] = ops.cst1[c]; }
     const unsigned long long onmask = __ballot(on);           // lane LPB q = block q is live (in range, window still iterating)
     d4 chain11 = {0.0, 0.0, 0.0, 0.0};                         // CHAIN: the jj tile of the block before (zero in front of a window's first block)
     // CHAIN: staging offsets of this lane's accumulator entries (row = mk + 4 r, column ml): ij | g_j image at row * 15 + ml (row 15 = the
@@ -485,6 +505,27 @@ __device__ __forceinline__ void imu_blocks(const LinArgs& A, const DevParams& P,
 // gets its derivative parts as  L * dM_e * R  with lane-selected double matrices; only log_SO3 and the scalar tail of the residual
 // run on LJN<3>.
 constexpr int WHEEL_PER_WAVE = 21;
+// record entry e -> columns (r, c) of Y = [J (3 x 12) | r] as (r << 8) | c: ii | ij | jj | gradient | cost (liw_kernels.hpp); -1 = padding.
+// A table in constant memory (built per wave in LDS until round 5: divisions and searches, ~20 of the ~45 instructions of an output element
+// before that).
+struct WheelRcTab { int e[PWS]; };
+constexpr WheelRcTab make_wheel_rc() {
+    WheelRcTab t{};
+    for (int e = 0; e < PWS; ++e) {
+        int r = 12, c = 12;                                   // e == PW_C: sum r^2
+        if (e < PW_IJ(0, 0) || (e >= PW_JJ(0, 0) && e < PW_G(0))) {   // packed upper triangles of ii / jj: row r has 6 - r entries
+            const int jj = e >= PW_JJ(0, 0);
+            int q = e - (jj ? PW_JJ(0, 0) : 0);
+            r = 0;
+            while (q >= 6 - r) { q -= 6 - r; ++r; }
+            c = r + q + (jj ? 6 : 0); r += jj ? 6 : 0;
+        } else if (e < PW_JJ(0, 0)) { r = (e - PW_IJ(0, 0)) / 6; c = 6 + (e - PW_IJ(0, 0)) % 6; }
+        else if (e < PW_C) { r = e - PW_G(0); c = 12; }
+        t.e[e] = e <= PW_C ? (r << 8) | c : -1;
+    }
+    return t;
+}
+__constant__ WheelRcTab c_wheel_rc = make_wheel_rc();
 template <int ND, bool COSTCOPY>   // directions per lane: 3 (three lanes per block) or 1 (nine lanes per block, small batches), as in imu_blocks; COSTCOPY: see CS in LinArgs
 __device__ __forceinline__ void wheel_blocks(const LinArgs& A, const DevParams& P, int wave, double* lds, const int* const act) {
     constexpr int LPB = 9 / ND;
@@ -633,21 +674,6 @@ __device__ __forceinline__ void wheel_blocks(const LinArgs& A, const DevParams& 
         meta[32 + blk] = (int)fk;
         meta[64 + blk] = (int)cs_index(n, b, CS_WHEEL, k);   // its slot of the compact cost array
     }
-    // record entry e -> columns (r, c) of Y: ii | ij | jj | gradient | cost (liw_kernels.hpp), as a table built once per wave (the divisions
-    // and selects it replaces were ~20 of the ~45 instructions of every output element: 40 elements per lane and wave)
-    int* rc_tab = meta + 96;
-    for (int e = lane; e < PWS; e += 64) {
-        int r = 12, c = 12;                                   // e == PW_C: sum r^2
-        if (e < PW_IJ(0, 0) || (e >= PW_JJ(0, 0) && e < PW_G(0))) {   // packed upper triangles of ii / jj: row r has 6 - r entries
-            const int jj = e >= PW_JJ(0, 0);
-            int t = e - (jj ? PW_JJ(0, 0) : 0);
-            r = 0;
-            while (t >= 6 - r) { t -= 6 - r; ++r; }
-            c = r + t + (jj ? 6 : 0); r += jj ? 6 : 0;
-        } else if (e < PW_JJ(0, 0)) { r = (e - PW_IJ(0, 0)) / 6; c = 6 + (e - PW_IJ(0, 0)) % 6; }
-        else if (e < PW_C) { r = e - PW_G(0); c = 12; }
-        rc_tab[e] = e <= PW_C ? (r << 8) | c : -1;
-    }
     lds_sync();
     {   // a record (PWS = 92 doubles) leaves as 46 lanes x 16 bytes, one store per block; a lane's two (r, c) pairs are fixed for the
         // wave and the block meta words sit in registers (lane q holds block q's, read by v_readlane), so a block costs twelve LDS reads
@@ -658,7 +684,7 @@ __device__ __forceinline__ void wheel_blocks(const LinArgs& A, const DevParams& 
         const int selv = meta[ml], fkv = meta[32 + ml], csv = meta[64 + ml];
         const bool all_on = __builtin_amdgcn_ballot_w64(lane < nblk && selv < 0) == 0;   // (uniform; false only without the list of live windows)
         if (lane < PWS / 2) {
-            const int rc0 = rc_tab[2 * lane], rc1 = rc_tab[2 * lane + 1];
+            const int rc0 = c_wheel_rc.e[2 * lane], rc1 = c_wheel_rc.e[2 * lane + 1];
             const int r0 = rc0 >> 8, c0 = rc0 & 255;
             const int r1 = rc1 >= 0 ? rc1 >> 8 : 0, c1 = rc1 >= 0 ? rc1 & 255 : 0;
             auto block = [&](int q) {
@@ -696,6 +722,17 @@ __device__ __forceinline__ void wheel_blocks(const LinArgs& A, const DevParams& 
 // tf_w_o = make_tf(p, theta) * T_imu_to_wheel
 // 32 frames per wave, two lanes each: lane 0 the 3 directions of p, lane 1 of theta
 constexpr int GROUND_PER_WAVE = 32;
+struct GroundRcTab { int e[PGS]; };   // record entry e -> (r << 8) | c of the packed upper triangle of the 7 x 7 G (PG_H / PG_G / PG_C)
+constexpr GroundRcTab make_ground_rc() {
+    GroundRcTab t{};
+    for (int e = 0; e < PGS; ++e) {
+        int r = 0, c = e;
+        while (c >= 7 - r) { c -= 7 - r; ++r; }               // row r has 7 - r entries
+        t.e[e] = (r << 8) | (c + r);
+    }
+    return t;
+}
+__constant__ GroundRcTab c_ground_rc = make_ground_rc();
 template <bool COSTCOPY>
 __device__ __forceinline__ void ground_frames(const LinArgs& A, const DevParams& P, int wave, double* lds, const int* const act) {
     const int lane = threadIdx.x & 63, sub = lane >> 1, g = lane & 1;
@@ -730,12 +767,6 @@ __device__ __forceinline__ void ground_frames(const LinArgs& A, const DevParams&
     }
     int* meta = reinterpret_cast<int*>(lds + GROUND_PER_WAVE * 16);
     if (g == 0) { meta[sub] = on ? (A.lm ? (A.candidate ? 1 - A.lm[b].cur : A.lm[b].cur) : 0) : -1; meta[32 + sub] = (int)fi; meta[64 + sub] = (int)cs_index(n, b, CS_GROUND, (int)(gf % n)); }
-    int* rc_tab = meta + 96;                                   // record entry e -> (r, c) of the packed upper triangle of the 7x7 G (PG_H / PG_G / PG_C)
-    if (lane < PGS) {
-        int r = 0, c = lane;
-        while (c >= 7 - r) { c -= 7 - r; ++r; }               // row r has 7 - r entries
-        rc_tab[lane] = (r << 8) | (c + r);
-    }
     lds_sync();
     {   // n * Y^T Y (7 x 7 per frame; the block set is added once per outer frame index, solver.cpp:142-159): a record (PGS = 28 doubles)
         // leaves as 14 lanes x 16 bytes, four frames per store instruction; (r, c) pairs fixed per lane as in the wheel role
@@ -746,7 +777,7 @@ __device__ __forceinline__ void ground_frames(const LinArgs& A, const DevParams&
         const int j = lane / LPF, pr = lane - j * LPF;
         const bool all_on = __builtin_amdgcn_ballot_w64(lane < nfr && meta[lane & 31] < 0) == 0;   // (uniform)
         if (j < 4) {
-            const int rc0 = rc_tab[2 * pr], rc1 = rc_tab[2 * pr + 1];
+            const int rc0 = c_ground_rc.e[2 * pr], rc1 = c_ground_rc.e[2 * pr + 1];
             const int r0 = rc0 >> 8, c0 = rc0 & 255, r1 = rc1 >> 8, c1 = rc1 & 255;
             auto frame = [&](int q) {
                 const double* Yq = lds + q * 16;

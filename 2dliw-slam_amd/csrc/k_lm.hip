@@ -373,12 +373,16 @@ __device__ double window_cost(const AsmCtx& c, double* gchk = nullptr) {
     const bool track = c.mode == LIW_MODE_TRACK;
     double s = 0.0, gs = 0.0;
     for (int i = lane; i < n; i += 64) {
-        s += PLb[(size_t)i * LP + 120];
+        // (tracking: only the newest frame has laser / ground blocks with a free parameter.  The older frames' laser records are zero —
+        //  or, LinArgs::marg_older, hold their marginalisation-topology sums, which are no part of the tracking problem)
         const bool gon = !(track && i < n - 1);
+        if (gon) s += PLb[(size_t)i * LP + 120];
         if (gon) s += PGb[(size_t)i * PGS + PG_C];
         if (gchk) {
+            if (gon) {
 #pragma unroll
-            for (int k = 0; k < 12; ++k) gs += PLb[(size_t)i * LP + 108 + k];
+                for (int k = 0; k < 12; ++k) gs += PLb[(size_t)i * LP + 108 + k];
+            }
             if (gon) {
 #pragma unroll
                 for (int k = 0; k < 6; ++k) gs += PGb[(size_t)i * PGS + PG_G(k)];
@@ -544,6 +548,41 @@ __device__ __forceinline__ void lm_step_body(const StepArgs& a, const int b, LDS
     LdsStep& T = step_lds(TL);
     const int lane = threadIdx.x & 63;
     LmState& st = a.w.lm[b];
+    if constexpr (DENSE2) {
+        double pf_sink = 0.0;
+        int done0 = st.done;
+        // The step of a tracking window is a chain of DEPENDENT memory round trips (LM state -> cost slots of the buffer it names -> candidate
+        // states -> partial sums / prior / scales), and the producers ran on other XCDs: every trip goes past this XCD's L2 (~1.7 k cycles
+        // each, tools/clk_probe_track.py).  All of it is ~15 kB at addresses known up front: one batch of line-touching loads for BOTH
+        // partial buffers at entry, one wait, and the dependent loads below hit the vector L1.
+        const int n2 = a.n;   // (= 2: every region below is at most 64 lines)
+        const bool pr = a.mode == LIW_MODE_TRACK && !a.fast_mode;
+        double v[14];
+#pragma unroll
+        for (int k = 0; k < 2; ++k) {
+            v[4 * k + 0] = touch_lines(a.w.PL[k] + (size_t)b * n2 * LP, sizeof(double) * n2 * LP);
+            v[4 * k + 1] = touch_lines(a.w.PI[k] + (size_t)b * (n2 - 1) * PIS, sizeof(double) * (n2 - 1) * PIS);
+            v[4 * k + 2] = touch_lines(a.w.PW[k] + (size_t)b * (n2 - 1) * PWS, sizeof(double) * (n2 - 1) * PWS);
+            v[4 * k + 3] = touch_lines(a.w.PG[k] + (size_t)b * n2 * PGS, sizeof(double) * n2 * PGS);
+        }
+        v[8] = touch_lines(a.x + (size_t)b * n2 * 15, sizeof(double) * n2 * 15);
+        v[9] = touch_lines(a.w.x_cand + (size_t)b * n2 * 15, sizeof(double) * n2 * 15);
+        v[10] = touch_lines(st.scale, sizeof(double) * n2 * 15);
+        v[11] = touch_lines(st.diagonal, sizeof(double) * n2 * 15);
+        // (without a prior the two slots touch the states once more: the prior arrays may be null then)
+        {
+            const double* const xb = a.x + (size_t)b * n2 * 15;
+            const double* const PJ = a.prior_J; const double* const PX = a.prior_X;
+            const bool pj = pr && PJ != nullptr, px = pr && PX != nullptr;
+            const size_t qj = (size_t)(PJ + (size_t)b * 225), qx = (size_t)(PX + (size_t)b * 15), q0 = (size_t)xb;
+            v[12] = touch_lines(reinterpret_cast<const void*>(pj ? qj : q0), pj ? sizeof(double) * 225 : sizeof(double) * 8);
+            v[13] = touch_lines(reinterpret_cast<const void*>(px ? qx : q0), px ? sizeof(double) * 15 : sizeof(double) * 8);
+        }
+#pragma unroll
+        for (int k = 0; k < 14; ++k) pf_sink += v[k];
+        asm volatile("" : "+v"(pf_sink), "+v"(done0));   // ONE wait for the whole batch (and the loads cannot be dropped or sunk below a branch)
+        if (done0) return;
+    }
     if (st.done) return;
     if (a.only_slow) {   // behind k_lm_step_quad: that kernel marked the windows it stepped; the others (a rotation vector outside |theta| <= pi) are this one's
         const int taken = st.pad_;
@@ -1921,19 +1960,23 @@ __device__ __forceinline__ int jacobi15_block(const double* D, double* A2, doubl
             const double* Ac = A2 + 256 * cur; const double* Vc = V2 + 256 * cur;
             double* An = A2 + 256 * (1 - cur); double* Vn = V2 + 256 * (1 - cur);
             const int rp = partner_of(r, rnd), cp = partner_of(c, rnd);
-            const int rP = r < rp ? r : rp, rQ = r < rp ? rp : r, cP = c < cp ? c : cp, cQ = c < cp ? cp : c;
+            const int rP = r < rp ? r : rp, cP = c < cp ? c : cp, cQ = c < cp ? cp : c;
             // every load of the round
-            const double r_pq = Ac[rP * 16 + rQ], r_qq = Ac[rQ * 16 + rQ], r_pp = Ac[rP * 16 + rP];
             const double c_pq = Ac[cP * 16 + cQ], c_qq = Ac[cQ * 16 + cQ], c_pp = Ac[cP * 16 + cP];
             const double x00 = Ac[r * 16 + c], x01 = Ac[r * 16 + cp], x10 = Ac[rp * 16 + c], x11 = Ac[rp * 16 + cp];
             const double v0 = Vc[r * 16 + c], v1 = Vc[r * 16 + cp];
-            // the two rotations, side by side (independent dependent chains: they interleave)
-            double rcs, rsn, ccs, csn;
-            jacobi_rotation(r_qq - r_pp, 2.0 * r_pq, rcs, rsn);
+            // A thread computes the rotation of its COLUMN's pair; the rotation of its row's pair is the one the row's diagonal thread
+            // (column index = r: the same pair, the same three entries, the same instructions) computes for its column — fetched from that
+            // lane of the same wave (thread 17 r = lane 16 (r & 3) + r of wave r >> 2) instead of evaluated a second time by all 16 threads
+            // of the row: a wave is alone on its SIMD here, so a round costs what it ISSUES (~150 instructions, ~45 of them this rotation).
+            double ccs, csn;
             jacobi_rotation(c_qq - c_pp, 2.0 * c_pq, ccs, csn);
-            const bool ron = rp != r && r_pq != 0.0, con = cp != c && c_pq != 0.0;
-            const double gr = ron ? rcs : 1.0, sr = ron ? (r == rP ? -rsn : rsn) : 0.0;
-            const double gc = con ? ccs : 1.0, sc = con ? (c == cP ? -csn : csn) : 0.0;
+            const bool con = cp != c && c_pq != 0.0;
+            const double gc = con ? ccs : 1.0, scm = con ? csn : 0.0;
+            const double sc = c == cP ? -scm : scm;
+            const int dlane = (lane & 48) | r;
+            const double gr = __shfl(gc, dlane, 64), srm = __shfl(scm, dlane, 64);
+            const double sr = r == rP ? -srm : srm;
             const double b0 = gc * x00 + sc * x01;      // (A G)[r][c]
             const double b1 = gc * x10 + sc * x11;      // (A G)[r'][c]
             An[t] = gr * b0 + sr * b1;

@@ -1025,6 +1025,7 @@ int liw_solve(liw_ctx* c, int mode, int max_iters, liw_summary* summary) {
             LinArgs A = lin_args(b, mode, cand ? v.x_cand : b->x, v, cand, !first);
             if (first) { A.reset_lm = v.lm; A.reset_iters = K; first = false; }
             A.active = nullptr;
+            A.marg_older = spec ? 1 : 0;   // (the older frames' poses are constants of a tracking solve: their marginalisation records ride along)
             launch_linearize(A, c->dp, s, c->have_fork ? &c->fork : nullptr);
         };
         // the read-back record is written straight into the page-locked host block (device-visible under the same address): the packing
@@ -1051,14 +1052,10 @@ int liw_solve(liw_ctx* c, int mode, int max_iters, liw_summary* summary) {
             const int m = std::min(chunk, K + 1 - k);
             for (int i = 0; i < m; ++i) { lin(k + i > 0 ? 1 : 0); launch_lm_step(st, s); }
             k += m;
-            if (spec) {
-                // the current LM buffer of a finished TRACK solve IS the marginalisation's linearisation (same states, same kernels) except
-                // for the laser records of the older frames, which the tracking topology leaves out: only those are evaluated again
-                LinArgs A = lin_args(b, LIW_MODE_MARG, b->x, v, 0, true);
-                A.active = nullptr; A.gate = v.lm; A.eval_small = 0; A.older_only = 1;
-                launch_linearize(A, c->dp, s, c->have_fork ? &c->fork : nullptr);
-                launch_marg_schur(ma, s);
-            }
+            // the current LM buffer of a finished TRACK solve IS the marginalisation's linearisation (same states, same kernels): the laser
+            // records of the older frames, which the tracking topology leaves out, were evaluated by the solve's own linearisations
+            // (LinArgs::marg_older; until late round 5 a launch of its own here, 7 us of a 0.18 ms frame)
+            if (spec) launch_marg_schur(ma, s);
             pk.seq = ++c->pack_seq;
             launch_pack_result(pk, s);
             HIPCHK(c, hipGetLastError());

@@ -141,8 +141,10 @@ struct LinArgs {
     const LmState* gate;        // non-null: linearise window b only if gate[b].done (a marginalisation enqueued speculatively behind a solve)
     LmState* reset_lm;          // non-null (single-window liw_solve, first linearisation, lm == null): one more work-group of k_lin_all resets
     int reset_iters;            //    the LM state of every window (iteration cap reset_iters) — k_lm_begin without a launch of its own
-    int older_only;             // 1: the laser role leaves out frame n-1 (marginalisation behind a TRACK solve: the current buffer already
-                                //    holds that frame's record and every small role's partials, at the very states being marginalised)
+    int marg_older;             // TRACK only, 1: the laser role also evaluates the OLDER frames' groups (own pose free against the constant
+                                //    laser_match pose = their records in the marginalisation topology).  Their poses are constants of a tracking
+                                //    solve, so the step masks those entries and leaves their cost out; the marginalisation enqueued behind the
+                                //    solve then finds every record it needs in the window's current buffer (no launch of its own)
     int candidate;              // 1: write the small-factor partials of window b into buffer 1 - lm[b].cur
     int small_per_wave;         // wheel blocks per wave (set by launch_linearize)
     int imu_per_wave;           // IMU blocks per wave (set by launch_linearize)
@@ -247,6 +249,16 @@ __device__ __forceinline__ const int* usable_active_list(const int* active, int 
     const int cnt = __builtin_amdgcn_readfirstlane(active[0]);
     return (st == 1 && cnt >= 0 && cnt <= B) ? active : nullptr;
 }
+// one load per 128-byte line of [p, p + bytes), bytes <= 8 kB: lane l takes line l (lanes past the end take the last line again, so the
+// load is unconditional: no branch, no wait in between).  The value only keeps the load alive: what counts is that the lines are in this
+// CU's vector L1 when the dependent loads of the step ask for them.
+__device__ __forceinline__ double touch_lines(const void* p, size_t bytes) {
+    const int lane = threadIdx.x & 63;
+    const size_t a0 = (size_t)p & ~(size_t)127, last = ((size_t)p + bytes - 8) & ~(size_t)127;
+    const size_t q = a0 + 128 * (size_t)lane;
+    return *reinterpret_cast<const double*>(q < last ? q : last);
+}
+
 // is window b linearised by this launch?  (with a compacted `active` list the roles index live windows only and skip this test)
 __device__ __forceinline__ bool window_live(const LinArgs& A, int b) {
     if (A.gate) return A.gate[b].done != 0;

@@ -303,6 +303,40 @@ def _cpu_worker(job):
     return sec
 
 
+def track_frame_cpp(liw, d3, reps):
+    """The steady-state tracking frame driven from C++ (tools/track_frame_cpp.cpp through include/lvio_2d_solver.hpp): builds the tool with
+    g++ next to the library, hands it the three-frame window in the flat format of tests/test_cpp_host.py::dump_window."""
+    import struct
+    import subprocess
+    import tempfile
+    root = os.path.dirname(os.path.abspath(__file__))
+    libdir = os.path.dirname(liw.LIB_PATH)
+    src = os.path.join(root, "tools", "track_frame_cpp.cpp")
+    exe = os.path.join(libdir, "build", "track_frame_cpp")
+    os.makedirs(os.path.dirname(exe), exist_ok=True)
+    deps = [src, os.path.join(root, "include", "lvio_2d_solver.hpp"), os.path.join(root, "include", "liw_window.h")]
+    if (not os.path.exists(exe)) or any(os.path.getmtime(q) > os.path.getmtime(exe) for q in deps):
+        subprocess.check_call(["g++", "-O2", "-std=c++17", "-I", os.path.join(root, "include"), src, "-o", exe,
+                               "-L", libdir, "-lliw_window", "-Wl,-rpath," + libdir, "-Wl,-rpath,/opt/rocm/lib"])
+    with tempfile.TemporaryDirectory() as td:
+        path = os.path.join(td, "w3.bin")
+        n, L = int(d3["n"]), int(np.asarray(d3["laser_frame"]).shape[0])
+        with open(path, "wb") as f:
+            f.write(struct.pack("<ii", n, L))
+            f.write(np.asarray(d3["states"], dtype=np.float64).tobytes())
+            f.write(np.asarray(d3["laser_frame"], dtype=np.int32).tobytes())
+            f.write(np.asarray(d3["laser_pts"], dtype=np.float64).tobytes())
+            f.write(np.asarray(d3["match_pose"], dtype=np.float64).tobytes())
+            f.write(np.asarray(d3["has_match"], dtype=np.uint8).tobytes())
+            for k in ("imu_X", "imu_J", "imu_sqrtP", "imu_Dt", "wheel_T", "wheel_sqrtP", "wheel_Dt"):
+                f.write(np.asarray(d3[k], dtype=np.float64).tobytes())
+        r = subprocess.run([exe, path, str(reps)], capture_output=True, timeout=120)
+    if r.returncode != 0:
+        raise RuntimeError("track_frame_cpp rc %d: %s" % (r.returncode, r.stderr.decode(errors="replace")[-200:]))
+    tok = r.stdout.decode().split()
+    return {"ms_per_frame": float(tok[1]), "iterations": int(tok[3])}
+
+
 def parity_gate(liw, prm, windows, gate_ids, bs, marg_out, iters_cap, dev):
     """BASELINE.md 3 "equality gate": results of the TIMED batch (final states, LM iteration count, termination, marginalisation
     Delta_H / Delta_g of windows `gate_ids`) and the per-iteration state history of the same windows (re-solved with history
@@ -782,7 +816,16 @@ def main():
                     tg += time.perf_counter() - t0_
                     it_g = sg["iterations"]
             tracking = {"ms_per_frame": round(1e3 * tg / reps, 3), "frames_per_s": round(reps / tg, 1), "lm_iterations": it_g,
-                        "window": "n=2, %d laser blocks on the newest frame, prior on the older one" % int((np.asarray(d3["laser_frame"]) == 2).sum())}
+                        "window": "n=2, %d laser blocks on the newest frame, prior on the older one" % int((np.asarray(d3["laser_frame"]) == 2).sum()),
+                        "caller": "Python mirror (ctypes) of the C ABI; ms_per_frame_cpp_caller = the same frame, same window, same repetitions, driven from "
+                                  "C++ through lvio_2d::solver (include/lvio_2d_solver.hpp: deque flattening + liw_set_window / liw_solve / liw_marginalize + "
+                                  "scatter), the way the reference's trajectory.cpp:525-560 calls its solver"}
+            try:
+                cpp = track_frame_cpp(liw, d3, reps)
+                tracking["ms_per_frame_cpp_caller"] = round(cpp["ms_per_frame"], 3)
+                tracking["lm_iterations_cpp_caller"] = cpp["iterations"]
+            except Exception as e:
+                tracking["cpp_caller_error"] = str(e)[:200]
             if not args.no_cpu_baseline:
                 from oracle import pyoracle
                 orc2 = pyoracle.Oracle(prm)

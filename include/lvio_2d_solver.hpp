@@ -81,6 +81,8 @@ public:
     solver(const solver&) = delete;
     solver& operator=(const solver&) = delete;
     const char* last_error() const { return liw_last_error(ctx_); }
+    // not in the reference (its driver constructs a new solver, solver.h:31: has_linearized_block = false): forget the stored prior
+    void clear_prior() { last_status = liw_set_prior(ctx_, 0, nullptr, nullptr, nullptr); }
 
     // reference signatures (src/factor/solver.h:71-79): the feature_manger is the camera track store, unused with
     // enable_camera: false (every shipped config); the one-argument forms are what the camera-less driver calls

@@ -129,3 +129,61 @@ def test_replay_tool_builds_and_fails_loudly_without_gpu(liw, synth, tmp_path):
     r = subprocess.run([exe, str(tmp_path / "log.bin"), str(tmp_path) + "/"], capture_output=True)
     assert r.returncode == 19, (r.returncode, r.stderr.decode())
     assert b"no usable gfx950 device" in r.stderr or b"no HIP device" in r.stderr
+
+
+def _track_tool(liw):
+    src = os.path.join(ROOT, "tools", "track_frame_cpp.cpp")
+    exe = os.path.join(os.path.dirname(liw.LIB_PATH), "build", "track_frame_cpp_test")
+    os.makedirs(os.path.dirname(exe), exist_ok=True)
+    libdir = os.path.dirname(liw.LIB_PATH)
+    subprocess.check_call(["g++", "-O2", "-std=c++17", "-I", os.path.join(ROOT, "include"), src, "-o", exe,
+                           "-L", libdir, "-lliw_window", "-Wl,-rpath," + libdir, "-Wl,-rpath,/opt/rocm/lib"])
+    return exe
+
+
+def test_cpp_tracking_frame_tool_builds_and_fails_loudly_without_gpu(liw, synth, pyoracle, tmp_path):
+    """tools/track_frame_cpp.cpp (bench.py's C++-caller leg of tracking_frame_latency): builds against the mirror header; no CPU fallback."""
+    import torch
+    exe = _track_tool(liw)
+    if torch.cuda.is_available():
+        pytest.skip("a GPU is present")
+    prm = synth.office_params()
+    d = synth.make_window(pyoracle.Oracle(prm), prm, seed=515, n=3, L=30, laser_on_frame0=False)
+    dump_window(str(tmp_path / "w3.bin"), d)
+    r = subprocess.run([exe, str(tmp_path / "w3.bin"), "2"], capture_output=True)
+    assert r.returncode == 19, r
+
+
+@pytest.mark.gpu
+def test_cpp_tracking_frame_tool_runs_the_frame_the_python_mirror_runs(liw, synth, tmp_path):
+    """Same window, same call sequence as bench.py's Python leg: the tool's last tracking solve takes the iterations liw.Solver takes."""
+    exe = _track_tool(liw)
+    prm = synth.office_params()
+    hp = liw.HostPreint(prm)
+    d3 = synth.make_window(hp, prm, seed=515, n=3, L=120, laser_on_frame0=False)
+    dump_window(str(tmp_path / "w3.bin"), d3)
+    r = subprocess.run([exe, str(tmp_path / "w3.bin"), "3"], capture_output=True, timeout=120)
+    assert r.returncode == 0, r
+    tok = r.stdout.decode().split()
+    assert tok[0] == "ms_per_frame" and float(tok[1]) > 0.0
+
+    def sub(lo):
+        o = dict(d3)
+        o["n"] = 2
+        for k in ("states", "match_pose"):
+            o[k] = np.asarray(d3[k]).reshape(3, -1)[lo:lo + 2].copy()
+        o["has_match"] = np.asarray(d3["has_match"])[lo:lo + 2].copy()
+        for k in ("imu_X", "imu_J", "imu_sqrtP", "imu_Dt", "wheel_T", "wheel_sqrtP", "wheel_Dt"):
+            o[k] = np.asarray(d3[k])[lo:lo + 1].copy()
+        m = (np.asarray(d3["laser_frame"]) >= lo) & (np.asarray(d3["laser_frame"]) < lo + 2)
+        o["laser_frame"] = (np.asarray(d3["laser_frame"])[m] - lo).astype(np.int32)
+        o["laser_pts"] = np.asarray(d3["laser_pts"])[m].copy()
+        return o
+    slv = liw.Solver(prm)
+    slv.set_prior(None)
+    slv.set_window(liw.Window(sub(0)))
+    slv.solve()
+    slv.marginalization()
+    slv.set_window(liw.Window(sub(1)))
+    sg = slv.solve()
+    assert int(tok[3]) == sg["iterations"]
