@@ -1946,6 +1946,18 @@ __device__ __forceinline__ int jacobi15_block(const double* D, double* A2, doubl
         int pr = 2 * rnd - i; pr += pr < 0 ? 15 : 0; pr -= pr >= 15 ? 15 : 0;
         return i >= 15 ? i : pr;
     };
+    // offsets (in doubles, inside the current A / V image) of what round rnd reads, and the round's three predicates
+    struct RoundIdx { int pq, qq, pp, x01, x10, x11; bool con, c_is_p, r_is_p; };
+    auto round_idx = [&](int rnd) {
+        const int rp = partner_of(r, rnd), cp = partner_of(c, rnd);
+        const int cP = c < cp ? c : cp, cQ = c < cp ? cp : c;
+        RoundIdx I;
+        I.pq = cP * 16 + cQ; I.qq = cQ * 17; I.pp = cP * 17;
+        I.x01 = r * 16 + cp; I.x10 = rp * 16 + c; I.x11 = rp * 16 + cp;
+        I.con = cp != c; I.c_is_p = c <= cp; I.r_is_p = r <= rp;   // (an index without a partner pairs with itself: "is p")
+        return I;
+    };
+    const int dlane = (lane & 48) | r;
     for (int sweep = 0; sweep < 60; ++sweep) {
         const double* A = A2 + 256 * cur;
         const double v = in ? A[t] : 0.0;
@@ -1956,33 +1968,37 @@ __device__ __forceinline__ int jacobi15_block(const double* D, double* A2, doubl
         off = (red[0] + red[1]) + (red[2] + red[3]); dgn = (red[4] + red[5]) + (red[6] + red[7]);
         __syncthreads();
         if (off <= 1e-34 * dgn || off == 0.0) break;   // (uniform) sums of squares: off-diagonal below 1e-17 of the diagonal
+        RoundIdx I = round_idx(0);
         for (int rnd = 0; rnd < 15; ++rnd) {
             const double* Ac = A2 + 256 * cur; const double* Vc = V2 + 256 * cur;
             double* An = A2 + 256 * (1 - cur); double* Vn = V2 + 256 * (1 - cur);
-            const int rp = partner_of(r, rnd), cp = partner_of(c, rnd);
-            const int rP = r < rp ? r : rp, cP = c < cp ? c : cp, cQ = c < cp ? cp : c;
             // every load of the round
-            const double c_pq = Ac[cP * 16 + cQ], c_qq = Ac[cQ * 16 + cQ], c_pp = Ac[cP * 16 + cP];
-            const double x00 = Ac[r * 16 + c], x01 = Ac[r * 16 + cp], x10 = Ac[rp * 16 + c], x11 = Ac[rp * 16 + cp];
-            const double v0 = Vc[r * 16 + c], v1 = Vc[r * 16 + cp];
+            const double c_pq = Ac[I.pq], c_qq = Ac[I.qq], c_pp = Ac[I.pp];
+            const double x00 = Ac[t], x01 = Ac[I.x01], x10 = Ac[I.x10], x11 = Ac[I.x11];
+            const double v0 = Vc[t], v1 = Vc[I.x01];
+            // the NEXT round's indices in the shadow of the loads: a wave is alone on its SIMD, and as the first ~35 instructions of a round
+            // this integer arithmetic sat in front of its loads (~150 of a round's ~890 cycles)
+            __builtin_amdgcn_sched_barrier(0);
+            const RoundIdx In = round_idx(rnd < 14 ? rnd + 1 : 0);
+            __builtin_amdgcn_sched_barrier(0);
             // A thread computes the rotation of its COLUMN's pair; the rotation of its row's pair is the one the row's diagonal thread
             // (column index = r: the same pair, the same three entries, the same instructions) computes for its column — fetched from that
             // lane of the same wave (thread 17 r = lane 16 (r & 3) + r of wave r >> 2) instead of evaluated a second time by all 16 threads
             // of the row: a wave is alone on its SIMD here, so a round costs what it ISSUES (~150 instructions, ~45 of them this rotation).
             double ccs, csn;
             jacobi_rotation(c_qq - c_pp, 2.0 * c_pq, ccs, csn);
-            const bool con = cp != c && c_pq != 0.0;
+            const bool con = I.con && c_pq != 0.0;
             const double gc = con ? ccs : 1.0, scm = con ? csn : 0.0;
-            const double sc = c == cP ? -scm : scm;
-            const int dlane = (lane & 48) | r;
+            const double sc = I.c_is_p ? -scm : scm;
             const double gr = __shfl(gc, dlane, 64), srm = __shfl(scm, dlane, 64);
-            const double sr = r == rP ? -srm : srm;
+            const double sr = I.r_is_p ? -srm : srm;
             const double b0 = gc * x00 + sc * x01;      // (A G)[r][c]
             const double b1 = gc * x10 + sc * x11;      // (A G)[r'][c]
             An[t] = gr * b0 + sr * b1;
             Vn[t] = gc * v0 + sc * v1;
             __syncthreads();
             cur = 1 - cur;
+            I = In;
         }
 #ifdef LIW_CLK
         if (t == 0 && blockIdx.x == 0) g_clk[5010] = sweep + 1;   // rotation sweeps executed (tools/clk_probe_track.py)
