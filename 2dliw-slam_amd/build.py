@@ -23,7 +23,7 @@ if os.environ.get("LIW_EXTRA_FLAGS"):   # A/B aid: any further -D... for a probe
     FLAGS += os.environ["LIW_EXTRA_FLAGS"].split()
 if os.environ.get("LIW_QUAD_TILE_ALIAS"):
     FLAGS.append("-DLIW_QUAD_TILE_ALIAS")
-if os.environ.get("LIW_CLK"):   # phase-timing build for tools/clk_probe.py
+if os.environ.get("LIW_CLK"):   # phase-timing build for tools/clk_probe_*.py
     FLAGS.append("-DLIW_CLK")
     if os.environ.get("LIW_CLK_IT"):
         FLAGS.append("-DLIW_CLK_IT=" + os.environ["LIW_CLK_IT"])

@@ -30,12 +30,17 @@ __device__ long long g_span[3 * 16384];   // per window: start, end (s_memtime),
 #define STAMP(id) do { if (b == 0 && lane == 0 && iteration_dbg == LIW_CLK_IT) g_clk[(id)] = clock64(); } while (0)
 #define STAMPE(id) do { if (b == 0 && lane == 0 && iteration == LIW_CLK_IT) g_clk[(id)] = clock64(); } while (0)   // before iteration_dbg exists
 #define STAMPM(id) do { if (b == 0 && lane == 0) g_clk[(id)] = clock64(); } while (0)                              // marginalisation kernel
+// inside a round of the four-wave Jacobi (thread 0, second sweep, fourth round); JSTAMPV first waits for the value v
+#define JSTAMP(id) do { if (t == 0 && blockIdx.x == 0 && sweep == 1 && rnd == 3) g_clk[(id)] = clock64(); } while (0)
+#define JSTAMPV(id, v) do { double w_ = (v); asm volatile("" : "+v"(w_)); if (t == 0 && blockIdx.x == 0 && sweep == 1 && rnd == 3) g_clk[(id)] = clock64(); } while (0)
 #define SPAN(k) do { if (lane == 0 && iteration_dbg == LIW_CLK_IT && b < 16384) { g_span[3 * b + (k)] = clock64(); \
                      if ((k) == 0) g_span[3 * b + 2] = __builtin_amdgcn_s_getreg((4 << 0) | (0 << 6) | (31 << 11)); } } while (0)
 #else
 #define STAMP(id) do { } while (0)
 #define STAMPE(id) do { } while (0)
 #define STAMPM(id) do { } while (0)
+#define JSTAMP(id) do { } while (0)
+#define JSTAMPV(id, v) do { } while (0)
 #define SPAN(k) do { } while (0)
 #endif
 
@@ -1976,6 +1981,7 @@ __device__ __forceinline__ int jacobi15_block(const double* D, double* A2, doubl
             const double c_pq = Ac[I.pq], c_qq = Ac[I.qq], c_pp = Ac[I.pp];
             const double x00 = Ac[t], x01 = Ac[I.x01], x10 = Ac[I.x10], x11 = Ac[I.x11];
             const double v0 = Vc[t], v1 = Vc[I.x01];
+            JSTAMP(5020);
             // the NEXT round's indices in the shadow of the loads: a wave is alone on its SIMD, and as the first ~35 instructions of a round
             // this integer arithmetic sat in front of its loads (~150 of a round's ~890 cycles)
             __builtin_amdgcn_sched_barrier(0);
@@ -1985,18 +1991,23 @@ __device__ __forceinline__ int jacobi15_block(const double* D, double* A2, doubl
             // (column index = r: the same pair, the same three entries, the same instructions) computes for its column — fetched from that
             // lane of the same wave (thread 17 r = lane 16 (r & 3) + r of wave r >> 2) instead of evaluated a second time by all 16 threads
             // of the row: a wave is alone on its SIMD here, so a round costs what it ISSUES (~150 instructions, ~45 of them this rotation).
+            JSTAMP(5021);
             double ccs, csn;
             jacobi_rotation(c_qq - c_pp, 2.0 * c_pq, ccs, csn);
+            JSTAMPV(5022, ccs + csn);
             const bool con = I.con && c_pq != 0.0;
             const double gc = con ? ccs : 1.0, scm = con ? csn : 0.0;
             const double sc = I.c_is_p ? -scm : scm;
             const double gr = __shfl(gc, dlane, 64), srm = __shfl(scm, dlane, 64);
             const double sr = I.r_is_p ? -srm : srm;
+            JSTAMPV(5023, sr + gr);
             const double b0 = gc * x00 + sc * x01;      // (A G)[r][c]
             const double b1 = gc * x10 + sc * x11;      // (A G)[r'][c]
             An[t] = gr * b0 + sr * b1;
             Vn[t] = gc * v0 + sc * v1;
+            JSTAMP(5024);
             __syncthreads();
+            JSTAMP(5025);
             cur = 1 - cur;
             I = In;
         }

@@ -52,6 +52,9 @@ for i in (1, 0):
     print(" frame", i, "assemble", t[1] - t[0], "diag/gmax", t[2] - t[1], "colload", t[3] - t[2], "chol", t[4] - t[3], "ldsW", t[5] - t[4],
           "mfma+record+C", (clk[10 + (i - 1) * 8] if i else clk[1]) - t[5])
 print("k_marg_schur: chain %d | eigen %d | tail %d | Jacobi sweeps %d" % (d(5000, 5001), d(5001, 5002), d(5002, 5003), int(clk[5010])))
+if clk[5025] > clk[5020] > 0:   # one round of the four-wave Jacobi (thread 0, second sweep, fourth round)
+    print(" Jacobi round: loads issued -> next round's indices %d | rotation %d | row rotation fetched %d | update + stores issued %d | barrier %d | (round = %d from the loads on)"
+          % (d(5020, 5021), d(5021, 5022), d(5022, 5023), d(5023, 5024), d(5024, 5025), d(5020, 5025)))
 # IMU role of the single-launch linearisation (k_lin_all: work-group n_laser + 0 is the IMU wave; LSTAMP picks gridDim / 2 = it at n = 2)
 slv.linearize(liw.LIW_MODE_TRACK)
 cl = np.zeros(512, dtype=np.int64)

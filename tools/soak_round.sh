@@ -1,8 +1,21 @@
-# the three GPU soak sweeps that exercise the step / linearise kernels, side by side in one gpurun call (25 minutes each at most):
-#   /usr/local/graft/bin/gpurun --timeout 1800 -- 'bash tools/soak_round.sh'   -> gpurun_out/soak_r05_*.log
-cd $GRAFT_REPO_ROOT
-( timeout 1500 python tests/soak/soak_batch.py 0 3000 > gpurun_out/soak_r05_batch.log 2>&1 ) &
-( timeout 1500 python tests/soak/soak_random_shapes.py 12 4000 > gpurun_out/soak_r05_shapes.log 2>&1 ) &
-( timeout 1500 python tests/soak/soak_c2.py 0 40 15 > gpurun_out/soak_r05_c2.log 2>&1 ) &
+#!/bin/bash
+# GPU soak sweeps side by side in one gpurun call: bash tools/soak_round.sh TAG SET   -> gpurun_out/soak_${TAG}_*.log
+#   /usr/local/graft/bin/gpurun --timeout 2700 -- 'bash tools/soak_round.sh r05d 4'
+# SET 1: the three sweeps that exercise the step / linearise kernels (25 minutes at most); 2: extended seed ranges + API fuzz / replay /
+# pose graph / pre-integration; 3, 4: seed ranges no earlier round has run (every tracking solve of soak_random_shapes.py is a two-frame
+# window: k_lm_step_dense2, k_marg_schur4).  Results: tests/soak/README.md, profiles/*_soak*.txt.
+TAG=${1:-r05}; SET=${2:-1}; T=${3:-2400}
+cd $GRAFT_REPO_ROOT; mkdir -p gpurun_out
+run() { name=$1; shift; ( timeout $T "$@" > gpurun_out/soak_${TAG}_$name.log 2>&1 ) & }
+case $SET in
+1) run batch python tests/soak/soak_batch.py 0 3000; run shapes python tests/soak/soak_random_shapes.py 12 4000; run c2 python tests/soak/soak_c2.py 0 40 15;;
+2) run batch python tests/soak/soak_batch.py 3000 5000; run shapes python tests/soak/soak_random_shapes.py 4000 9000
+   run fuzz python tests/soak/soak_api_fuzz.py 0 60; run replay python tests/soak/soak_replay.py 3 14
+   run pg python tests/soak/soak_posegraph.py 0 200; run preint python tests/soak/soak_preint.py 0 600;;
+3) run batch python tests/soak/soak_batch.py 5000 8000; run shapes python tests/soak/soak_random_shapes.py 9000 15000
+   run shapes2 python tests/soak/soak_random_shapes.py 15000 21000; run c2 python tests/soak/soak_c2.py 40 100 15;;
+4) run batch python tests/soak/soak_batch.py 8000 9500; run shapes python tests/soak/soak_random_shapes.py 21000 24500
+   run shapes2 python tests/soak/soak_random_shapes.py 24500 28000; run fuzz python tests/soak/soak_api_fuzz.py 60 100;;
+esac
 wait
-for f in batch shapes c2; do tail -n 1 gpurun_out/soak_r05_$f.log; done
+for f in gpurun_out/soak_${TAG}_*.log; do echo "== $f"; tail -n 2 $f; done
