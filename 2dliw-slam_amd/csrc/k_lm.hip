@@ -1932,11 +1932,21 @@ __device__ __forceinline__ void marg_schur_body(const MargArgs& a, const int b, 
 //   A'[r][c] = gr (A[r][c] gc + A[r][c'] sc) + sr (A[r'][c] gc + A[r'][c'] sc),   V'[r][c] = V[r][c] gc + V[r][c'] sc
 // reads the current buffer and writes the other one, so a round is ONE work-group barrier instead of three LDS hand-offs with 7 of 64
 // lanes computing parameters.  A2 / V2: two 16x16 buffers each; returns the index (0 / 1) of the buffer that holds the result.
+// value of lane 0 of this lane's 16-lane row (DP-ALU DPP: row_newbcast is the one control 64-bit moves take on gfx90a+).  volatile and in
+// uniform control flow only: a DPP read of a disabled lane is not a read; s_nop: a VGPR written by a VALU instruction needs two wait states
+// before a DPP instruction reads it, and the hazard recogniser does not look inside inline asm.
+__device__ __forceinline__ double row_bc0(double v) {
+    double r;
+    asm volatile("s_nop 1\n\tv_mov_b64_dpp %0, %1 row_newbcast:0 row_mask:0xf bank_mask:0xf" : "=v"(r) : "v"(v));
+    return r;
+}
 __device__ __forceinline__ int jacobi15_block(const double* D, double* A2, double* V2, double* red) {
-    const int t = threadIdx.x, r = t >> 4, c = t & 15, lane = t & 63, wave = t >> 6;
+    // thread t owns element (r, c) = (t >> 4, (t + r) & 15), stored at t_ = 16 r + c: the columns of a row are rotated so that the row's DIAGONAL
+    // element sits in lane 0 of its 16-lane DPP row — what that thread computes reaches the row as a row_newbcast:0 operand (below)
+    const int t = threadIdx.x, r = t >> 4, c = (t + r) & 15, t_ = r * 16 + c, lane = t & 63, wave = t >> 6;
     const bool in = r < 15 && c < 15;
-    A2[t] = in ? 0.5 * (D[r * 16 + c] + D[c * 16 + r]) : 0.0;
-    V2[t] = r == c ? 1.0 : 0.0;
+    A2[t_] = in ? 0.5 * (D[r * 16 + c] + D[c * 16 + r]) : 0.0;
+    V2[t_] = r == c ? 1.0 : 0.0;
     __syncthreads();
     int cur = 0;
     // coefficients of index i in round rnd: new_i = g * x_i + s * x_partner.  partner = (2 rnd - i) mod 15 (the pairs of a round are the
@@ -1962,10 +1972,9 @@ __device__ __forceinline__ int jacobi15_block(const double* D, double* A2, doubl
         I.con = cp != c; I.c_is_p = c <= cp; I.r_is_p = r <= rp;   // (an index without a partner pairs with itself: "is p")
         return I;
     };
-    const int dlane = (lane & 48) | r;
     for (int sweep = 0; sweep < 60; ++sweep) {
         const double* A = A2 + 256 * cur;
-        const double v = in ? A[t] : 0.0;
+        const double v = in ? A[t_] : 0.0;
         double off = c > r ? v * v : 0.0, dgn = c == r ? v * v : 0.0;
         off = wave_sum(off); dgn = wave_sum(dgn);
         if (lane == 0) { red[wave] = off; red[4 + wave] = dgn; }
@@ -1979,8 +1988,8 @@ __device__ __forceinline__ int jacobi15_block(const double* D, double* A2, doubl
             double* An = A2 + 256 * (1 - cur); double* Vn = V2 + 256 * (1 - cur);
             // every load of the round
             const double c_pq = Ac[I.pq], c_qq = Ac[I.qq], c_pp = Ac[I.pp];
-            const double x00 = Ac[t], x01 = Ac[I.x01], x10 = Ac[I.x10], x11 = Ac[I.x11];
-            const double v0 = Vc[t], v1 = Vc[I.x01];
+            const double x00 = Ac[t_], x01 = Ac[I.x01], x10 = Ac[I.x10], x11 = Ac[I.x11];
+            const double v0 = Vc[t_], v1 = Vc[I.x01];
             JSTAMP(5020);
             // the NEXT round's indices in the shadow of the loads: a wave is alone on its SIMD, and as the first ~35 instructions of a round
             // this integer arithmetic sat in front of its loads (~150 of a round's ~890 cycles)
@@ -1988,9 +1997,10 @@ __device__ __forceinline__ int jacobi15_block(const double* D, double* A2, doubl
             const RoundIdx In = round_idx(rnd < 14 ? rnd + 1 : 0);
             __builtin_amdgcn_sched_barrier(0);
             // A thread computes the rotation of its COLUMN's pair; the rotation of its row's pair is the one the row's diagonal thread
-            // (column index = r: the same pair, the same three entries, the same instructions) computes for its column — fetched from that
-            // lane of the same wave (thread 17 r = lane 16 (r & 3) + r of wave r >> 2) instead of evaluated a second time by all 16 threads
-            // of the row: a wave is alone on its SIMD here, so a round costs what it ISSUES (~150 instructions, ~45 of them this rotation).
+            // (column index = r: the same pair, the same three entries, the same instructions) computes for its column — lane 0 of the
+            // thread's DPP row (the rotated column order above), i.e. a row_newbcast:0 move instead of a second evaluation by all 16 threads
+            // of the row (until late round 5) or a ds_bpermute (~200 of a round's ~890 cycles, stamps of tools/clk_probe_track.py):
+            // a wave is alone on its SIMD here, so a round costs what it ISSUES.
             JSTAMP(5021);
             double ccs, csn;
             jacobi_rotation(c_qq - c_pp, 2.0 * c_pq, ccs, csn);
@@ -1998,13 +2008,13 @@ __device__ __forceinline__ int jacobi15_block(const double* D, double* A2, doubl
             const bool con = I.con && c_pq != 0.0;
             const double gc = con ? ccs : 1.0, scm = con ? csn : 0.0;
             const double sc = I.c_is_p ? -scm : scm;
-            const double gr = __shfl(gc, dlane, 64), srm = __shfl(scm, dlane, 64);
+            const double gr = row_bc0(gc), srm = row_bc0(scm);
             const double sr = I.r_is_p ? -srm : srm;
             JSTAMPV(5023, sr + gr);
             const double b0 = gc * x00 + sc * x01;      // (A G)[r][c]
             const double b1 = gc * x10 + sc * x11;      // (A G)[r'][c]
-            An[t] = gr * b0 + sr * b1;
-            Vn[t] = gc * v0 + sc * v1;
+            An[t_] = gr * b0 + sr * b1;
+            Vn[t_] = gc * v0 + sc * v1;
             JSTAMP(5024);
             __syncthreads();
             JSTAMP(5025);
