@@ -807,6 +807,235 @@ __device__ __forceinline__ void ground_frames(const LinArgs& A, const DevParams&
     }
 }
 
+// ------------------------------------------------------------------------------------------- wheel + ground, two lanes per block
+// The batched form of the two small roles (k_lin_small; k_lin_all keeps the lane layouts above).  A wheel block (b, k) is two lanes:
+// lane 0 differentiates R_k, lane 1 R_{k+1} (three directions each, as above); the three directions of the RELATIVE translation, which
+// took a third lane with an idle exp_so3, ride along as three more dual parts of the scalar tail only (p -> length / direction angle: the
+// rotation magnitude does not depend on p; its translation derivative is the chain's slopes times a zero seed, kept as ONE more dual
+// part so that the NaN of norm() at an exactly stationary increment, wheel_factor.h:52-63, comes out as the reference's Jets give it).
+// 31 blocks per wave instead of 21.  The lane that holds exp_so3(theta) of a frame with its three derivatives also evaluates that
+// frame's ground factors (ground_factor.h:27-48, :59-82: frame k+1 by lane 1, frame k by lane 0 — stored for k = 0 only), so the ground
+// role costs no exp_so3 of its own and no waves: 0.141 of the kernel's 0.708 ms per 49 152 C2 windows were its waves.
+constexpr int WG_PER_WAVE = 31, WG_REC = 68;   // LDS doubles per block: Y [3][13] | ground of frame k+1 [2][7] at 39 | of frame k [2][7] at 53
+constexpr int WG_LDS = WG_PER_WAVE * WG_REC + 96;   // + six meta words per block
+__device__ __forceinline__ LJN<4> ext4(const J3& a) { LJN<4> r; r.v = a.v; r.d[0] = a.d[0]; r.d[1] = a.d[1]; r.d[2] = a.d[2]; r.d[3] = 0.0; return r; }
+template <bool COSTCOPY>
+__device__ __forceinline__ void wheel_ground2_blocks(const LinArgs& A, const DevParams& P, int wave, double* lds, const int* const act) {
+    typedef LJN<4> J4;
+    typedef LJN<6> J6;
+    const int lane = threadIdx.x & 63, blk = lane >> 1, f = lane & 1;
+    const int n = A.n, nb = n - 1;
+    const long total = (long)(act ? act[0] : A.B) * nb, gb = (long)wave * A.small_per_wave + blk;   // over the windows still iterating
+    bool on = blk < A.small_per_wave && blk < WG_PER_WAVE && gb < total;
+    const int wi = on ? (int)(gb / nb) : 0, k = on ? (int)(gb % nb) : 0;
+    const int b = act ? act[1 + wi] : wi;
+    if (on && !act) on = window_live(A, b);
+    double* Y = lds + (blk < WG_PER_WAVE ? blk : 0) * WG_REC;
+    const size_t fk = on ? (size_t)b * nb + k : 0, fi0 = on ? (size_t)b * n + k : 0;
+    if (on) {
+        const double* si_ = A.x + fi0 * 15;
+        const double* sj_ = si_ + 15;
+        const double* T12 = A.wheel_T + fk * 12;
+        const double* sq9 = A.wheel_sqrtP + fk * 9;
+        const V3<double> thi = cast_v3<double>(si_ + 3), thj = cast_v3<double>(sj_ + 3);
+        V3<J3> arg;   // the rotation this lane differentiates
+        arg.x = seed<3>(f ? thj.x : thi.x, 0, true); arg.y = seed<3>(f ? thj.y : thi.y, 1, true); arg.z = seed<3>(f ? thj.z : thi.z, 2, true);
+        const M3<J3> Md = exp_so3(arg);
+        M3<double> Ri, Rj;   // the two rotations as values: the value parts of the two lanes' differentiated rotations
+        {
+            const int l0 = lane - f;
+#pragma unroll
+            for (int q = 0; q < 9; ++q) {
+                const double mv = Md.m[q].v;
+                Ri.m[q] = __shfl(mv, l0, 64);
+                Rj.m[q] = __shfl(mv, l0 + 1, 64);
+            }
+        }
+        // ---- ground factors of this lane's frame (k + f) from the same exp_so3: height of the wheel-frame origin, tilt of its z axis
+        {
+            const double pz = f ? sj_[2] : si_[2];
+            const J3 r0 = (Md(2, 0) * P.tiw[0] + Md(2, 1) * P.tiw[1] + Md(2, 2) * P.tiw[2] + J3(pz)) * P.ground_p_info;
+            // (fourth dual part: a zero seed = any of the three position directions, whose derivative of the tilt is slope * 0 — NaN when
+            //  the axis is exactly level, as the reference's Jets give it)
+            const J4 zx = ext4(Md(0, 0)) * P.Riw[2] + ext4(Md(0, 1)) * P.Riw[5] + ext4(Md(0, 2)) * P.Riw[8];
+            const J4 zy = ext4(Md(1, 0)) * P.Riw[2] + ext4(Md(1, 1)) * P.Riw[5] + ext4(Md(1, 2)) * P.Riw[8];
+            const J4 r1 = dasin(dsqrt(zy * zy + zx * zx)) * P.ground_q_info;
+            double* Yg = Y + (f ? 39 : 53);
+            Yg[0] = 0.0; Yg[1] = 0.0; Yg[2] = P.ground_p_info;   // d (R(2,:) t + p_z) / d p, scaled
+#pragma unroll
+            for (int e = 0; e < 3; ++e) { Yg[3 + e] = r0.d[e]; Yg[7 + e] = r1.d[3]; Yg[10 + e] = r1.d[e]; }
+            Yg[6] = r0.v; Yg[13] = r1.v;
+            const size_t fi = fi0 + f;
+            if ((f || k == 0) && A.dbg_ground_res) { A.dbg_ground_res[fi * 2] = r0.v; A.dbg_ground_res[fi * 2 + 1] = r1.v; }
+            if ((f || k == 0) && A.dbg_ground_jac)
+                for (int e = 0; e < 6; ++e) { A.dbg_ground_jac[(fi * 2) * 6 + e] = Yg[e]; A.dbg_ground_jac[(fi * 2 + 1) * 6 + e] = Yg[7 + e]; }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        const M3<double> Riw = cast_m3<double>(P.Riw);
+        const V3<double> tiw(P.tiw[0], P.tiw[1], P.tiw[2]);
+        const M3<double> Rwi = mul(Ri, Riw);                      // tf_i.R
+        const M3<double> Am = transpose(Rwi);                     // R_iw^T R_i^T
+        const M3<double> RjRiw = mul(Rj, Riw);
+        const V3<double> Rjt = mul(Rj, tiw);
+        const V3<double> w(Rjt.x + sj_[0] - si_[0], Rjt.y + sj_[1] - si_[1], Rjt.z + sj_[2] - si_[2]);
+        const M3<double> Rrel = mul(Am, RjRiw);
+        const V3<double> trel = mul(Am, w) - mulT(Riw, tiw);
+        M3<J4> E;      // relative rotation: parts 0..2 this lane's rotation directions, part 3 the zero seed of the translation directions
+        V3<J6> p;      // relative translation: parts 0..2 this lane's rotation directions, 3..5 the translation directions
+#pragma unroll
+        for (int q = 0; q < 9; ++q) E.m[q] = J4(Rrel.m[q]);
+        p.x = J6(trel.x); p.y = J6(trel.y); p.z = J6(trel.z);
+        p.x.d[3] = 1.0; p.y.d[4] = 1.0; p.z.d[5] = 1.0;
+        {
+            const M3<double> RiwT = transpose(Riw);
+            M3<double> Lm, Rm;
+#pragma unroll
+            for (int q = 0; q < 9; ++q) { Lm.m[q] = f == 0 ? RiwT.m[q] : Am.m[q]; Rm.m[q] = f == 0 ? RjRiw.m[q] : Riw.m[q]; }
+            const V3<double> wv(f == 0 ? w.x : tiw.x, f == 0 ? w.y : tiw.y, f == 0 ? w.z : tiw.z);
+#pragma unroll
+            for (int e = 0; e < 3; ++e) {
+                M3<double> X;   // f = 0: (dR_i / d theta_i_e)^T, f = 1: dR_j / d theta_j_e
+#pragma unroll
+                for (int r = 0; r < 3; ++r)
+#pragma unroll
+                    for (int c = 0; c < 3; ++c) X(r, c) = f == 0 ? Md(c, r).d[e] : Md(r, c).d[e];
+                const M3<double> LX = mul(Lm, X);
+                const M3<double> dR = mul(LX, Rm);
+                const V3<double> dt = mul(LX, wv);
+#pragma unroll
+                for (int q = 0; q < 9; ++q) E.m[q].d[e] = dR.m[q];
+                p.x.d[e] = dt.x; p.y.d[e] = dt.y; p.z.d[e] = dt.z;
+            }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        // wheel_odom_factor::operator() from (p, q) on (wheel_factor.h:36-70)
+        const V3<J4> q = log_SO3(E);
+        const V3<double> oq = log_SO3(cast_m3<double>(T12));      // log_SE3 of the constant odometry increment: plain doubles
+        const double opx = T12[9], opy = T12[10];
+        const double o_len = sqrt(opx * opx + opy * opy);
+        const J6 len = dsqrt(p.x * p.x + p.y * p.y);
+        J6 res0, res1, angle(0.0);
+        if (o_len > 0.0001 && len.v > 0.0001) {
+            const double odx = opx / o_len, ody = opy / o_len;     // normalized(o_dir)
+            const J6 dx = p.x / len, dy = p.y / len;
+            const J6 cz = dy * odx - dx * ody;                     // |cross(o_dir, dir)| through norm() = sqrt(z^2), as the reference computes it
+            angle = dasin(dsqrt(cz * cz));
+        } else {
+            angle = len;
+        }
+        if (len.v < 0.0001 || o_len < 0.0001) res0 = len * sq9[0];
+        else res0 = (J6(o_len) - len) * sq9[0];
+        res1 = angle * sq9[4];
+        const J4 nq = norm(q);
+        const double noq = sqrt(oq.x * oq.x + oq.y * oq.y + oq.z * oq.z);
+        J4 res2;
+        if (nq.v < 0.001 || noq < 0.001) res2 = nq * sq9[8];
+        else res2 = (J4(noq) - nq) * sq9[8];
+        // rotation columns of this lane: theta_i (3..5) or theta_j (9..11)
+#pragma unroll
+        for (int e = 0; e < 3; ++e) {
+            const int col = f ? 9 + e : 3 + e;
+            Y[col] = res0.d[e]; Y[13 + col] = res1.d[e]; Y[26 + col] = res2.d[e];
+        }
+        if (f == 0) {
+            // position columns: Y[r][p_j c] = sum_k Dp[r][k] R_wi[c][k],  Y[r][p_i c] = -Y[r][p_j c];  residual column
+            const double Dp[3][3] = {{res0.d[3], res0.d[4], res0.d[5]}, {res1.d[3], res1.d[4], res1.d[5]}, {res2.d[3], res2.d[3], res2.d[3]}};
+#pragma unroll
+            for (int r = 0; r < 3; ++r) {
+#pragma unroll
+                for (int c = 0; c < 3; ++c) {
+                    const double v = Dp[r][0] * Rwi.m[c * 3] + Dp[r][1] * Rwi.m[c * 3 + 1] + Dp[r][2] * Rwi.m[c * 3 + 2];
+                    Y[r * 13 + 6 + c] = v;
+                    Y[r * 13 + c] = -v;
+                }
+            }
+            Y[12] = res0.v; Y[25] = res1.v; Y[38] = res2.v;
+        }
+    }
+    lds_sync();
+    if (on && f == 0 && A.dbg_wheel_res)
+        for (int r = 0; r < 3; ++r) A.dbg_wheel_res[fk * 3 + r] = Y[r * 13 + 12];
+    if (on && A.dbg_wheel_jac)
+        for (int e = f; e < 36; e += 2) A.dbg_wheel_jac[fk * 36 + e] = Y[(e / 12) * 13 + e % 12];
+    // per block: partial buffer (0 / 1) or -1 = skip | wheel record | wheel cost slot | ground record of frame k | its cost slot | k
+    int* meta = reinterpret_cast<int*>(lds + WG_PER_WAVE * WG_REC);
+    if (f == 0 && blk < WG_PER_WAVE) {
+        meta[blk] = on ? (A.lm ? (A.candidate ? 1 - A.lm[b].cur : A.lm[b].cur) : 0) : -1;
+        meta[32 + blk] = (int)fk;
+        meta[64 + blk] = (int)cs_index(n, b, CS_WHEEL, k);
+        meta[96 + blk] = (int)fi0;
+        meta[128 + blk] = (int)cs_index(n, b, CS_GROUND, k);
+        meta[160 + blk] = k;
+    }
+    lds_sync();
+    const long gb0 = (long)wave * A.small_per_wave;
+    const int nblk = (int)min((long)min(A.small_per_wave, WG_PER_WAVE), total - gb0);
+    const int ml = lane < WG_PER_WAVE ? lane : 0;
+    const int selv = meta[ml], fkv = meta[32 + ml], csv = meta[64 + ml], fiv = meta[96 + ml], cgv = meta[128 + ml], kv = meta[160 + ml];
+    const bool all_on = __builtin_amdgcn_ballot_w64(lane < nblk && selv < 0) == 0;   // (uniform; false only without the list of live windows)
+    // ---- wheel records (PWS = 92 doubles): 46 lanes x 16 bytes, one store per block
+    if (lane < PWS / 2) {
+        const int rc0 = c_wheel_rc.e[2 * lane], rc1 = c_wheel_rc.e[2 * lane + 1];
+        const int r0 = rc0 >> 8, c0 = rc0 & 255;
+        const int r1 = rc1 >= 0 ? rc1 >> 8 : 0, c1 = rc1 >= 0 ? rc1 & 255 : 0;
+        auto block = [&](int q) {
+            const double* Yq = lds + q * WG_REC;
+            double2 v;
+            v.x = __builtin_fma(Yq[26 + r0], Yq[26 + c0], __builtin_fma(Yq[r0], Yq[c0], Yq[13 + r0] * Yq[13 + c0]));
+            const double w1 = __builtin_fma(Yq[26 + r1], Yq[26 + c1], __builtin_fma(Yq[r1], Yq[c1], Yq[13 + r1] * Yq[13 + c1]));
+            v.y = rc1 >= 0 ? w1 : 0.0;                         // entry 91 is padding
+            return v;
+        };
+        auto put = [&](int q, const double2& v) {
+            const int sel = __builtin_amdgcn_readlane(selv, q);
+            nt_store<8>(reinterpret_cast<double2*>(&(sel ? A.PW[1] : A.PW[0])[(size_t)__builtin_amdgcn_readlane(fkv, q) * PWS + 2 * lane]), v);
+        };
+        int q = 0;
+        if (all_on)
+            for (; q + 3 <= nblk; q += 3) {
+                const double2 va = block(q), vb = block(q + 1), vc = block(q + 2);
+                put(q, va); put(q + 1, vb); put(q + 2, vc);
+            }
+        for (; q < nblk; ++q) {
+            const double2 v = block(q);
+            if (__builtin_amdgcn_readlane(selv, q) >= 0) put(q, v);
+        }
+    }
+    // ---- ground records (PGS = 28 doubles): 14 lanes x 16 bytes, four frames per store; pass 0 = frame k+1 of every block, pass 1 = frame k
+    // of the blocks with k = 0 (a window's first)
+    {
+        const double mult = (double)n;
+        constexpr int LPF = PGS / 2;
+        const int j = lane / LPF, pr = lane - j * LPF;
+        const bool any_k0 = __builtin_amdgcn_ballot_w64(lane < nblk && kv == 0) != 0;   // (uniform)
+        if (j < 4) {
+            const int rc0 = c_ground_rc.e[2 * pr], rc1 = c_ground_rc.e[2 * pr + 1];
+            const int r0 = rc0 >> 8, c0 = rc0 & 255, r1 = rc1 >> 8, c1 = rc1 & 255;
+            for (int pass = 0; pass < (any_k0 ? 2 : 1); ++pass) {
+                const int yo = pass ? 53 : 39;
+                for (int q = j; q < nblk; q += 4) {
+                    const int sel = meta[q], fq = meta[96 + q] + (pass ? 0 : 1), kq = meta[160 + q];
+                    const double* Yq = lds + q * WG_REC + yo;
+                    double2 v;
+                    v.x = mult * __builtin_fma(Yq[7 + r0], Yq[7 + c0], Yq[r0] * Yq[c0]);
+                    v.y = mult * __builtin_fma(Yq[7 + r1], Yq[7 + c1], Yq[r1] * Yq[c1]);
+                    if (sel >= 0 && (pass == 0 || kq == 0))
+                        nt_store<8>(reinterpret_cast<double2*>(&(sel ? A.PG[1] : A.PG[0])[(size_t)fq * PGS + 2 * pr]), v);
+                }
+            }
+        }
+        // compact cost array: lane q writes block q's three entries, the same operations as the records' cost entries
+        if (COSTCOPY && A.CS[0] && lane < nblk && selv >= 0) {
+            const double* Yq = lds + lane * WG_REC;
+            double* CSb = selv ? A.CS[1] : A.CS[0];
+            CSb[csv] = __builtin_fma(Yq[38], Yq[38], __builtin_fma(Yq[12], Yq[12], Yq[25] * Yq[25]));
+            CSb[cgv + 1] = mult * __builtin_fma(Yq[39 + 13], Yq[39 + 13], Yq[39 + 6] * Yq[39 + 6]);
+            if (kv == 0) CSb[cgv] = mult * __builtin_fma(Yq[53 + 13], Yq[53 + 13], Yq[53 + 6] * Yq[53 + 6]);
+        }
+        (void)fiv;
+    }
+}
+
 // ------------------------------------------------------------------------------------------- dispatch
 // The IMU / wheel / ground roles index their blocks over the whole batch (21 / 21 / 32 per wave), so no wave is partly empty
 // because of window boundaries; `done` windows are skipped lane by lane.
@@ -875,11 +1104,14 @@ void launch_imu_pack(int B, int n, const double* imu_X, const double* imu_J, con
     hipLaunchKernelGGL(k_imu_pack, dim3((unsigned)blocks), dim3(256), 0, s, blocks, imu_X, imu_J, imu_sqrtP, imu_Dt, pk, bad);
 }
 #ifndef LIW_SMALL_OCC
-#define LIW_SMALL_OCC 3
+#define LIW_SMALL_OCC 2   // (two waves per SIMD: 17.6 kB of LDS per wave, no scratch; two and three waves tied before the roles were merged)
 #endif
 __global__ __launch_bounds__(64, LIW_SMALL_OCC) void k_lin_small(LinArgs A, DevParams P) {
-    __shared__ double lds[SMALL_LDS];
-    small_role<3, true>(A, P, (int)blockIdx.x, lds, usable_active_list(A.active, A.B));
+    __shared__ double lds[WG_LDS > SMALL_LDS ? WG_LDS : SMALL_LDS];
+    static_assert(sizeof(double) * (WG_LDS > SMALL_LDS ? WG_LDS : SMALL_LDS) * 4 * LIW_SMALL_OCC <= 160 * 1024, "LDS of the waves of a CU");
+    const int* const act = usable_active_list(A.active, A.B);
+    if (A.n > 1) wheel_ground2_blocks<true>(A, P, (int)blockIdx.x, lds, act);   // wheel blocks; the ground frames ride along
+    else ground_frames<true>(A, P, (int)blockIdx.x, lds, act);                   // a one-frame window has no wheel block
 }
 __global__ void k_lm_reset(int B, LmState* lm, int max_iters) {
     const int b = blockIdx.x * blockDim.x + threadIdx.x;
@@ -1041,7 +1273,12 @@ void launch_linearize(const LinArgs& A_, const DevParams& P, hipStream_t s, cons
     }
     if (imu_waves && (rm & 2) && A.pi_frame) hipLaunchKernelGGL(k_lin_imu_chain, dim3((unsigned)(B * imu_chain_parts(n - 1))), dim3(64), 0, s_imu, A, P);
     else if (imu_waves && (rm & 2)) hipLaunchKernelGGL(k_lin_imu, dim3((unsigned)imu_waves), dim3(64), 0, s_imu, A, P);
-    if (small_waves && (rm & 4)) hipLaunchKernelGGL(k_lin_small, dim3((unsigned)small_waves), dim3(64), 0, s_small, A, P);
+    if (small_waves && (rm & 4)) {
+        // k_lin_small: two lanes per wheel block (31 per wave once the batch fills the chip), the ground frames evaluated by the wheel lanes
+        if (A.small_per_wave == WHEEL_PER_WAVE) A.small_per_wave = WG_PER_WAVE;
+        const int waves = n > 1 ? wheel_wave_count(B, n, A.small_per_wave) : ground_wave_count(B, n);
+        hipLaunchKernelGGL(k_lin_small, dim3((unsigned)waves), dim3(64), 0, s_small, A, P);
+    }
     if (fork) {
         hipEventRecord(fk->ev_join[0], fk->side[0]);
         hipEventRecord(fk->ev_join[1], fk->side[1]);
