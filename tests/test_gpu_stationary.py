@@ -206,3 +206,54 @@ def test_exactly_stationary_interval_fails_the_evaluation_like_ceres(liw, synth,
     assert so["termination"] == 6 and so["iterations"] == 0
     assert (sg["iterations"], sg["termination"]) == (0, 6), sg
     assert np.array_equal(wg["states"], d["states"]) and np.array_equal(wo["states"], d["states"])
+
+
+def _same_with_nan(a, b, tol):
+    a, b = np.asarray(a), np.asarray(b)
+    fa, fb = np.isfinite(a), np.isfinite(b)
+    assert np.array_equal(fa, fb), "non-finite entries in different places"
+    if fa.any():
+        assert np.abs(a[fa] - b[fa]).max() <= tol * max(1.0, np.abs(b[fb]).max())
+
+
+@pytest.mark.parametrize("level", [False, True])
+def test_merged_wheel_ground_role_of_batches_on_every_arm(liw, synth, pyoracle, level):
+    """k_lin_small (batches: two lanes per wheel block, the translation directions as extra dual parts of the scalar tail, the ground factors
+    evaluated by the wheel lanes) against the lane layouts of k_lin_all (a single window: three / nine lanes per block, ground waves of their
+    own), which test_wheel_factor_arms / test_ground_tilt_exactly_level compare with the oracle's Jets factor by factor: every threshold arm
+    of wheel_factor.h:36-70, an exactly stationary interval (NaN derivative of norm(), :63) and — `level` — a wheel frame whose z axis is
+    exactly vertical in one frame (NaN derivative of the tilt, ground_factor.h:78).  Normal equations window by window, non-finite entries in
+    the same places."""
+    prm = synth.office_params()
+    if level:
+        T = np.eye(4)
+        T[:3, 3] = [-0.061, 0.919, -0.224]
+        prm["T_imu_to_wheel"] = list(T.reshape(16))
+    orc = pyoracle.Oracle(prm)
+    n, L = 7, 60
+    base = [synth.make_window(orc, prm, seed=31, n=n, L=L, **CASES[c][0]) for c in sorted(CASES)]
+    base.append(synth.make_window(orc, prm, seed=3, n=n, L=L, motion="stationary", odom_noise=0.0, state_noise=0.0))
+    if level:
+        for w in base[:3]:
+            w["states"][2, 3:6] = 0.0
+            w["match_pose"][2, 9:12] = 0.0
+            w["states"][0, 3:6] = 0.0      # frame 0: evaluated by the first block's lane 0
+            w["match_pose"][0, 9:12] = 0.0
+    B = 96                                 # 672 laser waves: the roles run as kernels of their own (k_lin_small), 31 wheel blocks per wave
+    wins = [base[b % len(base)] for b in range(B)]
+    big = liw.BatchSolver(prm, wins)
+    assert (B * n + 2 * B * (n - 1)) > 256
+    for mode in (liw.LIW_MODE_INIT, liw.LIW_MODE_MARG):
+        big.linearize(mode)
+        Hb, gb, cb = [t.cpu().numpy() for t in big.export_dense(mode)]
+        nonfinite = 0
+        for k, w in enumerate(base):
+            one = liw.BatchSolver(prm, [w])
+            one.linearize(mode)
+            H1, g1, c1 = [t.cpu().numpy() for t in one.export_dense(mode)]
+            nonfinite += int(not np.isfinite(H1[0]).all())
+            for b in (k, k + len(base) * ((B - 1 - k) // len(base))):      # first and last copy of this window in the batch
+                _same_with_nan(Hb[b], H1[0], 1e-12)
+                _same_with_nan(gb[b], g1[0], 1e-12)
+                _same_with_nan(cb[b], c1[0], 1e-12)
+        assert nonfinite >= (4 if level else 1), "the exactly stationary / exactly level windows must show up as non-finite entries"
