@@ -2060,6 +2060,187 @@ __global__ __launch_bounds__(64, LIW_MARG_OCC) void k_marg_schur(MargArgs a) {
     marg_schur_body(a, (int)blockIdx.x, T, T.R, T.O, T.Cg);
 }
 
+
+// ---------------------------------------------------------------------------------------------------
+// Large batches, since the end of round 5: the chain and the eigen square root are TWO kernels.  k_marg_schur_chain is marg_chain by one wave
+// per window as before and leaves Delta_H | Delta_g | ok in the window's (dead) factorisation scratch; k_marg_schur_eigq takes FOUR windows
+// per wave, 16 lanes per window: lane r holds row r of the rotated matrix and row r of the eigenvector matrix in REGISTERS.  The one-wave
+// Jacobi spent a round on three LDS hand-offs with 7 of 64 lanes computing the rotations and 105 of 128 lane slots updating elements
+// (~270 instructions per window and round); here every lane computes the rotation of the pair its own row is in (both lanes of a pair
+// from the same three matrix words, so they agree bit for bit), takes the partner's row from LDS (eight 16-byte reads, issued with the
+// three words of the rotation), combines the two rows (the row half of G^T A G), receives the seven (cos, sin) of the round as
+// row_newbcast DPP operands — the pairs of a round are compile-time constants, the 15 rounds are unrolled — and rotates its 7 column
+// pairs of A and V in registers: ~190 instructions per round for four windows.  Same rotations, same round-robin order, same stop test
+// (per window: a window that has met it keeps identity rotations while its neighbours in the wave finish) as jacobi15_wave.
+constexpr int JQ_LD = 18;                        // row stride of a window's matrix image in LDS (doubles): 144 B — 16-byte row reads of 16 lanes touch 16 different bank groups
+constexpr int JQ_WIN = 16 * JQ_LD;
+constexpr int MARG_SCR_G = 225, MARG_SCR_OK = 240;   // hand-over record (in solve_ws of the window): Delta_H (row-major 15) | Delta_g (reference sign) | 1.0 / 0.0
+static_assert(SOLVE_WS > MARG_SCR_OK, "the hand-over record fits the scratch of a one-frame window");
+
+template <int N>
+__device__ __forceinline__ double row_bc(double v) {   // value of lane N of this lane's 16-lane row (see row_bc0)
+    double r;
+    asm volatile("s_nop 1\n\tv_mov_b64_dpp %0, %1 row_newbcast:%2 row_mask:0xf bank_mask:0xf" : "=v"(r) : "v"(v), "n"(N));
+    return r;
+}
+__host__ __device__ constexpr int jq_pair(int rnd, int i, bool hi) {   // slot i of round rnd, as pair_of in jacobi15_wave
+    const int k = i + 1;
+    int p = rnd + k; p = p >= 15 ? p - 15 : p;
+    int q = rnd + 15 - k; q = q >= 15 ? q - 15 : q;
+    return hi ? (p > q ? p : q) : (p > q ? q : p);
+}
+template <int RND, int I>
+__device__ __forceinline__ void jq_cols(double (&t)[16], double (&V)[15], const double cs, const double sn) {
+    constexpr int p = jq_pair(RND, I, false), q = jq_pair(RND, I, true);
+    const double ci = row_bc<p>(cs), si = row_bc<p>(sn);
+    const double tp = t[p], tq = t[q], vp = V[p], vq = V[q];
+    t[p] = ci * tp - si * tq;
+    t[q] = si * tp + ci * tq;
+    V[p] = ci * vp - si * vq;
+    V[q] = si * vp + ci * vq;
+}
+template <int RND>
+__device__ __forceinline__ void jq_round(double (&A)[16], double (&V)[15], double* LAg, const int r_, const bool active) {
+    typedef double __attribute__((ext_vector_type(2))) dbl2;
+    // (the round's partner / address arithmetic is a dozen integer instructions of the lane index; opaque to the optimiser, or the
+    // invariant parts of all 15 unrolled rounds are hoisted out of the sweep loop and live across it: 400 spilled registers)
+    int r = r_;
+    asm volatile("" : "+v"(r));
+    // partner row: p + q = 2 RND (mod 15); row RND (and the pad lane 15) has none this round
+    int m = 2 * RND - r;
+    m = m < 0 ? m + 15 : m;
+    m = m >= 15 ? m - 15 : m;
+    m = r == 15 ? 15 : m;
+    const double* rowm = LAg + m * JQ_LD;
+    double T[16];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+        const dbl2 v = *reinterpret_cast<const dbl2*>(rowm + 2 * k);
+        T[2 * k] = v.x; T[2 * k + 1] = v.y;
+    }
+    const int lo = r < m ? r : m, hi = r < m ? m : r;
+    const double apq = LAg[lo * JQ_LD + hi], all = LAg[r * JQ_LD + r], amm = rowm[m];
+    const bool isp = r < m;
+    double cs = 1.0, sn = 0.0;
+    if (active && m != r && apq != 0.0) jacobi_rotation(isp ? amm - all : all - amm, 2.0 * apq, cs, sn);
+    // rows: row_p' = cs row_p - sn row_q, row_q' = sn row_p + cs row_q
+    const double sr = isp ? -sn : sn;
+    double t[16];
+#pragma unroll
+    for (int k = 0; k < 15; ++k) t[k] = cs * A[k] + sr * T[k];
+    t[15] = 0.0;
+    // columns of A and V: the seven rotations of the round from the lanes that hold their smaller index
+    jq_cols<RND, 0>(t, V, cs, sn); jq_cols<RND, 1>(t, V, cs, sn); jq_cols<RND, 2>(t, V, cs, sn); jq_cols<RND, 3>(t, V, cs, sn);
+    jq_cols<RND, 4>(t, V, cs, sn); jq_cols<RND, 5>(t, V, cs, sn); jq_cols<RND, 6>(t, V, cs, sn);
+    // (pin the eigenvector row to this round: its rotations depend on nothing in LDS, and left alone the compiler sinks those of all 15
+    // rounds to the end of the sweep, keeping 210 broadcast values alive in scratch)
+#pragma unroll
+    for (int k = 0; k < 15; ++k) asm volatile("" : "+v"(V[k]));
+    lds_sync();                                   // (every lane has read its partner's row)
+    double* rowr = LAg + r * JQ_LD;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+        A[2 * k] = t[2 * k]; A[2 * k + 1] = t[2 * k + 1];
+        dbl2 v; v.x = t[2 * k]; v.y = t[2 * k + 1];
+        *reinterpret_cast<dbl2*>(rowr + 2 * k) = v;
+    }
+    lds_sync();
+}
+
+__global__ __launch_bounds__(64, LIW_MARG_OCC) void k_marg_schur_chain(MargArgs a) {
+    __shared__ LdsMarg T;
+    const int b = blockIdx.x, lane = threadIdx.x & 63;
+    double* S = a.w.solve_ws + (size_t)b * a.n * SOLVE_WS;
+    if (a.gate && !a.gate[b].done) {
+        if (lane == 0) { if (a.status) a.status[b] = 2; S[MARG_SCR_OK] = 0.0; }
+        return;
+    }
+    const bool ok = marg_chain(a, b, T);
+    if (ok) {
+        for (int e = lane; e < 225; e += 64) S[e] = T.D[(e / 15) * 16 + e % 15];
+        if (lane < 15) S[MARG_SCR_G + lane] = -T.g[lane];
+    }
+    if (lane == 0) S[MARG_SCR_OK] = ok ? 1.0 : 0.0;
+}
+
+__global__ __launch_bounds__(64, 4) void k_marg_schur_eigq(MargArgs a) {
+    __shared__ __attribute__((aligned(16))) double LA[4 * JQ_WIN];
+    __shared__ double Wd[64];
+    const int lane = threadIdx.x & 63, g = lane >> 4, r = lane & 15, n = a.n;
+    const int b = (int)blockIdx.x * 4 + g;
+    const double* S = a.w.solve_ws + (size_t)(b < a.B ? b : 0) * n * SOLVE_WS;
+    const bool ok = b < a.B && S[MARG_SCR_OK] != 0.0;
+    double* LAg = LA + g * JQ_WIN;
+    double A[16], V[15];
+    // A = (Delta_H + Delta_H^T) / 2, V = I
+#pragma unroll
+    for (int c = 0; c < 15; ++c) {
+        const bool in = ok && r < 15;
+        const double u = in ? S[r * 15 + c] : 0.0, l = in ? S[c * 15 + r] : 0.0;
+        A[c] = 0.5 * (u + l);
+        V[c] = c == r ? 1.0 : 0.0;
+    }
+    A[15] = 0.0;
+    {
+        typedef double __attribute__((ext_vector_type(2))) dbl2;
+        double* rowr = LAg + r * JQ_LD;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) { dbl2 v; v.x = A[2 * k]; v.y = A[2 * k + 1]; *reinterpret_cast<dbl2*>(rowr + 2 * k) = v; }
+    }
+    lds_sync();
+    bool active = ok;
+    for (int sweep = 0; sweep < 60; ++sweep) {
+        double off = 0.0, dgn = 0.0;
+#pragma unroll
+        for (int c = 0; c < 15; ++c) {
+            const double sq = A[c] * A[c];
+            off += c > r ? sq : 0.0;
+            dgn += c == r ? sq : 0.0;
+        }
+        off = row_sum(off); dgn = row_sum(dgn);
+        if (off <= 1e-34 * dgn || off == 0.0) active = false;   // sums of squares: off-diagonal below 1e-17 of the diagonal (per window)
+        if (!__any(active)) break;
+        jq_round<0>(A, V, LAg, r, active); jq_round<1>(A, V, LAg, r, active); jq_round<2>(A, V, LAg, r, active);
+        jq_round<3>(A, V, LAg, r, active); jq_round<4>(A, V, LAg, r, active); jq_round<5>(A, V, LAg, r, active);
+        jq_round<6>(A, V, LAg, r, active); jq_round<7>(A, V, LAg, r, active); jq_round<8>(A, V, LAg, r, active);
+        jq_round<9>(A, V, LAg, r, active); jq_round<10>(A, V, LAg, r, active); jq_round<11>(A, V, LAg, r, active);
+        jq_round<12>(A, V, LAg, r, active); jq_round<13>(A, V, LAg, r, active); jq_round<14>(A, V, LAg, r, active);
+    }
+    // eigenvalue r and the eigenvector matrix (row r from this lane) through LDS: lane k of a window takes eigenvector k = column k
+    Wd[lane] = LAg[r * JQ_LD + r];
+    lds_sync();
+#pragma unroll
+    for (int c = 0; c < 15; ++c) LAg[r * JQ_LD + c] = V[c];
+    lds_sync();
+    // eigen square root and prior write-back (solver.cpp:390-441), as marg_tail
+    double* oX = a.out_X ? a.out_X : a.prior_X; double* oJ = a.out_J ? a.out_J : a.prior_J; double* oR = a.out_R ? a.out_R : a.prior_R;
+    int* oHas = a.out_has ? a.out_has : a.has_prior;
+    if (ok && r < 15) {
+        const double* Wg = Wd + 16 * g;
+        const double w = Wg[r];
+        int rank = 0;
+        for (int k = 0; k < 15; ++k) { const double wk = Wg[k]; if (wk < w || (wk == w && k < r)) ++rank; }
+        int mx = 0;
+        for (int k = 1; k < 15; ++k) if (fabs(LAg[k * JQ_LD + r]) > fabs(LAg[mx * JQ_LD + r])) mx = k;
+        const double sg = LAg[mx * JQ_LD + r] < 0.0 ? -1.0 : 1.0;
+        const double eps = 1e-8;
+        const double Sv = w > eps ? w : 0.0, Sinv = w > eps ? 1.0 / w : 0.0;
+        const double ssq = sqrt(Sv), sisq = sqrt(Sinv);
+        double dotg = 0.0;
+        for (int k = 0; k < 15; ++k) dotg += sg * LAg[k * JQ_LD + r] * S[MARG_SCR_G + k];   // V^T Delta_g
+        for (int k = 0; k < 15; ++k) oJ[(size_t)b * 225 + rank * 15 + k] = ssq * sg * LAg[k * JQ_LD + r];
+        oR[(size_t)b * 15 + rank] = -(sisq * dotg);
+    }
+    wave_mem_sync();
+    __threadfence_block();
+    if (ok) {
+        const double* xw = a.x + (size_t)b * n * 15;
+        if (r < 15) oX[(size_t)b * 15 + r] = xw[(size_t)(n - 1) * 15 + r];
+        if (a.sqrt_H) for (int e = r; e < 36; e += 16) a.sqrt_H[(size_t)b * 36 + e] = oJ[(size_t)b * 225 + (e / 6) * 15 + e % 6];
+        if (r == 0) oHas[b] = 1;
+    }
+}
+
 #ifdef LIW_CLK
 extern "C" void liw_debug_clk(long long* out, int nn) { hipMemcpyFromSymbol(out, HIP_SYMBOL(g_clk), sizeof(long long) * nn); }
 extern "C" void liw_debug_span(long long* out, int nn) { hipMemcpyFromSymbol(out, HIP_SYMBOL(g_span), sizeof(long long) * nn); }
@@ -2096,8 +2277,13 @@ void launch_export_dense(const ExportArgs& a, hipStream_t s) { hipLaunchKernelGG
 void launch_marg_schur(const MargArgs& a, hipStream_t s) {
     static const char* env = getenv("LIW_MARG_WAVES");   // 1 / 4: force the one-wave / four-wave kernel (profiling / test aid)
     const bool four = env ? env[0] == '4' : a.B <= 256;  // four waves per window while that takes no CUs away from other windows
+    const char* eig = getenv("LIW_MARG_EIG");            // (read per launch) 1: the eigen square root by the wave that ran the chain (k_marg_schur, until the end of round 5: A/B aid)
     if (four) hipLaunchKernelGGL(k_marg_schur4, dim3(a.B), dim3(256), 0, s, a);
-    else hipLaunchKernelGGL(k_marg_schur, dim3(a.B), dim3(64), 0, s, a);
+    else if (eig && eig[0] == '1') hipLaunchKernelGGL(k_marg_schur, dim3(a.B), dim3(64), 0, s, a);
+    else {
+        hipLaunchKernelGGL(k_marg_schur_chain, dim3(a.B), dim3(64), 0, s, a);
+        hipLaunchKernelGGL(k_marg_schur_eigq, dim3((a.B + 3) / 4), dim3(64), 0, s, a);
+    }
 }
 
 }  // namespace liw

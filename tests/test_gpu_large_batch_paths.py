@@ -253,3 +253,67 @@ def test_factor_sharded_solve_in_the_large_batch_format(liw, synth, pyoracle, mo
             for bb in {k, B - nb + k if B > nb else k}:
                 assert sa[bb]["iterations"] == want[k][0]["iterations"] and sa[bb]["termination"] == want[k][0]["termination"], (xch, bb)
                 assert rel(a[bb], want[k][1]) <= 1e-6, (xch, bb)
+
+
+def test_quad_eigen_square_root_matches_one_wave_kernel_and_oracle(liw, synth, pyoracle, monkeypatch):
+    """Batches above 256 windows marginalise with two kernels (k_marg_schur_chain: the chain by one wave per window;
+    k_marg_schur_eigq: the Jacobi eigen square root of solver.cpp:390-402 for FOUR windows per wave, rows in registers).  Same rotations
+    in the same order as the one-wave kernel it replaces (LIW_MARG_EIG=1): the new prior (X, J^T J, J^T R, sqrt_H^T sqrt_H — eigenvector
+    order among equal eigenvalues and signs are free) must agree with that kernel to round-off and with the oracle as before.  B = 301:
+    the last wave of the eigen kernel holds one window and three empty lane groups.  Windows with and without a carried prior."""
+    prm = synth.office_params()
+    orc = pyoracle.Oracle(prm)
+    n, B, K = 5, 301, 6
+    base = [synth.make_window(orc, prm, seed=4410 + k, n=n, L=30 + 20 * k) for k in range(6)]
+    nb = len(base)
+
+    def run(eig_env):
+        if eig_env:
+            monkeypatch.setenv("LIW_MARG_EIG", "1")
+        else:
+            monkeypatch.delenv("LIW_MARG_EIG", raising=False)
+        bs = liw.BatchSolver(prm, [base[b % nb] for b in range(B)])
+        bs.solve(liw.LIW_MODE_INIT, K)
+        out = []
+        for _ in range(2):                               # second pass: with the prior the first one wrote
+            sH, dH, dg = bs.marginalize()
+            out.append(dict(sH=sH.cpu().numpy().reshape(B, 6, 6), dH=dH.cpu().numpy().reshape(B, 15, 15), dg=dg.cpu().numpy().reshape(B, 15),
+                            J=bs.t["prior_J"].cpu().numpy().reshape(B, 15, 15).copy(), R=bs.t["prior_R"].cpu().numpy().reshape(B, 15).copy(),
+                            X=bs.t["prior_X"].cpu().numpy().reshape(B, 15).copy(), has=bs.t["has_prior"].cpu().numpy().copy()))
+        return bs.states(), bs.t["match_pose"].cpu().numpy().reshape(B, n, 12), out
+
+    xq, mpq, new = run(False)
+    xw, _, old = run(True)
+    assert np.array_equal(xq, xw)
+    worst = 0.0
+    for p in range(2):
+        a, o = new[p], old[p]
+        assert np.array_equal(a["dH"], o["dH"]) and np.array_equal(a["dg"], o["dg"]) and np.array_equal(a["X"], o["X"])   # the chain is the same code
+        assert np.all(a["has"] == 1) and np.all(o["has"] == 1)
+        for b in list(range(0, 12)) + [150, 151, 299, 300]:
+            JJa, JJo = a["J"][b].T @ a["J"][b], o["J"][b].T @ o["J"][b]
+            sc = np.abs(JJo).max()
+            e1 = np.abs(JJa - JJo).max() / sc
+            JRa, JRo = a["J"][b].T @ a["R"][b], o["J"][b].T @ o["R"][b]
+            e2 = np.abs(JRa - JRo).max() / max(1.0, np.abs(JRo).max())
+            # sqrt_H = the pose block of the prior Jacobian's rows in either kernel
+            assert np.array_equal(a["sH"][b], a["J"][b][:6, :6])
+            worst = max(worst, e1, e2)
+            assert e1 <= 1e-12 and e2 <= 1e-9, (p, b, e1, e2)
+            # J^T J is Delta_H up to the eigenvalue floor (1e-8 on a matrix of norm ~1e11)
+            assert np.abs(JJa - 0.5 * (a["dH"][b] + a["dH"][b].T)).max() / sc <= 1e-12, (p, b)
+    # oracle at the same linearisation point, first pass
+    for k in range(nb):
+        w = pyoracle.Window(base[k])
+        w["states"][:] = xq[k].reshape(w["states"].shape)
+        w["match_pose"][:] = mpq[k].reshape(w["match_pose"].shape)
+        orc.set_prior(None)
+        orc.marginalization(w)
+        Xo, Jo, Ro = orc.get_prior()
+        for b in (k, nb * 40 + k, B - 1 - ((B - 1 - k) % nb)):
+            if b % nb != k:
+                continue
+            J, R = new[0]["J"][b], new[0]["R"][b]
+            assert np.abs(J.T @ J - Jo.T @ Jo).max() / np.abs(Jo.T @ Jo).max() <= 1e-9, (k, b)
+            assert np.abs(J.T @ R - Jo.T @ Ro).max() / max(1.0, np.abs(Jo.T @ Ro).max()) <= 1e-7, (k, b)
+    print("quad eigen kernel vs one-wave kernel: worst relative difference of J^T J / J^T R over the sampled windows %.2e" % worst)
