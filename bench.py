@@ -682,7 +682,7 @@ def main():
             "k_lm_step": {"ms": round(kt["k_lm_step"], 4), "flops_frac": round(B * step_model(n)["flops"] / t["k_lm_step"] / F64, 4),
                           "hbm_GBps": round(B * (step_model(n)["read"] + step_model(n)["write"]) / t["k_lm_step"] / 1e9, 1),
                           "hbm_frac": round(B * (step_model(n)["read"] + step_model(n)["write"]) / t["k_lm_step"] / 1e9 / HBM_PEAK_GBS, 4)},
-            "roofline_schur": {"kernel": "k_marg_schur (chain Schur complement of frames 0..n-2 onto the newest frame + 15x15 eigen square root)",
+            "roofline_schur": {"kernel": "k_marg_schur_chain (chain Schur complement of frames 0..n-2 onto the newest frame, one wave per window) + k_marg_schur_eigq (15x15 Jacobi eigen square root, four windows per wave); one HIP-event bracket around both",
                                "avg_launch_ms": round(kt["k_marg_schur"], 4), "mfma_insts": int(ib * 4),
                                "mfma_util": round(ib * 4 * mf / t["k_marg_schur"] / F64, 5) if t["k_marg_schur"] > 0 else None,
                                "bytes": int(schur_bytes),

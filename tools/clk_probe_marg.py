@@ -10,6 +10,7 @@ import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 os.environ.setdefault("LIW_MARG_WAVES", "1")
+os.environ.setdefault("LIW_MARG_EIG", "1")   # the stamps are in k_marg_schur (chain + eigen by one wave), not in the two kernels large batches run since the end of round 5
 liw = importlib.import_module("2dliw-slam_amd")
 synth = importlib.import_module("2dliw-slam_amd.synth")
 prm = synth.office_params()
