@@ -760,6 +760,7 @@ int liw_batch_time_kernels(liw_ctx* c, const liw_batch* b, int mode, void* ws, v
         hipEvent_t* e = &ev[(size_t)r * 5];
         lin(1, 8);                                        // (the list of windows still iterating, as every linearisation of a solve builds it)
         (void)hipEventRecord(e[0], s); lin(1, 1);
+        if (getenv("LIW_KT_IMU_TWICE")) lin(1, 2);       // probe: the timed IMU role behind an IMU role instead of behind the laser role (the laser figure then includes it)
         (void)hipEventRecord(e[1], s); lin(1, 2);
         (void)hipEventRecord(e[2], s); lin(1, 4);
         (void)hipEventRecord(e[3], s); launch_lm_step(st, s);

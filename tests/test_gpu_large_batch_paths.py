@@ -285,10 +285,22 @@ def test_quad_eigen_square_root_matches_one_wave_kernel_and_oracle(liw, synth, p
     xq, mpq, new = run(False)
     xw, _, old = run(True)
     assert np.array_equal(xq, xw)
+    # the same batch through the same kernels once more, in newly allocated buffers: bit-identical (nothing uninitialised is read)
+    xq2, _, new2 = run(False)
+    assert np.array_equal(xq, xq2)
+    for p in range(2):
+        for key in ("sH", "dH", "dg", "J", "R", "X"):
+            assert np.array_equal(new[p][key], new2[p][key]), (p, key)
     worst = 0.0
     for p in range(2):
         a, o = new[p], old[p]
-        assert np.array_equal(a["dH"], o["dH"]) and np.array_equal(a["dg"], o["dg"]) and np.array_equal(a["X"], o["X"])   # the chain is the same code
+        assert np.array_equal(a["X"], o["X"]), p
+        if p == 0:   # the chain is the same code on the same records
+            assert np.array_equal(a["dH"], o["dH"]) and np.array_equal(a["dg"], o["dg"]), p
+        else:        # second pass: the chain starts from the prior of the first, which the two eigen kernels leave a round-off apart
+            sc = np.abs(o["dH"]).max(axis=(1, 2), keepdims=True)
+            assert (np.abs(a["dH"] - o["dH"]) / sc).max() <= 1e-12, p
+            assert (np.abs(a["dg"] - o["dg"]) / np.maximum(1.0, np.abs(o["dg"]).max(axis=1, keepdims=True))).max() <= 1e-9, p
         assert np.all(a["has"] == 1) and np.all(o["has"] == 1)
         for b in list(range(0, 12)) + [150, 151, 299, 300]:
             JJa, JJo = a["J"][b].T @ a["J"][b], o["J"][b].T @ o["J"][b]
