@@ -18,6 +18,7 @@
 // described in liw_kernels.hpp; k_lm.hip assembles them.  Jacobians here are w.r.t. the AMBIENT parameters, exactly like
 // auto_diff::compute_res_and_jacobi (src/utilies/common.h:201-217); the so3 local parameterisation is applied at assembly.
 #include <type_traits>
+#include <cstring>
 #include "liw_kernels.hpp"
 
 #ifndef LIW_IMU_PROBE_NOSTORE
@@ -1266,18 +1267,31 @@ void launch_linearize(const LinArgs& A_, const DevParams& P, hipStream_t s, cons
     }
     hipStream_t s_imu = fork ? fk->side[0] : s, s_small = fork ? fk->side[1] : s;
     const int rm = A.role_mask ? A.role_mask : 7;
-    if (rm & 1) {
+    auto role_laser = [&]() {
+        if (!(rm & 1)) return;
         if (A.mode == LIW_MODE_INIT && A.laser_pk) launch_lin_laser_slab(A, P, s);   // large 2-D batches: a lane per (window, frame) group
         else if (A.mode == LIW_MODE_INIT) hipLaunchKernelGGL(k_lin_laser<true>, dim3((unsigned)laser_waves), dim3(64), 0, s, A, P, G);
         else hipLaunchKernelGGL(k_lin_laser<false>, dim3((unsigned)laser_waves), dim3(64), 0, s, A, P, G);
-    }
-    if (imu_waves && (rm & 2) && A.pi_frame) hipLaunchKernelGGL(k_lin_imu_chain, dim3((unsigned)(B * imu_chain_parts(n - 1))), dim3(64), 0, s_imu, A, P);
-    else if (imu_waves && (rm & 2)) hipLaunchKernelGGL(k_lin_imu, dim3((unsigned)imu_waves), dim3(64), 0, s_imu, A, P);
-    if (small_waves && (rm & 4)) {
+    };
+    auto role_imu = [&]() {
+        if (imu_waves && (rm & 2) && A.pi_frame) hipLaunchKernelGGL(k_lin_imu_chain, dim3((unsigned)(B * imu_chain_parts(n - 1))), dim3(64), 0, s_imu, A, P);
+        else if (imu_waves && (rm & 2)) hipLaunchKernelGGL(k_lin_imu, dim3((unsigned)imu_waves), dim3(64), 0, s_imu, A, P);
+    };
+    auto role_small = [&]() {
+        if (!(small_waves && (rm & 4))) return;
         // k_lin_small: two lanes per wheel block (31 per wave once the batch fills the chip), the ground frames evaluated by the wheel lanes
         if (A.small_per_wave == WHEEL_PER_WAVE) A.small_per_wave = WG_PER_WAVE;
         const int waves = n > 1 ? wheel_wave_count(B, n, A.small_per_wave) : ground_wave_count(B, n);
         hipLaunchKernelGGL(k_lin_small, dim3((unsigned)waves), dim3(64), 0, s_small, A, P);
+    };
+    // submission order of the three role kernels (they sit on three streams and drain roughly in this order).  LIW_LIN_ORDER (read once):
+    // a permutation of "lis" (laser, IMU, small) — A/B aid, tools/bracket_time.py
+    static const char* order_env = getenv("LIW_LIN_ORDER");
+    const char* order = (order_env && strlen(order_env) == 3) ? order_env : "lis";
+    for (int k = 0; k < 3; ++k) {
+        if (order[k] == 'l') role_laser();
+        else if (order[k] == 'i') role_imu();
+        else if (order[k] == 's') role_small();
     }
     if (fork) {
         hipEventRecord(fk->ev_join[0], fk->side[0]);
