@@ -329,3 +329,25 @@ def test_quad_eigen_square_root_matches_one_wave_kernel_and_oracle(liw, synth, p
             assert np.abs(J.T @ J - Jo.T @ Jo).max() / np.abs(Jo.T @ Jo).max() <= 1e-9, (k, b)
             assert np.abs(J.T @ R - Jo.T @ Ro).max() / max(1.0, np.abs(Jo.T @ Ro).max()) <= 1e-7, (k, b)
     print("quad eigen kernel vs one-wave kernel: worst relative difference of J^T J / J^T R over the sampled windows %.2e" % worst)
+    # a window whose chain fails (a pivot that is not positive and finite: here NaN states) leaves its prior alone, in either form of the
+    # kernel — the eigen kernel must skip it although its three neighbours in the wave (and, for the last window, nobody) go on
+    for eig_env in (False, True):
+        if eig_env:
+            monkeypatch.setenv("LIW_MARG_EIG", "1")
+        else:
+            monkeypatch.delenv("LIW_MARG_EIG", raising=False)
+        bs = liw.BatchSolver(prm, [base[b % nb] for b in range(B)])
+        bs.solve(liw.LIW_MODE_INIT, K)
+        x = bs.states().copy()
+        for b in (7, 130, B - 1):
+            x[b, 2, 3:6] = np.nan
+        bs.set_states(x)
+        bs.marginalize()
+        has = bs.t["has_prior"].cpu().numpy()
+        J = bs.t["prior_J"].cpu().numpy().reshape(B, 15, 15)
+        bad = np.zeros(B, dtype=bool)
+        bad[[7, 130, B - 1]] = True
+        assert np.all(has[bad] == 0) and np.all(J[bad] == 0.0), eig_env
+        assert np.all(has[~bad] == 1) and np.all(np.isfinite(J[~bad])), eig_env
+        for b in (4, 5, 6, 128, 129, 131, B - 2):      # the neighbours are what they are without the poisoned windows
+            assert np.array_equal(J[b], (old if eig_env else new)[0]["J"][b]), (eig_env, b)
