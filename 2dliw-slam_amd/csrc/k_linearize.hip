@@ -100,8 +100,8 @@ typedef LJN<3> J3;
 // and the pre-integration Jacobian; they are never materialised: the MFMA operand of the whitening  Y = sqrt_info [J_raw | r_raw]
 // (imu_factor.h:85-86) is composed per lane from the compact block record below, and  G = Y^T Y  follows on the matrix cores
 // (8 + 12 v_mfma_f64_16x16x4_f64 per block, the accumulator layout of Y being the operand layout of Y^T Y).
-// Blocks per wave: 16 (48 of the 64 lanes in the dual-number part) x 132 doubles of LDS each (+ the chain kernel's output staging area)
-// = 19 kB per wave, so that EIGHT waves fit a CU (two per SIMD, the register limit).  The role is bound by the fp64 pipe its matrix-core and
+// Blocks per wave: 16 (48 of the 64 lanes in the dual-number part) x 135 doubles of LDS each (+ the chain kernel's output staging area)
+// = 19.2 kB per wave, so that EIGHT waves fit a CU (two per SIMD, the register limit).  The role is bound by the fp64 pipe its matrix-core and
 // vector instructions share (~80 % busy with two waves per SIMD, tools/clk_probe_imu.py), not by HBM: with 21 blocks x 188 doubles
 // (31.6 kB, five waves per CU) the kernel took 563 us per 12 288 C2 windows, with the packed inputs alone 3 % less.
 constexpr int IMU_PER_WAVE = 16;    // (18 until the chain kernel's output staging area took the room of two blocks)
@@ -109,10 +109,12 @@ constexpr int IMU_STAGE = 244;      // k_lin_imu_chain: one frame record's large
 // compact block record in LDS (doubles): Xc[9][10] = rows alpha, beta, gamma: the 9 derivative columns (theta_i 0-2, theta_j 3-5,
 // bw_i 6-8) + r_raw (9); Rb[6] = r_raw of the bias rows (their derivative columns are constants); Rt[9] = R_i^T; RtDt[9];
 // Jb[18] = alpha_J_ba (9), beta_J_ba (9)
-constexpr int IR_XS = 10, IR_RB = 90, IR_RT = 96, IR_RTDT = 105, IR_JB = 114, IMU_REC = 132;
+constexpr int IR_XS = 10, IR_RB = 90, IR_RT = 96, IR_RTDT = 105, IR_JB = 114, IR_K0 = 132, IR_K1 = 133, IR_KM1 = 134, IMU_REC = 135;
+// (IR_K0 / IR_K1 / IR_KM1: the constants 0, 1, -1 of the Jacobian as words of the record, so that EVERY operand entry of the matrix-core part is
+// one LDS read at a per-lane offset — as (record entry or constant) selects they were ~20 v_cndmask per block; 19.2 kB per wave: still eight per CU)
 
-// column `col` (0..30: x_i 15 | r_raw | x_j 15) of row kk of [J_raw | r_raw] as (record offset | negate flag) or a constant:
-// returns offset >= 0 (bit 30 = negated) or -1 with *cst set
+// column `col` (0..30: x_i 15 | r_raw | x_j 15) of row kk of [J_raw | r_raw] as a record offset (bit 30 = negated); the constant entries
+// (0, +-1) are words of the record too (imu_entry_code0 maps the -1-with-constant form of this function onto them)
 __host__ __device__ constexpr int imu_entry_code(int kk, int col, double* cst) {
     *cst = 0.0;
     if (kk >= 15 || col > 30) return -1;
@@ -143,17 +145,20 @@ __host__ __device__ constexpr int imu_entry_code(int kk, int col, double* cst) {
 // The operand entry codes of a lane of the matrix-core part (lane = 16 mk + ml: x0 = column ml of [J_raw wrt x_i | r_raw], x1 = column ml
 // of [J_raw wrt x_j], rows kk = mk + 4 c) are constants of the lane: a table in constant memory, fetched with the block's inputs.
 // Evaluated per wave they were 2.5 k of the 19.8 k cycles of the IMU wave a tracking frame waits for (tools/clk_probe_track.py).
-struct ImuLaneOps { int code0[4], code1[4]; double cst0[4], cst1[4]; };
+__host__ __device__ constexpr int imu_entry_code0(int kk, int col) {   // always a record offset (| negate flag)
+    double k = 0.0;
+    const int c = imu_entry_code(kk, col, &k);
+    return c >= 0 ? c : (k == 0.0 ? IR_K0 : (k > 0.0 ? IR_K1 : IR_KM1));
+}
+struct ImuLaneOps { int code0[4], code1[4]; };
 struct ImuOpTab { ImuLaneOps lane[64]; };
 constexpr ImuOpTab make_imu_optab() {
     ImuOpTab t{};
     for (int l = 0; l < 64; ++l) {
         const int ml = l & 15, mk = l >> 4;
         for (int c = 0; c < 4; ++c) {
-            double k0 = 0.0, k1 = 0.0;
-            t.lane[l].code0[c] = imu_entry_code(mk + 4 * c, ml, &k0);
-            t.lane[l].code1[c] = imu_entry_code(mk + 4 * c, ml < 15 ? 16 + ml : 31, &k1);
-            t.lane[l].cst0[c] = k0; t.lane[l].cst1[c] = k1;
+            t.lane[l].code0[c] = imu_entry_code0(mk + 4 * c, ml);
+            t.lane[l].code1[c] = imu_entry_code0(mk + 4 * c, ml < 15 ? 16 + ml : 31);
         }
     }
     return t;
@@ -318,6 +323,7 @@ __device__ __forceinline__ void imu_blocks(const LinArgs& A, const DevParams& P,
                     rec[IR_RB + r] = sj_[9 + r] - si_[9 + r];                                 // res_ba
                     rec[IR_RB + 3 + r] = sj_[12 + r] - si_[12 + r];                           // res_bw
                 }
+                rec[IR_K0] = 0.0; rec[IR_K1] = 1.0; rec[IR_KM1] = -1.0;
 #pragma unroll
                 for (int q = 0; q < 9; ++q) {
                     rec[IR_RT + q] = Rt.m[q];
@@ -369,10 +375,9 @@ __device__ __forceinline__ void imu_blocks(const LinArgs& A, const DevParams& P,
     // ---- matrix-core part, one block at a time (the whole wave cooperates).  Operand entry codes of this lane: x0 = column ml of
     // [J_raw wrt x_i | r_raw], x1 = column ml of [J_raw wrt x_j] for the four k-chunks (row kk = mk + 4c)
     if constexpr (ND != 1) ops = c_imu_optab.lane[lane];      // (throughput kernels: 24 registers that must not live across the dual-number part)
-    int code0[4], code1[4];
-    double cst0[4], cst1[4];
+    int off0[4], off1[4], sgn1[4];    // record offsets of this lane's eight operand entries; sign bit of the x_j entries that are -R_i^T
 #pragma unroll
-    for (int c = 0; c < 4; ++c) { code0[c] = ops.code0[c]; code1[c] = ops.code1[c]; cst0[c] = ops.cst0[c]; cst1[c] = ops.cst1[c]; }
+    for (int c = 0; c < 4; ++c) { off0[c] = ops.code0[c] & 0xffff; off1[c] = ops.code1[c] & 0xffff; sgn1[c] = (ops.code1[c] >> 30) << 31; }
     const unsigned long long onmask = __ballot(on);           // lane LPB q = block q is live (in range, window still iterating)
     d4 chain11 = {0.0, 0.0, 0.0, 0.0};                         // CHAIN: the jj tile of the block before (zero in front of a window's first block)
     // CHAIN: staging offsets of this lane's accumulator entries (row = mk + 4 r, column ml): ij | g_j image at row * 15 + ml (row 15 = the
@@ -405,9 +410,8 @@ __device__ __forceinline__ void imu_blocks(const LinArgs& A, const DevParams& P,
             d4 y0 = {0.0, 0.0, 0.0, 0.0}, y1 = {0.0, 0.0, 0.0, 0.0};
 #pragma unroll
             for (int c = 0; c < 4; ++c) {
-                const double l0 = R_[code0[c] >= 0 ? (code0[c] & 0xffff) : 0], l1 = R_[code1[c] >= 0 ? (code1[c] & 0xffff) : 0];
-                const double x0v = code0[c] >= 0 ? l0 : cst0[c];
-                const double x1v = code1[c] >= 0 ? ((code1[c] >> 30) ? -l1 : l1) : cst1[c];
+                const double x0v = R_[off0[c]], l1 = R_[off1[c]];
+                const double x1v = __hiloint2double(__double2hiint(l1) ^ sgn1[c], __double2loint(l1));
                 y0 = __builtin_amdgcn_mfma_f64_16x16x4f64(sop[q][c], x0v, y0, 0, 0, 0);
                 y1 = __builtin_amdgcn_mfma_f64_16x16x4f64(sop[q][c], x1v, y1, 0, 0, 0);
             }
