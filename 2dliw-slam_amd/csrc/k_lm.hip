@@ -2089,6 +2089,30 @@ __host__ __device__ constexpr int jq_pair(int rnd, int i, bool hi) {   // slot i
     int q = rnd + 15 - k; q = q >= 15 ? q - 15 : q;
     return hi ? (p > q ? p : q) : (p > q ? q : p);
 }
+// compile-time check of the schedule the unrolled rounds rely on: every round pairs 14 of the 15 indices into 7 disjoint (p < q) pairs and
+// leaves index `rnd` idle, the partner of row r is (2 rnd - r) mod 15 (jq_round), and the 15 rounds meet each of the 105 pairs exactly once
+constexpr bool jq_schedule_ok() {
+    bool seen[15][15] = {};
+    for (int rnd = 0; rnd < 15; ++rnd) {
+        bool used[15] = {};
+        for (int i = 0; i < 7; ++i) {
+            const int p = jq_pair(rnd, i, false), q = jq_pair(rnd, i, true);
+            if (!(p < q) || used[p] || used[q] || seen[p][q]) return false;
+            int m = 2 * rnd - p;
+            m = m < 0 ? m + 15 : m;
+            m = m >= 15 ? m - 15 : m;
+            int m2 = 2 * rnd - q;
+            m2 = m2 < 0 ? m2 + 15 : m2;
+            m2 = m2 >= 15 ? m2 - 15 : m2;
+            if (m != q || m2 != p) return false;
+            used[p] = used[q] = true;
+            seen[p][q] = true;
+        }
+        if (used[rnd]) return false;
+    }
+    return true;
+}
+static_assert(jq_schedule_ok(), "round-robin schedule of k_marg_schur_eigq");
 template <int RND, int I>
 __device__ __forceinline__ void jq_cols(double (&t)[16], double (&V)[15], const double cs, const double sn) {
     constexpr int p = jq_pair(RND, I, false), q = jq_pair(RND, I, true);
