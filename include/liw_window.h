@@ -197,7 +197,7 @@ int liw_batch_linearize(liw_ctx* ctx, const liw_batch* b, int mode, void* ws, vo
 /* Profiling aid (bench.py `kernel_times`; no reference counterpart): average device time in ms — HIP events on `stream`, `reps` repeats —
  * of the kernels of ONE LM iteration of the batch as it stands (every window active), each launched ALONE back to back, and of the
  * marginalisation: out_ms[0] laser role, [1] IMU role, [2] wheel + ground role, [3] the LM step (not the first of the solve, which also
- * builds the Jacobi scaling), [4] chain Schur complement + eigen square root (k_marg_schur), [5] laser role of the marginalisation
+ * builds the Jacobi scaling), [4] chain Schur complement + eigen square root (k_marg_schur4 / k_marg_schur_chain + k_marg_schur_eigq), [5] laser role of the marginalisation
  * topology.  Opens a solve (liw_batch_lm_begin) and moves b->x along `reps` + 1 LM steps; the caller's prior is left alone. */
 int liw_batch_time_kernels(liw_ctx* ctx, const liw_batch* b, int mode, void* ws, void* stream, int reps, double* out_ms);
 /* NOT purely stream-asynchronous for large batches: when the batch qualifies for the lane-per-group laser kernel (INIT topology, 2-D
@@ -262,7 +262,9 @@ int liw_batch_exchange_pack(liw_ctx* ctx, const liw_batch* b, int mode, int cand
 int liw_batch_exchange_unpack(liw_ctx* ctx, const liw_batch* b, int mode, int candidate, void* ws, const double* buf, int copies, void* stream);
 int liw_batch_solve(liw_ctx* ctx, const liw_batch* b, int mode, int max_iters, void* ws, void* stream, int use_graph);
 /* marginalisation of every window of the batch (linearise in MARG topology + chain Schur + eigen sqrt);
- * sqrt_H [B][36], Delta_H [B][225], Delta_g [B][15] optional device outputs */
+ * sqrt_H [B][36], Delta_H [B][225], Delta_g [B][15] optional device outputs.  Batches above 256 windows run two kernels on `stream`
+ * (the chain, then the eigen square root of four windows per wave) and hand Delta_H | Delta_g over in the windows' factorisation scratch
+ * inside `ws` — like every other region of `ws`, not to be touched by another stream while the call is in flight. */
 int liw_batch_marg_linearize(liw_ctx* ctx, const liw_batch* b, void* ws, void* stream);
 int liw_batch_marg_schur(liw_ctx* ctx, const liw_batch* b, void* ws, double* sqrt_H, double* Delta_H, double* Delta_g, void* stream);
 /* dense export of the assembled normal equations of buffer `buf` (tests / liw_linearize) */
