@@ -159,9 +159,21 @@ class _Truth:
         return (self.T_w_i(t + h)[:3, 3] - self.T_w_i(t - h)[:3, 3]) / (2.0 * h)
 
 
+def ragged_frame_counts(rng, n, L, p_empty=0.15, spread=3.0):
+    """Laser blocks per owning frame of a ragged window: frame 0 owns none (init topology), every other frame is empty with probability
+    p_empty, the rest share L blocks with weights u ** spread (u uniform): a few frames with hundreds of matched lines next to frames with
+    a handful — the shape real scans give do_match (laser_manager.cpp:316-345), unlike the even spread of the C2 recipe."""
+    w = rng.uniform(0.0, 1.0, n) ** spread
+    w[rng.uniform(0.0, 1.0, n) < p_empty] = 0.0
+    w[0] = 0.0
+    if w.sum() == 0.0:
+        w[n - 1] = 1.0
+    return rng.multinomial(int(L), w / w.sum()).astype(np.int64)
+
+
 def make_window(preint, prm=None, seed=20240, n=30, L=2000, frame_dt=0.1, imu_rate=200.0, wheel_period=0.0505,
                 laser_on_frame0=False, state_noise=1.0, motion="arc", state_motion=None, odom_noise=2e-4,
-                state_p_sigma=0.02, state_q_sigma=np.deg2rad(0.5), t0=1.0):
+                state_p_sigma=0.02, state_q_sigma=np.deg2rad(0.5), t0=1.0, frame_counts=None):
     """Returns a dict of numpy arrays in the flat `liw_window` layout (+ 'truth_states').
 
     preint: object with imu_preint(samples[N,7], t_start, t_end, bias6) -> (X15, J15x15, sqrtP15x15, Dt)
@@ -174,6 +186,8 @@ def make_window(preint, prm=None, seed=20240, n=30, L=2000, frame_dt=0.1, imu_ra
     values give the mixed arms of reference src/factor/wheel_factor.h:45-66: the odometry increment at rest while the states move
     (motion="stationary", state_motion="arc") and the mirror.  odom_noise: position noise of the odometry samples (0 for the
     identical readings of a parked robot).
+    frame_counts: laser blocks PER owning frame (length n; overrides L and the even spread) — ragged scans: frames with no matched
+    line at all next to frames with hundreds (real scans: the count is whatever do_match keeps, laser_manager.cpp:316-345).
     """
     prm = prm or office_params()
     rng = np.random.default_rng(seed)
@@ -226,6 +240,11 @@ def make_window(preint, prm=None, seed=20240, n=30, L=2000, frame_dt=0.1, imu_ra
     # ---- laser blocks
     first = 0 if laser_on_frame0 else 1
     owners = np.sort(first + (np.arange(L) % max(n - first, 1))) if (L > 0 and n > first) else np.zeros(0, dtype=np.int64)
+    if frame_counts is not None:
+        fc = np.asarray(frame_counts, dtype=np.int64)
+        assert fc.shape == (n,) and (fc >= 0).all() and (laser_on_frame0 or fc[0] == 0)
+        owners = np.repeat(np.arange(n), fc)
+        L = int(fc.sum())
     laser_frame = owners.astype(np.int32)
     laser_pts = np.zeros((L, 12))
     T_w_l0 = tr.T_w_i(times[0]) @ tr.T_i_l

@@ -150,11 +150,26 @@ class TiledWindows:
         return dict(B=len(self), states=self.states, match_pose=self.match_pose)
 
 
-def make_tiled(liw, synth, prm, B, n, L, seed0, n_base=64):
-    """the same windows as make_batch(...) (same seeds, same jitter stream), as a TiledWindows"""
+def ragged_shapes(synth, n, L, nb, seed):
+    """per-base-window laser block counts per frame of a RAGGED batch with the same total as nb even windows of L blocks: per-window L drawn
+    from [L / 4, 2 L] and rescaled to the total, per-frame counts from synth.ragged_frame_counts (empty frames next to frames with hundreds)"""
+    rng = np.random.default_rng(seed)
+    Ls = rng.uniform(0.25 * L, 2.0 * L, nb)
+    Ls = np.maximum(1, np.round(Ls * (L * nb / Ls.sum()))).astype(np.int64)
+    Ls[-1] += L * nb - Ls.sum()
+    return [synth.ragged_frame_counts(rng, n, int(Lk)) for Lk in Ls]
+
+
+def make_tiled(liw, synth, prm, B, n, L, seed0, n_base=64, ragged=False):
+    """the same windows as make_batch(...) (same seeds, same jitter stream), as a TiledWindows; ragged: the distinct windows get the laser
+    block counts of ragged_shapes (same total) instead of L blocks spread evenly over frames 1 .. n-1"""
     hp = liw.HostPreint(prm)
     nb = min(n_base, B)
-    base = [synth.make_window(hp, prm, seed=seed0 + k, n=n, L=L) for k in range(nb)]
+    if ragged:
+        shapes = ragged_shapes(synth, n, L, nb, seed0 + 7)
+        base = [synth.make_window(hp, prm, seed=seed0 + k, n=n, frame_counts=shapes[k]) for k in range(nb)]
+    else:
+        base = [synth.make_window(hp, prm, seed=seed0 + k, n=n, L=L) for k in range(nb)]
     rng = np.random.default_rng(seed0 + 1000)
     idx = np.arange(B) % nb
     st = np.stack([np.asarray(w["states"], dtype=np.float64).reshape(n, 15) for w in base])[idx]

@@ -77,3 +77,22 @@ def wheel_arms(synth, prm, d, k):
     ln, oln, nq, noq = float(np.hypot(p[0], p[1])), float(np.hypot(op[0], op[1])), float(np.linalg.norm(q)), float(np.linalg.norm(oq))
     return dict(moving45=bool(oln > 1e-4 and ln > 1e-4), moving58=bool(not (ln < 1e-4 or oln < 1e-4)),
                 moving63=bool(not (nq < 1e-3 or noq < 1e-3)), len=ln, o_len=oln, q=nq, oq=noq)
+
+
+def init_solve_sensitivity(pyoracle, orc, win, its, trials=3, eps=1e-13, seed=7):
+    """Referee for round-off-chaotic LM crawls: the ORACLE against itself on `win` with the pre-integrated IMU means scaled by
+    1 + eps N(0,1) — the size of the difference between two correct fp64 implementations — per LM iteration.
+    its = orc.iterations() of the unperturbed init_solve.  -> sens[it] = max over the trials of the relative state difference after iteration it."""
+    sens, rp = np.zeros(len(its)), np.random.default_rng(seed)
+    for _ in range(trials):
+        alt = dict(win)
+        alt["imu_X"] = np.asarray(win["imu_X"]) * (1.0 + eps * rp.standard_normal(np.asarray(win["imu_X"]).shape))
+        wa = pyoracle.Window(alt)
+        orc.set_prior(None)
+        orc.init_solve(wa)
+        ia = orc.iterations()
+        for it in range(min(len(its), len(ia))):
+            sens[it] = max(sens[it], rel_inf(ia[it]["x"], its[it]["x"]))
+        if len(ia) < len(its):
+            sens[len(ia):] = np.inf          # a perturbed run that stops earlier: everything after that is undetermined at round-off level
+    return sens

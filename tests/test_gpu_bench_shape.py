@@ -102,6 +102,142 @@ def test_bench_configuration_per_iteration_parity(liw, synth, pyoracle, env):
     print("bench-shape per-iteration state error (max over %d windows): %.2e" % (len(sample), worst))
 
 
+def marg_reference(pyoracle, orc, win, x, mp, passes):
+    """The oracle's marginalisation (solver.cpp:257-442) at the linearisation point (x, mp) the GPU batch holds, `passes` times in a row
+    (pass 2 carries the prior pass 1 wrote) -> per pass (Delta_H, Delta_g, prior X / J / R, the round-off scale of Delta_g).
+
+    Scale of Delta_g ("state the bar that is physically right"): Delta_g = g_r - W g_m with W = H_rm H_mm^-1 and
+    g = -J^T R a sum of ~6 300 signed terms that cancels towards 0 at the optimum, so its round-off does not scale with |Delta_g| but
+    with a = |J|^T |R| (what one ulp of every term adds up to): a_r + |W| a_m.  |Delta_g_gpu - Delta_g_oracle| is compared with THAT."""
+    w = pyoracle.Window(win)
+    w["states"][:] = x.reshape(w["states"].shape)
+    w["match_pose"][:] = mp.reshape(w["match_pose"].shape)
+    orc.set_prior(None)
+    out = []
+    for _ in range(passes):
+        orc.marginalization(w)
+        m = orc.marg_pieces()
+        J, R, H = m["J"], m["R"], m["H"]
+        N = H.shape[0]
+        a = np.abs(J).T @ np.abs(R)
+        Hmm, Hrm = H[:N - 15, :N - 15], H[N - 15:, :N - 15]
+        W = np.linalg.solve(Hmm, Hrm.T).T
+        X, Jp, Rp = orc.get_prior()
+        out.append(dict(dH=m["Delta_H"].copy(), dg=m["Delta_g"].copy(), X=X.copy(), J=Jp.copy(), R=Rp.copy(), g_scale=float((a[N - 15:] + np.abs(W) @ a[:N - 15]).max())))
+    return out
+
+
+def test_bench_launch_shape_marginalisation_chain_and_eigq_against_the_oracle(liw, synth, pyoracle, env):
+    """VERDICT r5 missing 5 / next 1a: the marginalisation kernels behind bench.py's `value` — k_lin_laser<false> + k_lin_imu_chain +
+    k_marg_schur_chain + k_marg_schur_eigq (batches above 256 windows) — meet the oracle at n = 30 / L = 2 000 on the 4 421-window launch
+    shape, twice in a row (the second pass carries the prior the first one wrote).  Windows {0, 63, 64, B-65, B-1} + two jittered copies:
+    Delta_H, Delta_g and what k_marg_schur_eigq writes as the NEW prior (solver.cpp:390-402): linearized_X, J^T J, J^T R (eigenvector signs
+    and the order among equal eigenvalues are free, these are not), sqrt_H = the pose block of the prior Jacobian."""
+    import importlib
+    import sys
+    import os
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    bench = importlib.import_module("bench")
+    prm, orc = env
+    B, n, L, K, nd = 4421, 30, 2000, 8, 8
+    tw = bench.make_tiled(liw, synth, prm, B, n, L, seed0=20240, n_base=nd)
+    bs = liw.BatchSolver(prm, tw.base, tile=tw.tile())
+    bs.solve(liw.LIW_MODE_INIT, K)
+    xg = bs.states()
+    mpg = bs.t["match_pose"].cpu().numpy().reshape(B, n, 12)
+    got = []
+    for _ in range(2):
+        sH, dH, dg = bs.marginalize()
+        got.append(dict(sH=sH.cpu().numpy().reshape(B, 6, 6), dH=dH.cpu().numpy().reshape(B, 15, 15), dg=dg.cpu().numpy().reshape(B, 15),
+                        J=bs.t["prior_J"].cpu().numpy().reshape(B, 15, 15).copy(), R=bs.t["prior_R"].cpu().numpy().reshape(B, 15).copy(),
+                        X=bs.t["prior_X"].cpu().numpy().reshape(B, 15).copy(), has=bs.t["has_prior"].cpu().numpy().copy()))
+    assert np.array_equal(bs.states(), xg)                    # marginalisation moves no state
+    worst = dict(dH=0.0, dg=0.0, JJ=0.0, JR=0.0)
+    for b in [0, 63, 64, B - 65, B - 1, nd + 3, B // 2 + 1]:
+        ref = marg_reference(pyoracle, orc, tw[b], xg[b], mpg[b], 2)
+        for p in range(2):
+            g, o = got[p], ref[p]
+            assert g["has"][b] == 1
+            sc = np.abs(o["dH"]).max()
+            eH = np.abs(g["dH"][b] - o["dH"]).max() / sc
+            eg = np.abs(g["dg"][b] - o["dg"]).max() / o["g_scale"]
+            assert np.array_equal(g["X"][b], xg[b, n - 1])                           # linearized_X = the newest frame's state (solver.cpp:385)
+            assert np.array_equal(g["X"][b], o["X"])
+            JJ, JJo = g["J"][b].T @ g["J"][b], o["J"].T @ o["J"]
+            eJJ = np.abs(JJ - JJo).max() / sc
+            JR, JRo = g["J"][b].T @ g["R"][b], o["J"].T @ o["R"]
+            eJR = np.abs(JR - JRo).max() / o["g_scale"]
+            assert np.array_equal(g["sH"][b], g["J"][b][:6, :6])                     # sqrt_H (solver.cpp:401)
+            sHo = o["J"][:6, :6]
+            assert np.abs(g["sH"][b].T @ g["sH"][b] - sHo.T @ sHo).max() / np.abs(sHo.T @ sHo).max() <= 1e-9, (b, p)
+            for k, e in (("dH", eH), ("dg", eg), ("JJ", eJJ), ("JR", eJR)):
+                worst[k] = max(worst[k], e)
+            # Delta_H: relative to its own largest entry (BASELINE.md 3's 1e-10 on H, measured 1e-15); Delta_g, J^T R: relative to the round-off
+            # scale of the gradient sums (marg_reference); the prior reproduces Delta_H above the 1e-8 eigenvalue floor
+            assert eH <= 1e-12 and eg <= 1e-11 and eJJ <= 1e-11 and eJR <= 1e-10, (b, p, eH, eg, eJJ, eJR)
+    print("bench launch shape marginalisation (chain + eigq), worst over 7 windows x 2 passes: Delta_H %.2e Delta_g %.2e (of its round-off scale) "
+          "prior J^T J %.2e J^T R %.2e" % (worst["dH"], worst["dg"], worst["JJ"], worst["JR"]))
+
+
+def test_ragged_slab_batch_per_iteration_parity(liw, synth, pyoracle, env):
+    """VERDICT r5 missing 6 / next 1c: a RAGGED batch through the lane-per-group laser kernel — 4 421 windows cycling through 8 distinct
+    ones whose L runs from ~950 to ~3 300 with per-frame groups from 0 (a quarter of the frames own no block at all) to > 500 blocks,
+    so that the 64 lanes of a k_lin_laser_slab wave run out of blocks at different rows, whole lanes idle through a frame, and the packed
+    rows are 3.6x the data.  Per-iteration states against the oracle (solver.cpp:50-169).
+
+    Frames without laser blocks hang on IMU / wheel / ground alone and five of the eight windows crawl into the 50-iteration cap, where the
+    LM path is round-off chaotic: the ORACLE moves by 1e-4 when its IMU means are scaled by 1 + 1e-13 N(0,1), and the
+    lane-per-block laser kernel leaves the oracle just as the lane-per-group kernel does (tools/ragged_diag.py, gpurun_out/r6_ragged_diag.log).
+    So: every iteration within 1e-9 for the first 16 iterations (any kernel fault shows at iteration 1), and after that within
+    max(1e-6, 3 x what that perturbation moves the oracle at the SAME iteration), never above 1e-3; iteration counts and terminations must be
+    equal wherever the oracle's own end state is determined to 1e-7."""
+    import ctypes as C
+    import importlib
+    import sys
+    import os
+    from parity_util import init_solve_sensitivity
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    bench = importlib.import_module("bench")
+    prm, orc = env
+    B, n, L, K, nd = 4421, 30, 2000, 50, 8
+    tw = bench.make_tiled(liw, synth, prm, B, n, L, seed0=30240, n_base=nd, ragged=True)
+    counts = np.stack([np.bincount(np.asarray(w["laser_frame"]), minlength=n) for w in tw.base])
+    assert counts.sum() == nd * L and counts.sum(1).min() < 0.5 * L and counts.sum(1).max() > 1.3 * L
+    assert (counts[:, 1:] == 0).sum() >= nd and counts.max() > 200
+    pad = counts.max(0).sum() * nd / counts.sum()
+    assert 1.5 < pad < 4.0, pad                              # ragged, and still below the 4x cut-off of laser_slab_begin
+    bs = liw.BatchSolver(prm, tw.base, tile=tw.tile(), history_records=K + 1)
+    bs.solve(liw.LIW_MODE_INIT, K)
+    flags = C.c_int(0)
+    assert bs.L.liw_batch_launch_paths(bs.h, C.byref(bs.b), bs._wsp(), C.byref(flags)) == 0
+    assert flags.value == 3, flags.value
+    hist, summ, xg = bs.history(), bs.summaries(), bs.states()
+    orc.set_max_iterations(K)
+    worst_early, worst_ratio, determined = 0.0, 0.0, 0
+    for b in list(range(nd)) + [63, 64, B - 65, B - 1, nd + 3]:
+        w = pyoracle.Window(tw[b])
+        orc.set_prior(None)
+        orc.init_solve(w)
+        so, its = orc.summary(), orc.iterations()
+        sens = init_solve_sensitivity(pyoracle, orc, tw[b], its)
+        if sens[-1] <= 1e-7:
+            determined += 1
+            assert summ[b]["iterations"] == so["iterations"] and summ[b]["termination"] == so["termination"], (b, summ[b], so)
+            assert rel_inf(xg[b], w["states"].reshape(n, 15)) <= 1e-6
+        for it in range(min(so["iterations"], summ[b]["iterations"]) + 1):
+            e = rel_inf(hist[it, b], its[it]["x"].reshape(n, 15))
+            if it <= 16:
+                worst_early = max(worst_early, e)
+                assert e <= 1e-9, (b, it, e)
+            bar = min(max(1e-6, 3.0 * sens[it]), 1e-3)
+            worst_ratio = max(worst_ratio, e / bar)
+            assert e <= bar, (b, it, e, sens[it])
+    orc.set_max_iterations(50)
+    assert determined >= 3
+    print("ragged slab batch (padding ratio %.2f): per-iteration state error over 13 windows: first 16 iterations %.2e; worst fraction of the "
+          "per-iteration bar max(1e-6, 3 x oracle sensitivity) %.2f; %d windows with a determined end state" % (pad, worst_early, worst_ratio, determined))
+
+
 @pytest.mark.parametrize("n,L,seed", [(30, 2000, 20240), (50, 5000, 77)])
 def test_batch_marginalization_at_bench_sizes(liw, synth, pyoracle, env, n, L, seed):
     """C2- / C5-size marginalisation (Hmm = 435^2 / 735^2 in the reference's dense form) after a short init solve, both sides
