@@ -262,6 +262,18 @@ class BatchSolver:
         nd = int(lay.laser_partial_bytes) // 8
         self.PL = [self.ws[int(lay.laser_partial_off[k]):int(lay.laser_partial_off[k]) + nd * 8].view(torch.float64) for k in range(2)]
 
+    INPUT_KEYS = ("x", "laser_off", "laser_frame", "laser_pts", "match_pose", "has_match", "imu_X", "imu_J", "imu_sqrtP", "imu_Dt", "wheel_T", "wheel_sqrtP")
+
+    def rebind(self, t, Ltot):
+        """Point the batch at ANOTHER set of caller arrays of the same B and n (the next frame of B robots that track in lock-step:
+        trajectory.cpp:525-560 calls solve + marginalization once per laser frame on a new 2-frame window).  The solver's persistent
+        linearised block (prior_X / J / R, has_prior: solver.h:31-37) and the workspace stay."""
+        for k in self.INPUT_KEYS:
+            self.t[k] = t[k]
+            setattr(self.b, k, t[k].data_ptr())
+        self.Ltot = int(Ltot)
+        self.b.Ltot = int(Ltot)
+
     def close(self):
         if self.h:
             self.L.liw_destroy(self.h)

@@ -352,6 +352,267 @@ def track_frame_cpp(liw, d3, reps):
     return {"ms_per_frame": float(tok[1]), "iterations": int(tok[3])}
 
 
+
+def sub_window(d, lo, m=2):
+    """frames lo .. lo + m - 1 of window `d` as an m-frame window: their states / laser_match poses / laser blocks, the IMU and wheel blocks
+    between them — the window the reference's tracking holds after pop_frame_for_tracking (trajectory.cpp:590-617) for m = 2"""
+    N = int(d["n"])
+    o = dict(d)
+    o["n"] = m
+    for k in ("states", "match_pose", "truth_states"):
+        o[k] = np.asarray(d[k]).reshape(N, -1)[lo:lo + m].copy()
+    o["has_match"] = np.asarray(d["has_match"])[lo:lo + m].copy()
+    for k in ("imu_X", "imu_J", "imu_sqrtP", "imu_Dt", "wheel_T", "wheel_sqrtP", "wheel_Dt"):
+        o[k] = np.asarray(d[k])[lo:lo + m - 1].copy()
+    lf = np.asarray(d["laser_frame"])
+    msk = (lf >= lo) & (lf < lo + m)
+    o["laser_frame"] = (lf[msk] - lo).astype(np.int32)
+    o["laser_pts"] = np.asarray(d["laser_pts"])[msk].copy()
+    return o
+
+
+class TrackBatch:
+    """The reference's STEADY STATE at scale: B robots tracking in lock-step.  Per laser frame and robot the front-end
+    calls solver::solve on the 2-frame window (previous frame, new frame) — laser blocks of the new frame against the constant pose of their
+    reference scan, one IMU and one wheel block, ground blocks, the prior of the last marginalisation on the older frame — and then
+    solver::marginalization, whose result is the prior of the next frame (src/trajectory/trajectory.cpp:525-560, src/factor/solver.cpp:631-820,
+    :257-442).  Here: K + 1 consecutive frames of nb distinct synthetic trajectories (60 - 70 matched line pairs per scan), tiled to B windows
+    with 2 mm jitter on every new frame's initial guess; frame 0 only produces the first prior and is not timed.  The solved state and
+    laser_match pose of frame k is the older frame of step k + 1 (device-to-device copies inside the timed region); inputs of every step are
+    resident in HBM before the timed region starts."""
+
+    def __init__(self, liw, synth, prm, B, K, nb, dev, seed0=60240, iters=0, blocks=(60, 71)):
+        import torch
+        self.liw, self.prm, self.B, self.K, self.dev, self.iters = liw, prm, int(B), int(K), dev, int(iters)
+        self.torch = torch
+        hp = liw.HostPreint(prm)
+        nb = self.nb = min(int(nb), self.B)
+        rng = np.random.default_rng(seed0 + 1)
+        steps = self.steps = self.K + 1
+        self.traj = [synth.make_window(hp, prm, seed=seed0 + k, n=steps + 1, frame_counts=np.concatenate([[0], rng.integers(blocks[0], blocks[1], steps)]))
+                     for k in range(nb)]
+        self.sub = [[sub_window(tr, k) for tr in self.traj] for k in range(steps)]
+        idx = np.arange(self.B) % nb
+        self.t, self.Ltot, self.x0, self.mp0 = [], [], [], []
+        for k in range(steps):
+            st = np.stack([np.asarray(w["states"], dtype=np.float64).reshape(2, 15) for w in self.sub[k]])[idx]
+            mp = np.stack([np.asarray(w["match_pose"], dtype=np.float64).reshape(2, 12) for w in self.sub[k]])[idx]
+            if self.B > nb:
+                rows = (0, 1) if k == 0 else (1,)           # the older frame of every later step is the previous step's solved frame
+                for r in rows:
+                    st[nb:, r, 0:3] += rng.normal(0.0, 2e-3, (self.B - nb, 3))
+                    st[nb:, r, 6:9] += rng.normal(0.0, 2e-3, (self.B - nb, 3))
+                mp[nb:, :, 6:12] = st[nb:, :, 0:6]
+            t, _, Ltot = liw.batch.tiled_tensors(self.sub[k], dict(B=self.B, states=st, match_pose=mp), dev)
+            self.t.append(t)
+            self.Ltot.append(Ltot)
+            self.x0.append(t["x"].clone())
+            self.mp0.append(t["match_pose"].clone())
+        st0 = self.x0[0].cpu().numpy().reshape(self.B, 2, 15)
+        mp0 = self.mp0[0].cpu().numpy().reshape(self.B, 2, 12)
+        self.bs = liw.BatchSolver(prm, self.sub[0], device=dev, tile=dict(B=self.B, states=st0, match_pose=mp0))
+        self.blocks_new = float(np.mean([(np.asarray(w["laser_frame"]) == 1).sum() for ws in self.sub[1:] for w in ws]))
+        self.blocks_window = float(np.mean([len(w["laser_frame"]) for ws in self.sub[1:] for w in ws]))
+
+    def window(self, k, b):
+        return self.sub[k][b % self.nb]
+
+    def run(self, capture_ids=None):
+        """all K + 1 frames once -> (seconds of frames 1 .. K, per-frame LM iterations [K + 1][B] (None without capture), capture records)"""
+        torch, bs, B, liw = self.torch, self.bs, self.B, self.liw
+        bs.t["has_prior"].zero_()
+        cap, its = [], []
+        ids = None if capture_ids is None else torch.as_tensor(list(capture_ids), device=self.dev, dtype=torch.long)
+        t0 = None
+        for k in range(self.steps):
+            if k == 1:
+                torch.cuda.synchronize()
+                t0 = time.perf_counter()
+            t = self.t[k]
+            t["x"].copy_(self.x0[k])
+            t["match_pose"].copy_(self.mp0[k])
+            if k > 0:
+                px, pm = self.t[k - 1]["x"].view(B, 2, 15), self.t[k - 1]["match_pose"].view(B, 2, 12)
+                t["x"].view(B, 2, 15)[:, 0].copy_(px[:, 1])
+                t["match_pose"].view(B, 2, 12)[:, 0, 6:12].copy_(pm[:, 1, 6:12])
+            bs.rebind(t, self.Ltot[k])
+            rec = None
+            if ids is not None:
+                g = lambda name, w: bs.t[name].view(B, *w)[ids].cpu().numpy().copy()
+                rec = dict(x_in=g("x", (2, 15)), mp_in=g("match_pose", (2, 12)), pX_in=g("prior_X", (15,)), pJ_in=g("prior_J", (15, 15)), pR_in=g("prior_R", (15,)), has_in=g("has_prior", ()))
+            bs.solve(liw.LIW_MODE_TRACK, self.iters)
+            if ids is not None:
+                rec.update(x_out=g("x", (2, 15)), mp_out=g("match_pose", (2, 12)))
+                sm = bs.summaries()
+                its.append(np.array([s_["iterations"] for s_ in sm]))
+                rec["summ"] = [sm[int(b)] for b in capture_ids]
+            sH, dH, dg = bs.marginalize()
+            if ids is not None:
+                rec.update(dH=dH.view(B, 15, 15)[ids].cpu().numpy(), dg=dg[ids].cpu().numpy(), sH=sH.view(B, 6, 6)[ids].cpu().numpy(),
+                           pX_out=g("prior_X", (15,)), pJ_out=g("prior_J", (15, 15)), pR_out=g("prior_R", (15,)), has_out=g("has_prior", ()))
+                cap.append(rec)
+        torch.cuda.synchronize()
+        return time.perf_counter() - t0, (its if ids is not None else None), cap
+
+    def teacher_forced_parity(self, capture_ids, cap):
+        """every captured (window, frame >= 1): the oracle's solver::solve from the SAME inputs the GPU batch had (states, laser_match poses, the
+        carried prior), then its marginalisation at the GPU's solved states -> counts and worst errors"""
+        from oracle import pyoracle
+        orc = pyoracle.Oracle(self.prm)
+        orc.set_max_iterations(self.iters if self.iters > 0 else (10 if self.prm.get("fast_mode") else 50))
+        rel = lambda a, b: float(np.abs(a - b).max() / max(np.abs(b).max(), 1e-12))
+        out = dict(frames=0, within_1e_6=0, iterations_equal=0, terminations_equal=0, worst_rel_state=0.0, worst_rel_Delta_H=0.0, worst_Delta_g_of_roundoff_scale=0.0,
+                   worst_rel_prior_JtJ=0.0, worst_prior_JtR_of_roundoff_scale=0.0)
+        for k in range(1, self.steps):
+            r = cap[k]
+            for j, b in enumerate(capture_ids):
+                w = dict(self.window(k, int(b)))
+                w["states"], w["match_pose"] = r["x_in"][j], r["mp_in"][j]
+                prior = (r["pX_in"][j], r["pJ_in"][j], r["pR_in"][j]) if r["has_in"][j] else None
+                wo = pyoracle.Window(w)
+                orc.set_prior(prior)
+                orc.solve(wo)
+                so = orc.summary()
+                e = rel(r["x_out"][j], wo["states"].reshape(2, 15))
+                out["frames"] += 1
+                out["within_1e_6"] += int(e <= 1e-6)
+                out["iterations_equal"] += int(r["summ"][j]["iterations"] == so["iterations"])
+                out["terminations_equal"] += int(r["summ"][j]["termination"] == so["termination"])
+                out["worst_rel_state"] = max(out["worst_rel_state"], e)
+                if not self.prm.get("fast_mode"):
+                    mo = marg_reference(pyoracle, orc, w, r["x_out"][j], r["mp_out"][j], 1, prior=prior)[0]
+                    sc = float(np.abs(mo["dH"]).max())
+                    pJ, pR = r["pJ_out"][j], r["pR_out"][j]
+                    out["worst_rel_Delta_H"] = max(out["worst_rel_Delta_H"], rel(r["dH"][j], mo["dH"]))
+                    out["worst_Delta_g_of_roundoff_scale"] = max(out["worst_Delta_g_of_roundoff_scale"], float(np.abs(r["dg"][j] - mo["dg"]).max() / mo["g_scale"]))
+                    out["worst_rel_prior_JtJ"] = max(out["worst_rel_prior_JtJ"], float(np.abs(pJ.T @ pJ - mo["J"].T @ mo["J"]).max() / sc))
+                    out["worst_prior_JtR_of_roundoff_scale"] = max(out["worst_prior_JtR_of_roundoff_scale"], float(np.abs(pJ.T @ pR - mo["J"].T @ mo["R"]).max() / mo["g_scale"]))
+        for k_ in list(out):
+            if isinstance(out[k_], float):
+                out[k_] = float("%.3e" % out[k_])
+        return out
+
+    def cpu_oracle_frames_per_s(self, min_seconds=2.0):
+        """trajectory 0 free-running through the oracle on one core: solve + marginalization per frame, the prior carried like the reference does"""
+        from oracle import pyoracle
+        orc = pyoracle.Oracle(self.prm)
+        orc.set_max_iterations(self.iters if self.iters > 0 else (10 if self.prm.get("fast_mode") else 50))
+        tot, frames, its = 0.0, 0, 0
+        while tot < min_seconds:
+            orc.set_prior(None)
+            prev = None
+            for k in range(self.steps):
+                w = dict(self.window(k, 0))
+                if prev is not None:
+                    w["states"] = np.array(w["states"], copy=True)
+                    w["match_pose"] = np.array(w["match_pose"], copy=True)
+                    w["states"][0] = prev[0]
+                    w["match_pose"][0, 6:12] = prev[1]
+                wo = pyoracle.Window(w)
+                t0 = time.perf_counter()
+                orc.solve(wo)
+                orc.marginalization(wo)
+                dt = time.perf_counter() - t0
+                if k > 0:
+                    tot += dt
+                    frames += 1
+                    its += orc.summary()["iterations"]
+                prev = (wo["states"].reshape(2, 15)[1].copy(), wo["match_pose"].reshape(2, 12)[1, 6:12].copy())
+        return dict(frames_per_s=round(frames / tot, 1), ms_per_frame=round(1e3 * tot / frames, 4), cores=1, frames=frames, lm_iterations_mean=round(its / frames, 2),
+                    sample="trajectory 0, %d frames free-running (solve + marginalization, prior carried), %.1f s" % (frames, tot))
+
+
+
+def track_model(blocks_new, blocks_window):
+    """HBM bytes per 2-frame window of the kernels of one batched tracking frame, from what each kernel addresses (the large-batch record
+    format: linearise_model / step_model with n = 2).  TRACK linearisation: laser blocks of the NEW frame only (64 B per block of a 2-D scan:
+    solver.cpp:669-698), one packed IMU record, one wheel block, two ground records.  The marginalisation's linearisation reads the blocks of
+    both frames (solver.cpp:443-590)."""
+    n = 2
+    lin = {"read": 64 * blocks_new + 120 * n + 1536 + 120 * n + 168 + 120 * n, "write": n * (LP_BYTES + 8) + n * PIFS_BYTES + 8 + (PWS_BYTES + 8) + n * (PGS_BYTES + 8)}
+    lin_marg = {"read": lin["read"] + 64 * (blocks_window - blocks_new), "write": lin["write"]}
+    sm = step_model(n, arrow=False)
+    pack = {"read": 3728 + 104 * blocks_window, "write": 1536}     # per solve: k_imu_pack reads the caller's IMU block (3 728 B), k_laser_z_scan the four z planes, k_group_offsets the frame ids
+    return {"linearise": lin, "linearise_marg": lin_marg, "step": sm, "per_solve_packing": pack}
+
+
+def track_batch_leg(liw, synth, prm, dev, B, K, nb, gate_windows, cpu=True):
+    import ctypes as C
+    import torch
+    tb = TrackBatch(liw, synth, prm, B, K, nb, dev)
+    ids = []
+    for c_ in (0, B - 1, B // 2, min(nb, B) - 1, 63 % B, 64 % B, max(B - 65, 0), min(nb + 1, B - 1)):
+        if c_ not in ids:
+            ids.append(c_)
+    ids = ids[:max(1, gate_windows)]
+    _, its, cap = tb.run(capture_ids=ids)                       # warm-up pass with capture (the passes are bit-reproducible)
+    flags = C.c_int(0)
+    tb.bs.L.liw_batch_launch_paths(tb.bs.h, C.byref(tb.bs.b), tb.bs._wsp(), C.byref(flags))
+    tb.bs.set_timing(True)
+    secs = min(tb.run()[0] for _ in range(3))
+    tm = tb.bs.get_timing()
+    tb.bs.set_timing(False)
+    kt = tb.bs.time_kernels(liw.LIW_MODE_TRACK, 3)
+    itk = np.stack(its[1:])
+    model = track_model(tb.blocks_new, tb.blocks_window)
+    lin_b = model["linearise"]["read"] + model["linearise"]["write"]
+    stp_b = model["step"]["read"] + model["step"]["write"]
+    out = {"frames_per_s": round(B * K / secs, 1), "ms_per_frame_of_batch": round(1e3 * secs / K, 4), "robots": B, "frames_timed": K, "distinct_trajectories": tb.nb,
+           "window": "n=2: %.1f laser blocks on the new frame (%.1f in the window: the marginalisation linearises both frames), 1 IMU + 1 wheel block, 8 ground blocks, prior on the older frame"
+                     % (tb.blocks_new, tb.blocks_window),
+           "per_frame": "x / laser_match carry (device copies) + solve(TRACK) + marginalization; reference call pattern trajectory.cpp:525-560, solver.cpp:631-820, :257-442",
+           "lm_iterations_mean": round(float(itk.mean()), 3), "lm_iterations_histogram": {str(int(k)): int((itk == k).sum()) for k in np.unique(itk)},
+           "launch_paths": {"flags": int(flags.value), "large_batch_record_format (k_lin_imu_chain, k_lm_step_quad, k_marg_schur_chain + k_marg_schur_eigq)": bool(flags.value & 1),
+                            "lane_per_group_laser_kernel": bool(flags.value & 2)},
+           "brackets": {"linearize_avg_ms": round(tm["linearize_ms"], 5), "linearize_launches": tm["linearize_launches"], "step_avg_ms": round(tm["step_ms"], 5), "step_launches": tm["step_launches"],
+                        "share_of_frame_time": round((tm["linearize_ms"] * tm["linearize_launches"] + tm["step_ms"] * tm["step_launches"]) * 1e-3 / (3 * secs), 3),
+                        "note": "HIP-event brackets of the LM linearisations / steps over three passes of the K frames; the rest of a frame is the per-solve packing, the marginalisation and the carry"},
+           "kernel_times_alone_ms": {k: round(v, 4) for k, v in kt.items()},
+           "model_bytes_per_window": {"linearise": lin_b, "step": stp_b, "linearise_marg": model["linearise_marg"]["read"] + model["linearise_marg"]["write"]}}
+    # roofline of the dominant bracket, every window active (stand-alone kernel times): the records written per window dwarf the inputs read
+    lin_alone = kt["k_lin_laser"] + kt["k_lin_imu"] + kt["k_lin_small"]
+    dom = max((("linearise (k_lin_laser<false> + k_lin_imu_chain + k_lin_small, serial sum of the stand-alone times)", lin_alone, lin_b), ("k_lm_step_quad (TRACK)", kt["k_lm_step"], stp_b)), key=lambda r: r[1])
+    out["roofline"] = {"bound": "hbm", "kernel": dom[0], "avg_launch_ms": round(dom[1], 4), "achieved": round(B * dom[2] / (dom[1] * 1e-3) / 1e9, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                       "frac": round(B * dom[2] / (dom[1] * 1e-3) / 1e9 / HBM_PEAK_GBS, 4), "traffic": None,
+                       "bytes_model": "analytic (track_model): bytes the kernels address per 2-frame window, all windows active; rocprofv3 kernel trace of this leg under profiles/"}
+    out["parity_teacher_forced"] = tb.teacher_forced_parity(ids, cap)
+    out["parity_teacher_forced"]["robots"] = [int(b) for b in ids]
+    out["parity_teacher_forced"]["note"] = ("every frame of these robots: oracle solver::solve from the inputs the GPU batch had (states, laser_match poses, carried prior), bar 1e-6 on the "
+                                            "state vector, then the oracle's marginalisation at the GPU's solved states (Delta_H relative; Delta_g / prior J^T R of the gradient sums' round-off scale)")
+    if cpu:
+        out["cpu_oracle"] = tb.cpu_oracle_frames_per_s()
+        out["speedup_vs_cpu_1core"] = round(out["frames_per_s"] / out["cpu_oracle"]["frames_per_s"], 1)
+    tb.bs.close()
+    del tb
+    torch.cuda.empty_cache()
+    return out
+
+
+def marg_reference(pyoracle, orc, win, x, mp, passes, prior=None):
+    """The oracle's marginalisation (solver.cpp:257-442) at the linearisation point (x, mp) the GPU batch holds, `passes` times in a row
+    (pass 2 carries the prior pass 1 wrote) -> per pass (Delta_H, Delta_g, prior X / J / R, the round-off scale of Delta_g).
+
+    Scale of Delta_g ("state the bar that is physically right"): Delta_g = g_r - W g_m with W = H_rm H_mm^-1 and
+    g = -J^T R a sum of ~6 300 signed terms that cancels towards 0 at the optimum, so its round-off does not scale with |Delta_g| but
+    with a = |J|^T |R| (what one ulp of every term adds up to): a_r + |W| a_m.  |Delta_g_gpu - Delta_g_oracle| is compared with THAT."""
+    w = pyoracle.Window(win)
+    w["states"][:] = x.reshape(w["states"].shape)
+    w["match_pose"][:] = mp.reshape(w["match_pose"].shape)
+    orc.set_prior(prior)              # the linearised block the solver carries in (solver.h:31-37); None: no prior rows
+    out = []
+    for _ in range(passes):
+        orc.marginalization(w)
+        m = orc.marg_pieces()
+        J, R, H = m["J"], m["R"], m["H"]
+        N = H.shape[0]
+        a = np.abs(J).T @ np.abs(R)
+        Hmm, Hrm = H[:N - 15, :N - 15], H[N - 15:, :N - 15]
+        W = np.linalg.solve(Hmm, Hrm.T).T
+        X, Jp, Rp = orc.get_prior()
+        out.append(dict(dH=m["Delta_H"].copy(), dg=m["Delta_g"].copy(), X=X.copy(), J=Jp.copy(), R=Rp.copy(), g_scale=float((a[N - 15:] + np.abs(W) @ a[:N - 15]).max())))
+    return out
+
+
 def parity_gate(liw, prm, windows, gate_ids, bs, marg_out, iters_cap, dev):
     """BASELINE.md 3 "equality gate": results of the TIMED batch (final states, LM iteration count, termination, marginalisation
     Delta_H / Delta_g of windows `gate_ids`) and the per-iteration state history of the same windows (re-solved with history
@@ -370,7 +631,12 @@ def parity_gate(liw, prm, windows, gate_ids, bs, marg_out, iters_cap, dev):
     hist = hs.history()
     hsum = hs.summaries()
     out = {"windows": len(gate_ids), "window_ids": [int(b) for b in gate_ids], "max_rel_state_err_final": 0.0, "max_rel_state_err_per_iteration": 0.0, "iterations_equal": True,
-           "terminations_equal": True, "max_rel_marg_Delta_H": 0.0, "max_rel_marg_Delta_g": 0.0, "tolerance_state": 1e-6, "tolerance_marg": 1e-6}
+           "terminations_equal": True, "max_rel_marg_Delta_H": 0.0, "max_rel_marg_Delta_g": 0.0, "max_marg_Delta_g_of_roundoff_scale": 0.0,
+           "max_rel_prior_JtJ": 0.0, "max_prior_JtR_of_roundoff_scale": 0.0, "tolerance_state": 1e-6,
+           "tolerance_marg": {"Delta_H": 1e-12, "Delta_g_of_roundoff_scale": 1e-11, "prior_JtJ": 1e-11, "prior_JtR_of_roundoff_scale": 1e-10},
+           "tolerance_marg_note": "Delta_H and the new prior's J^T J relative to |Delta_H|max (BASELINE.md 3 asks 1e-10 on H; measured 1e-15).  Delta_g and the prior's J^T R: "
+                                  "relative to the round-off scale of the gradient sums a_r + |H_rm H_mm^-1| a_m, a = |J|^T |R| — g = -J^T R cancels towards 0 at the optimum, so "
+                                  "|Delta_g| itself is not the scale of its error (max_rel_marg_Delta_g, the old measure, is kept for comparison with earlier rounds)"}
     for k, b in enumerate(gate_ids):
         w = pyoracle.Window(windows[b])
         orc.set_prior(None)
@@ -387,15 +653,23 @@ def parity_gate(liw, prm, windows, gate_ids, bs, marg_out, iters_cap, dev):
             # same linearisation point on both sides (|H| ~ 1e11: a 1e-13 state difference alone moves g by 1e-2)
             w["states"][:] = xg[b].reshape(w["states"].shape)
             w["match_pose"][:] = mpg[b].reshape(w["match_pose"].shape)
-            orc.marginalization(w)
-            mo = orc.marg_pieces()
+            mo = marg_reference(pyoracle, orc, windows[b], xg[b], mpg[b], 1)[0]
             dH = marg_out[1][b].cpu().numpy().reshape(15, 15)
             dg = marg_out[2][b].cpu().numpy()
-            out["max_rel_marg_Delta_H"] = max(out["max_rel_marg_Delta_H"], rel(dH, mo["Delta_H"]))
-            out["max_rel_marg_Delta_g"] = max(out["max_rel_marg_Delta_g"], rel(dg, mo["Delta_g"]))
+            pJ = bs.t["prior_J"][225 * b:225 * (b + 1)].cpu().numpy().reshape(15, 15)     # the prior k_marg_schur_eigq wrote (solver.cpp:390-402)
+            pR = bs.t["prior_R"][15 * b:15 * (b + 1)].cpu().numpy()
+            sc = float(np.abs(mo["dH"]).max())
+            out["max_rel_marg_Delta_H"] = max(out["max_rel_marg_Delta_H"], rel(dH, mo["dH"]))
+            out["max_rel_marg_Delta_g"] = max(out["max_rel_marg_Delta_g"], rel(dg, mo["dg"]))
+            out["max_marg_Delta_g_of_roundoff_scale"] = max(out["max_marg_Delta_g_of_roundoff_scale"], float(np.abs(dg - mo["dg"]).max() / mo["g_scale"]))
+            out["max_rel_prior_JtJ"] = max(out["max_rel_prior_JtJ"], float(np.abs(pJ.T @ pJ - mo["J"].T @ mo["J"]).max() / sc))
+            out["max_prior_JtR_of_roundoff_scale"] = max(out["max_prior_JtR_of_roundoff_scale"], float(np.abs(pJ.T @ pR - mo["J"].T @ mo["R"]).max() / mo["g_scale"]))
     hs.close()
+    tm_ = out["tolerance_marg"]
     out["passed"] = bool(out["iterations_equal"] and out["terminations_equal"] and out["max_rel_state_err_final"] <= 1e-6 and
-                         out["max_rel_state_err_per_iteration"] <= 1e-6 and out["max_rel_marg_Delta_H"] <= 1e-6 and out["max_rel_marg_Delta_g"] <= 1e-6)
+                         out["max_rel_state_err_per_iteration"] <= 1e-6 and out["max_rel_marg_Delta_H"] <= tm_["Delta_H"] and
+                         out["max_marg_Delta_g_of_roundoff_scale"] <= tm_["Delta_g_of_roundoff_scale"] and out["max_rel_prior_JtJ"] <= tm_["prior_JtJ"] and
+                         out["max_prior_JtR_of_roundoff_scale"] <= tm_["prior_JtR_of_roundoff_scale"])
     for k in list(out):
         if isinstance(out[k], float):
             out[k] = float("%.3e" % out[k])
@@ -430,6 +704,10 @@ def main():
     ap.add_argument("--sharded-windows", type=int, default=256, help="windows of the factor-sharded C4 section (256; tests of the 8-rank control flow on one GPU use fewer)")
     ap.add_argument("--converging-scale", type=float, default=0.1, help="initial state error of the `converging_c2` side measurement, as a fraction of the C2 perturbation")
     ap.add_argument("--no-single", action="store_true", help="skip the B=1 latency measurement (clean per-kernel profiles)")
+    ap.add_argument("--track-batch", type=int, default=int(os.environ.get("LIW_BENCH_TRACK_BATCH", 49152)), help="robots of the batched TRACK leg (the reference's steady state: 2-frame window, "
+                    "solve + marginalization per laser frame, prior carried); 0 = skip")
+    ap.add_argument("--track-frames", type=int, default=8, help="timed consecutive frames of the batched TRACK leg")
+    ap.add_argument("--track-gate-windows", type=int, default=6, help="robots of the TRACK leg whose every frame is checked teacher-forced against the oracle")
     ap.add_argument("--record-md", default=None, help="after the timed region, write a reference-shaped `record` table (labels "
                     "'solve' / 'marginalization', src/utilies/record.h) of per-batch durations to this path")
     args = ap.parse_args()
@@ -917,6 +1195,14 @@ def main():
         except Exception as e:   # a latency side-measurement must never take the headline line down
             keepn = {"error": str(e)[:200]}
 
+    # ---- the reference's steady state at scale: batched 2-frame TRACK solves + marginalisation over consecutive frames
+    track_batch = None
+    if rank == 0 and world == 1 and not args.no_single and args.track_batch > 0:
+        try:
+            track_batch = track_batch_leg(liw, synth, prm, dev, args.track_batch, args.track_frames, args.distinct, args.track_gate_windows, cpu=not args.no_cpu_baseline)
+        except Exception as e:   # a side measurement must never take the headline line down
+            track_batch = {"error": repr(e)[:300]}
+
     # ---- factor-sharded mode (north_star's multi-GPU mode): C4-shaped windows, the laser blocks of every window split over the ranks,
     #      the compact laser record (45 pair totals per (window, frame)) exchanged once per LM iteration on the main stream while the
     #      IMU / wheel / ground roles still run on side streams.  Same total work at every N (strong scaling); N = 1 is the un-sharded
@@ -1043,6 +1329,8 @@ def main():
         if keepn:
             out["keep30_tracking_frame_latency"] = keepn
             out["keep30_tracking_frame_latency"]["note"] = "keep-N is this repository's window policy for BASELINE C3 / C5, not a reference behaviour (the reference keeps 1 frame)"
+        if track_batch:
+            out["tracking_batch"] = track_batch
         if ktimes:
             out["kernel_times"] = ktimes
             out["roofline_schur"] = ktimes["roofline_schur"]
