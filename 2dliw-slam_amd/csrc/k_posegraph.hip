@@ -197,16 +197,17 @@ __global__ __launch_bounds__(64) void k_pg_assemble(int N, int ld, const int* in
                 for (int k = 0; k < 6; ++k) s += Y[k * 13 + 6 * side + (lane - 36)] * Y[k * 13 + 12];
             }
             acc += s;
-            // off-diagonal block H[j, i] (lower triangle: row index > column index), written by side 0 of the edge
-            if (side == 0) {
-                const int j = eidx[e * 2 + 1];
-                if (j != const_pose && j != i && lane < 36) {
-                    double o = 0.0;   // (J_j^T J_i)(r, c)
+            // off-diagonal block H[j, i] of the pair (i, j), j > i (lower triangle): added by the wave of the LOWER key frame only, whichever
+            // side of the edge it is, in the order of its incidence list (= edge order).  Any number of edges between the same pair —
+            // in either direction — sums in that one order, by one wave: bit-reproducible without atomics (round 6; until then the side-0
+            // wave added with fp64 atomicAdd, which is order-free for two terms only).  H is zeroed in front of this kernel.
+            {
+                const int j = eidx[e * 2 + (1 - side)];
+                if (j != const_pose && j > i && lane < 36) {
+                    double o = 0.0;   // (J_j^T J_i)(r, c): J_i = the columns of this key frame's side, J_j = the other side's
 #pragma unroll
-                    for (int k = 0; k < 6; ++k) o += Y[k * 13 + 6 + r] * Y[k * 13 + c];
-                    // two edges between the same pair add commutatively (two terms): atomics keep that deterministic
-                    if (j > i) atomicAdd(&H[(size_t)(j * 6 + r) * ld + i * 6 + c], o);
-                    else atomicAdd(&H[(size_t)(i * 6 + c) * ld + j * 6 + r], o);
+                    for (int k = 0; k < 6; ++k) o += Y[k * 13 + 6 * (1 - side) + r] * Y[k * 13 + 6 * side + c];
+                    H[(size_t)(j * 6 + r) * ld + i * 6 + c] += o;
                 }
             }
         }

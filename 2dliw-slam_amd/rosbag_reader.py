@@ -2,7 +2,7 @@
 log of replay.py / tools/replay_log.cpp ("ROS-bag-v2 or flat-log reader").  No ROS installation needed.
 
 Bag v2.0 layout: "#ROSBAG V2.0\\n", then records  <u32 header_len><header fields><u32 data_len><data>; a header field is
-<u32 len>name=value.  op 0x03 bag header, 0x05 chunk (compression none / bz2; lz4 is not supported here), 0x07 connection
+<u32 len>name=value.  op 0x03 bag header, 0x05 chunk (compression none / bz2 / lz4 = the LZ4 frame format roslz4 writes), 0x07 connection
 (topic, type), 0x02 message data (conn, time), 0x04 / 0x06 index records (skipped).  Messages are ROS1-serialised
 (little-endian; string = u32 len + bytes; T[] = u32 count + items; Header = u32 seq, u32 secs, u32 nsecs, string frame_id):
   sensor_msgs/Imu        Header, Quaternion orientation, f64[9], Vector3 angular_velocity, f64[9], Vector3 linear_acceleration, f64[9]
@@ -16,6 +16,112 @@ import bz2
 import struct
 
 import numpy as np
+
+
+def lz4_block_decode(src, out=None):
+    """One LZ4 block (the sequence format: token = literal length << 4 | match length - 4, 255-continued lengths, literals, u16
+    little-endian match offset; the last sequence ends after its literals).  Matches may overlap their own output (offset < length:
+    run-length encoding), so they are copied in pieces of at most `offset` bytes.  `out`: bytearray holding the history the block may
+    reference (linked blocks); the decoded bytes are appended to it."""
+    out = bytearray() if out is None else out
+    i, n = 0, len(src)
+    while i < n:
+        tok = src[i]
+        i += 1
+        ll = tok >> 4
+        if ll == 15:
+            while True:
+                b = src[i]
+                i += 1
+                ll += b
+                if b != 255:
+                    break
+        if i + ll > n:
+            raise ValueError("lz4: literal run past the end of the block")
+        out += src[i:i + ll]
+        i += ll
+        if i >= n:                       # the last sequence has no match part
+            break
+        off = src[i] | (src[i + 1] << 8)
+        i += 2
+        if off == 0 or off > len(out):
+            raise ValueError("lz4: match offset outside the decoded data")
+        ml = tok & 15
+        if ml == 15:
+            while True:
+                b = src[i]
+                i += 1
+                ml += b
+                if b != 255:
+                    break
+        ml += 4
+        start = len(out) - off
+        while ml > 0:
+            piece = out[start:start + min(ml, off)]
+            out += piece
+            ml -= len(piece)
+            start += len(piece)
+    return out
+
+
+def lz4_frame_decode(buf):
+    """LZ4 frame (magic 0x184D2204; what roslz4 / `rosbag compress --lz4` writes into a chunk): frame descriptor FLG (version 01, block
+    independence, block checksum, content size, content checksum, dictionary id), BD, optional u64 content size / u32 dictionary id, header
+    checksum byte; then blocks <u32 size, bit 31 = stored uncompressed> ... until a zero size word; optional xxh32 content checksum
+    (verified when the xxhash module is importable).  Several frames may follow each other."""
+    out, o = bytearray(), 0
+    while o < len(buf):
+        (magic,) = struct.unpack_from("<I", buf, o)
+        o += 4
+        if 0x184D2A50 <= magic <= 0x184D2A5F:              # skippable frame
+            (sl,) = struct.unpack_from("<I", buf, o)
+            o += 4 + sl
+            continue
+        if magic != 0x184D2204:
+            raise ValueError("lz4: bad frame magic %#x" % magic)
+        flg, bd = buf[o], buf[o + 1]
+        o += 2
+        if (flg >> 6) != 1:
+            raise ValueError("lz4: unsupported frame version")
+        indep, bsum, csize, csum, dictid = (flg >> 5) & 1, (flg >> 4) & 1, (flg >> 3) & 1, (flg >> 2) & 1, flg & 1
+        want = None
+        if csize:
+            (want,) = struct.unpack_from("<Q", buf, o)
+            o += 8
+        if dictid:
+            o += 4
+        o += 1                                             # header checksum byte
+        start = len(out)
+        while True:
+            (bs,) = struct.unpack_from("<I", buf, o)
+            o += 4
+            if bs == 0:
+                break
+            raw, bs = bs >> 31, bs & 0x7fffffff
+            blk = buf[o:o + bs]
+            if len(blk) != bs:
+                raise ValueError("lz4: truncated block")
+            o += bs + (4 if bsum else 0)
+            if raw:
+                out += blk
+            elif indep:
+                out += lz4_block_decode(blk)
+            else:                                          # linked blocks: matches reach back into the previous blocks of the frame
+                tail = bytearray(out[max(start, len(out) - 65536):])
+                k = len(tail)
+                out += lz4_block_decode(blk, tail)[k:]
+        if csum:
+            (cs,) = struct.unpack_from("<I", buf, o)
+            o += 4
+            try:
+                import xxhash
+                if xxhash.xxh32(bytes(out[start:]), seed=0).intdigest() != cs:
+                    raise ValueError("lz4: content checksum mismatch")
+            except ImportError:
+                pass
+        if want is not None and len(out) - start != want:
+            raise ValueError("lz4: content size mismatch")
+    return bytes(out)
 
 
 def _fields(buf):
@@ -108,8 +214,12 @@ def read_bag(path, topics=None):
             comp = hdr["compression"].decode()
             if comp == "bz2":
                 data = bz2.decompress(data)
+            elif comp == "lz4":
+                data = lz4_frame_decode(data)
             elif comp != "none":
                 raise ValueError("chunk compression %r is not supported (re-compress the bag: rosbag decompress)" % comp)
+            if "size" in hdr and len(hdr["size"]) == 4 and struct.unpack("<I", hdr["size"])[0] != len(data):
+                raise ValueError("chunk: %d bytes after decompression, header says %d" % (len(data), struct.unpack("<I", hdr["size"])[0]))
             for h2, d2 in _records(data):
                 handle(h2, d2)
     for hdr, data in _records(raw, len(b"#ROSBAG V2.0\n")):

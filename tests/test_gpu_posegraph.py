@@ -38,6 +38,50 @@ def test_posegraph_normal_equations_match_oracle(liw, synth, pyoracle):
     assert len(const) == 6 and np.array_equal(Hg[np.ix_(const, const)], np.eye(6)) and not gg[const].any()
 
 
+def test_many_parallel_loop_edges_sum_in_edge_order_bit_reproducibly(liw, synth, pyoracle):
+    """FIVE loop edges between the same pair of key frames, three in one direction and two in the other (a place
+    revisited several times: keyframe_manager.cpp:642-712 adds an edge per detection).  The off-diagonal block of the pair is the sum of
+    five terms; it is formed by ONE wave (the lower key frame's) in edge order, without atomics: repeated linearisations are bit-identical
+    (they were not guaranteed to be with fp64 atomicAdd from two waves and three or more terms) and agree with the oracle's edge-order sum."""
+    prm = synth.office_params()
+    pg = liw.posegraph.office_pg_params()
+    G = liw.posegraph.make_pose_graph(prm, N=50, seed=9, n_loop=4)
+    a, b = int(G["loop_idx"][0, 0]), int(G["loop_idx"][0, 1])
+    rng = np.random.default_rng(3)
+    extra_idx, extra_tf = [], []
+    for k in range(4):
+        tf = G["loop_tf12"][0].copy()
+        tf[9:12] += rng.normal(0.0, 0.01, 3)                    # distinct measurements of the same relative pose
+        if k % 2 == 0:
+            extra_idx.append([a, b])
+            extra_tf.append(tf)
+        else:                                                     # the reverse edge: the inverse transform, index1 / index2 swapped
+            R = tf[:9].reshape(3, 3)
+            extra_idx.append([b, a])
+            extra_tf.append(np.concatenate([R.T.reshape(9), -R.T @ tf[9:12]]))
+    G["loop_idx"] = np.vstack([G["loop_idx"], np.asarray(extra_idx, dtype=G["loop_idx"].dtype)])
+    G["loop_tf12"] = np.vstack([G["loop_tf12"], np.asarray(extra_tf)])
+    pgs, orc = liw.posegraph.PoseGraph(prm), pyoracle.Oracle(prm)
+    args = (G["poses"], G["seq_idx"], G["seq_tf12"], G["loop_idx"], G["loop_tf12"])
+    runs = [pgs.linearize(pg, *args) for _ in range(5)]
+    for Hk, gk, ck in runs[1:]:
+        assert np.array_equal(Hk, runs[0][0]) and np.array_equal(gk, runs[0][1]) and ck == runs[0][2]
+    Hg, gg, cg = runs[0]
+    Ho, go, co, idx = pyoracle.posegraph_linearize(orc, pg, *args)
+    assert abs(cg - co) <= 1e-12 * co
+    assert np.abs(gg[idx] - go).max() <= 1e-10 * np.abs(go).max()
+    assert np.abs(Hg[np.ix_(idx, idx)] - Ho).max() <= 1e-10 * np.abs(Ho).max()
+    lo, hi = min(a, b), max(a, b)
+    blk = Hg[6 * hi:6 * hi + 6, 6 * lo:6 * lo + 6]
+    assert np.abs(blk).max() > 0 and np.array_equal(Hg, Hg.T)                # the pair's block is there, H comes back symmetric
+    # the capped solve on this graph is reproducible run to run as well
+    x1, s1 = pgs.solve(pg, *args, max_iters=6)
+    x2, s2 = pgs.solve(pg, *args, max_iters=6)
+    assert np.array_equal(x1, x2) and s1 == s2
+    xo, so = pyoracle.posegraph_solve(orc, pg, *args, max_iters=6)
+    assert s1["iterations"] == so["iterations"] and np.abs(x1 - xo).max() <= 1e-6 * max(1.0, np.abs(xo).max())
+
+
 @pytest.mark.parametrize("N,n_loop,seed", [(12, 0, 1), (60, 5, 2), (150, 8, 3)])
 def test_posegraph_matches_oracle(liw, synth, pyoracle, N, n_loop, seed):
     """Per-iteration parity.  With the reference's cone-shaped ground_factor_q residual (|tilt| / sigma, non-smooth at 0) the LM

@@ -62,12 +62,15 @@ def test_random_window_init_then_track(liw, synth, pyoracle, seed):
     assert rel(wg2["states"], wo2["states"]) <= 1e-6
 
 
-@pytest.mark.parametrize("seed", [641, 693])
+@pytest.mark.parametrize("seed", [641, 693, 32585, 33425])
 def test_soak_outliers_are_within_the_problems_own_round_off_sensitivity(liw, synth, pyoracle, seed):
     """Two of the ten seeds (of 29 988, tests/soak/soak_random_shapes.py) whose tracking solve misses the 1e-6 bar: 40-50-iteration crawls
     along the ground_factor_q cone.  Referee: the ORACLE against itself with the pre-integrated IMU means scaled by
     1 + 1e-13 N(0,1) — the size of the round-off difference between two correct implementations.  The product must be no further from the
-    oracle than three times what that perturbation moves the oracle itself (and agree to 1e-9 for the first 20 iterations)."""
+    oracle than three times what that perturbation moves the oracle itself (and agree to 1e-9 for the first 20 iterations).
+    Round 6: two of the four outliers of the round-5 sweeps over seeds 31 000 .. 34 999 join — 32585, whose GPU solve runs
+    into the 50-iteration cap (termination 4) where the oracle stops on its function tolerance after 48, and 33425 (1e-14 through iteration
+    27, x3 per iteration after: gpurun_out/diag_33425.log).  Absolute ceiling: whatever the referee says, never above 1e-3."""
     rng = np.random.default_rng(1000 + seed)
     prm = synth.office_params()
     if seed % 4 == 3:
@@ -125,4 +128,6 @@ def test_soak_outliers_are_within_the_problems_own_round_off_sensitivity(liw, sy
     print("seed %d: n=%d L=%d, %d / %d iterations; product vs oracle %.2e (first %d iterations %.2e); oracle vs itself with 1e-13 IMU noise %.2e"
           % (seed, n, L, sg["iterations"], so["iterations"], err, lead, early, sens))
     assert early <= 1e-9
-    assert err <= max(1e-6, 3.0 * sens), (err, sens)
+    assert err <= min(max(1e-6, 3.0 * sens), 1e-3), (err, sens)
+    if sens <= 1e-8:      # an end state that is determined at round-off level must also be reached the same way
+        assert (sg["iterations"], sg["termination"]) == (so["iterations"], so["termination"]), (sg, so)

@@ -143,7 +143,9 @@ def _teacher_forced_tracking(liw, pyoracle, prm, caps, tol=1e-6):
             assert c["termination"] == 4, (k, c["n"], c["termination"], e)
             sens = oracle_round_off_sensitivity(pyoracle, prm, c)
             referee.append((k, e, sens))
-            assert e <= 3.0 * sens, (k, c["n"], e, sens)
+            print("replay solve %d (n = %d, cap-terminated): product vs oracle %.2e, oracle vs itself with 1e-13 IMU noise %.2e" % (k, c["n"], e, sens))
+            # absolute ceiling next to the referee: a chaotic oracle (sens ~ 1e-3) must not make ANY product result acceptable
+            assert e <= min(3.0 * sens, 1e-4), (k, c["n"], e, sens)
         # marginalise at the oracle's post-solve point so that the comparison is at one linearisation point
         w["states"].reshape(-1)[:] = c["states_after"]
         w["match_pose"].reshape(-1)[:] = c["match_after"]
