@@ -1273,7 +1273,7 @@ void launch_linearize(const LinArgs& A_, const DevParams& P, hipStream_t s, cons
     const int rm = A.role_mask ? A.role_mask : 7;
     auto role_laser = [&]() {
         if (!(rm & 1)) return;
-        if (A.mode == LIW_MODE_INIT && A.laser_pk) launch_lin_laser_slab(A, P, s);   // large 2-D batches: a lane per (window, frame) group
+        if (A.laser_pk) launch_lin_laser_slab(A, P, s);   // large 2-D batches: a lane per (window, frame) group (both poses free: INIT; one: MARG / TRACK)
         else if (A.mode == LIW_MODE_INIT) hipLaunchKernelGGL(k_lin_laser<true>, dim3((unsigned)laser_waves), dim3(64), 0, s, A, P, G);
         else hipLaunchKernelGGL(k_lin_laser<false>, dim3((unsigned)laser_waves), dim3(64), 0, s, A, P, G);
     };

@@ -1742,17 +1742,19 @@ __device__ __forceinline__ bool marg_chain(const MargArgs& a, const int b, TILES
         __builtin_amdgcn_sched_barrier(0);
         if (i + 2 < n) areg = asm_issue(c, i + 2, nullptr, nullptr);
         __builtin_amdgcn_sched_barrier(0);
-        // this lane's column as the sum of two strided LDS reads (matrix lanes: D + carried term; coupling lanes: O + a word of the arrow
-        // tile R, which is all zeros in this topology; gradient lane: g + carried gradient, stride 1) — written as a chain of lane tests the
-        // loop was five reads and a nest of selects per row
+        // this lane's column as the sum of two strided LDS reads (matrix lanes: D + carried term; coupling lanes: O + the zero word
+        // T.Cg[15] at stride 0; gradient lane: g + carried gradient, stride 1) — written as a chain of lane tests the loop was five reads
+        // and a nest of selects per row.  (Until round 6 the coupling lanes added words of the arrow tile R, which holds the laser H_ab
+        // slots of the partial buffer: zero after a one-pose linearisation, NOT after an init-topology one — ADVICE r5.  T.Cg[15] is
+        // cleared at entry and never written.)
         double col[15];
         {
             const bool ml_ = lane < 15, ol_ = lane >= 16 && lane < 31, gl_ = lane == 40;
             const double* pA = ml_ ? Dc + lane : (ol_ ? T.O + (lane - 16) : (gl_ ? gc : T.R));
-            const double* pB = ml_ ? T.CD + lane : (gl_ ? T.Cg : T.R);
-            const int st = gl_ ? 1 : 16;
+            const double* pB = ml_ ? T.CD + lane : (gl_ ? T.Cg : (ol_ ? T.Cg + 15 : T.R));
+            const int st = gl_ ? 1 : 16, stB = ol_ ? 0 : st;
 #pragma unroll
-            for (int r = 0; r < 15; ++r) col[r] = pA[r * st] + pB[r * st];
+            for (int r = 0; r < 15; ++r) col[r] = pA[r * st] + pB[r * stB];
         }
         if (!fused_chol_solve(col)) { ok = false; break; }
         if ((lane >= 16 && lane < 31) || lane == 40) {

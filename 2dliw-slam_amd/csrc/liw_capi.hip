@@ -307,9 +307,13 @@ static bool lpk_matches(const liw_ctx* c, const liw_batch* b, const void* ws) {
 // (>= 2 048 (slab, frame) waves), never under stream capture.  LIW_NO_LASER_SLAB=1: always the lane-per-block kernel.
 static int laser_slab_begin(liw_ctx* c, const liw_batch* b, int mode, const WsView& v, void* ws, hipStream_t s, bool may_sync) {
     c->lpk_on = false;
-    if (mode != LIW_MODE_INIT || !may_sync || std::getenv("LIW_NO_LASER_SLAB")) return LIW_OK;
+    if (!may_sync || std::getenv("LIW_NO_LASER_SLAB")) return LIW_OK;
     const int S = laser_slab_count(b->B), N = S * b->n;
-    if (N < 2048 || b->Ltot <= 0) return LIW_OK;
+    // INIT: every (slab, frame) is a wave -> 2 048 of them fill the chip.  TRACK (round 6, k_lin_laser_slab1): only the newest frame's
+    // groups carry blocks, S working waves; from 256 of them on (16 384 windows) the lane-per-group walk beats the lane-per-block kernel's
+    // per-group wave reductions (49 152 two-frame windows: 0.24 -> 0.0x ms per linearisation), and the marginalisation behind the solve
+    // reuses the rows.
+    if ((mode == LIW_MODE_INIT ? N < 2048 : S < 256) || b->Ltot <= 0) return LIW_OK;
     if (c->lpk_mx.ensure(sizeof(int) * (size_t)N) || c->lpk_off.ensure(sizeof(long long) * ((size_t)N + 2))) return fail(c, LIW_ENOMEM, "hipMalloc");
     launch_laser_slab_prepare(b->B, b->n, v.group_off, c->lpk_mx.as<int>(), c->lpk_off.as<long long>(), v.imu_pk_bad + 1, s);
     long long tail[2] = {0, 1};
@@ -339,7 +343,7 @@ static LinArgs lin_args(const liw_batch* b, int mode, const double* x, const WsV
     for (int k = 0; k < 2; ++k) A.CS[k] = v.pi_frame ? v.CS[k] : nullptr;
     if (packed && b->n > 1 && b->eval_small) { A.imu_pk = v.imu_pk; A.imu_pk_bad = v.imu_pk_bad; }
     if (packed) A.laser_hz = v.imu_pk_bad + 1;
-    if (packed && mode == LIW_MODE_INIT && lpk_matches(c, b, ws)) { A.laser_pk = c->lpk.as<double>(); A.laser_slab_off = c->lpk_off.as<long long>(); }
+    if (packed && lpk_matches(c, b, ws)) { A.laser_pk = c->lpk.as<double>(); A.laser_slab_off = c->lpk_off.as<long long>(); }
     return A;
 }
 static StepArgs step_args(liw_ctx* c, const liw_batch* b, int mode, int max_iters, const WsView& v) {
@@ -706,6 +710,10 @@ int liw_batch_marg_linearize(liw_ctx* c, const liw_batch* b, void* ws, void* str
     hipStream_t s = (hipStream_t)stream;
     launch_group_offsets(b->B, b->n, b->laser_off, b->laser_frame, v.group_off, s);
     LinArgs A = lin_args(b, LIW_MODE_MARG, b->x, v, 0, false);
+    // the packed laser rows of the solve that ran on these very arrays (same allocations, same block counts: lpk_matches) serve the
+    // marginalisation's one-pose linearisation too — solver::marginalization follows solver::solve / init_solve on the same frames
+    // (trajectory.cpp:446-479, :534-544); include/liw_window.h states the contract (the arrays must not be rewritten in between)
+    if (lpk_matches(c, b, ws)) { A.laser_pk = c->lpk.as<double>(); A.laser_slab_off = c->lpk_off.as<long long>(); }
     if (c->timing) (void)hipEventRecord(next_event(c->ev_lin, c->ev_lin_used), s);
     launch_linearize(A, c->dp, s, c->have_fork ? &c->fork : nullptr);
     if (c->timing) (void)hipEventRecord(next_event(c->ev_lin, c->ev_lin_used), s);
@@ -793,6 +801,7 @@ int liw_batch_time_kernels(liw_ctx* c, const liw_batch* b, int mode, void* ws, v
     {   // marginalisation: its laser role (one pose free), then the chain Schur complement + eigen square root
         launch_group_offsets(b->B, b->n, b->laser_off, b->laser_frame, v.group_off, s);
         LinArgs A = lin_args(b, LIW_MODE_MARG, b->x, v, 0, false);
+        if (lpk_matches(c, b, ws)) { A.laser_pk = c->lpk.as<double>(); A.laser_slab_off = c->lpk_off.as<long long>(); }   // as liw_batch_marg_linearize
         A.role_mask = 6;
         launch_linearize(A, c->dp, s, nullptr);
         (void)hipEventRecord(m[0], s);
@@ -1032,7 +1041,18 @@ int liw_solve(liw_ctx* c, int mode, int max_iters, liw_summary* summary) {
     // TRACK solves also enqueue the marginalisation the reference runs next (trajectory.cpp:548-559: solver.solve();
     // solver.marginalization();) behind the solve, gated on the device by the window's `done` flag: its outputs wait in the read-back
     // record and its prior in a second set of buffers until liw_marginalize asks for them (or a new window / prior drops them).
-    const bool spec = c->spec_marg && mode == LIW_MODE_TRACK && !c->prm.fast_mode && c->n >= 2;
+    bool spec = c->spec_marg && mode == LIW_MODE_TRACK && !c->prm.fast_mode && c->n >= 2;
+    if (spec && c->L > 0) {
+        // The speculative marginalisation rides on LinArgs::marg_older: EVERY linearisation of the tracking solve also evaluates the laser
+        // groups of the older frames (constants of the solve), so that no launch is needed behind it — 7 us less per 2-frame window.  In a
+        // keep-N window (30 frames, ~2 000 blocks on the older frames against ~70 on the new one) that is n times the laser work per LM
+        // iteration for records only the last buffer needs: there the marginalisation linearises for itself when it is asked for.
+        const int* lf = c->hw.laser_frame;
+        const long older = std::lower_bound(lf, lf + c->L, c->n - 1) - lf, newest = (long)c->L - older;
+        static const char* lim_env = std::getenv("LIW_SPEC_OLDER_MAX");      // A/B aid: older-frame blocks up to which the records ride along
+        const long lim = lim_env ? std::atol(lim_env) : 256;
+        if (older > std::max(lim, 4 * newest)) spec = false;
+    }
     const size_t rdoubles = LIW_RESULT_HDR + (size_t)c->n * 27 + 276;
     char* rb = (char*)c->pinned + 2 * c->img_cap;
     {

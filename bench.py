@@ -840,7 +840,10 @@ def main():
     lmod = linearise_model(n, L)
     model_bytes_total = args.steps * (lm_window_launches + B) * lmod["total"]
     achieved_model = model_bytes_total / lin_time_s / 1e9 if lin_time_s > 0 else 0.0
-    roofline = {"bound": "hbm", "kernel": "linearise = k_lin_laser_slab + k_lin_imu_chain + k_lin_small (Jacobian evaluation fused into J^T J partial sums, one HIP-event bracket)",
+    roofline = {"schema_version": 2,
+                "schema_note": "version 2 (rounds 5+): achieved / frac = analytic bytes of the role kernels (frac_model in ADVICE r5's wording) over the bracket time; "
+                               "version 1 (BENCH_r01 .. r04): achieved / frac were what is now achieved_survey_convention / frac_survey_convention — compare those keys across rounds",
+                "bound": "hbm", "kernel": "linearise = k_lin_laser_slab + k_lin_imu_chain + k_lin_small (Jacobian evaluation fused into J^T J partial sums, one HIP-event bracket)",
                 "achieved": round(achieved_model, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": round(achieved_model / HBM_PEAK_GBS, 4), "traffic": traffic,
                 "bytes_model": "analytic: bytes the role kernels address per window-linearisation (bench.py linearise_model: packed laser rows 64 B x L, packed IMU "

@@ -264,7 +264,12 @@ int liw_batch_solve(liw_ctx* ctx, const liw_batch* b, int mode, int max_iters, v
 /* marginalisation of every window of the batch (linearise in MARG topology + chain Schur + eigen sqrt);
  * sqrt_H [B][36], Delta_H [B][225], Delta_g [B][15] optional device outputs.  Batches above 256 windows run two kernels on `stream`
  * (the chain, then the eigen square root of four windows per wave) and hand Delta_H | Delta_g over in the windows' factorisation scratch
- * inside `ws` — like every other region of `ws`, not to be touched by another stream while the call is in flight. */
+ * inside `ws` — like every other region of `ws`, not to be touched by another stream while the call is in flight.
+ * Packed laser rows (round 6): a solve of a large 2-D batch (liw_batch_solve / liw_batch_lm_begin) re-packs the batch's laser blocks once into
+ * ctx-owned memory; liw_batch_marg_linearize on the SAME arrays (same laser_pts / laser_frame allocations, B, n, Ltot, ws) reads those rows
+ * instead of the arrays — the reference marginalises the frames it has just solved (trajectory.cpp:446-479, :534-544).  A caller that
+ * REWRITES laser_pts / laser_off / laser_frame in place between the solve and the marginalisation must start a new solve first (or hand
+ * over other allocations): the rows are keyed by address and size, not by content. */
 int liw_batch_marg_linearize(liw_ctx* ctx, const liw_batch* b, void* ws, void* stream);
 int liw_batch_marg_schur(liw_ctx* ctx, const liw_batch* b, void* ws, double* sqrt_H, double* Delta_H, double* Delta_g, void* stream);
 /* dense export of the assembled normal equations of buffer `buf` (tests / liw_linearize) */

@@ -155,3 +155,99 @@ def test_a_zero_length_reference_segment_takes_the_general_form_on_the_slab_path
     fin = ~np.isnan(ra)
     assert np.abs(rb[fin] - ra[fin]).max() <= 1e-11 * np.abs(ra[fin]).max()
     a.close(); b.close()
+
+
+def test_one_pose_slab_kernel_marg_records_and_tracking_solves(liw, synth, pyoracle, monkeypatch):
+    """k_lin_laser_slab1 (round 6): the one-free-pose topologies over the packed rows of the solve.
+      * MARG: the group records bs.marginalize() linearises into (H_bb | g_b | cost of every frame incl. the zero-length-segment and
+        on-the-line special cases) against the lane-per-block kernel k_lin_laser<false>, Delta_H / Delta_g / the new prior against it and
+        against the oracle (solver.cpp:453-476, :257-442);
+      * TRACK: 17 000 two-frame windows (S = 266 slabs >= the 256-slab arming threshold), the marginalisation behind it, against the
+        lane-per-block path and the oracle (solver.cpp:669-698)."""
+    import ctypes as C
+    import torch
+    prm, orc, base, wins = _batch(liw, synth, pyoracle)
+    B, n = len(wins), 30
+    ws = list(wins)
+    for k in (5, 70):                                     # a zero-length reference segment (general form on either path)
+        bad = {key: (np.array(v, copy=True) if isinstance(v, np.ndarray) else v) for key, v in ws[k].items()}
+        fr = int(np.bincount(bad["laser_frame"], minlength=n).argmax())
+        j = int(np.flatnonzero(bad["laser_frame"] == fr)[0])
+        bad["laser_pts"][j, 3:6] = bad["laser_pts"][j, 0:3]
+        ws[k] = bad
+
+    def run(no_slab):
+        if no_slab:
+            monkeypatch.setenv("LIW_NO_LASER_SLAB", "1")
+        else:
+            monkeypatch.delenv("LIW_NO_LASER_SLAB", raising=False)
+        bs = liw.BatchSolver(prm, ws)
+        bs.solve(liw.LIW_MODE_INIT, 5)
+        flags = C.c_int(0)
+        bs.L.liw_batch_launch_paths(bs.h, C.byref(bs.b), bs._wsp(), C.byref(flags))
+        x = bs.states().copy()
+        sH, dH, dg = bs.marginalize()
+        torch.cuda.synchronize()
+        rec = bs.PL[0].cpu().numpy().reshape(B, n, 128).copy()       # the marginalisation linearises into buffer 0
+        out = dict(flags=flags.value, x=x, rec=rec, dH=dH.cpu().numpy().reshape(B, 15, 15), dg=dg.cpu().numpy().reshape(B, 15),
+                   pJ=bs.t["prior_J"].cpu().numpy().reshape(B, 15, 15).copy(), mp=bs.t["match_pose"].cpu().numpy().reshape(B, n, 12).copy())
+        bs.close()
+        return out
+    new, old = run(False), run(True)
+    assert new["flags"] == 3 and old["flags"] == 1
+    ra, rb = old["rec"], new["rec"]
+    assert np.array_equal(np.isnan(ra), np.isnan(rb))
+    assert np.all(rb[:, :, 0:36] == 0.0) and np.all(rb[:, :, 72:114] == 0.0) and np.all(rb[:, :, 121:] == 0.0)     # one pose free: H_aa, H_ab, g_a are structural zeros
+    fin = ~np.isnan(ra)
+    # the two runs linearise at states 1e-13 apart (different init-solve summation orders): compare group by group at 1e-9 of the group's scale
+    sc = np.nanmax(np.abs(ra), axis=2, keepdims=True) + 1e-300
+    assert np.nanmax(np.abs(rb - ra) / sc) <= 1e-9
+    assert np.abs(rb[fin]).max() > 0 and not np.array_equal(ra, rb, equal_nan=True)
+    good = ~np.isnan(old["dH"]).any(axis=(1, 2))
+    assert good.sum() >= B - 4
+    assert (np.abs(new["dH"][good] - old["dH"][good]).max(axis=(1, 2)) / np.abs(old["dH"][good]).max(axis=(1, 2))).max() <= 1e-9
+    # oracle at the slab run's own linearisation point
+    import importlib, os, sys
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    bench = importlib.import_module("bench")
+    for b in (0, 1, 2, 3, 4, B - 1):
+        ref = bench.marg_reference(pyoracle, orc, ws[b], new["x"][b], new["mp"][b], 1)[0]
+        assert np.abs(new["dH"][b] - ref["dH"]).max() <= 1e-11 * np.abs(ref["dH"]).max(), b
+        assert np.abs(new["dg"][b] - ref["dg"]).max() <= 1e-10 * ref["g_scale"], b
+        assert np.abs(new["pJ"][b].T @ new["pJ"][b] - ref["J"].T @ ref["J"]).max() <= 1e-10 * np.abs(ref["dH"]).max(), b
+
+    # ---- TRACK: two-frame windows, prior from a first marginalisation
+    Bt = 17000
+    tb = [bench.sub_window(synth.make_window(orc, prm, seed=8100 + k, n=3, frame_counts=[0, 40 + 13 * k, 55 + 7 * k]), 1) for k in range(4)]
+    tw = [tb[b % 4] for b in range(Bt)]
+
+    def track(no_slab):
+        if no_slab:
+            monkeypatch.setenv("LIW_NO_LASER_SLAB", "1")
+        else:
+            monkeypatch.delenv("LIW_NO_LASER_SLAB", raising=False)
+        bs = liw.BatchSolver(prm, tw)
+        bs.marginalize()                                   # leaves a prior on the newest frame ... of THIS window pair: good enough as a carried prior
+        bs.t["prior_X"].view(Bt, 15).copy_(bs.t["x"].view(Bt, 2, 15)[:, 0])     # sit it on the older frame, where a tracking solve expects it
+        bs.solve(liw.LIW_MODE_TRACK, 0)
+        flags = C.c_int(0)
+        bs.L.liw_batch_launch_paths(bs.h, C.byref(bs.b), bs._wsp(), C.byref(flags))
+        prior = [bs.t[k].cpu().numpy().copy() for k in ("prior_X", "prior_J", "prior_R")]
+        x, sm = bs.states().copy(), bs.summaries()
+        sH, dH, dg = bs.marginalize()
+        out = dict(flags=flags.value, x=x, sm=sm, dH=dH.cpu().numpy().reshape(Bt, 15, 15), prior=prior)
+        bs.close()
+        return out
+    tn, to = track(False), track(True)
+    assert tn["flags"] == 3 and to["flags"] == 1, (tn["flags"], to["flags"])
+    assert [(s["iterations"], s["termination"]) for s in tn["sm"]] == [(s["iterations"], s["termination"]) for s in to["sm"]]
+    assert (np.abs(tn["x"] - to["x"]).max(axis=(1, 2)) / np.abs(to["x"]).max(axis=(1, 2))).max() <= 1e-9
+    assert (np.abs(tn["dH"] - to["dH"]).max(axis=(1, 2)) / np.abs(to["dH"]).max(axis=(1, 2))).max() <= 1e-8
+    for b in (0, 1, 2, 3, Bt - 1):
+        w = pyoracle.Window(tw[b])
+        orc.set_prior((tn["prior"][0].reshape(Bt, 15)[b], tn["prior"][1].reshape(Bt, 15, 15)[b], tn["prior"][2].reshape(Bt, 15)[b]))
+        orc.solve(w)
+        so = orc.summary()
+        assert (tn["sm"][b]["iterations"], tn["sm"][b]["termination"]) == (so["iterations"], so["termination"]), (b, tn["sm"][b], so)
+        assert np.abs(tn["x"][b] - w["states"].reshape(2, 15)).max() <= 1e-6 * np.abs(w["states"]).max(), b
+    orc.set_prior(None)

@@ -72,30 +72,19 @@ constexpr int slab_slot_code(int s) {
     if (s == 120) return slab_pairidx(8, 8);
     return -1;
 }
-// the same for the ONE-free-pose record (MARG / TRACK topology: the block's a-pose is the constant laser_match pose, solver.cpp:471-472,
-// :669-698): unique columns px py th0 th1 th2 of the owning frame + the residual = 21 pair totals, H_bb / g_b / cost slots only, no sign
-// (the constexpr twin of laser_slot_code<false>)
-constexpr int slab_pairidx1(int c1, int c2) { return c1 > c2 ? slab_pairidx1(c2, c1) : c1 * 6 - c1 * (c1 - 1) / 2 + (c2 - c1); }
-constexpr int slab_col_b1(int idx) { return idx == 2 ? -1 : (idx < 2 ? idx : idx - 1); }
-constexpr int slab_slot_code1(int s) {
-    if (s >= 36 && s < 72) { const int ca = slab_col_b1((s - 36) / 6), cb = slab_col_b1((s - 36) % 6); return (ca >= 0 && cb >= 0) ? slab_pairidx1(ca, cb) : -1; }
-    if (s >= 114 && s < 120) { const int cb = slab_col_b1(s - 114); return cb >= 0 ? slab_pairidx1(cb, 5) : -1; }
-    if (s == 120) return slab_pairidx1(5, 5);
-    return -1;
-}
-template <bool BOTH, int S_> __device__ __forceinline__ double slab_slot(const double* acc) {
-    constexpr int code = BOTH ? slab_slot_code(S_) : slab_slot_code1(S_);
+template <int S_> __device__ __forceinline__ double slab_slot(const double* acc) {
+    constexpr int code = slab_slot_code(S_);
     if constexpr (code < 0) return 0.0;
     else if constexpr ((code & 64) != 0) return -acc[code & 63];
     else return acc[code & 63];
 }
-template <bool BOTH, int S_> __device__ __forceinline__ void slab_store(double* out, const double* acc) {
+template <int S_> __device__ __forceinline__ void slab_store(double* out, const double* acc) {
     if constexpr (S_ < LP) {
         typedef double __attribute__((ext_vector_type(2))) dbl2;
         dbl2 v;
-        v.x = slab_slot<BOTH, S_>(acc); v.y = slab_slot<BOTH, S_ + 1>(acc);
+        v.x = slab_slot<S_>(acc); v.y = slab_slot<S_ + 1>(acc);
         *reinterpret_cast<dbl2*>(out + S_) = v;
-        slab_store<BOTH, S_ + 2>(out, acc);
+        slab_store<S_ + 2>(out, acc);
     }
 }
 
@@ -107,20 +96,20 @@ template <bool BOTH, int S_> __device__ __forceinline__ void slab_store(double* 
 #define LIW_SLAB_NT 3                 // bit 0: the packed rows are loaded, bit 1: the records stored with the nontemporal hint (both are touched once per
 #endif                                // launch; 1.67 -> 1.53 ms per 49 152 C2 windows on one box, 1.64 / 1.58 with one of the two)
 constexpr int STG = 34;               // doubles per lane of a staged chunk (32 slots + 2 of padding: conflict-free 16-byte accesses)
-template <bool BOTH, int C_, int I_ = 0> __device__ __forceinline__ void slab_stage(double* st, const double* acc) {
+template <int C_, int I_ = 0> __device__ __forceinline__ void slab_stage(double* st, const double* acc) {
     if constexpr (I_ < 16) {
         typedef double __attribute__((ext_vector_type(2))) dbl2;
         dbl2 v;
-        v.x = slab_slot<BOTH, 32 * C_ + 2 * I_>(acc); v.y = slab_slot<BOTH, 32 * C_ + 2 * I_ + 1>(acc);
+        v.x = slab_slot<32 * C_ + 2 * I_>(acc); v.y = slab_slot<32 * C_ + 2 * I_ + 1>(acc);
         *reinterpret_cast<dbl2*>(st + 2 * I_) = v;
-        slab_stage<BOTH, C_, I_ + 1>(st, acc);
+        slab_stage<C_, I_ + 1>(st, acc);
     }
 }
-template <bool BOTH, int C_> __device__ __forceinline__ void slab_flush(double* lds, const unsigned long long* pw, const double* acc, int lane) {
+template <int C_> __device__ __forceinline__ void slab_flush(double* lds, const unsigned long long* pw, const double* acc, int lane) {
     if constexpr (C_ < 4) {
         typedef double __attribute__((ext_vector_type(2))) dbl2;
         lds_sync();
-        slab_stage<BOTH, C_>(lds + lane * STG, acc);
+        slab_stage<C_>(lds + lane * STG, acc);
         lds_sync();
         const int wq = lane >> 4, pc = lane & 15;
 #pragma unroll
@@ -134,7 +123,7 @@ template <bool BOTH, int C_> __device__ __forceinline__ void slab_flush(double* 
             if (p) *reinterpret_cast<dbl2*>(reinterpret_cast<double*>(p) + 32 * C_ + 2 * pc) = v;
 #endif
         }
-        slab_flush<BOTH, C_ + 1>(lds, pw, acc, lane);
+        slab_flush<C_ + 1>(lds, pw, acc, lane);
     }
 }
 
@@ -163,10 +152,6 @@ constexpr int NPL = ROWD / SLAB;       // planes per row: 8 end-point components
 // (ISA count; 289 by hand), i.e. the two waves keep the SIMD's fp64 pipe ~55 % busy.
 // What did not help (each built and timed in round 4): blocks taken in pairs or as branch-free straight-line code for more instruction-level
 // parallelism (register pressure: 1.23 ms / spills).
-// BOTH = false (round 6): the one-free-pose topologies — MARG (every frame's blocks against the constant laser_match pose of the frame,
-// solver.cpp:453-476) and TRACK (the newest frame's only, :669-698; the older frames' too when LinArgs::marg_older) — over the SAME packed
-// rows: pose a is match_pose[window][frame][0:6], the theta_a columns and their ~40 % of a block's arithmetic drop out, 21 accumulators.
-template <bool BOTH>
 __device__ __forceinline__ void slab_item(const LinArgs& A, const DevParams& P, const int item) {
     const int lane = threadIdx.x & 63, n = A.n;
     const int s = item / n, f = item % n;
@@ -181,15 +166,10 @@ __device__ __forceinline__ void slab_item(const LinArgs& A, const DevParams& P, 
     const int curv = A.lm ? A.lm[bb].cur : 0;
     double pa6[6], pb6[6];
 #pragma unroll
-    for (int k = 0; k < 6; ++k) {
-        pa6[k] = BOTH ? A.x[(size_t)bb * n * 15 + k] : A.match_pose[((size_t)bb * n + f) * 12 + k];
-        pb6[k] = A.x[((size_t)bb * n + f) * 15 + k];
-    }
+    for (int k = 0; k < 6; ++k) { pa6[k] = A.x[(size_t)bb * n * 15 + k]; pb6[k] = A.x[((size_t)bb * n + f) * 15 + k]; }
     if (in) in = window_live(A, bb);
     if (!__any(in)) return;
-    // (tracking: only the newest frame's blocks are part of the problem; the older frames' records are written as zeros — or, marg_older,
-    //  as their marginalisation-topology sums — exactly as k_lin_laser<false> leaves them)
-    const bool fon = in && hm != 0 && (BOTH || A.mode != LIW_MODE_TRACK || f == n - 1 || A.marg_older);
+    const bool fon = in && hm != 0;
     const int cnt = fon ? g1 - g0 : 0;
     int maxc = cnt;
 #pragma unroll
@@ -220,10 +200,9 @@ __device__ __forceinline__ void slab_item(const LinArgs& A, const DevParams& P, 
     }
     lds_sync();
     SSTAMP(2);
-    constexpr int NACC = BOTH ? 45 : 21;
-    double acc[NACC];
+    double acc[45];
 #pragma unroll
-    for (int e = 0; e < NACC; ++e) acc[e] = 0.0;
+    for (int e = 0; e < 45; ++e) acc[e] = 0.0;
     const double* row0 = A.laser_pk + (size_t)A.laser_slab_off[(size_t)s * n + f] * ROWD + lane;
     auto load_row = [&](double* q, int j) {
 #if defined(LIW_SLAB_PROBE) && LIW_SLAB_PROBE == 1
@@ -325,18 +304,10 @@ __device__ __forceinline__ void slab_item(const LinArgs& A, const DevParams& P, 
 #pragma unroll
             for (int c = 0; c < 8; ++c) rw[c] = ws * jc[c];
             rw[8] = sum * (w0 * dist);
-            if constexpr (BOTH) {
 #pragma unroll
-                for (int c1 = 0; c1 < 9; ++c1)
+            for (int c1 = 0; c1 < 9; ++c1)
 #pragma unroll
-                    for (int c2 = c1; c2 < 9; ++c2) acc[c1 * 9 - c1 * (c1 - 1) / 2 + (c2 - c1)] += rw[c1] * rw[c2];
-            } else {   // own-pose columns: d/dp_b = -d/dp_a, theta_b, residual
-                const double r1[6] = {-rw[0], -rw[1], rw[5], rw[6], rw[7], rw[8]};
-#pragma unroll
-                for (int c1 = 0; c1 < 6; ++c1)
-#pragma unroll
-                    for (int c2 = c1; c2 < 6; ++c2) acc[c1 * 6 - c1 * (c1 - 1) / 2 + (c2 - c1)] += r1[c1] * r1[c2];
-            }
+                for (int c2 = c1; c2 < 9; ++c2) acc[c1 * 9 - c1 * (c1 - 1) / 2 + (c2 - c1)] += rw[c1] * rw[c2];
         }
     };
 #ifndef LIW_SLAB_ALG
@@ -375,18 +346,16 @@ __device__ __forceinline__ void slab_item(const LinArgs& A, const DevParams& P, 
         const double rlw = rlen * w;
         const double lxw = ux * rlw, lyw = uy * rlw;
         double dlxw[3], dlyw[3], kap[3];
-        if constexpr (BOTH) {
 #pragma unroll
-            for (int k = 0; k < 3; ++k) {
-                const double m0 = TA(6 + 4 * k), m1 = TA(6 + 4 * k + 1), m3 = TA(6 + 4 * k + 2), m4 = TA(6 + 4 * k + 3);
-                const double dux = -(m0 * d1x + m1 * d1y), duy = -(m3 * d1x + m4 * d1y);
-                const double pr = lx * dux + ly * duy;
-                dlxw[k] = (dux - lx * pr) * rlw;
-                dlyw[k] = (duy - ly * pr) * rlw;
-                const double dBx = TA(18 + 2 * k) + m0 * p[2] + m1 * p[3];
-                const double dBy = TA(18 + 2 * k + 1) + m3 * p[2] + m4 * p[3];
-                kap[k] = lyw * dBx - lxw * dBy;
-            }
+        for (int k = 0; k < 3; ++k) {
+            const double m0 = TA(6 + 4 * k), m1 = TA(6 + 4 * k + 1), m3 = TA(6 + 4 * k + 2), m4 = TA(6 + 4 * k + 3);
+            const double dux = -(m0 * d1x + m1 * d1y), duy = -(m3 * d1x + m4 * d1y);
+            const double pr = lx * dux + ly * duy;
+            dlxw[k] = (dux - lx * pr) * rlw;
+            dlyw[k] = (duy - ly * pr) * rlw;
+            const double dBx = TA(18 + 2 * k) + m0 * p[2] + m1 * p[3];
+            const double dBy = TA(18 + 2 * k + 1) + m3 * p[2] + m4 * p[3];
+            kap[k] = lyw * dBx - lxw * dBy;
         }
         __builtin_amdgcn_sched_barrier(0);
         double al[3], be[3], ga[3];
@@ -401,49 +370,28 @@ __device__ __forceinline__ void slab_item(const LinArgs& A, const DevParams& P, 
         for (int k = 0; k < 2; ++k) {
             __builtin_amdgcn_sched_barrier(0);
             const double pt0 = p[4 + 2 * k], pt1 = p[5 + 2 * k];
-            if constexpr (BOTH) {
-                double rw[9];
-                rw[0] = lyw; rw[1] = -lxw;
-                rw[8] = lxw * ey[k] - lyw * ex[k];               // w sg, signed
+            double rw[9];
+            rw[0] = lyw; rw[1] = -lxw;
+            rw[8] = lxw * ey[k] - lyw * ex[k];               // w sg, signed
 #pragma unroll
-                for (int m = 0; m < 3; ++m) {
-                    rw[2 + m] = dlxw[m] * ey[k] - dlyw[m] * ex[k] + kap[m];
-                    rw[5 + m] = al[m] + be[m] * pt0 + ga[m] * pt1;
-                }
-                if (__builtin_expect(fabs(rw[8]) <= tiny * (fabs(ex[k]) + fabs(ey[k])), 0)) {
-                    // a point exactly on the line: norm() of a zero Jet in the reference (common.h:94) -> NaN derivative (k_lin_laser_body.inc)
-                    const double prj = lx * ex[k] + ly * ey[k];
-                    const double vx = ex[k] - prj * lx, vy = ey[k] - prj * ly;
-                    if (vx * vx + vy * vy == 0.0) {
-#pragma unroll
-                        for (int c = 0; c < 8; ++c) rw[c] = __builtin_nan("");
-                    }
-                }
-                __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-                for (int c1 = 0; c1 < 9; ++c1)
-#pragma unroll
-                    for (int c2 = c1; c2 < 9; ++c2) acc[c1 * 9 - c1 * (c1 - 1) / 2 + (c2 - c1)] += rw[c1] * rw[c2];
-            } else {
-                double rw[6];                                    // own-pose columns px py th0 th1 th2 | residual (d/dp_b = -d/dp_a)
-                rw[0] = -lyw; rw[1] = lxw;
-                rw[5] = lxw * ey[k] - lyw * ex[k];
-#pragma unroll
-                for (int m = 0; m < 3; ++m) rw[2 + m] = al[m] + be[m] * pt0 + ga[m] * pt1;
-                if (__builtin_expect(fabs(rw[5]) <= tiny * (fabs(ex[k]) + fabs(ey[k])), 0)) {
-                    const double prj = lx * ex[k] + ly * ey[k];
-                    const double vx = ex[k] - prj * lx, vy = ey[k] - prj * ly;
-                    if (vx * vx + vy * vy == 0.0) {
-#pragma unroll
-                        for (int c = 0; c < 5; ++c) rw[c] = __builtin_nan("");
-                    }
-                }
-                __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-                for (int c1 = 0; c1 < 6; ++c1)
-#pragma unroll
-                    for (int c2 = c1; c2 < 6; ++c2) acc[c1 * 6 - c1 * (c1 - 1) / 2 + (c2 - c1)] += rw[c1] * rw[c2];
+            for (int m = 0; m < 3; ++m) {
+                rw[2 + m] = dlxw[m] * ey[k] - dlyw[m] * ex[k] + kap[m];
+                rw[5 + m] = al[m] + be[m] * pt0 + ga[m] * pt1;
             }
+            if (__builtin_expect(fabs(rw[8]) <= tiny * (fabs(ex[k]) + fabs(ey[k])), 0)) {
+                // a point exactly on the line: norm() of a zero Jet in the reference (common.h:94) -> NaN derivative (k_lin_laser_body.inc)
+                const double prj = lx * ex[k] + ly * ey[k];
+                const double vx = ex[k] - prj * lx, vy = ey[k] - prj * ly;
+                if (vx * vx + vy * vy == 0.0) {
+#pragma unroll
+                    for (int c = 0; c < 8; ++c) rw[c] = __builtin_nan("");
+                }
+            }
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int c1 = 0; c1 < 9; ++c1)
+#pragma unroll
+                for (int c2 = c1; c2 < 9; ++c2) acc[c1 * 9 - c1 * (c1 - 1) / 2 + (c2 - c1)] += rw[c1] * rw[c2];
         }
     };
 #define LIW_SLAB_BLOCK block_fast
@@ -528,7 +476,7 @@ __device__ __forceinline__ void slab_item(const LinArgs& A, const DevParams& P, 
 #if defined(LIW_SLAB_DIRECT_STORE)
     if (in) {
         double* out = (psel ? A.PL[1] : A.PL[0]) + ((size_t)bb * n + f) * LP;
-        slab_store<BOTH, 0>(out, acc);
+        slab_store<0>(out, acc);
     }
 #else
     {
@@ -536,15 +484,13 @@ __device__ __forceinline__ void slab_item(const LinArgs& A, const DevParams& P, 
         unsigned long long* pw = reinterpret_cast<unsigned long long*>(lds + SLAB * STG);
         lds_sync();                                  // every lane is past its last transform read
         pw[lane] = in ? (unsigned long long)((psel ? A.PL[1] : A.PL[0]) + ((size_t)bb * n + f) * LP) : 0ull;
-        slab_flush<BOTH, 0>(lds, pw, acc, lane);
+        slab_flush<0>(lds, pw, acc, lane);
     }
 #endif
-    if (in && A.CS[0]) (psel ? A.CS[1] : A.CS[0])[cs_index(n, bb, CS_LASER, f)] = acc[BOTH ? slab_pairidx(8, 8) : slab_pairidx1(5, 5)];
+    if (in && A.CS[0]) (psel ? A.CS[1] : A.CS[0])[cs_index(n, bb, CS_LASER, f)] = acc[slab_pairidx(8, 8)];
     SSTAMP(4);
 }
-__global__ __launch_bounds__(64, 2) void k_lin_laser_slab(LinArgs A, DevParams P) { slab_item<true>(A, P, (int)blockIdx.x); }
-// one pose free (MARG / TRACK): ~205 fp64 instructions per block instead of ~360, 21 accumulators; same rows, same epilogue
-__global__ __launch_bounds__(64, 2) void k_lin_laser_slab1(LinArgs A, DevParams P) { slab_item<false>(A, P, (int)blockIdx.x); }
+__global__ __launch_bounds__(64, 2) void k_lin_laser_slab(LinArgs A, DevParams P) { slab_item(A, P, (int)blockIdx.x); }
 // (Measured late in round 5, tools/bracket_time.py: a grid capped at 768 ... 2 048 persistent work-groups, so that the IMU role's waves run
 //  NEXT TO this kernel's instead of behind them, makes the linearise bracket slower — 4.45 - 4.65 against 4.38 ms per 49 152 windows: the
 //  throughput of either kernel follows its resident waves, a memory-bound and a pipe-bound wave on one SIMD do not add up.)
@@ -638,8 +584,7 @@ void launch_laser_slab_pack(int B, int n, long Ltot, const int* group_off, const
     hipLaunchKernelGGL(k_laser_slab_pack, dim3((unsigned)(laser_slab_count(B) * n)), dim3(256), 0, s, B, n, Ltot, group_off, pts, off, mx, pk);
 }
 void launch_lin_laser_slab(const LinArgs& A, const DevParams& P, hipStream_t s) {
-    if (A.mode == LIW_MODE_INIT) hipLaunchKernelGGL(k_lin_laser_slab, dim3((unsigned)(laser_slab_count(A.B) * A.n)), dim3(64), 0, s, A, P);
-    else hipLaunchKernelGGL(k_lin_laser_slab1, dim3((unsigned)(laser_slab_count(A.B) * A.n)), dim3(64), 0, s, A, P);
+    hipLaunchKernelGGL(k_lin_laser_slab, dim3((unsigned)(laser_slab_count(A.B) * A.n)), dim3(64), 0, s, A, P);
 }
 
 }  // namespace liw

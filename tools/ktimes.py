@@ -6,7 +6,7 @@ liw = importlib.import_module("2dliw-slam_amd"); synth = importlib.import_module
 import bench
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 24576
 prm = synth.office_params()
-wins = bench.make_batch(liw, synth, prm, B, 30, 2000, seed0=20240, n_base=64)
-bs = liw.BatchSolver(prm, wins)
+tw = bench.make_tiled(liw, synth, prm, B, 30, 2000, seed0=20240, n_base=64)      # (tiled on the device: no B-fold host concatenation)
+bs = liw.BatchSolver(prm, tw.base, tile=tw.tile())
 kt = bs.time_kernels(liw.LIW_MODE_INIT, 3)
 print("LIW_NO_LASER_SLAB=%s" % os.environ.get("LIW_NO_LASER_SLAB"), {k: round(v, 4) for k, v in kt.items()})
