@@ -70,7 +70,7 @@ class WsLayoutC(C.Structure):
 EXPORTS = [
     "liw_create", "liw_destroy", "liw_last_error", "liw_get_extrinsics", "liw_set_window", "liw_clear_window", "liw_solve", "liw_get_history",
     "liw_linearize", "liw_eval_factors", "liw_marginalize", "liw_get_prior", "liw_set_prior", "liw_batch_ws_layout",
-    "liw_batch_set_max_iters", "liw_batch_launch_paths", "liw_batch_linearize", "liw_batch_time_kernels", "liw_batch_lm_begin", "liw_batch_lm_linearize", "liw_batch_lm_step",
+    "liw_batch_set_max_iters", "liw_batch_launch_paths", "liw_batch_packed_rows", "liw_batch_linearize", "liw_batch_time_kernels", "liw_batch_lm_begin", "liw_batch_lm_linearize", "liw_batch_lm_step",
     "liw_batch_lm_finish", "liw_batch_lm_linearize_async", "liw_batch_lm_join", "liw_batch_exchange_doubles", "liw_batch_exchange_pack",
     "liw_batch_exchange_unpack", "liw_batch_solve_sharded", "liw_batch_exchange_timing", "liw_batch_p2p_area_doubles", "liw_batch_p2p_setup", "liw_batch_p2p_status", "liw_batch_solve", "liw_batch_marg_linearize", "liw_batch_marg_schur", "liw_batch_export_dense",
     "liw_set_timing", "liw_get_timing", "liw_batch_imu_preint", "liw_batch_wheel_preint", "liw_imu_preint_create", "liw_imu_preint_destroy", "liw_imu_preint_reset",

@@ -296,6 +296,14 @@ class BatchSolver:
     def _wsp(self):
         return C.c_void_p(self.ws.data_ptr())
 
+    def launch_paths(self):
+        """-> dict(large_batch_format, lane_per_group_laser, packed_rows, blocks, padding_ratio) of the solve opened last on this batch"""
+        flags, rows, blocks = C.c_int(0), C.c_longlong(0), C.c_longlong(0)
+        self._chk(self.L.liw_batch_launch_paths(self.h, C.byref(self.b), self._wsp(), C.byref(flags)))
+        self._chk(self.L.liw_batch_packed_rows(self.h, C.byref(self.b), self._wsp(), C.byref(rows), C.byref(blocks)))
+        return dict(flags=flags.value, large_batch_format=bool(flags.value & 1), lane_per_group_laser=bool(flags.value & 2), packed_rows=rows.value,
+                    blocks=blocks.value, padding_ratio=(64.0 * rows.value / blocks.value) if (rows.value and blocks.value) else None)
+
     # ---- LM pieces
     def solve(self, mode, max_iters=0, use_graph=False):
         """Runs the whole LM loop.  Single rank: one native call (optionally a captured hipGraph).  Factor-sharded:

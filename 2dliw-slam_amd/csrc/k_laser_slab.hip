@@ -171,8 +171,10 @@ __device__ __forceinline__ void slab_item(const LinArgs& A, const DevParams& P, 
     const int lane = threadIdx.x & 63, n = A.n;
     const int s = item / n, f = item % n;
     SSTAMP(0);
-    const int b = s * SLAB + lane;
-    bool in = b < A.B;
+    // lane -> window through the per-frame order of the windows by group length (k_laser_slab_order): the 64 lanes of a wave walk groups of
+    // (nearly) equal length, whatever the spread of the batch
+    const int b = A.laser_perm[(size_t)f * ((size_t)laser_slab_count(A.B) * SLAB) + (size_t)s * SLAB + lane];
+    bool in = b >= 0;
     const int bb = in ? b : 0;
     // every index / state load of the prologue in ONE batch, unconditionally (bb is a valid window): as written until late round 5 — live
     // test, then the group range, then the partial-buffer selector, then the poses — a wave spent 13 k cycles on four dependent round trips
@@ -549,16 +551,52 @@ __global__ __launch_bounds__(64, 2) void k_lin_laser_slab1(LinArgs A, DevParams 
 //  NEXT TO this kernel's instead of behind them, makes the linearise bracket slower — 4.45 - 4.65 against 4.38 ms per 49 152 windows: the
 //  throughput of either kernel follows its resident waves, a memory-bound and a pipe-bound wave on one SIMD do not add up.)
 
-// longest group of every (slab, frame): mx[s * n + f] = max over the slab's windows of the block count of (window, f)
-__global__ void k_laser_slab_max(int B, int n, const int* group_off, int* mx) {
+// Per-frame order of the windows (round 6).  A (slab, frame) wave pads its 64 groups to the longest one; with the
+// windows taken in batch order a ragged batch (per-window L from 500 to 4 000, frames with 0 .. 400 blocks) packed 4.1 rows per row of data
+// and fell back to the lane-per-block kernel.  The 64 lanes of a wave need not be the same windows for every frame — a (slab, frame) item is
+// independent of every other — so each frame gets its own order: windows sorted by the length of THEIR group of that frame, longest first
+// (the heavy waves start first), perm[f][position] = window, -1 behind the last.  Counting sort by one work-group per frame (lengths
+// clamped to 4 095; the cursor of a bin is an integer LDS atomic: windows of equal length may change places from run to run, which no result
+// can see — a lane forms its (window, frame) record alone, in block order).
+constexpr int SORT_BINS = 4096;
+__global__ __launch_bounds__(1024) void k_laser_slab_order(int B, int n, const int* group_off, int* perm) {
+    __shared__ int bin[SORT_BINS];
+    __shared__ int part[1024];
+    const int f = (int)blockIdx.x, t = (int)threadIdx.x;
+    const size_t Bp = (size_t)((B + SLAB - 1) / SLAB) * SLAB;
+    for (int e = t; e < SORT_BINS; e += 1024) bin[e] = 0;
+    __syncthreads();
+    auto key = [&](int b) { return SORT_BINS - 1 - min(group_off[b * (n + 1) + f + 1] - group_off[b * (n + 1) + f], SORT_BINS - 1); };   // bin 0 = longest
+    for (int b = t; b < B; b += 1024) atomicAdd(&bin[key(b)], 1);
+    __syncthreads();
+    int sum = 0;
+#pragma unroll
+    for (int k = 0; k < SORT_BINS / 1024; ++k) sum += bin[t * (SORT_BINS / 1024) + k];
+    part[t] = sum;
+    __syncthreads();
+    for (int d = 1; d < 1024; d <<= 1) {
+        const int v = t >= d ? part[t - d] : 0;
+        __syncthreads();
+        part[t] += v;
+        __syncthreads();
+    }
+    int base = part[t] - sum;
+#pragma unroll
+    for (int k = 0; k < SORT_BINS / 1024; ++k) { const int h = bin[t * (SORT_BINS / 1024) + k]; bin[t * (SORT_BINS / 1024) + k] = base; base += h; }
+    __syncthreads();
+    for (int b = t; b < B; b += 1024) perm[(size_t)f * Bp + atomicAdd(&bin[key(b)], 1)] = b;
+    for (size_t e = (size_t)B + t; e < Bp; e += 1024) perm[(size_t)f * Bp + e] = -1;
+}
+// longest group of every (slab, frame): mx[s * n + f] = max over the slab's windows (in the frame's order) of the block count of (window, f)
+__global__ void k_laser_slab_max(int B, int n, const int* group_off, const int* perm, int* mx) {
     const int t = blockIdx.x * blockDim.x + threadIdx.x;
     const int S = (B + SLAB - 1) / SLAB;
     if (t >= S * n) return;
     const int s = t / n, f = t % n;
     int m = 0;
     for (int l = 0; l < SLAB; ++l) {
-        const int b = s * SLAB + l;
-        if (b < B) m = max(m, group_off[b * (n + 1) + f + 1] - group_off[b * (n + 1) + f]);
+        const int b = perm[(size_t)f * ((size_t)S * SLAB) + (size_t)s * SLAB + l];
+        if (b >= 0) m = max(m, group_off[b * (n + 1) + f + 1] - group_off[b * (n + 1) + f]);
     }
     mx[t] = m;
 }
@@ -583,14 +621,14 @@ __global__ __launch_bounds__(1024) void k_laser_slab_scan(int N, const int* mx, 
 // re-pack: work-group (s, f) turns, plane by plane, the 64 windows' runs of consecutive blocks (each contiguous in the caller's plane) into rows
 // of 64 lanes through an LDS tile: 128-byte segments in (16 lanes along a window's run), 512-byte rows out.  (The first version read
 // one window per lane: 64 scattered 8-byte loads per instruction, 4.9 ms per 24 576 C2 windows.)
-__global__ __launch_bounds__(256) void k_laser_slab_pack(int B, int n, long Ltot, const int* group_off, const double* pts, const long long* off, const int* mx, double* pk) {
+__global__ __launch_bounds__(256) void k_laser_slab_pack(int B, int n, long Ltot, const int* group_off, const int* perm, const double* pts, const long long* off, const int* mx, double* pk) {
     __shared__ double tile[64 * 65];
     __shared__ int g0s[SLAB], cnts[SLAB];
     const int s = (int)blockIdx.x / n, f = (int)blockIdx.x % n, t = threadIdx.x;
     if (t < SLAB) {
-        const int b = s * SLAB + t;
-        g0s[t] = b < B ? group_off[b * (n + 1) + f] : 0;
-        cnts[t] = b < B ? group_off[b * (n + 1) + f + 1] - g0s[t] : 0;
+        const int b = perm[(size_t)f * ((size_t)((B + SLAB - 1) / SLAB) * SLAB) + (size_t)s * SLAB + t];
+        g0s[t] = b >= 0 ? group_off[b * (n + 1) + f] : 0;
+        cnts[t] = b >= 0 ? group_off[b * (n + 1) + f + 1] - g0s[t] : 0;
     }
     __syncthreads();
     const int maxc = mx[(size_t)s * n + f];
@@ -628,14 +666,21 @@ __global__ __launch_bounds__(256) void k_laser_slab_pack(int B, int n, long Ltot
 #ifdef LIW_CLK
 extern "C" void liw_debug_clk_slab(long long* out, int nn) { hipMemcpyFromSymbol(out, HIP_SYMBOL(g_clk_slab), sizeof(long long) * nn); }
 #endif
-int laser_slab_count(int B) { return (B + SLAB - 1) / SLAB; }
-void launch_laser_slab_prepare(int B, int n, const int* group_off, int* mx, long long* off, const int* hz, hipStream_t s) {
+// A/B aid (LIW_SLAB_BATCH_ORDER=1): the windows in batch order for every frame — the layout until round 5
+__global__ void k_laser_slab_identity(int B, int n, int* perm) {
+    const size_t Bp = (size_t)((B + SLAB - 1) / SLAB) * SLAB;
+    const size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t < Bp * n) perm[t] = (int)(t % Bp) < B ? (int)(t % Bp) : -1;
+}
+void launch_laser_slab_prepare(int B, int n, const int* group_off, int* perm, int* mx, long long* off, const int* hz, hipStream_t s) {
     const int N = laser_slab_count(B) * n;
-    hipLaunchKernelGGL(k_laser_slab_max, dim3((N + 255) / 256), dim3(256), 0, s, B, n, group_off, mx);
+    if (std::getenv("LIW_SLAB_BATCH_ORDER")) hipLaunchKernelGGL(k_laser_slab_identity, dim3((unsigned)(((size_t)N * SLAB + 255) / 256)), dim3(256), 0, s, B, n, perm);
+    else hipLaunchKernelGGL(k_laser_slab_order, dim3((unsigned)n), dim3(1024), 0, s, B, n, group_off, perm);
+    hipLaunchKernelGGL(k_laser_slab_max, dim3((N + 255) / 256), dim3(256), 0, s, B, n, group_off, (const int*)perm, mx);
     hipLaunchKernelGGL(k_laser_slab_scan, dim3(1), dim3(1024), 0, s, N, (const int*)mx, off, hz);
 }
-void launch_laser_slab_pack(int B, int n, long Ltot, const int* group_off, const double* pts, const long long* off, const int* mx, double* pk, hipStream_t s) {
-    hipLaunchKernelGGL(k_laser_slab_pack, dim3((unsigned)(laser_slab_count(B) * n)), dim3(256), 0, s, B, n, Ltot, group_off, pts, off, mx, pk);
+void launch_laser_slab_pack(int B, int n, long Ltot, const int* group_off, const int* perm, const double* pts, const long long* off, const int* mx, double* pk, hipStream_t s) {
+    hipLaunchKernelGGL(k_laser_slab_pack, dim3((unsigned)(laser_slab_count(B) * n)), dim3(256), 0, s, B, n, Ltot, group_off, perm, pts, off, mx, pk);
 }
 void launch_lin_laser_slab(const LinArgs& A, const DevParams& P, hipStream_t s) {
     if (A.mode == LIW_MODE_INIT) hipLaunchKernelGGL(k_lin_laser_slab, dim3((unsigned)(laser_slab_count(A.B) * A.n)), dim3(64), 0, s, A, P);

@@ -80,9 +80,10 @@ struct liw_ctx {
     bool have_fork = false;
     // lane-per-group laser role of large 2-D batches (k_laser_slab.hip): the batch's laser blocks re-packed once per solve into ctx-owned
     // memory (its size depends on the block counts, which liw_batch_ws_layout does not know), valid for the solve `lpk_key` names
-    DevBuf lpk, lpk_off, lpk_mx;
+    DevBuf lpk, lpk_off, lpk_mx, lpk_perm;
     struct { const void* ws; const void* pts; const void* frame; int B, n; long Ltot; } lpk_key{};
     bool lpk_on = false;
+    long long lpk_rows = 0;
     // graph cache
     hipGraphExec_t gexec = nullptr;
     std::vector<unsigned char> gkey;
@@ -195,7 +196,7 @@ void liw_destroy(liw_ctx* c) {
     if (!c) return;
     if (c->have_device) {
         (void)hipSetDevice(c->prm.device);
-        DevBuf* bufs[] = {&c->lpk, &c->lpk_off, &c->lpk_mx, &c->arena, &c->prior_X, &c->prior_J, &c->prior_R, &c->has_prior, &c->ws, &c->scratch,
+        DevBuf* bufs[] = {&c->lpk, &c->lpk_off, &c->lpk_mx, &c->lpk_perm, &c->p2p_err, &c->arena, &c->prior_X, &c->prior_J, &c->prior_R, &c->has_prior, &c->ws, &c->scratch,
                           &c->priorn_X, &c->priorn_J, &c->priorn_R, &c->has_priorn, &c->result, &c->marg_status};
         if (c->pinned) (void)hipHostFree(c->pinned);
         if (c->ev_upload) (void)hipEventDestroy(c->ev_upload);
@@ -314,8 +315,9 @@ static int laser_slab_begin(liw_ctx* c, const liw_batch* b, int mode, const WsVi
     // per-group wave reductions (49 152 two-frame windows: 0.24 -> 0.0x ms per linearisation), and the marginalisation behind the solve
     // reuses the rows.
     if ((mode == LIW_MODE_INIT ? N < 2048 : S < 256) || b->Ltot <= 0) return LIW_OK;
-    if (c->lpk_mx.ensure(sizeof(int) * (size_t)N) || c->lpk_off.ensure(sizeof(long long) * ((size_t)N + 2))) return fail(c, LIW_ENOMEM, "hipMalloc");
-    launch_laser_slab_prepare(b->B, b->n, v.group_off, c->lpk_mx.as<int>(), c->lpk_off.as<long long>(), v.imu_pk_bad + 1, s);
+    if (c->lpk_mx.ensure(sizeof(int) * (size_t)N) || c->lpk_off.ensure(sizeof(long long) * ((size_t)N + 2)) || c->lpk_perm.ensure(sizeof(int) * (size_t)N * 64))
+        return fail(c, LIW_ENOMEM, "hipMalloc");
+    launch_laser_slab_prepare(b->B, b->n, v.group_off, c->lpk_perm.as<int>(), c->lpk_mx.as<int>(), c->lpk_off.as<long long>(), v.imu_pk_bad + 1, s);
     long long tail[2] = {0, 1};
     HIPCHK(c, hipMemcpyAsync(tail, c->lpk_off.as<long long>() + N, sizeof(tail), hipMemcpyDeviceToHost, s));
     HIPCHK(c, hipStreamSynchronize(s));
@@ -323,9 +325,10 @@ static int laser_slab_begin(liw_ctx* c, const liw_batch* b, int mode, const WsVi
     if (tail[1] != 0 || rows <= 0) return LIW_OK;                               // 3-D end points: the lane-per-block kernel handles them
     if (rows * 64 > 4 * (long long)b->Ltot + 64ll * N) return LIW_OK;           // very ragged groups: padding would exceed 4x the data
     if (c->lpk.ensure(sizeof(double) * LASER_SLAB_ROWD * (size_t)rows)) { c->lpk.release(); return LIW_OK; }   // (no memory for the copy: not an error)
-    launch_laser_slab_pack(b->B, b->n, (long)b->Ltot, v.group_off, b->laser_pts, c->lpk_off.as<long long>(), c->lpk_mx.as<int>(), c->lpk.as<double>(), s);
+    launch_laser_slab_pack(b->B, b->n, (long)b->Ltot, v.group_off, c->lpk_perm.as<int>(), b->laser_pts, c->lpk_off.as<long long>(), c->lpk_mx.as<int>(), c->lpk.as<double>(), s);
     c->lpk_key = {ws, b->laser_pts, b->laser_frame, b->B, b->n, (long)b->Ltot};
     c->lpk_on = true;
+    c->lpk_rows = rows;
     return LIW_OK;
 }
 static LinArgs lin_args(const liw_batch* b, int mode, const double* x, const WsView& v, int candidate, bool use_lm, bool packed = false, const liw_ctx* c = nullptr, const void* ws = nullptr) {
@@ -343,7 +346,7 @@ static LinArgs lin_args(const liw_batch* b, int mode, const double* x, const WsV
     for (int k = 0; k < 2; ++k) A.CS[k] = v.pi_frame ? v.CS[k] : nullptr;
     if (packed && b->n > 1 && b->eval_small) { A.imu_pk = v.imu_pk; A.imu_pk_bad = v.imu_pk_bad; }
     if (packed) A.laser_hz = v.imu_pk_bad + 1;
-    if (packed && lpk_matches(c, b, ws)) { A.laser_pk = c->lpk.as<double>(); A.laser_slab_off = c->lpk_off.as<long long>(); }
+    if (packed && lpk_matches(c, b, ws)) { A.laser_pk = c->lpk.as<double>(); A.laser_slab_off = c->lpk_off.as<long long>(); A.laser_perm = c->lpk_perm.as<int>(); }
     return A;
 }
 static StepArgs step_args(liw_ctx* c, const liw_batch* b, int mode, int max_iters, const WsView& v) {
@@ -398,6 +401,13 @@ int liw_batch_launch_paths(liw_ctx* c, const liw_batch* b, const void* ws, int* 
     if (int r = check_batch(c, b)) return r;
     if (!flags) return fail(c, LIW_EINVAL, "liw_batch_launch_paths: null flags");
     *flags = (pi_frame_format(b->B) ? 1 : 0) | (lpk_matches(c, b, ws) ? 2 : 0);
+    return LIW_OK;
+}
+int liw_batch_packed_rows(liw_ctx* c, const liw_batch* b, const void* ws, long long* rows, long long* blocks) {
+    if (!c) return LIW_EINVAL;
+    if (int r = check_batch(c, b)) return r;
+    if (rows) *rows = lpk_matches(c, b, ws) ? c->lpk_rows : 0;
+    if (blocks) *blocks = (long long)b->Ltot;
     return LIW_OK;
 }
 int liw_batch_lm_linearize(liw_ctx* c, const liw_batch* b, int mode, int candidate, void* ws, void* stream) {
@@ -713,7 +723,7 @@ int liw_batch_marg_linearize(liw_ctx* c, const liw_batch* b, void* ws, void* str
     // the packed laser rows of the solve that ran on these very arrays (same allocations, same block counts: lpk_matches) serve the
     // marginalisation's one-pose linearisation too — solver::marginalization follows solver::solve / init_solve on the same frames
     // (trajectory.cpp:446-479, :534-544); include/liw_window.h states the contract (the arrays must not be rewritten in between)
-    if (lpk_matches(c, b, ws)) { A.laser_pk = c->lpk.as<double>(); A.laser_slab_off = c->lpk_off.as<long long>(); }
+    if (lpk_matches(c, b, ws)) { A.laser_pk = c->lpk.as<double>(); A.laser_slab_off = c->lpk_off.as<long long>(); A.laser_perm = c->lpk_perm.as<int>(); }
     if (c->timing) (void)hipEventRecord(next_event(c->ev_lin, c->ev_lin_used), s);
     launch_linearize(A, c->dp, s, c->have_fork ? &c->fork : nullptr);
     if (c->timing) (void)hipEventRecord(next_event(c->ev_lin, c->ev_lin_used), s);
@@ -801,7 +811,7 @@ int liw_batch_time_kernels(liw_ctx* c, const liw_batch* b, int mode, void* ws, v
     {   // marginalisation: its laser role (one pose free), then the chain Schur complement + eigen square root
         launch_group_offsets(b->B, b->n, b->laser_off, b->laser_frame, v.group_off, s);
         LinArgs A = lin_args(b, LIW_MODE_MARG, b->x, v, 0, false);
-        if (lpk_matches(c, b, ws)) { A.laser_pk = c->lpk.as<double>(); A.laser_slab_off = c->lpk_off.as<long long>(); }   // as liw_batch_marg_linearize
+        if (lpk_matches(c, b, ws)) { A.laser_pk = c->lpk.as<double>(); A.laser_slab_off = c->lpk_off.as<long long>(); A.laser_perm = c->lpk_perm.as<int>(); }   // as liw_batch_marg_linearize
         A.role_mask = 6;
         launch_linearize(A, c->dp, s, nullptr);
         (void)hipEventRecord(m[0], s);

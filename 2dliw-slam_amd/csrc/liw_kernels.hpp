@@ -156,7 +156,8 @@ struct LinArgs {
     const int* imu_pk_bad;      //   ... usable iff *imu_pk_bad == 0
     const int* laser_hz;        // null, or -> 0 when no laser end point of the batch has a z component (2-D scans): the z planes are skipped
     const double* laser_pk;     // non-null: the batch's laser blocks re-packed per (slab of 64 windows, frame, block) rows (k_laser_slab.hip) ...
-    const long long* laser_slab_off;   // ... and the first row of every (slab, frame): the laser role of an INIT linearisation runs lane-per-group
+    const long long* laser_slab_off;   // ... and the first row of every (slab, frame): the laser role runs lane-per-group
+    const int* laser_perm;             // ... with lane l of (slab s, frame f) = window laser_perm[f][64 s + l] (per-frame order by group length; -1: no window)
     int role_mask;              // 0 = every role; else bit 0 laser, bit 1 IMU, bit 2 wheel + ground (liw_batch_time_kernels: one role kernel alone)
     // optional per-factor outputs (liw_eval_factors)
     double* dbg_laser_res; double* dbg_laser_jac; double* dbg_imu_res; double* dbg_imu_jac;
@@ -319,15 +320,15 @@ void launch_p2p_exchange(size_t nd, const double* buf, const P2pPeers& peers, in
 void launch_group_offsets(int B, int n, const int* laser_off, const int* laser_frame, int* group_off, hipStream_t s);
 void launch_laser_z_scan(long Ltot, const double* laser_pts, int* flag, hipStream_t s);
 // k_laser_slab.hip: lane-per-(window, frame) laser role of large 2-D batches
-int laser_slab_count(int B);
-void launch_laser_slab_prepare(int B, int n, const int* group_off, int* mx, long long* off, const int* hz, hipStream_t s);
+__host__ __device__ inline int laser_slab_count(int B) { return (B + 63) / 64; }   // slabs of 64 windows
+void launch_laser_slab_prepare(int B, int n, const int* group_off, int* perm, int* mx, long long* off, const int* hz, hipStream_t s);
 #ifndef LIW_SLAB_WPLANE
 #define LIW_SLAB_WPLANE 0     // 1: the re-pack appends the block's weight sqrt(min(len1, len2) / 0.04) (laser_factor.h:38-42, constant over the LM
                               // iterations) as a ninth plane: -30 of a block's 274 VALU instructions for +12.5 % of row bytes.  Measured twice (round 5): the
                               // kernel alone 1.51 -> 1.56 ms (it is bandwidth-bound), the linearise bracket 3.907 -> 3.897 ms, 130.2 k -> 130.7 k solves/s: off
 #endif
 constexpr int LASER_SLAB_ROWD = (8 + LIW_SLAB_WPLANE) * 64;      // doubles per packed row of k_laser_slab.hip
-void launch_laser_slab_pack(int B, int n, long Ltot, const int* group_off, const double* pts, const long long* off, const int* mx, double* pk, hipStream_t s);
+void launch_laser_slab_pack(int B, int n, long Ltot, const int* group_off, const int* perm, const double* pts, const long long* off, const int* mx, double* pk, hipStream_t s);
 void launch_lin_laser_slab(const LinArgs& A, const DevParams& P, hipStream_t s);
 void launch_imu_pack(int B, int n, const double* imu_X, const double* imu_J, const double* imu_sqrtP, const double* imu_Dt, double* pk, int* bad, hipStream_t s);
 void launch_pack_result(const PackArgs& a, hipStream_t s);

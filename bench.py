@@ -523,6 +523,56 @@ class TrackBatch:
 
 
 
+
+def ragged_leg(liw, synth, prm, dev, B, n, L, iters, nb):
+    """`ragged_c2`: B windows cycling through nb distinct RAGGED ones (ragged_shapes: the same total as nb x L blocks, per-window L from L / 4 to
+    2 L, per-frame groups from 0 to several hundred) — init solve + marginalisation, one warm-up pass and one timed pass; which laser kernel
+    ran and how much padding the packed rows carry; the same batch once more with the windows taken in batch order (LIW_SLAB_BATCH_ORDER=1:
+    the round-5 layout) for the before / after of the per-frame order."""
+    import torch
+    tw = make_tiled(liw, synth, prm, B, n, L, seed0=40240, n_base=nb, ragged=True)
+    counts = np.stack([np.bincount(np.asarray(w["laser_frame"]), minlength=n) for w in tw.base])
+    out = {"windows": B, "distinct_windows": len(tw.base), "blocks_per_window_min_mean_max": [int(counts.sum(1).min()), float(counts.sum(1).mean()), int(counts.sum(1).max())],
+           "blocks_per_frame_max": int(counts.max()), "empty_frames_pct": round(100.0 * float((counts[:, 1:] == 0).mean()), 1),
+           "padding_ratio_in_batch_order": round(float(counts.max(0).sum() * len(tw.base) / counts.sum()), 3)}
+
+    def run(env):
+        for k, v in env.items():
+            os.environ[k] = v
+        try:
+            bs = liw.BatchSolver(prm, tw.base, device=dev, tile=tw.tile())
+            x0, mp0 = bs.t["x"].clone(), bs.t["match_pose"].clone()
+            secs = []
+            for rep in range(2):
+                bs.t["x"].copy_(x0); bs.t["match_pose"].copy_(mp0); bs.t["has_prior"].zero_()
+                torch.cuda.synchronize()
+                t0 = time.perf_counter()
+                bs.solve(liw.LIW_MODE_INIT, iters)
+                bs.marginalize()
+                torch.cuda.synchronize()
+                secs.append(time.perf_counter() - t0)
+            lp = bs.launch_paths()
+            kt = bs.time_kernels(liw.LIW_MODE_INIT, 3)
+            sm = bs.summaries()
+            r = {"solves_per_s": round(B / secs[-1], 1), "ms_per_step": round(1e3 * secs[-1], 2), "lane_per_group_laser_kernel": lp["lane_per_group_laser"],
+                 "packed_rows_padding_ratio": round(lp["padding_ratio"], 3) if lp["padding_ratio"] else None,
+                 "k_lin_laser_alone_ms": round(kt["k_lin_laser"], 4), "k_lin_laser_marg_alone_ms": round(kt["k_lin_laser_marg"], 4),
+                 "lm_iterations_mean": round(float(np.mean([s_["iterations"] for s_ in sm])), 2)}
+            bs.close()
+            del bs
+            torch.cuda.empty_cache()
+            return r
+        finally:
+            for k in env:
+                os.environ.pop(k, None)
+    out["per_frame_order"] = run({})
+    out["batch_order_round5_layout"] = run({"LIW_SLAB_BATCH_ORDER": "1"})
+    out["note"] = ("same factors per window on average as C2; the lane-per-group laser kernel pads a (slab, frame) wave to its longest group: in batch order "
+                   "that is padding_ratio_in_batch_order rows per row of data (above 4 the solve falls back to the lane-per-block kernel), in the per-frame order "
+                   "by group length (round 6) packed_rows_padding_ratio")
+    return out
+
+
 def track_model(blocks_new, blocks_window):
     """HBM bytes per 2-frame window of the kernels of one batched tracking frame, from what each kernel addresses (the large-batch record
     format: linearise_model / step_model with n = 2).  TRACK linearisation: laser blocks of the NEW frame only (64 B per block of a 2-D scan:
@@ -706,6 +756,8 @@ def main():
     ap.add_argument("--no-single", action="store_true", help="skip the B=1 latency measurement (clean per-kernel profiles)")
     ap.add_argument("--track-batch", type=int, default=int(os.environ.get("LIW_BENCH_TRACK_BATCH", 49152)), help="robots of the batched TRACK leg (the reference's steady state: 2-frame window, "
                     "solve + marginalization per laser frame, prior carried); 0 = skip")
+    ap.add_argument("--ragged-batch", type=int, default=int(os.environ.get("LIW_BENCH_RAGGED_BATCH", 49152)), help="windows of the ragged-workload leg (same totals as C2, per-window L and per-frame "
+                    "group sizes drawn wide); 0 = skip")
     ap.add_argument("--track-frames", type=int, default=8, help="timed consecutive frames of the batched TRACK leg")
     ap.add_argument("--track-gate-windows", type=int, default=6, help="robots of the TRACK leg whose every frame is checked teacher-forced against the oracle")
     ap.add_argument("--record-md", default=None, help="after the timed region, write a reference-shaped `record` table (labels "
@@ -1198,6 +1250,15 @@ def main():
         except Exception as e:   # a latency side-measurement must never take the headline line down
             keepn = {"error": str(e)[:200]}
 
+    # ---- ragged workload: the C2 totals with per-window L drawn from [L / 4, 2 L] and per-frame groups from 0 to several
+    #      hundred blocks — what real scans give do_match — through the same solve + marginalisation, beside the even C2 batch above
+    ragged = None
+    if rank == 0 and world == 1 and not args.no_single and args.ragged_batch > 0:
+        try:
+            ragged = ragged_leg(liw, synth, prm, dev, args.ragged_batch, n, L, args.iters, args.distinct)
+        except Exception as e:   # a side measurement must never take the headline line down
+            ragged = {"error": repr(e)[:300]}
+
     # ---- the reference's steady state at scale: batched 2-frame TRACK solves + marginalisation over consecutive frames
     track_batch = None
     if rank == 0 and world == 1 and not args.no_single and args.track_batch > 0:
@@ -1334,6 +1395,8 @@ def main():
             out["keep30_tracking_frame_latency"]["note"] = "keep-N is this repository's window policy for BASELINE C3 / C5, not a reference behaviour (the reference keeps 1 frame)"
         if track_batch:
             out["tracking_batch"] = track_batch
+        if ragged:
+            out["ragged_c2"] = ragged
         if ktimes:
             out["kernel_times"] = ktimes
             out["roofline_schur"] = ktimes["roofline_schur"]

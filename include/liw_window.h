@@ -209,8 +209,14 @@ int liw_batch_time_kernels(liw_ctx* ctx, const liw_batch* b, int mode, void* ws,
 int liw_batch_lm_begin(liw_ctx* ctx, const liw_batch* b, int mode, int max_iters, void* ws, void* stream);
 /* Which kernels the solve opened by the last liw_batch_lm_begin(ctx, b, ..., ws, ...) runs (tests pin the benchmarked launch shape with
  * it; no reference counterpart): *flags bit 0 = large-batch record format (per-frame IMU records + compact cost array: k_lin_imu_chain,
- * k_lm_step_quad), bit 1 = the lane-per-group laser kernel is armed for this (batch, workspace) (k_lin_laser_slab; INIT topology). */
+ * k_lm_step_quad), bit 1 = the lane-per-group laser kernel is armed for this (batch, workspace) (k_lin_laser_slab; k_lin_laser_slab1 for TRACK and
+ * for the marginalisation that follows on the same arrays). */
 int liw_batch_launch_paths(liw_ctx* ctx, const liw_batch* b, const void* ws, int* flags);
+/* Size of the re-packed laser rows of that solve (measurement aid, no reference counterpart): *rows = 64-block rows packed (0: the
+ * lane-per-group kernel is not armed for this batch), *blocks = laser blocks of the batch; 64 * rows / blocks = the padding ratio — 1.0
+ * means every lane of every row carries a block.  Since round 6 the windows are taken in a per-frame order by group length, so ragged
+ * batches stay near 1 (they packed 4x the data in batch order). */
+int liw_batch_packed_rows(liw_ctx* ctx, const liw_batch* b, const void* ws, long long* rows, long long* blocks);
 int liw_batch_lm_linearize(liw_ctx* ctx, const liw_batch* b, int mode, int candidate, void* ws, void* stream);
 int liw_batch_lm_step(liw_ctx* ctx, const liw_batch* b, int mode, void* ws, void* stream);
 int liw_batch_lm_finish(liw_ctx* ctx, const liw_batch* b, int mode, void* ws, void* stream);
