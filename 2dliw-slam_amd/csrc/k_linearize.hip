@@ -24,6 +24,9 @@
 #ifndef LIW_IMU_PROBE_NOSTORE
 #define LIW_IMU_PROBE_NOSTORE 0     // probe build (wrong results): k_lin_imu_chain without its frame-record stores
 #endif
+#ifndef LIW_IMU_PROBE_PHASE
+#define LIW_IMU_PROBE_PHASE 0       // probe builds (wrong results, round 6): 1 = the dual-number part only (the block records stay in LDS, nothing is stored),
+#endif                              // 2 = the matrix-core part only (on whatever the LDS holds): the two halves of the split VERDICT r5 proposed, each alone
 namespace liw {
 
 // ------------------------------------------------------------------------------------------- laser
@@ -182,7 +185,13 @@ __device__ __forceinline__ V3<double> mulc(const double* m, int ld, const V3<dou
 // several waves; a wave that starts in the middle of a window evaluates the block in front of its first one once more, for that block's
 // jj tile only (a "ghost": nothing of it is stored) — one block in 15 for the 29 blocks of a 30-frame window.
 __host__ __device__ inline int imu_chain_parts(int nb) { return nb <= IMU_PER_WAVE ? 1 : (nb + IMU_PER_WAVE - 2) / (IMU_PER_WAVE - 1); }
-template <int ND, bool PK = false, bool CHAIN = false>
+// MULTI (round 6; CHAIN only, nb <= IMU_PER_WAVE / 2): SEVERAL windows per wave, imu_chain_windows(nb) of them — a two-frame tracking window
+// has ONE IMU block, and a wave per window left 15 of its 16 block slots (and 45 of the 48 dual-number lanes) empty: 0.20 ms per 49 152
+// two-frame windows against the 0.075 ms the role takes per 49 152 blocks of a C2 batch.  Slot blk = window blk / nb of the wave, block
+// blk % nb; the jj -> ii hand-over starts from zero at every window's first block; the window of a block is a lane value, its record
+// addresses are formed from scalars read off the block's first lane.  No ghosts (a window never straddles two waves).
+__host__ __device__ inline int imu_chain_windows(int nb) { return (nb >= 1 && 2 * nb <= IMU_PER_WAVE) ? IMU_PER_WAVE / nb : 1; }
+template <int ND, bool PK = false, bool CHAIN = false, bool MULTI = false>
 __device__ __forceinline__ void imu_blocks(const LinArgs& A, const DevParams& P, int wave, double* lds, const int* const act) {
     constexpr int LPB = 9 / ND;
     constexpr int MAXB = 63 / LPB;
@@ -197,7 +206,14 @@ __device__ __forceinline__ void imu_blocks(const LinArgs& A, const DevParams& P,
     // act: the compacted list of the windows still iterating, or null (index by window); the kernel checks that the list is complete
     const long total = (long)(act ? act[0] : A.B) * nb, gb0 = CHAIN ? 0 : (long)wave * ipw;
     int chain_b = 0, chain_k0 = 0, chain_nblk = 0, ghost = 0;
-    if constexpr (CHAIN) {
+    int multi_w0 = 0;                                      // MULTI: first position of this wave in the list of windows (compacted or all)
+    if constexpr (CHAIN && MULTI) {
+        if (nb < 1) return;
+        const int wpw = imu_chain_windows(nb), cnt = act ? act[0] : A.B;
+        multi_w0 = wave * wpw;
+        if (multi_w0 >= cnt) return;
+        chain_nblk = min(wpw, cnt - multi_w0) * nb;
+    } else if constexpr (CHAIN) {
         if (nb < 1) return;
         const int npw = imu_chain_parts(nb), bpw = (nb + npw - 1) / npw;
         const int wiw = wave / npw, part = wave % npw;
@@ -214,9 +230,10 @@ __device__ __forceinline__ void imu_blocks(const LinArgs& A, const DevParams& P,
     }
     const long gb = gb0 + blk;
     bool on = CHAIN ? blk < chain_nblk : (blk < ipw && gb < total);
-    const int wi = (!CHAIN && on) ? (int)(gb / nb) : 0, k = CHAIN ? (on ? chain_k0 + blk : 0) : (on ? (int)(gb % nb) : 0);
-    const int b = CHAIN ? chain_b : (act ? act[1 + wi] : wi);
-    if (!CHAIN && on && !act) on = window_live(A, b);
+    const int wi = (CHAIN && MULTI) ? (on ? multi_w0 + blk / nb : 0) : ((!CHAIN && on) ? (int)(gb / nb) : 0);
+    const int k = (CHAIN && MULTI) ? (on ? blk % nb : 0) : (CHAIN ? (on ? chain_k0 + blk : 0) : (on ? (int)(gb % nb) : 0));
+    const int b = (CHAIN && !MULTI) ? chain_b : (act ? act[1 + wi] : wi);
+    if ((!CHAIN || MULTI) && on && !act) on = window_live(A, b);
     double* rec = lds + (blk < MAXB ? blk : 0) * IMU_REC;
     const int sel_lane = (on && A.lm) ? (A.candidate ? 1 - A.lm[b].cur : A.lm[b].cur) : 0;   // partial buffer of this lane's block
     const int fk_lane = on ? b * nb + k : 0;                                                   // its record in the input / partial arrays
@@ -243,7 +260,7 @@ __device__ __forceinline__ void imu_blocks(const LinArgs& A, const DevParams& P,
         for (int q = 0; q < GRP; ++q) load_sop(q, sop[q]);
     }
     LSTAMP(300);
-    if (on) {
+    if (on && LIW_IMU_PROBE_PHASE != 2) {
         const size_t fk = (size_t)b * nb + k;   // record of this block in the (uncompacted) input / partial arrays
         const double* si_ = A.x + ((size_t)b * n + k) * 15;
         const double* sj_ = si_ + 15;
@@ -372,6 +389,10 @@ __device__ __forceinline__ void imu_blocks(const LinArgs& A, const DevParams& P,
     }
     lds_sync();
     LSTAMP(304);
+#if LIW_IMU_PROBE_PHASE == 1
+    if (lane < 16 && A.dbg_imu_res) A.dbg_imu_res[lane] = lds[lane * IMU_REC + 9];      // (keeps the dual-number part alive: the pointer is null outside tests)
+    return;
+#endif
     // ---- matrix-core part, one block at a time (the whole wave cooperates).  Operand entry codes of this lane: x0 = column ml of
     // [J_raw wrt x_i | r_raw], x1 = column ml of [J_raw wrt x_j] for the four k-chunks (row kk = mk + 4c)
     if constexpr (ND != 1) ops = c_imu_optab.lane[lane];      // (throughput kernels: 24 registers that must not live across the dual-number part)
@@ -417,6 +438,7 @@ __device__ __forceinline__ void imu_blocks(const LinArgs& A, const DevParams& P,
             }
             // y_t[r] = Y[mk + 4r][ml + 16t]  ==  operand chunk r of Y^T Y
             d4 g00 = {0.0, 0.0, 0.0, 0.0}, g01 = g00, g11 = g00;
+            if constexpr (CHAIN && MULTI) { if (gq % nb == 0) chain11 = d4{0.0, 0.0, 0.0, 0.0}; }   // a window's first block: no block before it
             if constexpr (CHAIN) g00 = chain11;   // + jj of the block before: frame k's diagonal tile is complete when this product is
 #pragma unroll
             for (int c = 0; c < 4; ++c) {
@@ -434,8 +456,9 @@ __device__ __forceinline__ void imu_blocks(const LinArgs& A, const DevParams& P,
                 if (ghost && gq == 0) continue;   // evaluated for its jj tile only
                 // frame kq's record: diagonal tile (upper triangle), gradient part of block (kq, kq+1); frame kq+1's: coupling, gradient
                 // part and cost of the block; behind a window's last block the jj tile is frame n-1's diagonal
-                const int kq = chain_k0 + gq;
-                double* rf = (sel ? A.PI[1] : A.PI[0]) + ((size_t)b * n + kq) * PIFS;
+                const int kq = MULTI ? gq % nb : chain_k0 + gq;
+                const int bq = MULTI ? (int)(fg / (size_t)nb) : b;            // the block's window (fg = window * nb + block: scalar)
+                double* rf = (sel ? A.PI[1] : A.PI[0]) + ((size_t)bq * n + kq) * PIFS;
                 const bool lastb = kq == nb - 1;
                 // The tiles leave through LDS: in the accumulator layout a store instruction covers four 15-double row segments of a tile
                 // (~8 lines, ~20 masked instructions and ~160 line writes per block for a 3-kB record: 0.22 of the kernel's 1.10 ms per
@@ -465,7 +488,7 @@ __device__ __forceinline__ void imu_blocks(const LinArgs& A, const DevParams& P,
                 };
                 diag_out(g00, rf, true);
                 if (lastb) diag_out(g11, rf + PIFS, false);
-                if (mk == 3 && ml == 15) { rf[PIFS + PIF_C] = g00[3]; if (A.CS[0]) (sel ? A.CS[1] : A.CS[0])[cs_index(n, b, CS_IMU, kq)] = g00[3]; }
+                if (mk == 3 && ml == 15) { rf[PIFS + PIF_C] = g00[3]; if (A.CS[0]) (sel ? A.CS[1] : A.CS[0])[cs_index(n, bq, CS_IMU, kq)] = g00[3]; }
                 continue;
             }
             double* out = (sel ? A.PI[1] : A.PI[0]) + fg * PIS;   // (a select, not an indexed load: an indexed kernel argument sends the whole struct through scratch)
@@ -1066,6 +1089,14 @@ __global__ __launch_bounds__(64, 2) void k_lin_imu_chain(LinArgs A, DevParams P)
     if (A.imu_pk && *A.imu_pk_bad == 0) imu_blocks<3, true, true>(A, P, (int)blockIdx.x, lds, act);   // (uniform)
     else imu_blocks<3, false, true>(A, P, (int)blockIdx.x, lds, act);
 }
+// windows of at most IMU_PER_WAVE / 2 blocks (two-frame tracking windows: one block): several windows per wave.  A kernel of its own, so that
+// its per-lane window bookkeeping does not enter the register allocation of the 30-frame kernel above (249 of 256)
+__global__ __launch_bounds__(64, 2) void k_lin_imu_chain_multi(LinArgs A, DevParams P) {
+    __shared__ __attribute__((aligned(16))) double lds[IMU_PER_WAVE * IMU_REC + IMU_STAGE];
+    const int* const act = usable_active_list(A.active, A.B);
+    if (A.imu_pk && *A.imu_pk_bad == 0) imu_blocks<3, true, true, true>(A, P, (int)blockIdx.x, lds, act);   // (uniform)
+    else imu_blocks<3, false, true, true>(A, P, (int)blockIdx.x, lds, act);
+}
 // Packed IMU block records of a solve (IMU_PK doubles per block, liw_kernels.hpp): one thread per entry; `bad` is raised when a
 // sqrt_inverse_P has a non-zero entry below its diagonal (not what imu_preintegraption.h:149 produces: the role then reads the full arrays).
 __global__ void k_imu_pack(long blocks, const double* X, const double* J, const double* S, const double* Dt, double* pk, int* bad) {
@@ -1278,7 +1309,11 @@ void launch_linearize(const LinArgs& A_, const DevParams& P, hipStream_t s, cons
         else hipLaunchKernelGGL(k_lin_laser<false>, dim3((unsigned)laser_waves), dim3(64), 0, s, A, P, G);
     };
     auto role_imu = [&]() {
-        if (imu_waves && (rm & 2) && A.pi_frame) hipLaunchKernelGGL(k_lin_imu_chain, dim3((unsigned)(B * imu_chain_parts(n - 1))), dim3(64), 0, s_imu, A, P);
+        const bool no_multi = getenv("LIW_NO_IMU_MULTI") != nullptr;      // A/B / test aid (read per launch): a wave per window whatever n
+        if (imu_waves && (rm & 2) && A.pi_frame && imu_chain_windows(n - 1) > 1 && !no_multi) {
+            const int wpw = imu_chain_windows(n - 1);
+            hipLaunchKernelGGL(k_lin_imu_chain_multi, dim3((unsigned)((B + wpw - 1) / wpw)), dim3(64), 0, s_imu, A, P);
+        } else if (imu_waves && (rm & 2) && A.pi_frame) hipLaunchKernelGGL(k_lin_imu_chain, dim3((unsigned)(B * imu_chain_parts(n - 1))), dim3(64), 0, s_imu, A, P);
         else if (imu_waves && (rm & 2)) hipLaunchKernelGGL(k_lin_imu, dim3((unsigned)imu_waves), dim3(64), 0, s_imu, A, P);
     };
     auto role_small = [&]() {

@@ -612,19 +612,44 @@ def track_batch_leg(liw, synth, prm, dev, B, K, nb, gate_windows, cpu=True):
                      % (tb.blocks_new, tb.blocks_window),
            "per_frame": "x / laser_match carry (device copies) + solve(TRACK) + marginalization; reference call pattern trajectory.cpp:525-560, solver.cpp:631-820, :257-442",
            "lm_iterations_mean": round(float(itk.mean()), 3), "lm_iterations_histogram": {str(int(k)): int((itk == k).sum()) for k in np.unique(itk)},
-           "launch_paths": {"flags": int(flags.value), "large_batch_record_format (k_lin_imu_chain, k_lm_step_quad, k_marg_schur_chain + k_marg_schur_eigq)": bool(flags.value & 1),
-                            "lane_per_group_laser_kernel": bool(flags.value & 2)},
+           "launch_paths": {"flags": int(flags.value), "large_batch_record_format (k_lin_imu_chain_multi: 16 two-frame windows per wave, k_lm_step_quad, k_marg_schur_chain + k_marg_schur_eigq)": bool(flags.value & 1),
+                            "lane_per_group_laser_kernel (k_lin_laser_slab1 on the solve's packed rows, also for the marginalisation)": bool(flags.value & 2)},
            "brackets": {"linearize_avg_ms": round(tm["linearize_ms"], 5), "linearize_launches": tm["linearize_launches"], "step_avg_ms": round(tm["step_ms"], 5), "step_launches": tm["step_launches"],
                         "share_of_frame_time": round((tm["linearize_ms"] * tm["linearize_launches"] + tm["step_ms"] * tm["step_launches"]) * 1e-3 / (3 * secs), 3),
                         "note": "HIP-event brackets of the LM linearisations / steps over three passes of the K frames; the rest of a frame is the per-solve packing, the marginalisation and the carry"},
            "kernel_times_alone_ms": {k: round(v, 4) for k, v in kt.items()},
            "model_bytes_per_window": {"linearise": lin_b, "step": stp_b, "linearise_marg": model["linearise_marg"]["read"] + model["linearise_marg"]["write"]}}
-    # roofline of the dominant bracket, every window active (stand-alone kernel times): the records written per window dwarf the inputs read
+    # roofline of the dominant kernel, every window active (stand-alone kernel times).  `traffic`: FETCH_SIZE x 2 + WRITE_SIZE of that kernel's full
+    # launch from the rocprofv3 --pmc passes of tools/track_batch_probe.py (tools/pmc_track.py -> profiles/pmc_track.json; separate runs, the
+    # guide's gfx950 correction), scaled to this batch.  A frame's working set (~1.2 GB of records per launch) is only five times the 256 MiB
+    # Infinity Cache, whose hits the counters include: `frac` is of the HBM peak and can exceed what HBM alone delivers.
+    pmct = {}
+    try:
+        pmct = json.load(open(os.path.join(ROOT, "profiles", "pmc_track.json")))
+    except Exception:
+        pmct = {}
+
+    def pmc_bytes(key):
+        for k_, v_ in (pmct.get("kernels") or {}).items():
+            if key in k_:
+                return int(v_["hbm_bytes_per_robot_full_launch"] * B)
+        return None
     lin_alone = kt["k_lin_laser"] + kt["k_lin_imu"] + kt["k_lin_small"]
-    dom = max((("linearise (k_lin_laser<false> + k_lin_imu_chain + k_lin_small, serial sum of the stand-alone times)", lin_alone, lin_b), ("k_lm_step_quad (TRACK)", kt["k_lm_step"], stp_b)), key=lambda r: r[1])
-    out["roofline"] = {"bound": "hbm", "kernel": dom[0], "avg_launch_ms": round(dom[1], 4), "achieved": round(B * dom[2] / (dom[1] * 1e-3) / 1e9, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                       "frac": round(B * dom[2] / (dom[1] * 1e-3) / 1e9 / HBM_PEAK_GBS, 4), "traffic": None,
-                       "bytes_model": "analytic (track_model): bytes the kernels address per 2-frame window, all windows active; rocprofv3 kernel trace of this leg under profiles/"}
+    lin_traffic = [pmc_bytes(k_) for k_ in ("k_lin_laser_slab1" if (flags.value & 2) else "k_lin_laser<", "k_lin_imu_chain_multi", "k_lin_small")]
+    cands = (("linearise (%s + k_lin_imu_chain_multi + k_lin_small, serial sum of the stand-alone times)" % ("k_lin_laser_slab1" if (flags.value & 2) else "k_lin_laser<false>"),
+              lin_alone, lin_b, sum(lin_traffic) if all(lin_traffic) else None),
+             ("k_lm_step_quad (TRACK topology: assembly of the two frames + prior, block elimination, back substitution; four windows per wave)", kt["k_lm_step"], stp_b, pmc_bytes("k_lm_step_quad")))
+    dom = max(cands, key=lambda r: r[1])
+    out["roofline"] = {"bound": "hbm (+ Infinity Cache: the per-launch working set is ~5x the 256 MiB cache)", "kernel": dom[0], "avg_launch_ms": round(dom[1], 4),
+                       "achieved": round(B * dom[2] / (dom[1] * 1e-3) / 1e9, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                       "frac": round(B * dom[2] / (dom[1] * 1e-3) / 1e9 / HBM_PEAK_GBS, 4), "traffic": dom[3],
+                       "achieved_counter_gbs": round(dom[3] / (dom[1] * 1e-3) / 1e9, 1) if dom[3] else None,
+                       "bytes_model": "analytic (track_model): bytes the kernel addresses per 2-frame window, all windows active",
+                       "traffic_note": "FETCH_SIZE x 2 + WRITE_SIZE of a full launch (profiles/pmc_track.json, rocprofv3 --pmc passes of tools/track_batch_probe.py; not re-measured by this run); "
+                                       "the fabric-side counters include Infinity Cache hits",
+                       "other_kernel": {"kernel": [c_ for c_ in cands if c_ is not dom][0][0], "ms": round([c_ for c_ in cands if c_ is not dom][0][1], 4),
+                                        "model_GBps": round(B * [c_ for c_ in cands if c_ is not dom][0][2] / ([c_ for c_ in cands if c_ is not dom][0][1] * 1e-3) / 1e9, 1),
+                                        "traffic": [c_ for c_ in cands if c_ is not dom][0][3]}}
     out["parity_teacher_forced"] = tb.teacher_forced_parity(ids, cap)
     out["parity_teacher_forced"]["robots"] = [int(b) for b in ids]
     out["parity_teacher_forced"]["note"] = ("every frame of these robots: oracle solver::solve from the inputs the GPU batch had (states, laser_match poses, carried prior), bar 1e-6 on the "

@@ -351,3 +351,55 @@ def test_quad_eigen_square_root_matches_one_wave_kernel_and_oracle(liw, synth, p
         assert np.all(has[~bad] == 1) and np.all(np.isfinite(J[~bad])), eig_env
         for b in (4, 5, 6, 128, 129, 131, B - 2):      # the neighbours are what they are without the poisoned windows
             assert np.array_equal(J[b], (old if eig_env else new)[0]["J"][b]), (eig_env, b)
+
+
+@pytest.mark.parametrize("n,B,mode_name", [(2, 1101, "track"), (3, 1030, "init"), (5, 1101, "init"), (9, 1027, "init")])
+def test_multi_window_imu_chain_is_bit_identical_to_one_window_per_wave(liw, synth, pyoracle, monkeypatch, n, B, mode_name):
+    """k_lin_imu_chain_multi (round 6): windows of at most 8 IMU blocks share a wave (16 / (n - 1) windows: 16 two-frame tracking windows,
+    8 three-frame, 4 five-frame, 2 nine-frame ones) instead of one window per wave.  Same arithmetic per block, the jj -> ii hand-over
+    restarts at every window: the per-frame IMU records, the solve and its LM history must be BIT-identical to the one-window-per-wave
+    kernel (LIW_NO_IMU_MULTI=1) — including a batch size that leaves the last wave partly empty and windows that finish early (the
+    compacted list re-groups the windows of a wave from iteration to iteration)."""
+    import torch
+    prm = synth.office_params()
+    orc = pyoracle.Oracle(prm)
+    nb_ = 5
+    base = [synth.make_window(orc, prm, seed=9300 + 10 * n + k, n=n, L=12 * (n - 1) + 9 * k, state_noise=(0.3 if k % 2 else 1.0)) for k in range(nb_)]
+    wins = [base[b % nb_] for b in range(B)]
+    mode = liw.LIW_MODE_TRACK if mode_name == "track" else liw.LIW_MODE_INIT
+
+    def run(no_multi):
+        if no_multi:
+            monkeypatch.setenv("LIW_NO_IMU_MULTI", "1")
+        else:
+            monkeypatch.delenv("LIW_NO_IMU_MULTI", raising=False)
+        bs = liw.BatchSolver(prm, wins, history_records=22)
+        if mode_name == "track":
+            bs.marginalize()
+            bs.t["prior_X"].view(B, 15).copy_(bs.t["x"].view(B, n, 15)[:, n - 2])
+        bs.solve(mode, 20)
+        torch.cuda.synchronize()
+        out = (bs.states().copy(), bs.summaries(), bs.history().copy())
+        sH, dH, dg = bs.marginalize()
+        out += (dH.cpu().numpy().copy(), dg.cpu().numpy().copy())
+        bs.close()
+        return out
+    xa, sa, ha, dHa, dga = run(False)
+    xb, sb, hb, dHb, dgb = run(True)
+    assert [(s["iterations"], s["termination"]) for s in sa] == [(s["iterations"], s["termination"]) for s in sb]
+    if n <= 3:
+        assert len({s["iterations"] for s in sa}) > 1                  # windows finish at different iterations (larger windows all run into the cap of 20)
+    assert np.array_equal(xa, xb) and np.array_equal(ha, hb)
+    assert np.array_equal(dHa, dHb) and np.array_equal(dga, dgb)
+    # and the oracle on the distinct windows (INIT) / the first window pair (TRACK is covered by tests/test_gpu_track_batch.py)
+    if mode_name == "init":
+        orc.set_max_iterations(20)
+        for k in range(nb_):
+            w = pyoracle.Window(base[k])
+            orc.set_prior(None)
+            orc.init_solve(w)
+            so = orc.summary()
+            for b in (k, B - nb_ + k if (B - nb_ + k) % nb_ == k else k):
+                assert (sa[b]["iterations"], sa[b]["termination"]) == (so["iterations"], so["termination"]), (k, b)
+                assert rel(xa[b], w["states"].reshape(n, 15)) <= 1e-6, (k, b)
+        orc.set_max_iterations(50)

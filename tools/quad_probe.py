@@ -10,8 +10,8 @@ liw = importlib.import_module("2dliw-slam_amd"); synth = importlib.import_module
 import bench
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 24576
 prm = synth.office_params()
-wins = bench.make_batch(liw, synth, prm, B, 30, 2000, seed0=20240, n_base=64)
-bs = liw.BatchSolver(prm, wins)
+tw = bench.make_tiled(liw, synth, prm, B, 30, 2000, seed0=20240, n_base=64)      # (tiled on the device: no B-fold host concatenation)
+bs = liw.BatchSolver(prm, tw.base, tile=tw.tile())
 x0 = bs.t["x"].clone()
 M = liw.LIW_MODE_INIT
 res = []
