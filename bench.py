@@ -684,7 +684,10 @@ def marg_reference(pyoracle, orc, win, x, mp, passes, prior=None):
         Hmm, Hrm = H[:N - 15, :N - 15], H[N - 15:, :N - 15]
         W = np.linalg.solve(Hmm, Hrm.T).T
         X, Jp, Rp = orc.get_prior()
-        out.append(dict(dH=m["Delta_H"].copy(), dg=m["Delta_g"].copy(), X=X.copy(), J=Jp.copy(), R=Rp.copy(), g_scale=float((a[N - 15:] + np.abs(W) @ a[:N - 15]).max())))
+        # H_rr_scale: |H_rr|max — Delta_H = H_rr - H_rm H_mm^-1 H_mr cancels against it (a window with little information on the newest frame keeps
+        # 5e7 of 1e11): the round-off of Delta_H scales with the terms that cancel, not with what is left (tests/soak/soak_slab.py)
+        out.append(dict(dH=m["Delta_H"].copy(), dg=m["Delta_g"].copy(), X=X.copy(), J=Jp.copy(), R=Rp.copy(), g_scale=float((a[N - 15:] + np.abs(W) @ a[:N - 15]).max()),
+                        H_rr_scale=float(np.abs(H[N - 15:, N - 15:]).max())))
     return out
 
 

@@ -266,6 +266,14 @@ int liw_batch_exchange_timing(liw_ctx* ctx, int enable, double* avg_ms, int* cou
 int liw_batch_exchange_doubles(int B, int n, int mode);
 int liw_batch_exchange_pack(liw_ctx* ctx, const liw_batch* b, int mode, int candidate, void* ws, double* buf, void* stream);
 int liw_batch_exchange_unpack(liw_ctx* ctx, const liw_batch* b, int mode, int candidate, void* ws, const double* buf, int copies, void* stream);
+/* The whole LM solve of the batch (reference: solver::init_solve / solver::solve for every window, src/factor/solver.cpp:50-195, :631-820):
+ * lm_begin, linearise, max_iters x [step, linearise(candidate)], step, finish on `stream`.
+ * Blocking points (round 6): besides the one of liw_batch_lm_begin, batches of 512 windows and more read back the number of windows still
+ * iterating (4 bytes + a status word, hipStreamSynchronize on `stream`) after LM iteration 3 and then every 2 .. 8 iterations (the fewer
+ * windows are left, the more often), and stop launching once it is 0 — the launches of an iteration in which no window iterates cost ~0.2 ms per
+ * 49 152 windows, two thirds of a batched tracking frame.  Results are bit-identical to the full-length loop (a finished window's kernels
+ * return at once).  Not under stream capture (use_graph != 0, or `stream` being captured by the caller): the captured sequence runs every
+ * iteration.  LIW_NO_EARLY_EXIT=1 restores the fixed-length loop. */
 int liw_batch_solve(liw_ctx* ctx, const liw_batch* b, int mode, int max_iters, void* ws, void* stream, int use_graph);
 /* marginalisation of every window of the batch (linearise in MARG topology + chain Schur + eigen sqrt);
  * sqrt_H [B][36], Delta_H [B][225], Delta_g [B][15] optional device outputs.  Batches above 256 windows run two kernels on `stream`

@@ -16,6 +16,8 @@ case $SET in
    run shapes2 python tests/soak/soak_random_shapes.py 15000 21000; run c2 python tests/soak/soak_c2.py 40 100 15;;
 4) run batch python tests/soak/soak_batch.py 8000 9500; run shapes python tests/soak/soak_random_shapes.py 21000 24500
    run shapes2 python tests/soak/soak_random_shapes.py 24500 28000; run fuzz python tests/soak/soak_api_fuzz.py 60 100;;
+5) run batch python tests/soak/soak_batch.py 9500 11500; run shapes python tests/soak/soak_random_shapes.py 35000 38000
+   run slab python tests/soak/soak_slab.py 0 400; run c2 python tests/soak/soak_c2.py 100 130 15;;
 esac
 wait
 for f in gpurun_out/soak_${TAG}_*.log; do echo "== $f"; tail -n 2 $f; done
