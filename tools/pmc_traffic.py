@@ -26,6 +26,9 @@ def per_kernel(path, counter):
 def pick(d, key):
     if key == "k_marg_schur":   # since the end of round 5 two kernels on large batches (k_marg_schur_chain + k_marg_schur_eigq): their sum
         return sum(v for k, v in d.items() if key in k)
+    for k, v in d.items():          # the kernel of exactly that name first (k_lin_laser_slab is a prefix of round 6's k_lin_laser_slab1)
+        if key + "(" in k or k.endswith(key):
+            return v
     for k, v in d.items():
         if key in k:
             return v
