@@ -84,6 +84,7 @@ struct liw_ctx {
     struct { const void* ws; const void* pts; const void* frame; int B, n; long Ltot; } lpk_key{};
     bool lpk_on = false;
     long long lpk_rows = 0;
+    int* rb_pin = nullptr;        // page-locked words for the small read-backs of the batched solve (a pageable destination sends hipMemcpyAsync down a slow, serialising path)
     // graph cache
     hipGraphExec_t gexec = nullptr;
     std::vector<unsigned char> gkey;
@@ -199,6 +200,7 @@ void liw_destroy(liw_ctx* c) {
         DevBuf* bufs[] = {&c->lpk, &c->lpk_off, &c->lpk_mx, &c->lpk_perm, &c->p2p_err, &c->arena, &c->prior_X, &c->prior_J, &c->prior_R, &c->has_prior, &c->ws, &c->scratch,
                           &c->priorn_X, &c->priorn_J, &c->priorn_R, &c->has_priorn, &c->result, &c->marg_status};
         if (c->pinned) (void)hipHostFree(c->pinned);
+        if (c->rb_pin) (void)hipHostFree(c->rb_pin);
         if (c->ev_upload) (void)hipEventDestroy(c->ev_upload);
         for (DevBuf* b : bufs) b->release();
         for (auto e : c->ev_lin) (void)hipEventDestroy(e);
@@ -318,8 +320,10 @@ static int laser_slab_begin(liw_ctx* c, const liw_batch* b, int mode, const WsVi
     if (c->lpk_mx.ensure(sizeof(int) * (size_t)N) || c->lpk_off.ensure(sizeof(long long) * ((size_t)N + 2)) || c->lpk_perm.ensure(sizeof(int) * (size_t)N * 64))
         return fail(c, LIW_ENOMEM, "hipMalloc");
     launch_laser_slab_prepare(b->B, b->n, v.group_off, c->lpk_perm.as<int>(), c->lpk_mx.as<int>(), c->lpk_off.as<long long>(), v.imu_pk_bad + 1, s);
-    long long tail[2] = {0, 1};
-    HIPCHK(c, hipMemcpyAsync(tail, c->lpk_off.as<long long>() + N, sizeof(tail), hipMemcpyDeviceToHost, s));
+    if (!c->rb_pin) HIPCHK(c, hipHostMalloc((void**)&c->rb_pin, 64, hipHostMallocDefault));
+    long long* const tail = reinterpret_cast<long long*>(c->rb_pin) + 2;      // (bytes 16 .. 31 of the page-locked block)
+    tail[0] = 0; tail[1] = 1;
+    HIPCHK(c, hipMemcpyAsync(tail, c->lpk_off.as<long long>() + N, 2 * sizeof(long long), hipMemcpyDeviceToHost, s));
     HIPCHK(c, hipStreamSynchronize(s));
     const long long rows = tail[0];
     if (tail[1] != 0 || rows <= 0) return LIW_OK;                               // 3-D end points: the lane-per-block kernel handles them
@@ -672,7 +676,9 @@ static int enqueue_solve(liw_ctx* c, const liw_batch* b, int mode, int K, void* 
         step();
         lin(1);
         if (k + 1 == next_check && k + 1 < K) {
-            int act[2] = {-1, 0};                                   // count, status word of the list (1 = complete: usable_active_list)
+            if (!c->rb_pin) HIPCHK(c, hipHostMalloc((void**)&c->rb_pin, 64, hipHostMallocDefault));
+            int* const act = c->rb_pin;                             // count, status word of the list (1 = complete: usable_active_list)
+            act[0] = -1; act[1] = 0;
             HIPCHK(c, hipMemcpyAsync(act, v.active, sizeof(int), hipMemcpyDeviceToHost, s));
             HIPCHK(c, hipMemcpyAsync(act + 1, v.active + b->B + 2, sizeof(int), hipMemcpyDeviceToHost, s));
             HIPCHK(c, hipStreamSynchronize(s));

@@ -675,6 +675,13 @@ def marg_reference(pyoracle, orc, win, x, mp, passes, prior=None):
     w["match_pose"][:] = mp.reshape(w["match_pose"].shape)
     orc.set_prior(prior)              # the linearised block the solver carries in (solver.h:31-37); None: no prior rows
     out = []
+    # (single-threaded BLAS for the few dense products below: numpy's thread pool — one spinning thread per logical CPU of a 256-thread host inside a
+    #  16-CPU cgroup — starved the launching thread of the NEXT GPU measurement: the fixed-10 side measurement behind the gate read 310 k instead of 515 k)
+    try:
+        from threadpoolctl import threadpool_limits
+        limit = threadpool_limits(limits=1)
+    except Exception:
+        limit = None
     for _ in range(passes):
         orc.marginalization(w)
         m = orc.marg_pieces()
@@ -688,6 +695,8 @@ def marg_reference(pyoracle, orc, win, x, mp, passes, prior=None):
         # 5e7 of 1e11): the round-off of Delta_H scales with the terms that cancel, not with what is left (tests/soak/soak_slab.py)
         out.append(dict(dH=m["Delta_H"].copy(), dg=m["Delta_g"].copy(), X=X.copy(), J=Jp.copy(), R=Rp.copy(), g_scale=float((a[N - 15:] + np.abs(W) @ a[:N - 15]).max()),
                         H_rr_scale=float(np.abs(H[N - 15:, N - 15:]).max())))
+    if limit is not None:
+        limit.restore_original_limits()
     return out
 
 
@@ -987,9 +996,14 @@ def main():
         torch.cuda.synchronize()
         t0_ = time.perf_counter()
         bs.solve(liw.LIW_MODE_INIT, 10)
+        if os.environ.get("LIW_BENCH_K10_SPLIT"):
+            torch.cuda.synchronize()
+            sys.stderr.write("k10: solve %.2f ms\n" % (1e3 * (time.perf_counter() - t0_)))
         bs.marginalize()
         torch.cuda.synchronize()
         k10 = round(B / (time.perf_counter() - t0_), 1)
+        if os.environ.get("LIW_BENCH_K10_SPLIT"):
+            sys.stderr.write("k10: total %.2f ms, iterations histogram %s\n" % (1e3 * (time.perf_counter() - t0_), np.bincount([s_["iterations"] for s_ in bs.summaries()]).tolist()))
 
     # ---- "converging" C2 variant: the same windows started closer to the truth, so that the LM stops on Ceres' function
     #      tolerance instead of crawling along the ground_factor_q cone into the iteration cap; `value` stays on the workload above
