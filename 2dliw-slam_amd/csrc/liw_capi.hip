@@ -644,13 +644,8 @@ static int enqueue_solve(liw_ctx* c, const liw_batch* b, int mode, int K, void* 
         if (int r = laser_slab_begin(c, b, mode, v, ws, s, cap == hipStreamCaptureStatusNone)) return r;
     }
     StepArgs st = step_args(c, b, mode, K, v);
-    // The lane-per-group laser kernel reads whole 64-lane rows as long as ONE window of a slab still iterates; once few windows are left (the
-    // read-backs of the early exit below say how many) the lane-per-block kernel, whose waves end at once for finished windows, is the
-    // cheaper one: a tracking frame of 49 152 robots spends its iterations 8 .. 18 on the last 3 % of them (round 6)
-    bool laser_rows = true;
     auto lin = [&](int cand) {
         LinArgs A = lin_args(b, mode, cand ? v.x_cand : b->x, v, cand, true, pack, c, ws);
-        if (!laser_rows) { A.laser_pk = nullptr; A.laser_slab_off = nullptr; A.laser_perm = nullptr; }
         if (timed) (void)hipEventRecord(next_event(c->ev_lin, c->ev_lin_used), s);
         launch_linearize(A, c->dp, s, c->have_fork ? &c->fork : nullptr);
         if (timed) (void)hipEventRecord(next_event(c->ev_lin, c->ev_lin_used), s);
@@ -684,8 +679,8 @@ static int enqueue_solve(liw_ctx* c, const liw_batch* b, int mode, int K, void* 
             HIPCHK(c, hipStreamSynchronize(s));
             if (act[1] != 1 || act[0] < 0 || act[0] > b->B) { next_check = K + 1; continue; }   // no complete list: run the full loop
             if (act[0] == 0) break;
-            static const bool no_switch = std::getenv("LIW_NO_TAIL_SWITCH") != nullptr;     // A/B aid
-            if (act[0] < b->B / 8 && !no_switch) laser_rows = false;
+            // (measured and dropped, round 6: handing the laser role back to the lane-per-block kernel once fewer than an eighth of the windows iterate —
+            //  a tracking frame of 49 152 robots 6.78 ms with the switch, 6.65 ms without: the dead windows' waves of that kernel cost what the half-empty rows do)
             // (tracking solves end within a few iterations of each other — mean 5, 97 % by 8 —: a denser cadence there)
             next_check += act[0] > b->B / 4 ? (mode == LIW_MODE_TRACK ? 3 : 8) : (act[0] > b->B / 64 ? 3 : 2);
         }
