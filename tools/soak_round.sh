@@ -18,6 +18,9 @@ case $SET in
    run shapes2 python tests/soak/soak_random_shapes.py 24500 28000; run fuzz python tests/soak/soak_api_fuzz.py 60 100;;
 5) run batch python tests/soak/soak_batch.py 9500 11500; run shapes python tests/soak/soak_random_shapes.py 35000 38000
    run slab python tests/soak/soak_slab.py 0 400; run c2 python tests/soak/soak_c2.py 100 130 15;;
+6) run batch python tests/soak/soak_batch.py 13600 15600; run slab python tests/soak/soak_slab.py 400 1000
+   run fuzz python tests/soak/soak_api_fuzz.py 130 170; run replay python tests/soak/soak_replay.py 14 22
+   run pg python tests/soak/soak_posegraph.py 200 400; run preint python tests/soak/soak_preint.py 600 1000;;
 esac
 wait
 for f in gpurun_out/soak_${TAG}_*.log; do echo "== $f"; tail -n 2 $f; done
