@@ -251,3 +251,44 @@ def test_one_pose_slab_kernel_marg_records_and_tracking_solves(liw, synth, pyora
         assert (tn["sm"][b]["iterations"], tn["sm"][b]["termination"]) == (so["iterations"], so["termination"]), (b, tn["sm"][b], so)
         assert np.abs(tn["x"][b] - w["states"].reshape(2, 15)).max() <= 1e-6 * np.abs(w["states"]).max(), b
     orc.set_prior(None)
+
+
+def test_groups_longer_than_the_sort_bins_and_empty_windows(liw, synth, pyoracle, monkeypatch):
+    """k_laser_slab_order sorts the windows of every frame by group length with 4 096 bins (longer groups share the last bin): a batch in which
+    one distinct window carries 4 500 blocks on ONE frame, another none at all, next to ordinary ones — packed rows stay near the data volume,
+    the solve matches the lane-per-block kernel and the oracle."""
+    prm = synth.office_params()
+    orc = pyoracle.Oracle(prm)
+    n, B, K = 30, 4480 + 11, 6
+    fcs = [synth.ragged_frame_counts(np.random.default_rng(70 + k), n, 300) for k in range(4)]
+    giant = np.zeros(n, dtype=np.int64); giant[17] = 4500; giant[3] = 40
+    none = np.zeros(n, dtype=np.int64)
+    base = [synth.make_window(orc, prm, seed=7300 + k, n=n, frame_counts=fc) for k, fc in enumerate(fcs + [giant, none])]
+    wins = [base[b % len(base)] for b in range(B)]
+
+    def run(no_slab):
+        if no_slab:
+            monkeypatch.setenv("LIW_NO_LASER_SLAB", "1")
+        else:
+            monkeypatch.delenv("LIW_NO_LASER_SLAB", raising=False)
+        bs = liw.BatchSolver(prm, wins)
+        bs.solve(liw.LIW_MODE_INIT, K)
+        out = (bs.states().copy(), bs.summaries(), bs.launch_paths())
+        bs.close()
+        return out
+    xn, sn, lp = run(False)
+    xo, so, lpo = run(True)
+    assert lp["flags"] == 3 and lpo["flags"] == 1
+    assert 1.0 <= lp["padding_ratio"] < 1.1, lp          # equal lengths share slabs: the 4 500-block groups fill twelve slabs of their own
+    assert [(s["iterations"], s["termination"]) for s in sn] == [(s["iterations"], s["termination"]) for s in so]
+    assert (np.abs(xn - xo).max(axis=(1, 2)) / np.abs(xo).max(axis=(1, 2))).max() <= 1e-9
+    orc.set_max_iterations(K)
+    for k in range(len(base)):
+        w = pyoracle.Window(base[k])
+        orc.set_prior(None)
+        orc.init_solve(w)
+        for b in (k, B - 1 - ((B - 1 - k) % len(base))):
+            assert b % len(base) == k
+            assert orc.summary()["iterations"] == sn[b]["iterations"], (k, b)
+            assert np.abs(xn[b] - w["states"].reshape(n, 15)).max() <= 1e-6 * np.abs(w["states"]).max(), (k, b)
+    orc.set_max_iterations(50)
