@@ -242,18 +242,35 @@ __device__ __forceinline__ void imu_blocks(const LinArgs& A, const DevParams& P,
     // The one-direction instantiation (a wave per block: latency) issues its fetch HERE, ahead of the dual-number part.
     const int ml = lane & 15, mk = lane >> 4;
     const int nblk = CHAIN ? chain_nblk : (int)min((long)ipw, total - gb0);
-    constexpr int GRP = ND == 3 ? 7 : 1;
+    // blocks per operand group.  Round 6: 8 (was 7) and BOTH groups of a 16-block wave are fetched in ONE batch in front of the matrix-core loop.
+    // As "group g + 1 is fetched while group g runs" every group's fetch was a load-and-wait — the compiler drains vmcnt before the first MFMA
+    // of a group (the blocks' conditional stores make the count of outstanding operations unknowable across the loop) —, i.e. three exposed
+    // memory round trips per wave: 0.6 of the role's 2.15 ms (probe build with constant operands: 1.56 ms).  One batch = one round trip.
+    constexpr int GRP = ND == 3 ? 8 : 1;
     auto load_sop = [&](int gq, double* o) {
+#if defined(LIW_IMU_PROBE_NOSOP)      // probe build (wrong results): the sqrt-information operands are constants — no global loads in front of / inside the matrix-core loop
+        for (int c = 0; c < 4; ++c) o[c] = 1.0 + 0.001 * (gq + c);
+        return;
+#endif
         const int fq = __shfl(fk_lane, gq < nblk ? LPB * gq : 0, 64);
         const double* S = PK ? A.imu_pk + (size_t)fq * IMU_PK + IPK_S : A.imu_sqrtP + (size_t)fq * 225;
 #pragma unroll
         for (int c = 0; c < 4; ++c) {
             const int kk = mk + 4 * c;
             const bool in = ml < 15 && kk < 15 && (!PK || kk >= ml);          // (packed: row ml of the upper triangle)
-            const double v = S[in ? (PK ? ml * 15 - (ml * (ml - 1)) / 2 + (kk - ml) : ml * 15 + kk) : 0];
-            o[c] = in ? v : 0.0;
+            if constexpr (PK) {
+                // Round 6: entries outside the triangle READ the record's zero word (IPK_S + 120: k_imu_pack writes 0.0 behind the 120 entries) instead
+                // of being selected to 0.0 behind the load.  The select made every prefetched group a load-and-wait: the scheduling fences
+                // around the prefetch keep it next to its load, so the NEXT group's 28 loads were waited for before the current group's first
+                // MFMA — three exposed memory round trips per 16-block wave, 0.6 of the role's 2.15 ms (probe with constant operands: 1.56 ms).
+                o[c] = S[in ? ml * 15 - (ml * (ml - 1)) / 2 + (kk - ml) : 120];
+            } else {
+                const double v = S[in ? ml * 15 + kk : 0];
+                o[c] = in ? v : 0.0;
+            }
         }
     };
+    static_assert(IPK_S + 120 < IMU_PK, "the packed record's zero word behind the sqrt-information triangle");
     double sop[GRP][4], sopn[GRP][4];
     if constexpr (ND == 1) {
 #pragma unroll
@@ -412,15 +429,20 @@ __device__ __forceinline__ void imu_blocks(const LinArgs& A, const DevParams& P,
         so_d[r] = row < 15 ? (ml == 15 ? 120 + row : (ml >= row ? row * 15 - (row * (row - 1)) / 2 + (ml - row) : IMU_SPARE)) : IMU_SPARE;
     }
     if constexpr (ND == 3) {
+        static_assert(2 * 8 >= IMU_PER_WAVE, "two operand groups cover a wave's blocks");
 #pragma unroll
         for (int q = 0; q < GRP; ++q) load_sop(q, sop[q]);
+#pragma unroll
+        for (int q = 0; q < GRP; ++q) load_sop(GRP + q, sopn[q]);      // (a slot beyond nblk re-reads block 0's record: a valid address, never used)
     }
     for (int g0 = 0; g0 < nblk; g0 += GRP) {
         LSTAMP(305 + g0 / GRP);
         __builtin_amdgcn_sched_barrier(0);
-        if (g0 + GRP < nblk) {
+        if constexpr (ND != 3) {
+            if (g0 + GRP < nblk) {
 #pragma unroll
-            for (int q = 0; q < GRP; ++q) load_sop(g0 + GRP + q, sopn[q]);
+                for (int q = 0; q < GRP; ++q) load_sop(g0 + GRP + q, sopn[q]);
+            }
         }
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
@@ -453,6 +475,10 @@ __device__ __forceinline__ void imu_blocks(const LinArgs& A, const DevParams& P,
             const int sel = __builtin_amdgcn_readfirstlane(__shfl(sel_lane, LPB * gq, 64));
             if constexpr (CHAIN) {
                 chain11 = g11;
+#if defined(LIW_IMU_PROBE_NOOUT)      // probe build (wrong results): operands + the 20 MFMAs of a block only — no staging, no flush, no stores
+                if (g00[0] + g01[1] + g11[2] == 12345.678) lds[lane] = g00[3];
+                continue;
+#endif
                 if (ghost && gq == 0) continue;   // evaluated for its jj tile only
                 // frame kq's record: diagonal tile (upper triangle), gradient part of block (kq, kq+1); frame kq+1's: coupling, gradient
                 // part and cost of the block; behind a window's last block the jj tile is frame n-1's diagonal
