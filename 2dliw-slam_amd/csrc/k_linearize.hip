@@ -109,6 +109,10 @@ typedef LJN<3> J3;
 // (31.6 kB, five waves per CU) the kernel took 563 us per 12 288 C2 windows, with the packed inputs alone 3 % less.
 constexpr int IMU_PER_WAVE = 16;    // (18 until the chain kernel's output staging area took the room of two blocks)
 constexpr int IMU_STAGE = 244;      // k_lin_imu_chain: one frame record's larger part (ij | g_j: 240 doubles) on its way out
+#ifndef LIW_IMU_COAL
+#define LIW_IMU_COAL 1                // A/B aid: 0 = the sqrt-information operands as four 8-byte gathers per block (until round 6)
+#endif
+constexpr int IMU_SBUF = LIW_IMU_COAL ? 128 : 0;   // LDS copy of one block's packed sqrt-information triangle (COAL in imu_blocks): 19 232 -> 20 256 B, still eight waves per CU
 // compact block record in LDS (doubles): Xc[9][10] = rows alpha, beta, gamma: the 9 derivative columns (theta_i 0-2, theta_j 3-5,
 // bw_i 6-8) + r_raw (9); Rb[6] = r_raw of the bias rows (their derivative columns are constants); Rt[9] = R_i^T; RtDt[9];
 // Jb[18] = alpha_J_ba (9), beta_J_ba (9)
@@ -271,6 +275,21 @@ __device__ __forceinline__ void imu_blocks(const LinArgs& A, const DevParams& P,
         }
     };
     static_assert(IPK_S + 120 < IMU_PK, "the packed record's zero word behind the sqrt-information triangle");
+    // COAL (round 6, the chain kernels on packed records): a block's sqrt-information triangle is fetched as ONE coalesced 16-byte-per-lane load (61 lanes:
+    // 120 entries + the zero word) instead of four gathers of 8 bytes per lane, parked in registers (4 per block) and spread into the MFMA operand
+    // layout through a 1-KiB LDS buffer right before the block's products (one ds_write_b128 + four ds_read_b64 at per-lane offsets).
+    constexpr bool COAL = CHAIN && PK && ND == 3 && LIW_IMU_COAL;
+    typedef double __attribute__((ext_vector_type(2))) sraw_t;
+    auto load_raw = [&](int gq) -> sraw_t {
+        const int fq = __shfl(fk_lane, gq < nblk ? LPB * gq : 0, 64);
+        const double* S = A.imu_pk + (size_t)fq * IMU_PK + IPK_S;
+        return *reinterpret_cast<const sraw_t*>(S + 2 * (lane < 61 ? lane : 60));
+    };
+    static_assert((IPK_S * 8) % 16 == 0 && (IMU_PK * 8) % 16 == 0 && IPK_S + 122 <= IMU_PK, "16-byte pieces of the packed sqrt-information triangle");
+    sraw_t sraw[COAL ? GRP : 1], srawn[COAL ? GRP : 1];
+    int sidx[4];                                       // COAL: this lane's four operand entries as offsets into the LDS copy of the triangle
+#pragma unroll
+    for (int c = 0; c < 4; ++c) { const int kk = mk + 4 * c; sidx[c] = (ml < 15 && kk < 15 && kk >= ml) ? ml * 15 - (ml * (ml - 1)) / 2 + (kk - ml) : 120; }
     double sop[GRP][4], sopn[GRP][4];
     if constexpr (ND == 1) {
 #pragma unroll
@@ -428,7 +447,12 @@ __device__ __forceinline__ void imu_blocks(const LinArgs& A, const DevParams& P,
         so_ij[r] = ml < 15 ? row * 15 + ml : IMU_SPARE;        // (row <= 15)
         so_d[r] = row < 15 ? (ml == 15 ? 120 + row : (ml >= row ? row * 15 - (row * (row - 1)) / 2 + (ml - row) : IMU_SPARE)) : IMU_SPARE;
     }
-    if constexpr (ND == 3) {
+    if constexpr (COAL) {
+#pragma unroll
+        for (int q = 0; q < GRP; ++q) sraw[q] = load_raw(q);
+#pragma unroll
+        for (int q = 0; q < GRP; ++q) srawn[q] = load_raw(GRP + q);
+    } else if constexpr (ND == 3) {
         static_assert(2 * 8 >= IMU_PER_WAVE, "two operand groups cover a wave's blocks");
 #pragma unroll
         for (int q = 0; q < GRP; ++q) load_sop(q, sop[q]);
@@ -451,12 +475,23 @@ __device__ __forceinline__ void imu_blocks(const LinArgs& A, const DevParams& P,
             if (gq >= nblk || !((onmask >> (LPB * gq)) & 1ull)) continue;
             const double* R_ = lds + gq * IMU_REC;
             d4 y0 = {0.0, 0.0, 0.0, 0.0}, y1 = {0.0, 0.0, 0.0, 0.0};
+            double sq[4];
+            if constexpr (COAL) {
+                double* const sbuf = lds + IMU_PER_WAVE * IMU_REC + IMU_STAGE;      // 128 doubles behind the output staging area
+                *reinterpret_cast<sraw_t*>(sbuf + 2 * lane) = sraw[q];
+                lds_sync();
+#pragma unroll
+                for (int c = 0; c < 4; ++c) sq[c] = sbuf[sidx[c]];
+            } else {
+#pragma unroll
+                for (int c = 0; c < 4; ++c) sq[c] = sop[q][c];
+            }
 #pragma unroll
             for (int c = 0; c < 4; ++c) {
                 const double x0v = R_[off0[c]], l1 = R_[off1[c]];
                 const double x1v = __hiloint2double(__double2hiint(l1) ^ sgn1[c], __double2loint(l1));
-                y0 = __builtin_amdgcn_mfma_f64_16x16x4f64(sop[q][c], x0v, y0, 0, 0, 0);
-                y1 = __builtin_amdgcn_mfma_f64_16x16x4f64(sop[q][c], x1v, y1, 0, 0, 0);
+                y0 = __builtin_amdgcn_mfma_f64_16x16x4f64(sq[c], x0v, y0, 0, 0, 0);
+                y1 = __builtin_amdgcn_mfma_f64_16x16x4f64(sq[c], x1v, y1, 0, 0, 0);
             }
             // y_t[r] = Y[mk + 4r][ml + 16t]  ==  operand chunk r of Y^T Y
             d4 g00 = {0.0, 0.0, 0.0, 0.0}, g01 = g00, g11 = g00;
@@ -542,10 +577,15 @@ __device__ __forceinline__ void imu_blocks(const LinArgs& A, const DevParams& P,
                 }
             }
         }
+        if constexpr (COAL) {
 #pragma unroll
-        for (int q = 0; q < GRP; ++q)
+            for (int q = 0; q < GRP; ++q) sraw[q] = srawn[q];
+        } else {
 #pragma unroll
-            for (int c = 0; c < 4; ++c) sop[q][c] = sopn[q][c];
+            for (int q = 0; q < GRP; ++q)
+#pragma unroll
+                for (int c = 0; c < 4; ++c) sop[q][c] = sopn[q][c];
+        }
     }
     LSTAMP(311);
 }
@@ -1110,7 +1150,7 @@ __global__ __launch_bounds__(64, 2) void k_lin_imu(LinArgs A, DevParams P) {
     else imu_blocks<3>(A, P, (int)blockIdx.x, lds, act);
 }
 __global__ __launch_bounds__(64, 2) void k_lin_imu_chain(LinArgs A, DevParams P) {   // consecutive blocks of one window per wave: per-frame IMU records
-    __shared__ __attribute__((aligned(16))) double lds[IMU_PER_WAVE * IMU_REC + IMU_STAGE];
+    __shared__ __attribute__((aligned(16))) double lds[IMU_PER_WAVE * IMU_REC + IMU_STAGE + IMU_SBUF];
     const int* const act = usable_active_list(A.active, A.B);
     if (A.imu_pk && *A.imu_pk_bad == 0) imu_blocks<3, true, true>(A, P, (int)blockIdx.x, lds, act);   // (uniform)
     else imu_blocks<3, false, true>(A, P, (int)blockIdx.x, lds, act);
@@ -1118,7 +1158,7 @@ __global__ __launch_bounds__(64, 2) void k_lin_imu_chain(LinArgs A, DevParams P)
 // windows of at most IMU_PER_WAVE / 2 blocks (two-frame tracking windows: one block): several windows per wave.  A kernel of its own, so that
 // its per-lane window bookkeeping does not enter the register allocation of the 30-frame kernel above (249 of 256)
 __global__ __launch_bounds__(64, 2) void k_lin_imu_chain_multi(LinArgs A, DevParams P) {
-    __shared__ __attribute__((aligned(16))) double lds[IMU_PER_WAVE * IMU_REC + IMU_STAGE];
+    __shared__ __attribute__((aligned(16))) double lds[IMU_PER_WAVE * IMU_REC + IMU_STAGE + IMU_SBUF];
     const int* const act = usable_active_list(A.active, A.B);
     if (A.imu_pk && *A.imu_pk_bad == 0) imu_blocks<3, true, true, true>(A, P, (int)blockIdx.x, lds, act);   // (uniform)
     else imu_blocks<3, false, true, true>(A, P, (int)blockIdx.x, lds, act);
