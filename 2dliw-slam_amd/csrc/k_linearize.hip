@@ -298,11 +298,18 @@ __device__ __forceinline__ void imu_blocks(const LinArgs& A, const DevParams& P,
     LSTAMP(300);
     if (on && LIW_IMU_PROBE_PHASE != 2) {
         const size_t fk = (size_t)b * nb + k;   // record of this block in the (uncompacted) input / partial arrays
+#if defined(LIW_IMU_PROBE_INCACHE)   // probe build (wrong results): every block's states and packed inputs are those of block 0 (cache-resident)
+        const double* si_ = A.x;
+        const double* sj_ = si_ + 15;
+        constexpr int JLD = PK ? 6 : 15;
+        const double* pkr = PK ? A.imu_pk : nullptr;
+#else
         const double* si_ = A.x + ((size_t)b * n + k) * 15;
         const double* sj_ = si_ + 15;
         // Jp[r * JLD + c], r < 9, 9 <= c < 15: the bias blocks of the pre-integration Jacobian (the only entries the factor reads)
         constexpr int JLD = PK ? 6 : 15;
         const double* pkr = PK ? A.imu_pk + fk * IMU_PK : nullptr;
+#endif
         const double* Jp = PK ? pkr + IPK_J - 9 : A.imu_J + fk * 225;
         const double* X0 = PK ? pkr : A.imu_X + fk * 15;
         const double Dt = PK ? pkr[IPK_DT] : A.imu_Dt[fk];

@@ -21,6 +21,8 @@ case $SET in
 6) run batch python tests/soak/soak_batch.py 13600 15600; run slab python tests/soak/soak_slab.py 400 1000
    run fuzz python tests/soak/soak_api_fuzz.py 130 170; run replay python tests/soak/soak_replay.py 14 22
    run pg python tests/soak/soak_posegraph.py 200 400; run preint python tests/soak/soak_preint.py 600 1000;;
+7) run batch python tests/soak/soak_batch.py 15600 17000; run slab python tests/soak/soak_slab.py 1000 1300
+   run c2 python tests/soak/soak_c2.py 150 175 15; run shapes python tests/soak/soak_random_shapes.py 38000 39500;;
 esac
 wait
 for f in gpurun_out/soak_${TAG}_*.log; do echo "== $f"; tail -n 2 $f; done
