@@ -934,10 +934,17 @@ __device__ __forceinline__ void wheel_ground2_blocks(const LinArgs& A, const Dev
     double* Y = lds + (blk < WG_PER_WAVE ? blk : 0) * WG_REC;
     const size_t fk = on ? (size_t)b * nb + k : 0, fi0 = on ? (size_t)b * n + k : 0;
     if (on) {
+#if defined(LIW_SMALL_PROBE_INCACHE)   // probe build (wrong results): every block reads block 0's states and odometry increment (cache-resident)
+        const double* si_ = A.x;
+        const double* sj_ = si_ + 15;
+        const double* T12 = A.wheel_T;
+        const double* sq9 = A.wheel_sqrtP;
+#else
         const double* si_ = A.x + fi0 * 15;
         const double* sj_ = si_ + 15;
         const double* T12 = A.wheel_T + fk * 12;
         const double* sq9 = A.wheel_sqrtP + fk * 9;
+#endif
         const V3<double> thi = cast_v3<double>(si_ + 3), thj = cast_v3<double>(sj_ + 3);
         V3<J3> arg;   // the rotation this lane differentiates
         arg.x = seed<3>(f ? thj.x : thi.x, 0, true); arg.y = seed<3>(f ? thj.y : thi.y, 1, true); arg.z = seed<3>(f ? thj.z : thi.z, 2, true);
