@@ -403,3 +403,70 @@ def test_multi_window_imu_chain_is_bit_identical_to_one_window_per_wave(liw, syn
                 assert (sa[b]["iterations"], sa[b]["termination"]) == (so["iterations"], so["termination"]), (k, b)
                 assert rel(xa[b], w["states"].reshape(n, 15)) <= 1e-6, (k, b)
         orc.set_max_iterations(50)
+
+
+def test_factor_sharded_tracking_solve_and_marginalisation(liw, synth, pyoracle):
+    """The factor-sharded loop in the TRACK topology (the steady state on several GPUs: laser blocks of the new frame split over the ranks, 21
+    pair totals per group on the wire): 1 100 two-frame windows with a carried prior through two lock-step rank objects, both exchange
+    variants — ranks bit-identical, same iteration counts / terminations as the un-sharded solve and the oracle, states to round-off; then
+    the sharded marginalisation (MARG exchange) against the un-sharded one (solver.cpp:631-820, :257-442)."""
+    import sys, os, importlib, threading
+    import torch
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    bench = importlib.import_module("bench")
+    prm = synth.office_params()
+    orc = pyoracle.Oracle(prm)
+    B, nb_ = 1100, 5
+    base = [bench.sub_window(synth.make_window(orc, prm, seed=9500 + k, n=3, frame_counts=[0, 30 + 11 * k, 45 + 6 * k]), 1) for k in range(nb_)]
+    wins = [base[b % nb_] for b in range(B)]
+    ref = liw.BatchSolver(prm, wins)
+    ref.marginalize()                                                     # a prior to carry: sit it on the older frame
+    ref.t["prior_X"].view(B, 15).copy_(ref.t["x"].view(B, 2, 15)[:, 0])
+    prior = {k: ref.t[k].clone() for k in ("prior_X", "prior_J", "prior_R", "has_prior")}
+    ref.solve(liw.LIW_MODE_TRACK, 0)
+    xr, sr = ref.states().copy(), ref.summaries()
+    _, dHr, dgr = ref.marginalize()
+    dHr, dgr = dHr.cpu().numpy(), dgr.cpu().numpy()
+    for xch in ("allreduce", "oneshot"):
+        comms = liw.batch.LockstepComm.make(2)
+        ranks = [liw.BatchSolver(prm, wins, rank=r, world=2, exchange=xch, comm=comms[r]) for r in range(2)]
+        assert sum(rk.Ltot for rk in ranks) == ref.Ltot
+        assert ranks[0].exchange_bytes(liw.LIW_MODE_TRACK) == 8 * (B * 2 * 21 + 1)
+        for rk in ranks:
+            for k, v in prior.items():
+                rk.t[k].copy_(v)
+        errs, outs = [], [None, None]
+
+        def drive(i):
+            try:
+                ranks[i].solve(liw.LIW_MODE_TRACK, 0)
+                outs[i] = ranks[i].marginalize()
+            except Exception as e:   # noqa: BLE001
+                errs.append(e)
+                comms[0].sh["bar"].abort()
+        th = [threading.Thread(target=drive, args=(i,)) for i in range(2)]
+        for t in th:
+            t.start()
+        for t in th:
+            t.join(timeout=300)
+        assert not errs, errs
+        torch.cuda.synchronize()
+        a, b_ = ranks[0].states(), ranks[1].states()
+        assert np.array_equal(a, b_), xch
+        sa = ranks[0].summaries()
+        assert [(s["iterations"], s["termination"]) for s in sa] == [(s["iterations"], s["termination"]) for s in sr], xch
+        assert rel(a, xr) <= 1e-9, xch
+        dH0, dH1 = outs[0][1].cpu().numpy(), outs[1][1].cpu().numpy()
+        assert np.array_equal(dH0, dH1) and np.array_equal(outs[0][2].cpu().numpy(), outs[1][2].cpu().numpy()), xch
+        assert np.abs(dH0 - dHr).max() <= 1e-9 * np.abs(dHr).max() and np.abs(outs[0][2].cpu().numpy() - dgr).max() <= 1e-7 * max(1.0, np.abs(dgr).max()), xch
+        for rk in ranks:
+            rk.close()
+    for k in range(nb_):
+        w = pyoracle.Window(base[k])
+        orc.set_prior((prior["prior_X"].view(B, 15)[k].cpu().numpy(), prior["prior_J"].view(B, 15, 15)[k].cpu().numpy(), prior["prior_R"].view(B, 15)[k].cpu().numpy()))
+        orc.solve(w)
+        so = orc.summary()
+        assert (sr[k]["iterations"], sr[k]["termination"]) == (so["iterations"], so["termination"]), k
+        assert rel(xr[k], w["states"].reshape(2, 15)) <= 1e-6, k
+    orc.set_prior(None)
+    ref.close()
