@@ -23,6 +23,8 @@ case $SET in
    run pg python tests/soak/soak_posegraph.py 200 400; run preint python tests/soak/soak_preint.py 600 1000;;
 7) run batch python tests/soak/soak_batch.py 15600 17000; run slab python tests/soak/soak_slab.py 1000 1300
    run c2 python tests/soak/soak_c2.py 150 175 15; run shapes python tests/soak/soak_random_shapes.py 38000 39500;;
+8) run batch python tests/soak/soak_batch.py 17000 19500; run slab python tests/soak/soak_slab.py 1300 2300
+   run fuzz python tests/soak/soak_api_fuzz.py 170 220; run c2 python tests/soak/soak_c2.py 175 215 15;;
 esac
 wait
 for f in gpurun_out/soak_${TAG}_*.log; do echo "== $f"; tail -n 2 $f; done
